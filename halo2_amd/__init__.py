@@ -1,0 +1,8 @@
+"""halo2_amd: MI355X-native (gfx950) implementation of the halo2_proofs prover hot path --
+Pasta MSM (`best_multiexp`, `Params::commit*`) and NTT (`best_fft`, `EvaluationDomain`) -- behind a
+C ABI (include/halo2_mi355x.h, halo2_amd/libhalo2_mi355x.so).  This package is the thin host-side mirror
+of the reference's interface; all compute is hand-written HIP in halo2_amd/csrc/."""
+from ._lib import (FORM_CANONICAL, FORM_MONTGOMERY, FP, FQ, LIB_PATH, PALLAS, VESTA, H2Error, lib)  # noqa: F401
+from .arithmetic import best_fft, best_multiexp, msm_window_bits, points_sum  # noqa: F401
+from .commitment import Blind, Params  # noqa: F401
+from .domain import EvaluationDomain  # noqa: F401

@@ -1,0 +1,94 @@
+"""ctypes loader for libhalo2_mi355x.so (the C ABI declared in include/halo2_mi355x.h).
+
+The product path has no CPU fallback: if the shared library is missing this raises, and every
+entry point returns H2_ERR_NODEV (surfaced as RuntimeError) when no gfx950 device is present."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+H2_OK, H2_ERR_ARGS, H2_ERR_HIP, H2_ERR_NODEV, H2_ERR_HANDLE = 0, 1, 2, 3, 4
+FP, FQ = 0, 1
+PALLAS, VESTA = 0, 1
+FORM_CANONICAL, FORM_MONTGOMERY = 0, 1
+OUT_JACOBIAN, OUT_AFFINE = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhalo2_mi355x.so")
+_lib = None
+
+u64p = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+
+# every symbol include/halo2_mi355x.h declares: name -> (argtypes, restype)
+SIGNATURES = {
+    "h2_device_count": ([], C.c_int),
+    "h2_init": ([C.c_int], C.c_int),
+    "h2_last_error": ([], C.c_char_p),
+    "h2_msm_window_bits": ([C.c_size_t], C.c_int),
+    "h2_msm": ([C.c_int, u64p, u64p, C.c_size_t, C.c_int, C.c_int, u64p], C.c_int),
+    "h2_bases_register": ([C.c_int, u64p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)], C.c_int),
+    "h2_bases_free": ([C.c_uint64], C.c_int),
+    "h2_commit": ([C.c_uint64, u64p, C.c_size_t, u64p, u64p, C.c_int, C.c_int, u64p], C.c_int),
+    "h2_ntt": ([C.c_int, u64p, C.c_uint, u64p, C.c_int], C.c_int),
+    "h2_ifft": ([C.c_int, u64p, C.c_uint, u64p, u64p, C.c_int], C.c_int),
+    "h2_coeff_to_extended": ([C.c_int, u64p, u64p, C.c_uint, C.c_uint, u64p, u64p, u64p, C.c_int], C.c_int),
+    "h2_extended_to_coeff": ([C.c_int, u64p, C.c_uint, u64p, u64p, u64p, u64p, C.c_int], C.c_int),
+    "h2_msm_device": ([C.c_int, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp], C.c_int),
+    "h2_commit_device": ([C.c_uint64, vp, C.c_size_t, vp, vp, C.c_int, C.c_int, vp, vp], C.c_int),
+    "h2_ntt_device": ([C.c_int, vp, C.c_uint, u64p, C.c_int, vp], C.c_int),
+    "h2_ifft_device": ([C.c_int, vp, C.c_uint, u64p, u64p, C.c_int, vp], C.c_int),
+    "h2_coeff_to_extended_device": ([C.c_int, vp, vp, C.c_uint, C.c_uint, u64p, u64p, u64p, C.c_int, vp], C.c_int),
+    "h2_extended_to_coeff_device": ([C.c_int, vp, C.c_uint, u64p, u64p, u64p, u64p, C.c_int, vp], C.c_int),
+    "h2_points_sum": ([C.c_int, u64p, C.c_size_t, u64p], C.c_int),
+}
+
+
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP runtime.  The PyTorch wheel bundles its own libamdhip64.so
+    (SONAME libamdhip64.so.7, same as /opt/rocm's); if this library pulled in /opt/rocm's copy first,
+    torch would later load its own second copy and find no GPU.  Pre-loading torch's copy makes the
+    dynamic loader resolve our NEEDED libamdhip64.so.7 to it.  No torch installed -> /opt/rocm's."""
+    if os.environ.get("H2_NO_TORCH_RUNTIME"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C halo2_amd/csrc). There is no CPU fallback.")
+        _share_hip_runtime_with_torch()
+        _lib = C.CDLL(LIB_PATH)
+        for name, (args, res) in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = args
+            fn.restype = res
+    return _lib
+
+
+class H2Error(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    if rc == H2_OK:
+        return
+    if rc == H2_ERR_ARGS:
+        # the reference panics (assert_eq!) on bad lengths: arithmetic.rs:144, :205
+        raise ValueError(f"{what}: bad arguments")
+    msg = lib().h2_last_error().decode()
+    names = {H2_ERR_HIP: "HIP failure", H2_ERR_NODEV: "no MI355X device", H2_ERR_HANDLE: "bad handle"}
+    raise H2Error(f"{what}: {names.get(rc, rc)}: {msg}")

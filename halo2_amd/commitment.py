@@ -1,0 +1,86 @@
+"""`Params` (halo2_proofs/src/poly/commitment.rs:26-205) over the C ABI: `g` and `g_lagrange` are
+registered once and stay in HBM; `commit` / `commit_lagrange` (:119-150) ship only the column.
+
+`Params::new` derives its generators with pasta_curves' hash-to-curve (commitment.rs:51-62), which lives
+in an un-vendored dependency; here a Params is built from caller-supplied generators (`from_generators`),
+which is also what `Params::read` (:184) amounts to."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import fields
+from ._lib import FORM_MONTGOMERY, OUT_AFFINE, OUT_JACOBIAN, check, lib
+from .arithmetic import _is_torch, _np, _p, _stream_ptr
+
+
+class Blind:
+    """Blind<F> (commitment.rs:208-256): newtype around the blinding scalar, default 1."""
+
+    def __init__(self, value: np.ndarray | None = None, field: int | None = None):
+        self.value = fields.scalar_limbs(1, field, True) if value is None else np.ascontiguousarray(value, dtype=np.uint64)
+
+
+class Params:
+    def __init__(self, curve: int, k: int, g, g_lagrange, w, u):
+        self.curve, self.k, self.n = curve, k, 1 << k
+        self.g = _np(g, 8)
+        self.g_lagrange = _np(g_lagrange, 8)
+        if self.g.shape[0] != self.n or self.g_lagrange.shape[0] != self.n:
+            raise ValueError("Params: g / g_lagrange must have 2^k points")
+        self.w = np.ascontiguousarray(w, dtype=np.uint64).reshape(8)
+        self.u = np.ascontiguousarray(u, dtype=np.uint64).reshape(8)
+        self._h_g = C.c_uint64(0)
+        self._h_gl = C.c_uint64(0)
+        check(lib().h2_bases_register(curve, _p(self.g), self.n, FORM_MONTGOMERY, C.byref(self._h_g)), "h2_bases_register")
+        check(lib().h2_bases_register(curve, _p(self.g_lagrange), self.n, FORM_MONTGOMERY, C.byref(self._h_gl)),
+              "h2_bases_register")
+        self._w_dev = None
+
+    @classmethod
+    def from_generators(cls, curve: int, k: int, g, g_lagrange, w, u) -> "Params":
+        return cls(curve, k, g, g_lagrange, w, u)
+
+    def close(self):
+        for h in (self._h_g, self._h_gl):
+            if h.value:
+                lib().h2_bases_free(h)
+                h.value = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get_g(self) -> np.ndarray:
+        return self.g.copy()
+
+    def _commit(self, handle, poly, r: Blind, affine: bool):
+        out_kind = OUT_AFFINE if affine else OUT_JACOBIAN
+        out_len = 8 if affine else 12
+        if poly.shape[0] != self.n:
+            raise ValueError("commit: polynomial length != n")
+        if _is_torch(poly):
+            import torch
+            if self._w_dev is None or self._w_dev.device != poly.device:
+                self._w_dev = torch.from_numpy(self.w.view(np.int64)).to(poly.device)
+            blind = torch.from_numpy(np.ascontiguousarray(r.value).view(np.int64)).to(poly.device)
+            out = torch.empty(out_len, dtype=torch.int64, device=poly.device)
+            check(lib().h2_commit_device(handle, poly.data_ptr(), self.n, self._w_dev.data_ptr(), blind.data_ptr(),
+                                         FORM_MONTGOMERY, out_kind, out.data_ptr(), _stream_ptr()), "h2_commit_device")
+            return out
+        poly = _np(poly, 4)
+        out = np.zeros(out_len, dtype=np.uint64)
+        check(lib().h2_commit(handle, _p(poly), self.n, _p(self.w), _p(np.ascontiguousarray(r.value)), FORM_MONTGOMERY,
+                              out_kind, _p(out)), "h2_commit")
+        return out
+
+    def commit(self, poly, r: Blind, affine: bool = False):
+        """commitment.rs:119-130: sum poly[i] * g[i] + r * w."""
+        return self._commit(self._h_g, poly, r, affine)
+
+    def commit_lagrange(self, poly, r: Blind, affine: bool = False):
+        """commitment.rs:135-150: sum poly[i] * g_lagrange[i] + r * w."""
+        return self._commit(self._h_gl, poly, r, affine)

@@ -1,0 +1,55 @@
+// Host-side plumbing shared by the MSM / NTT translation units: status codes, HIP error mapping,
+// a tiny size-keyed device workspace cache.  No torch, no third-party types.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <mutex>
+
+#include "../../include/halo2_mi355x.h"
+
+namespace h2 {
+
+#define H2_HIP(expr)                                      \
+    do {                                                  \
+        hipError_t _e = (expr);                           \
+        if (_e != hipSuccess) {                           \
+            h2::set_last_hip_error(_e, __FILE__, __LINE__); \
+            return H2_ERR_HIP;                            \
+        }                                                 \
+    } while (0)
+
+void set_last_hip_error(hipError_t e, const char *file, int line);
+
+// Grow-only device buffer.  One instance per use site, guarded by the owning context's mutex.
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return H2_OK;
+        if (ptr) {
+            hipError_t e = hipFree(ptr);
+            ptr = nullptr;
+            cap = 0;
+            if (e != hipSuccess) { set_last_hip_error(e, __FILE__, __LINE__); return H2_ERR_HIP; }
+        }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&ptr, want);
+        if (e != hipSuccess) { ptr = nullptr; set_last_hip_error(e, __FILE__, __LINE__); return H2_ERR_HIP; }
+        cap = want;
+        return H2_OK;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(ptr); }
+};
+
+// Confirms a usable gfx950 device exists; every entry point calls this first so a missing GPU or
+// runtime fails loudly (H2_ERR_NODEV) instead of silently doing nothing.
+int ensure_device();
+
+}  // namespace h2

@@ -1,0 +1,252 @@
+// 255-bit Montgomery arithmetic for the Pasta fields on gfx950 (CDNA4), register-resident.
+//
+// Replaces the L0 field ops the reference calls from its hot loops (pasta_curves 0.5.1 Fp/Fq,
+// used at halo2_proofs/src/arithmetic.rs:242-246,288-292 and inside every point addition).
+// Representation: 8 x 32-bit little-endian limbs, Montgomery form with R = 2^256 -- bit-identical
+// to the 4 x u64 limbs a Rust `Fp`/`Fq` holds in memory, so buffers cross the FFI without conversion.
+//
+// Both moduli are 2^254 + t with t < 2^126:  32-bit limbs  [1, p1, p2, p3, 0, 0, 0, 2^30]  and
+// -p^-1 mod 2^32 = 0xffffffff, so the Montgomery quotient digit is a negation and the reduction
+// needs 4 multiplies per digit instead of 8.
+//
+// The multiplier is a product-scanning (Comba) Montgomery multiply: every column keeps a 96-bit
+// accumulator {lo:mid (aligned VGPR pair), hi}; one partial product costs
+//     v_mad_u64_u32 acc, vcc, a, b, acc ; v_addc_co_u32 hi, vcc, 0, hi, vcc
+// i.e. 96 quarter-rate multiplies + 96 carry adds per modular multiplication.  No MFMA: this is
+// modular-integer work, not a dense contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace h2 {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+enum { FP = 0, FQ = 1 };
+
+struct fe {
+    u32 v[8];
+};
+
+template <int F> struct Mod;
+template <> struct Mod<FP> {  // Pallas base / Vesta scalar
+    static constexpr u32 P1 = 0x992d30edu, P2 = 0x094cf91bu, P3 = 0x224698fcu;
+};
+template <> struct Mod<FQ> {  // Pallas scalar / Vesta base
+    static constexpr u32 P1 = 0x8c46eb21u, P2 = 0x0994a8ddu, P3 = 0x224698fcu;
+};
+static constexpr u32 P7 = 0x40000000u;
+
+template <int F> __device__ __forceinline__ u32 mod_limb(int i) {
+    return i == 0 ? 1u : i == 1 ? Mod<F>::P1 : i == 2 ? Mod<F>::P2 : i == 3 ? Mod<F>::P3 : i == 7 ? P7 : 0u;
+}
+
+// R mod p and R^2 mod p (verified against the Python oracle)
+template <int F> __device__ __forceinline__ fe fe_one() {
+    if (F == FP) return fe{{0xfffffffdu, 0x34786d38u, 0xe41914adu, 0x992c350bu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu}};
+    return fe{{0xfffffffdu, 0x5b2b3e9cu, 0xe3420567u, 0x992c350bu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu}};
+}
+template <int F> __device__ __forceinline__ fe fe_r2() {
+    if (F == FP) return fe{{0x0000000fu, 0x8c78ecb3u, 0x8b0de0e7u, 0xd7d30dbdu, 0xc3c95d18u, 0x7797a99bu, 0x7b9cb714u, 0x096d41afu}};
+    return fe{{0x0000000fu, 0xfc9678ffu, 0x891a16e3u, 0x67bb433du, 0x04ccf590u, 0x7fae2310u, 0x7ccfdaa9u, 0x096d41afu}};
+}
+__device__ __forceinline__ fe fe_zero() { return fe{{0, 0, 0, 0, 0, 0, 0, 0}}; }
+
+__device__ __forceinline__ bool fe_is_zero(const fe &a) {
+    return (a.v[0] | a.v[1] | a.v[2] | a.v[3] | a.v[4] | a.v[5] | a.v[6] | a.v[7]) == 0;
+}
+__device__ __forceinline__ bool fe_eq(const fe &a, const fe &b) {
+    u32 d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d |= a.v[i] ^ b.v[i];
+    return d == 0;
+}
+
+// r = a - p if a >= p else a          (a < 2p)
+template <int F> __device__ __forceinline__ fe fe_reduce_once(const fe &a) {
+    fe d;
+    u64 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 t = (u64)a.v[i] - mod_limb<F>(i) - br;
+        d.v[i] = (u32)t;
+        br = (t >> 32) & 1;
+    }
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = br ? a.v[i] : d.v[i];
+    return r;
+}
+
+template <int F> __device__ __forceinline__ fe fe_add(const fe &a, const fe &b) {
+    fe s;
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (u64)a.v[i] + b.v[i];
+        s.v[i] = (u32)c;
+        c >>= 32;
+    }
+    return fe_reduce_once<F>(s);  // a + b < 2p < 2^256: no carry out of limb 7
+}
+
+template <int F> __device__ __forceinline__ fe fe_sub(const fe &a, const fe &b) {
+    fe d;
+    u64 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 t = (u64)a.v[i] - b.v[i] - br;
+        d.v[i] = (u32)t;
+        br = (t >> 32) & 1;
+    }
+    // add p back when the subtraction borrowed
+    u32 mask = 0u - (u32)br;
+    fe r;
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (u64)d.v[i] + (mod_limb<F>(i) & mask);
+        r.v[i] = (u32)c;
+        c >>= 32;
+    }
+    return r;
+}
+
+template <int F> __device__ __forceinline__ fe fe_neg(const fe &a) { return fe_sub<F>(fe_zero(), a); }
+template <int F> __device__ __forceinline__ fe fe_dbl(const fe &a) { return fe_add<F>(a, a); }
+
+// ---- Montgomery multiplication ------------------------------------------------------------
+// 96-bit column accumulator step: {acc, hi} += x * y
+__device__ __forceinline__ void mac96(u64 &acc, u32 &hi, u32 x, u32 y) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(acc), "+v"(hi)
+        : "v"(x), "v"(y)
+        : "vcc");
+}
+// same with a compile-time constant multiplier (modulus limb): constant goes through an SGPR/literal
+__device__ __forceinline__ void mac96k(u64 &acc, u32 &hi, u32 x, u32 k) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(acc), "+v"(hi)
+        : "v"(x), "s"(k)
+        : "vcc");
+}
+
+template <int F> __device__ __forceinline__ fe fe_mul(const fe &a, const fe &b) {
+    u32 m[8];
+    fe r;
+    u64 acc = 0;
+    u32 hi = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        // partial products of column k
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int j = k - i;
+            if (j >= 0 && j < 8) mac96(acc, hi, a.v[i], b.v[j]);
+        }
+        // reduction products m[i] * p[k-i], p = [1, P1, P2, P3, 0, 0, 0, 2^30]
+        if (k >= 1 && k - 1 < 8) mac96k(acc, hi, m[k - 1], Mod<F>::P1);
+        if (k >= 2 && k - 2 < 8) mac96k(acc, hi, m[k - 2], Mod<F>::P2);
+        if (k >= 3 && k - 3 < 8) mac96k(acc, hi, m[k - 3], Mod<F>::P3);
+        if (k >= 7 && k - 7 < 8) mac96k(acc, hi, m[k - 7], P7);
+        u32 lo = (u32)acc, mid = (u32)(acc >> 32);
+        if (k < 8) {
+            // quotient digit m = -lo (since -p^-1 = -1 mod 2^32); adding m * p[0] = m clears lo and
+            // carries 1 into mid exactly when lo != 0
+            m[k] = 0u - lo;
+            u32 c = lo != 0;
+            u64 t = (u64)mid + c;
+            acc = ((u64)(hi + (u32)(t >> 32)) << 32) | (u32)t;
+        } else {
+            r.v[k - 8] = lo;
+            acc = ((u64)hi << 32) | mid;
+        }
+        hi = 0;
+    }
+    return fe_reduce_once<F>(r);  // (ab + mp)/R < 2p
+}
+
+// Variant: one asm statement per column (generated, see gen_field_mul.py)
+template <int F> __device__ __forceinline__ fe fe_mul_col(const fe &a, const fe &b) {
+#include "field_mul.inc"
+    return fe_reduce_once<F>(r);
+}
+
+// Variant: plain C operand-scanning (CIOS); the compiler picks the instructions.  Kept as the
+// readable specification of the multiplier and as an A/B baseline for the asm variants.
+template <int F> __device__ __forceinline__ fe fe_mul_c(const fe &a, const fe &b) {
+    u32 t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c = (u64)a.v[j] * b.v[i] + t[j] + (c >> 32);
+            t[j] = (u32)c;
+        }
+        t[8] = (u32)(c >> 32);
+        u32 m = 0u - t[0];
+        u64 k = (t[0] != 0);
+        c = (u64)m * Mod<F>::P1 + t[1] + k; t[0] = (u32)c;
+        c = (u64)m * Mod<F>::P2 + t[2] + (c >> 32); t[1] = (u32)c;
+        c = (u64)m * Mod<F>::P3 + t[3] + (c >> 32); t[2] = (u32)c;
+        c = (u64)t[4] + (c >> 32); t[3] = (u32)c;
+        c = (u64)t[5] + (c >> 32); t[4] = (u32)c;
+        c = (u64)t[6] + (c >> 32); t[5] = (u32)c;
+        c = ((u64)m << 30) + t[7] + (c >> 32); t[6] = (u32)c;
+        c = (u64)t[8] + (c >> 32); t[7] = (u32)c;
+    }
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    return fe_reduce_once<F>(r);
+}
+
+#ifndef H2_MUL_IMPL
+#define H2_MUL_IMPL 1
+#endif
+template <int F> __device__ __forceinline__ fe fe_mulx(const fe &a, const fe &b) {
+#if H2_MUL_IMPL == 0
+    return fe_mul_c<F>(a, b);
+#elif H2_MUL_IMPL == 1
+    return fe_mul_col<F>(a, b);
+#else
+    return fe_mul<F>(a, b);
+#endif
+}
+
+template <int F> __device__ __forceinline__ fe fe_sqr(const fe &a) { return fe_mulx<F>(a, a); }
+
+template <int F> __device__ __forceinline__ fe fe_to_mont(const fe &a) { return fe_mulx<F>(a, fe_r2<F>()); }
+template <int F> __device__ __forceinline__ fe fe_from_mont(const fe &a) {
+    return fe_mulx<F>(a, fe{{1, 0, 0, 0, 0, 0, 0, 0}});
+}
+
+// a^(p-2); used only for the handful of Jacobian -> affine conversions
+template <int F> __device__ fe fe_inv(const fe &a) {
+    // exponent p - 2 = [0xffffffff, P1 - 1, P2, P3, 0, 0, 0, 2^30] (p0 = 1 borrows from P1)
+    const u32 e[8] = {0xffffffffu, Mod<F>::P1 - 1, Mod<F>::P2, Mod<F>::P3, 0, 0, 0, P7};
+    fe acc = fe_one<F>();
+    for (int i = 255; i >= 0; i--) {
+        acc = fe_sqr<F>(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = fe_mulx<F>(acc, a);
+    }
+    return acc;
+}
+
+// ---- memory access: one field element = 32 B = two 16-B vectors ------------------------------
+__device__ __forceinline__ fe fe_load(const void *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    return fe{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ __forceinline__ void fe_store(void *p, const fe &a) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+
+}  // namespace h2

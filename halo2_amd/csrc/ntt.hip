@@ -1,0 +1,617 @@
+// Radix-2 NTT over the Pasta fields on gfx950.
+//
+// Replaces the body of `best_fft` (halo2_proofs/src/arithmetic.rs:192-295) and the EvaluationDomain
+// wrappers around it (poly/domain.rs:227-255, :303-325, :357-383).
+//
+// The reference bit-reverses, builds a twiddle table omega^0..omega^(n/2-1) and runs log n
+// decimation-in-time butterfly stages (recursively).  This implementation keeps EXACTLY that butterfly
+// network (same pairs, same twiddle omega^(i * n/m) per pair), so outputs agree element for element for
+// any omega -- but executes it as ceil(log n / 8) HBM passes of up to 8 stages each:
+//
+//   * a workgroup stages a tile of 2^r rows x T columns of 32-byte elements in LDS (<= 64 KiB, two
+//     workgroups per CU), runs r butterfly stages with one barrier each, one butterfly per lane per stage;
+//   * tiles are chosen so that every global access is a run of T*32 contiguous bytes (or 2^r*32 on the
+//     transposing store of the first pass); the bit-reversal permutation is folded into the first pass's
+//     gather, the 1/n scale (ifft) and the zeta coset factors into the first load / last store;
+//   * LDS holds each element as two 16-byte halves in separate planes, so consecutive lanes hit
+//     consecutive 16-byte slots (ds_read_b128 conflict-free);
+//   * twiddles come from a per-(field, omega, log n) table kept in HBM (n/2 x 32 B, built on the device
+//     once and cached; the reference rebuilds it serially on every call, :215-221).  Lanes of a wave
+//     read consecutive / broadcast entries; the table is L2/MALL resident.
+//
+// Cost model: (n/2) log n butterflies = 1 modular multiply + add + sub each; ~1.2e3 VALU cycles per
+// wave-butterfly against ~100 cycles of LDS + L2 traffic: VALU-bound, like the MSM.  No MFMA.
+#include <cstring>
+#include <list>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "common.h"
+#include "field.cuh"
+
+namespace h2 {
+
+// ---- host-side field arithmetic (only for a handful of constants per call) ----------------------
+typedef unsigned __int128 u128;
+struct HostField {
+    u64 p[4], inv, r2[4], one[4];
+};
+static const HostField kHostField[2] = {
+    {{0x992d30ed00000001ULL, 0x224698fc094cf91bULL, 0, 0x4000000000000000ULL}, 0x992d30ecffffffffULL,
+     {0x8c78ecb30000000fULL, 0xd7d30dbd8b0de0e7ULL, 0x7797a99bc3c95d18ULL, 0x096d41af7b9cb714ULL},
+     {0x34786d38fffffffdULL, 0x992c350be41914adULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL}},
+    {{0x8c46eb2100000001ULL, 0x224698fc0994a8ddULL, 0, 0x4000000000000000ULL}, 0x8c46eb20ffffffffULL,
+     {0xfc9678ff0000000fULL, 0x67bb433d891a16e3ULL, 0x7fae231004ccf590ULL, 0x096d41af7ccfdaa9ULL},
+     {0x5b2b3e9cfffffffdULL, 0x992c350be3420567ULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL}},
+};
+static void host_mul(int f, u64 r[4], const u64 a[4], const u64 b[4]) {
+    const HostField &F = kHostField[f];
+    u64 t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) {
+            c += (u128)a[j] * b[i] + t[j];
+            t[j] = (u64)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (u64)c;
+        t[5] = (u64)(c >> 64);
+        u64 m = t[0] * F.inv;
+        c = ((u128)m * F.p[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; j++) {
+            c += (u128)m * F.p[j] + t[j];
+            t[j - 1] = (u64)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (u64)c;
+        t[4] = t[5] + (u64)(c >> 64);
+    }
+    bool ge = t[4] != 0;
+    if (!ge) {
+        ge = true;
+        for (int i = 3; i >= 0; i--) {
+            if (t[i] > F.p[i]) break;
+            if (t[i] < F.p[i]) { ge = false; break; }
+        }
+    }
+    if (ge) {
+        u128 br = 0;
+        for (int i = 0; i < 4; i++) {
+            u128 d = (u128)t[i] - F.p[i] - (u64)br;
+            t[i] = (u64)d;
+            br = (d >> 64) & 1;
+        }
+    }
+    memcpy(r, t, 32);
+}
+// bring a caller-supplied constant into Montgomery form
+static void host_to_mont(int f, u64 r[4], const u64 *a, int form) {
+    if (form == H2_FORM_MONTGOMERY) memcpy(r, a, 32);
+    else host_mul(f, r, a, kHostField[f].r2);
+}
+
+struct feparam {
+    u32 v[8];
+};
+static feparam to_param(const u64 a[4]) {
+    feparam p;
+    memcpy(p.v, a, 32);
+    return p;
+}
+__device__ __forceinline__ fe from_param(const feparam &p) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = p.v[i];
+    return r;
+}
+
+// ---- twiddle table: tw[e] = omega^e, e < count (Montgomery) --------------------------------------
+// thread t owns e = t, t + T, t + 2T, ...: omega^t by square-and-multiply, then repeated * omega^T
+template <int F>
+__global__ void __launch_bounds__(256) ntt_twiddles(u32 *__restrict__ tw, feparam omega_p, feparam step_p, u32 T, size_t count) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    fe omega = from_param(omega_p), step = from_param(step_p);
+    fe cur = fe_one<F>();
+    for (int b = 31 - __clz(t | 1); b >= 0; --b) {
+        cur = fe_sqr<F>(cur);
+        if ((t >> b) & 1) cur = fe_mulx<F>(cur, omega);
+    }
+    for (size_t e = t; e < count; e += T) {
+        fe_store(tw + 8 * e, cur);
+        cur = fe_mulx<F>(cur, step);
+    }
+}
+
+__device__ __forceinline__ u32 bitrev(u32 x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+struct PassArgs {
+    int L;        // log2 n
+    int s0;       // first stage of this pass (stage t pairs x and x + 2^t)
+    int r;        // stages in this pass
+    int logT;     // log2 of tile columns
+    int first;    // 1: gather input through the bit-reversal permutation, transposing store
+    int load_mode;   // 0 none; 1: x {1, k0, k1}[j % 3] for j < n_in, zero for j >= n_in (coeff_to_extended)
+    int store_mode;  // 0 none; 1: x k0 (ifft divisor); 2: x {k0, k1, k2}[x % 3] (extended_to_coeff)
+    size_t n_in;     // valid input elements (first pass); elements beyond are read as zero
+    feparam lk0, lk1;       // load multipliers
+    feparam k0, k1, k2;     // store multipliers
+};
+
+// LDS planes: lo16[slot], hi16[slot], slot = mid * T + col
+template <int F>
+__global__ void __launch_bounds__(1024) ntt_pass(const u32 *__restrict__ in, u32 *__restrict__ out,
+                                                 const u32 *__restrict__ tw, PassArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    const int r = A.r, logT = A.logT, L = A.L, s0 = A.s0;
+    const u32 T = 1u << logT, rows = 1u << r, tile = rows << logT;
+    uint4 *lo16 = lds, *hi16 = lds + tile;
+    const u32 tid = threadIdx.x, nthr = blockDim.x;
+
+    // tile coordinates
+    size_t hi_idx = 0, lo0 = 0;   // general pass: x = hi_idx * 2^(s0+r) + mid * 2^s0 + lo0 + col
+    u32 c0 = 0;                   // first pass: columns c0 .. c0 + T - 1 of the 2^(L-r) column space
+    if (A.first) {
+        c0 = blockIdx.x << logT;
+    } else {
+        u32 tiles_per_hi = 1u << (s0 - logT);
+        hi_idx = blockIdx.x / tiles_per_hi;
+        lo0 = (size_t)(blockIdx.x % tiles_per_hi) << logT;
+    }
+
+    // ---- load ----
+    if (A.first) {
+        const int cb = L - r;  // column bits
+        for (u32 e = tid; e < tile; e += nthr) {
+            u32 col = e & (T - 1), row = e >> logT;
+            size_t j = ((size_t)row << cb) + c0 + col;
+            uint4 a = make_uint4(0, 0, 0, 0), b = a;
+            if (j < A.n_in) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(in + 8 * j);
+                a = src[0];
+                b = src[1];
+                if (A.load_mode == 1) {
+                    u32 m3 = (u32)(j % 3);
+                    if (m3) {
+                        fe v{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+                        v = fe_mulx<F>(v, from_param(m3 == 1 ? A.lk0 : A.lk1));
+                        a = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+                        b = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+                    }
+                }
+            }
+            u32 slot = (bitrev(row, r) << logT) + col;
+            lo16[slot] = a;
+            hi16[slot] = b;
+        }
+    } else {
+        const size_t base = (hi_idx << (s0 + r)) + lo0;
+        for (u32 e = tid; e < tile; e += nthr) {
+            u32 col = e & (T - 1), mid = e >> logT;
+            const uint4 *src = reinterpret_cast<const uint4 *>(in + 8 * (base + ((size_t)mid << s0) + col));
+            lo16[e] = src[0];
+            hi16[e] = src[1];
+        }
+    }
+    __syncthreads();
+
+    // ---- r butterfly stages, one butterfly per lane (loop if the tile has more than nthr butterflies) ----
+    const u32 nbf = tile >> 1;
+    for (int u = 0; u < r; ++u) {
+        const int t = s0 + u;
+        for (u32 bfl = tid; bfl < nbf; bfl += nthr) {
+            u32 col = bfl & (T - 1), q = bfl >> logT;
+            u32 mid0 = ((q >> u) << (u + 1)) | (q & ((1u << u) - 1));
+            u32 s_a = (mid0 << logT) + col, s_b = s_a + (T << u);
+            // twiddle exponent: (x mod 2^t) * 2^(L - t - 1)
+            size_t xm = ((size_t)(mid0 & ((1u << u) - 1)) << s0) + (A.first ? 0 : (lo0 + col));
+            size_t e = xm << (L - t - 1);
+            uint4 al = lo16[s_a], ah = hi16[s_a], bl = lo16[s_b], bh = hi16[s_b];
+            fe a{{al.x, al.y, al.z, al.w, ah.x, ah.y, ah.z, ah.w}};
+            fe b{{bl.x, bl.y, bl.z, bl.w, bh.x, bh.y, bh.z, bh.w}};
+            if (e != 0) {
+                fe w = fe_load(tw + 8 * e);
+                b = fe_mulx<F>(b, w);
+            }
+            fe s = fe_add<F>(a, b), d = fe_sub<F>(a, b);
+            lo16[s_a] = make_uint4(s.v[0], s.v[1], s.v[2], s.v[3]);
+            hi16[s_a] = make_uint4(s.v[4], s.v[5], s.v[6], s.v[7]);
+            lo16[s_b] = make_uint4(d.v[0], d.v[1], d.v[2], d.v[3]);
+            hi16[s_b] = make_uint4(d.v[4], d.v[5], d.v[6], d.v[7]);
+        }
+        __syncthreads();
+    }
+
+    // ---- store ----
+    for (u32 e = tid; e < tile; e += nthr) {
+        u32 col, mid;
+        size_t x;
+        if (A.first) {
+            mid = e & (rows - 1);
+            col = e >> r;
+            x = ((size_t)bitrev(c0 + col, L - r) << r) + mid;
+        } else {
+            col = e & (T - 1);
+            mid = e >> logT;
+            x = (hi_idx << (s0 + r)) + ((size_t)mid << s0) + lo0 + col;
+        }
+        u32 slot = (mid << logT) + col;
+        uint4 a = lo16[slot], b = hi16[slot];
+        if (A.store_mode) {
+            fe v{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+            u32 m3 = A.store_mode == 2 ? (u32)(x % 3) : 0;
+            v = fe_mulx<F>(v, from_param(m3 == 0 ? A.k0 : m3 == 1 ? A.k1 : A.k2));
+            a = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+            b = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(out + 8 * x);
+        dst[0] = a;
+        dst[1] = b;
+    }
+}
+
+// elementwise multiply for the degenerate log_n = 0 case
+template <int F> __global__ void ntt_scale1(u32 *a, feparam k) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) fe_store(a, fe_mulx<F>(fe_load(a), from_param(k)));
+}
+
+// ---- host: twiddle cache + pass plan ---------------------------------------------------------------
+struct TwKey {
+    int dev, field, L;
+    u64 w[4];
+    bool operator==(const TwKey &o) const {
+        return dev == o.dev && field == o.field && L == o.L && memcmp(w, o.w, 32) == 0;
+    }
+    bool operator<(const TwKey &o) const {
+        if (dev != o.dev) return dev < o.dev;
+        if (field != o.field) return field < o.field;
+        if (L != o.L) return L < o.L;
+        return memcmp(w, o.w, 32) < 0;
+    }
+};
+struct TwEntry {
+    void *d = nullptr;
+    hipEvent_t ready = nullptr;
+    ~TwEntry() {
+        if (d) (void)hipFree(d);
+        if (ready) (void)hipEventDestroy(ready);
+    }
+};
+struct NttContext {
+    std::mutex mu;
+    std::map<TwKey, std::shared_ptr<TwEntry>> cache;
+    std::list<TwKey> lru;
+    size_t cache_bytes = 0;
+    std::map<std::pair<int, hipStream_t>, DevBuf> tmp, stage;
+    bool attr_set = false;
+};
+static NttContext &ntt_ctx() {
+    static NttContext c;
+    return c;
+}
+static const size_t kTwCacheBytes = (size_t)6 << 30;  // HBM is 288 GB: keep tables around
+
+// returns the device table omega^0..omega^(n/2-1); builds it on `st` when missing
+static int get_twiddles(NttContext &cx, int field, int L, const u64 omega_m[4], hipStream_t st, std::shared_ptr<TwEntry> &out) {
+    TwKey key;
+    (void)hipGetDevice(&key.dev);
+    key.field = field;
+    key.L = L;
+    memcpy(key.w, omega_m, 32);
+    auto it = cx.cache.find(key);
+    if (it != cx.cache.end()) {
+        cx.lru.remove(key);
+        cx.lru.push_front(key);
+        out = it->second;
+        // order this stream behind the build
+        H2_HIP(hipStreamWaitEvent(st, out->ready, 0));
+        return H2_OK;
+    }
+    size_t count = L >= 1 ? ((size_t)1 << (L - 1)) : 1;
+    auto ent = std::make_shared<TwEntry>();
+    H2_HIP(hipMalloc(&ent->d, count * 32));
+    H2_HIP(hipEventCreateWithFlags(&ent->ready, hipEventDisableTiming));
+    u32 T = (u32)std::min<size_t>(count, 1u << 16);
+    u64 step[4];
+    memcpy(step, omega_m, 32);
+    for (u32 s = 1; s < T; s <<= 1) host_mul(field, step, step, step);  // omega^T, T a power of two
+    dim3 grid((T + 255) / 256), block(256);
+    if (field == H2_FP)
+        hipLaunchKernelGGL((ntt_twiddles<FP>), grid, block, 0, st, (u32 *)ent->d, to_param(omega_m), to_param(step), T, count);
+    else
+        hipLaunchKernelGGL((ntt_twiddles<FQ>), grid, block, 0, st, (u32 *)ent->d, to_param(omega_m), to_param(step), T, count);
+    H2_HIP(hipGetLastError());
+    H2_HIP(hipEventRecord(ent->ready, st));
+    cx.cache[key] = ent;
+    cx.lru.push_front(key);
+    cx.cache_bytes += count * 32;
+    while (cx.cache_bytes > kTwCacheBytes && cx.lru.size() > 1) {
+        TwKey old = cx.lru.back();
+        cx.lru.pop_back();
+        auto o = cx.cache.find(old);
+        if (o != cx.cache.end()) {
+            // entries still referenced by in-flight work stay alive through the shared_ptr held by the caller
+            H2_HIP(hipEventSynchronize(o->second->ready));
+            H2_HIP(hipDeviceSynchronize());
+            cx.cache_bytes -= (old.L >= 1 ? ((size_t)1 << (old.L - 1)) : 1) * 32;
+            cx.cache.erase(o);
+        }
+    }
+    out = ent;
+    return H2_OK;
+}
+
+struct NttJob {
+    int field;
+    unsigned L;
+    const void *d_in;   // first-pass source (n_in valid elements)
+    void *d_out;        // final destination (2^L elements)
+    size_t n_in;
+    int load_mode, store_mode;
+    u64 omega[4];       // Montgomery
+    u64 lk0[4], lk1[4];           // load multipliers (Montgomery)
+    u64 sk0[4], sk1[4], sk2[4];   // store multipliers (Montgomery)
+};
+
+static int ntt_run(const NttJob &J, hipStream_t st) {
+    NttContext &cx = ntt_ctx();
+    std::lock_guard<std::mutex> lk(cx.mu);
+    if (!cx.attr_set) {
+        H2_HIP(hipFuncSetAttribute((const void *)ntt_pass<FP>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        H2_HIP(hipFuncSetAttribute((const void *)ntt_pass<FQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        cx.attr_set = true;
+    }
+    const int L = (int)J.L;
+    if (L == 0) {
+        if (J.d_in != J.d_out) H2_HIP(hipMemcpyAsync(J.d_out, J.d_in, 32, hipMemcpyDeviceToDevice, st));
+        if (J.store_mode) {
+            if (J.field == H2_FP) hipLaunchKernelGGL((ntt_scale1<FP>), dim3(1), dim3(64), 0, st, (u32 *)J.d_out, to_param(J.sk0));
+            else hipLaunchKernelGGL((ntt_scale1<FQ>), dim3(1), dim3(64), 0, st, (u32 *)J.d_out, to_param(J.sk0));
+        }
+        return H2_OK;
+    }
+    std::shared_ptr<TwEntry> tw;
+    int rc = get_twiddles(cx, J.field, L, J.omega, st, tw);
+    if (rc != H2_OK) return rc;
+
+    // pass plan: ceil(L / 8) passes, stages spread evenly
+    const int P = (L + 7) / 8;
+    int stages[8];
+    for (int i = 0; i < P; ++i) stages[i] = L / P + (i < L % P ? 1 : 0);
+    const size_t n = (size_t)1 << L;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    void *tmp = nullptr;
+    if (P > 1 && J.d_in == J.d_out) {
+        DevBuf &tb = cx.tmp[std::make_pair(dev, st)];
+        if ((rc = tb.reserve(n * 32)) != H2_OK) return rc;
+        tmp = tb.ptr;
+    }
+    int s0 = 0;
+    for (int i = 0; i < P; ++i) {
+        PassArgs A;
+        memset(&A, 0, sizeof A);
+        A.L = L;
+        A.s0 = s0;
+        A.r = stages[i];
+        A.first = i == 0;
+        A.n_in = J.n_in;
+        const bool last = i == P - 1;
+        int colbits = A.first ? (L - A.r) : s0;
+        A.logT = std::min(3, colbits);
+        // keep >= 256 lanes per workgroup when the pass is narrow
+        while (A.logT < colbits && ((1 << (A.r - 1)) << A.logT) < 256 && ((32u << A.r) << (A.logT + 1)) <= 65536) A.logT++;
+        if (A.first) {
+            A.load_mode = J.load_mode;
+            A.lk0 = to_param(J.lk0);
+            A.lk1 = to_param(J.lk1);
+        }
+        if (last) {
+            A.store_mode = J.store_mode;
+            A.k0 = to_param(J.sk0);
+            A.k1 = to_param(J.sk1);
+            A.k2 = to_param(J.sk2);
+        }
+        // buffers: first pass is out of place (its store is a transposition); later passes in place;
+        // the last pass lands in d_out
+        const void *src;
+        void *dst;
+        if (P == 1) {
+            src = J.d_in;
+            dst = J.d_out;  // a single workgroup owns the whole vector: load-all then store-all
+        } else if (J.d_in != J.d_out) {
+            src = A.first ? J.d_in : J.d_out;
+            dst = J.d_out;
+        } else {
+            src = A.first ? J.d_in : tmp;
+            dst = last ? J.d_out : tmp;
+        }
+        u32 threads = (u32)std::min<size_t>(1024, (size_t)(1u << (A.r - 1)) << A.logT);
+        if (threads < 64) threads = 64;
+        size_t tiles = n >> (A.r + A.logT);
+        size_t lds = ((size_t)32 << A.r) << A.logT;
+        if (J.field == H2_FP)
+            hipLaunchKernelGGL((ntt_pass<FP>), dim3((unsigned)tiles), dim3(threads), lds, st, (const u32 *)src, (u32 *)dst,
+                               (const u32 *)tw->d, A);
+        else
+            hipLaunchKernelGGL((ntt_pass<FQ>), dim3((unsigned)tiles), dim3(threads), lds, st, (const u32 *)src, (u32 *)dst,
+                               (const u32 *)tw->d, A);
+        s0 += A.r;
+    }
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
+static bool bad_field(int field, int form) {
+    return (field != H2_FP && field != H2_FQ) || (form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY);
+}
+static const u64 kZero4[4] = {0, 0, 0, 0};
+
+static int job_ntt(NttJob &J, int field, void *d_a, unsigned log_n, const u64 *omega, int form) {
+    memset(&J, 0, sizeof J);
+    J.field = field;
+    J.L = log_n;
+    J.d_in = d_a;
+    J.d_out = d_a;
+    J.n_in = (size_t)1 << log_n;
+    host_to_mont(field, J.omega, omega, form);
+    return H2_OK;
+}
+
+}  // namespace h2
+
+using namespace h2;
+
+extern "C" int h2_ntt_device(int field, void *d_a, unsigned log_n, const uint64_t *omega, int form, void *stream) {
+    if (bad_field(field, form) || !d_a || !omega || log_n > 32) return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    NttJob J;
+    job_ntt(J, field, d_a, log_n, omega, form);
+    return ntt_run(J, (hipStream_t)stream);
+}
+
+extern "C" int h2_ifft_device(int field, void *d_a, unsigned log_n, const uint64_t *omega_inv, const uint64_t *divisor,
+                              int form, void *stream) {
+    if (bad_field(field, form) || !d_a || !omega_inv || !divisor || log_n > 32) return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    NttJob J;
+    job_ntt(J, field, d_a, log_n, omega_inv, form);
+    J.store_mode = 1;
+    host_to_mont(field, J.sk0, divisor, form);
+    return ntt_run(J, (hipStream_t)stream);
+}
+
+extern "C" int h2_coeff_to_extended_device(int field, const void *d_a, void *d_out, unsigned k, unsigned ext_k,
+                                           const uint64_t *g_coset, const uint64_t *g_coset_inv,
+                                           const uint64_t *extended_omega, int form, void *stream) {
+    if (bad_field(field, form) || !d_a || !d_out || d_a == d_out || !g_coset || !g_coset_inv || !extended_omega || ext_k > 32 ||
+        k > ext_k)
+        return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    NttJob J;
+    job_ntt(J, field, d_out, ext_k, extended_omega, form);
+    J.d_in = d_a;
+    J.n_in = (size_t)1 << k;
+    J.load_mode = 1;
+    host_to_mont(field, J.lk0, g_coset, form);
+    host_to_mont(field, J.lk1, g_coset_inv, form);
+    return ntt_run(J, (hipStream_t)stream);
+}
+
+extern "C" int h2_extended_to_coeff_device(int field, void *d_a, unsigned ext_k, const uint64_t *g_coset,
+                                           const uint64_t *g_coset_inv, const uint64_t *extended_omega_inv,
+                                           const uint64_t *extended_ifft_divisor, int form, void *stream) {
+    if (bad_field(field, form) || !d_a || !g_coset || !g_coset_inv || !extended_omega_inv || !extended_ifft_divisor || ext_k > 32)
+        return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    NttJob J;
+    job_ntt(J, field, d_a, ext_k, extended_omega_inv, form);
+    J.store_mode = 2;
+    // a[i] * divisor * {1, zeta^2, zeta}[i % 3]   (domain.rs:316, into_coset = false)
+    u64 div[4], z[4], zi[4];
+    host_to_mont(field, div, extended_ifft_divisor, form);
+    host_to_mont(field, z, g_coset, form);
+    host_to_mont(field, zi, g_coset_inv, form);
+    memcpy(J.sk0, div, 32);
+    host_mul(field, J.sk1, div, zi);
+    host_mul(field, J.sk2, div, z);
+    return ntt_run(J, (hipStream_t)stream);
+}
+
+// ---- host-pointer variants: stage through a per-stream device buffer --------------------------------
+namespace {
+struct Staged {
+    void *d = nullptr;
+    int rc = H2_OK;
+};
+Staged stage_buffer(size_t bytes, int slot) {
+    Staged s;
+    NttContext &cx = ntt_ctx();
+    std::lock_guard<std::mutex> lk(cx.mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    // slot-indexed staging buffers live beside the tmp buffers, keyed by a pseudo-stream
+    DevBuf &b = cx.stage[std::make_pair(dev * 4 + slot, (hipStream_t) nullptr)];
+    s.rc = b.reserve(bytes);
+    s.d = b.ptr;
+    return s;
+}
+std::mutex g_host_mu;  // host-pointer calls share staging buffers: serialise them
+}  // namespace
+
+extern "C" int h2_ntt(int field, uint64_t *a, unsigned log_n, const uint64_t *omega, int form) {
+    if (bad_field(field, form) || !a || !omega || log_n > 32) return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    size_t bytes = (size_t)32 << log_n;
+    Staged s = stage_buffer(bytes, 0);
+    if (s.rc != H2_OK) return s.rc;
+    H2_HIP(hipMemcpyAsync(s.d, a, bytes, hipMemcpyHostToDevice, 0));
+    if ((rc = h2_ntt_device(field, s.d, log_n, omega, form, nullptr)) != H2_OK) return rc;
+    H2_HIP(hipMemcpyAsync(a, s.d, bytes, hipMemcpyDeviceToHost, 0));
+    H2_HIP(hipStreamSynchronize(0));
+    return H2_OK;
+}
+
+extern "C" int h2_ifft(int field, uint64_t *a, unsigned log_n, const uint64_t *omega_inv, const uint64_t *divisor, int form) {
+    if (bad_field(field, form) || !a || !omega_inv || !divisor || log_n > 32) return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    size_t bytes = (size_t)32 << log_n;
+    Staged s = stage_buffer(bytes, 0);
+    if (s.rc != H2_OK) return s.rc;
+    H2_HIP(hipMemcpyAsync(s.d, a, bytes, hipMemcpyHostToDevice, 0));
+    if ((rc = h2_ifft_device(field, s.d, log_n, omega_inv, divisor, form, nullptr)) != H2_OK) return rc;
+    H2_HIP(hipMemcpyAsync(a, s.d, bytes, hipMemcpyDeviceToHost, 0));
+    H2_HIP(hipStreamSynchronize(0));
+    return H2_OK;
+}
+
+extern "C" int h2_coeff_to_extended(int field, const uint64_t *a, uint64_t *out, unsigned k, unsigned ext_k,
+                                    const uint64_t *g_coset, const uint64_t *g_coset_inv, const uint64_t *extended_omega,
+                                    int form) {
+    if (bad_field(field, form) || !a || !out || !g_coset || !g_coset_inv || !extended_omega || ext_k > 32 || k > ext_k)
+        return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    size_t in_bytes = (size_t)32 << k, out_bytes = (size_t)32 << ext_k;
+    Staged si = stage_buffer(in_bytes, 1), so = stage_buffer(out_bytes, 0);
+    if (si.rc != H2_OK) return si.rc;
+    if (so.rc != H2_OK) return so.rc;
+    H2_HIP(hipMemcpyAsync(si.d, a, in_bytes, hipMemcpyHostToDevice, 0));
+    if ((rc = h2_coeff_to_extended_device(field, si.d, so.d, k, ext_k, g_coset, g_coset_inv, extended_omega, form, nullptr)) != H2_OK)
+        return rc;
+    H2_HIP(hipMemcpyAsync(out, so.d, out_bytes, hipMemcpyDeviceToHost, 0));
+    H2_HIP(hipStreamSynchronize(0));
+    return H2_OK;
+}
+
+extern "C" int h2_extended_to_coeff(int field, uint64_t *a, unsigned ext_k, const uint64_t *g_coset,
+                                    const uint64_t *g_coset_inv, const uint64_t *extended_omega_inv,
+                                    const uint64_t *extended_ifft_divisor, int form) {
+    if (bad_field(field, form) || !a || !g_coset || !g_coset_inv || !extended_omega_inv || !extended_ifft_divisor || ext_k > 32)
+        return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    size_t bytes = (size_t)32 << ext_k;
+    Staged s = stage_buffer(bytes, 0);
+    if (s.rc != H2_OK) return s.rc;
+    H2_HIP(hipMemcpyAsync(s.d, a, bytes, hipMemcpyHostToDevice, 0));
+    if ((rc = h2_extended_to_coeff_device(field, s.d, ext_k, g_coset, g_coset_inv, extended_omega_inv, extended_ifft_divisor, form,
+                                          nullptr)) != H2_OK)
+        return rc;
+    H2_HIP(hipMemcpyAsync(a, s.d, bytes, hipMemcpyDeviceToHost, 0));
+    H2_HIP(hipStreamSynchronize(0));
+    return H2_OK;
+}

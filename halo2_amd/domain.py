@@ -1,0 +1,107 @@
+"""`EvaluationDomain` (halo2_proofs/src/poly/domain.rs:20-383) over the C ABI.
+
+Domain constants are computed on the host exactly as `EvaluationDomain::new` does (:40-146); the
+transforms run on the MI355X.  Vectors are (n, 4) uint64 Montgomery limbs (numpy, host) or torch CUDA
+tensors (device; asynchronous on the current stream)."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import fields
+from ._lib import FORM_MONTGOMERY, check, lib
+from .arithmetic import _is_torch, _p, _stream_ptr
+
+
+class EvaluationDomain:
+    def __init__(self, j: int, k: int, field: int):
+        """j = cs.degree(), k = log2 n  (domain.rs:40)."""
+        m = fields.MODULUS[field]
+        self.field, self.m, self.k = field, m, k
+        self.n = 1 << k
+        self.quotient_poly_degree = j - 1
+        extended_k = k
+        while (1 << extended_k) < self.n * self.quotient_poly_degree:
+            extended_k += 1
+        if extended_k > fields.S:
+            raise ValueError("extended_k exceeds the field's 2-adicity")   # assert!, domain.rs:56
+        self.extended_k = extended_k
+        w = fields.root_of_unity(field)
+        for _ in range(extended_k, fields.S):
+            w = w * w % m
+        self.extended_omega = w
+        for _ in range(k, extended_k):
+            w = w * w % m
+        self.omega = w
+        self.omega_inv = pow(self.omega, -1, m)
+        self.extended_omega_inv = pow(self.extended_omega, -1, m)
+        self.g_coset = fields.zeta(field)
+        self.g_coset_inv = self.g_coset * self.g_coset % m
+        self.ifft_divisor = pow(1 << k, -1, m)
+        self.extended_ifft_divisor = pow(1 << extended_k, -1, m)
+        self.barycentric_weight = pow(self.n, -1, m)
+        orig = pow(self.g_coset, self.n, m)
+        step = pow(self.extended_omega, self.n, m)
+        t, cur = [], orig
+        while True:
+            t.append(cur)
+            cur = cur * step % m
+            if cur == orig:
+                break
+        assert len(t) == 1 << (extended_k - k)
+        self.t_evaluations = [pow((v - 1) % m, -1, m) for v in t]
+
+    def extended_len(self) -> int:
+        return 1 << self.extended_k
+
+    def _c(self, v: int) -> np.ndarray:
+        return fields.scalar_limbs(v, self.field, True)
+
+    # -- domain.rs:227-237
+    def lagrange_to_coeff(self, a):
+        if a.shape[0] != self.n:
+            raise ValueError("lagrange_to_coeff: wrong length")
+        return self._ifft(a, self.omega_inv, self.k, self.ifft_divisor)
+
+    def _ifft(self, a, omega_inv, log_n, divisor):
+        """EvaluationDomain::ifft, domain.rs:375-383 (scale fused into the last NTT pass)."""
+        if _is_torch(a):
+            check(lib().h2_ifft_device(self.field, a.data_ptr(), log_n, _p(self._c(omega_inv)), _p(self._c(divisor)),
+                                       FORM_MONTGOMERY, _stream_ptr()), "h2_ifft_device")
+            return a
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        check(lib().h2_ifft(self.field, _p(a), log_n, _p(self._c(omega_inv)), _p(self._c(divisor)), FORM_MONTGOMERY),
+              "h2_ifft")
+        return a
+
+    # -- domain.rs:241-255
+    def coeff_to_extended(self, a):
+        if a.shape[0] != self.n:
+            raise ValueError("coeff_to_extended: wrong length")
+        args = (_p(self._c(self.g_coset)), _p(self._c(self.g_coset_inv)), _p(self._c(self.extended_omega)))
+        if _is_torch(a):
+            import torch
+            out = torch.empty((self.extended_len(), 4), dtype=a.dtype, device=a.device)
+            check(lib().h2_coeff_to_extended_device(self.field, a.data_ptr(), out.data_ptr(), self.k, self.extended_k,
+                                                    *args, FORM_MONTGOMERY, _stream_ptr()), "h2_coeff_to_extended_device")
+            return out
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        out = np.empty((self.extended_len(), 4), dtype=np.uint64)
+        check(lib().h2_coeff_to_extended(self.field, _p(a), _p(out), self.k, self.extended_k, *args, FORM_MONTGOMERY),
+              "h2_coeff_to_extended")
+        return out
+
+    # -- domain.rs:303-325
+    def extended_to_coeff(self, a):
+        if a.shape[0] != self.extended_len():
+            raise ValueError("extended_to_coeff: wrong length")
+        args = (_p(self._c(self.g_coset)), _p(self._c(self.g_coset_inv)), _p(self._c(self.extended_omega_inv)),
+                _p(self._c(self.extended_ifft_divisor)))
+        keep = self.n * self.quotient_poly_degree
+        if _is_torch(a):
+            check(lib().h2_extended_to_coeff_device(self.field, a.data_ptr(), self.extended_k, *args, FORM_MONTGOMERY,
+                                                    _stream_ptr()), "h2_extended_to_coeff_device")
+            return a[:keep]
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        check(lib().h2_extended_to_coeff(self.field, _p(a), self.extended_k, *args, FORM_MONTGOMERY),
+              "h2_extended_to_coeff")
+        return a[:keep]

@@ -1,0 +1,58 @@
+"""Pasta field constants and limb encodings (host-side; the analogue of the constants the reference
+takes from pasta_curves: MODULUS, ROOT_OF_UNITY, S, ZETA, TWO_INV -- halo2_proofs/src/poly/domain.rs:58-92)."""
+from __future__ import annotations
+
+import numpy as np
+
+from ._lib import FP, FQ, PALLAS, VESTA
+
+P = 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001
+Q = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001
+S = 32
+MULTIPLICATIVE_GENERATOR = 5
+R = 1 << 256
+MODULUS = {FP: P, FQ: Q}
+# curve -> (base field id, scalar field id)
+CURVE_FIELDS = {PALLAS: (FP, FQ), VESTA: (FQ, FP)}
+
+
+def root_of_unity(field: int) -> int:
+    m = MODULUS[field]
+    return pow(MULTIPLICATIVE_GENERATOR, (m - 1) >> S, m)
+
+
+def zeta(field: int) -> int:
+    """Primitive cube root of unity (pasta_curves ZETA)."""
+    m = MODULUS[field]
+    z = pow(MULTIPLICATIVE_GENERATOR, (m - 1) // 3, m)
+    return z * z % m if field == FP else z
+
+
+def to_limbs(vals, field: int | None = None, montgomery: bool = True) -> np.ndarray:
+    """ints -> (n, 4) uint64 limbs; Montgomery form (x * 2^256 mod p) when `montgomery`."""
+    vals = list(vals)
+    out = np.empty((len(vals), 4), dtype=np.uint64)
+    m = MODULUS[field] if field is not None else None
+    for i, v in enumerate(vals):
+        v = int(v)
+        if montgomery:
+            v = v * R % m
+        for j in range(4):
+            out[i, j] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def from_limbs(a: np.ndarray, field: int | None = None, montgomery: bool = True) -> list[int]:
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    rinv = pow(R, -1, MODULUS[field]) if montgomery else None
+    out = []
+    for r in a:
+        v = int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192
+        if montgomery:
+            v = v * rinv % MODULUS[field]
+        out.append(v)
+    return out
+
+
+def scalar_limbs(v: int, field: int, montgomery: bool = True) -> np.ndarray:
+    return to_limbs([v], field, montgomery)[0]

@@ -1,0 +1,134 @@
+/*
+ * halo2_mi355x.h -- C ABI of libhalo2_mi355x.so: the MI355X (gfx950) implementation of the
+ * halo2_proofs prover hot path (Pasta MSM + NTT).
+ *
+ * The reference (zcash/halo2, halo2_proofs 0.3.2) has no FFI seam of its own (`#![deny(unsafe_code)]`,
+ * halo2_proofs/src/lib.rs:9).  The narrowest seam is the pair of free functions every MSM and FFT in
+ * the crate funnels through -- `best_multiexp` (halo2_proofs/src/arithmetic.rs:143) and `best_fft`
+ * (arithmetic.rs:192) -- plus the EvaluationDomain / Params wrappers directly above them.  Each entry
+ * point below names the reference function whose body it replaces.  INTEGRATION.md shows the Rust
+ * `extern "C"` block and shim a maintainer would add.
+ *
+ * Conventions
+ *   field element : 4 x uint64_t little-endian limbs (32 bytes).
+ *   affine point  : {x, y} = 8 x uint64_t (64 bytes); the identity is all-zero.
+ *   Jacobian point: {X, Y, Z} = 12 x uint64_t (96 bytes); identity has Z = 0.  x = X/Z^2, y = Y/Z^3.
+ *   `form`        : H2_FORM_MONTGOMERY -- limbs are in Montgomery form, R = 2^256: exactly the bytes a
+ *                   Rust `Vec<Fp>` / `Vec<EpAffine>` holds in memory (zero-copy from pasta_curves);
+ *                   H2_FORM_CANONICAL -- limbs are the canonical integer (`to_repr()` / `from_repr()`),
+ *                   reachable from 100 % safe Rust.  Applies to inputs and outputs alike.
+ *   curve id      : H2_PALLAS (coordinates in Fp, scalars in Fq) / H2_VESTA (coordinates in Fq, scalars Fp).
+ *   field id      : H2_FP / H2_FQ.
+ *   pointers      : `const uint64_t *` arguments named h_* / plain are HOST memory, borrowed for the call;
+ *                   `d_*` arguments are DEVICE (HBM) pointers on the current HIP device.  The library never
+ *                   frees or retains caller memory (registered bases are copied to the device).
+ *   return value  : H2_OK or an H2_ERR_* code; never aborts.  The reference panics on bad lengths
+ *                   (arithmetic.rs:144, :205); the Rust shim turns H2_ERR_ARGS back into a panic.
+ *   threading     : all entry points are thread-safe and re-entrant (internal per-device lock).
+ *   results       : bit-exact with the reference as group / field elements: canonical affine (x, y) of
+ *                   an MSM and every canonical NTT output element are identical to the CPU path's.
+ */
+#ifndef HALO2_MI355X_H
+#define HALO2_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define H2_OK 0
+#define H2_ERR_ARGS 1   /* bad argument (null pointer, length mismatch, log_n out of range, bad id) */
+#define H2_ERR_HIP 2    /* a HIP runtime call failed; see h2_last_error() */
+#define H2_ERR_NODEV 3  /* no gfx950 device / HIP runtime unavailable */
+#define H2_ERR_HANDLE 4 /* unknown or freed handle */
+
+#define H2_FP 0
+#define H2_FQ 1
+#define H2_PALLAS 0
+#define H2_VESTA 1
+#define H2_FORM_CANONICAL 0
+#define H2_FORM_MONTGOMERY 1
+#define H2_OUT_JACOBIAN 0 /* 12 limbs, what `best_multiexp` returns (`C::Curve`) */
+#define H2_OUT_AFFINE 1   /* 8 limbs, what `to_affine()` / `batch_normalize` would give */
+
+typedef uint64_t h2_bases_t; /* opaque handle to a device-resident basis (Params::g / g_lagrange) */
+
+/* ---- library ------------------------------------------------------------------------------ */
+int h2_device_count(void);
+/* Binds the calling thread to `device` (hipSetDevice) and warms the per-device context. */
+int h2_init(int device);
+/* Human-readable description of the last failure on this thread (static storage). */
+const char *h2_last_error(void);
+/* Window width the MSM would use for n points (informational; the result does not depend on it). */
+int h2_msm_window_bits(size_t n);
+
+/* ---- MSM: replaces best_multiexp (halo2_proofs/src/arithmetic.rs:143-180) -------------------- */
+/* out = sum_i scalars[i] * bases[i].  n may be 0 (identity).  `out_kind` selects 12- or 8-limb output. */
+int h2_msm(int curve, const uint64_t *scalars, const uint64_t *bases_xy, size_t n, int form,
+           int out_kind, uint64_t *out);
+
+/* Params::{new,read} keep `g` / `g_lagrange` for the life of the Params (poly/commitment.rs:26-33):
+ * register them once, commit many times. */
+int h2_bases_register(int curve, const uint64_t *bases_xy, size_t n, int form, h2_bases_t *handle);
+int h2_bases_free(h2_bases_t handle);
+
+/* replaces Params::commit / commit_lagrange (halo2_proofs/src/poly/commitment.rs:119-150):
+ * out = sum_{i<n} scalars[i]*g[i] + blind*w.  The reference copies poly+blind and g+w into fresh
+ * (n+1)-vectors per call; here g stays on the device and (w, blind) ride along.  `w_xy` / `blind`
+ * may both be NULL for a plain MSM over the first n registered bases (IPA rounds,
+ * poly/commitment/prover.rs:107-108). */
+int h2_commit(h2_bases_t g, const uint64_t *scalars, size_t n, const uint64_t *w_xy,
+              const uint64_t *blind, int form, int out_kind, uint64_t *out);
+
+/* ---- NTT: replaces best_fft (halo2_proofs/src/arithmetic.rs:192-295) ------------------------- */
+/* In place, natural order in and out: a[j] <- sum_i a[i] * omega^(i*j), n = 2^log_n, 0 <= log_n <= 32
+ * (device memory permitting).  Reproduces the reference's butterfly network exactly, so the output
+ * matches the CPU path for ANY omega, including the non-root omega of benches/fft.rs:17. */
+int h2_ntt(int field, uint64_t *a, unsigned log_n, const uint64_t *omega, int form);
+
+/* replaces EvaluationDomain::ifft (halo2_proofs/src/poly/domain.rs:375-383; lagrange_to_coeff :227):
+ * best_fft with omega_inv, then every element times `divisor` (fused into the last pass). */
+int h2_ifft(int field, uint64_t *a, unsigned log_n, const uint64_t *omega_inv, const uint64_t *divisor,
+            int form);
+
+/* replaces EvaluationDomain::coeff_to_extended (poly/domain.rs:241-255, :357-373):
+ * out[i] = a[i] * {1, zeta, zeta^2}[i % 3] for i < 2^k, zero-extended to 2^ext_k, forward NTT with
+ * extended_omega.  `a` has 2^k elements, `out` 2^ext_k (may not alias). */
+int h2_coeff_to_extended(int field, const uint64_t *a, uint64_t *out, unsigned k, unsigned ext_k,
+                         const uint64_t *g_coset, const uint64_t *g_coset_inv,
+                         const uint64_t *extended_omega, int form);
+
+/* replaces EvaluationDomain::extended_to_coeff (poly/domain.rs:303-325): inverse NTT of size 2^ext_k,
+ * times extended_ifft_divisor, then a[i] *= {1, zeta^2, zeta}[i % 3].  In place; the caller truncates
+ * to n*(degree-1) as the reference does (:321-322). */
+int h2_extended_to_coeff(int field, uint64_t *a, unsigned ext_k, const uint64_t *g_coset,
+                         const uint64_t *g_coset_inv, const uint64_t *extended_omega_inv,
+                         const uint64_t *extended_ifft_divisor, int form);
+
+/* ---- device-resident variants (data already in HBM; `stream` is a hipStream_t or NULL) -------- */
+/* Same contracts as above with device pointers; asynchronous on `stream`; outputs land in device
+ * memory.  Used by batched provers and by bench.py (inputs resident in HBM before timing starts). */
+int h2_msm_device(int curve, const void *d_scalars, const void *d_bases_xy, size_t n, int form,
+                  int out_kind, void *d_out, void *stream);
+int h2_commit_device(h2_bases_t g, const void *d_scalars, size_t n, const void *d_w_xy,
+                     const void *d_blind, int form, int out_kind, void *d_out, void *stream);
+int h2_ntt_device(int field, void *d_a, unsigned log_n, const uint64_t *omega, int form, void *stream);
+int h2_ifft_device(int field, void *d_a, unsigned log_n, const uint64_t *omega_inv,
+                   const uint64_t *divisor, int form, void *stream);
+int h2_coeff_to_extended_device(int field, const void *d_a, void *d_out, unsigned k, unsigned ext_k,
+                                const uint64_t *g_coset, const uint64_t *g_coset_inv,
+                                const uint64_t *extended_omega, int form, void *stream);
+int h2_extended_to_coeff_device(int field, void *d_a, unsigned ext_k, const uint64_t *g_coset,
+                                const uint64_t *g_coset_inv, const uint64_t *extended_omega_inv,
+                                const uint64_t *extended_ifft_divisor, int form, void *stream);
+
+/* Sum of `count` Jacobian points laid out contiguously (12 limbs each, Montgomery) -> one Jacobian
+ * point.  The local step after the 96-byte all-gather of a range-split MSM (one partial per GPU). */
+int h2_points_sum(int curve, const uint64_t *points_xyz, size_t count, uint64_t *out_xyz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HALO2_MI355X_H */

@@ -1,0 +1,120 @@
+// Native parity + throughput check of the gfx950 field arithmetic against the C oracle.
+// TEST CODE: links oracle/h2_oracle.c (allowed: tests may use the oracle as the checker).
+// Build: hipcc --offload-arch=gfx950 -O3 tests/native/field_check.hip oracle/h2_oracle.c -o build/field_check
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "../../halo2_amd/csrc/field.cuh"
+
+extern "C" {
+void orc_f_mul(int field, uint64_t *r, const uint64_t *a, const uint64_t *b);
+void orc_f_add(int field, uint64_t *r, const uint64_t *a, const uint64_t *b);
+void orc_f_sub(int field, uint64_t *r, const uint64_t *a, const uint64_t *b);
+void orc_f_inv(int field, uint64_t *r, const uint64_t *a);
+void orc_random_field(int field, uint64_t seed, uint64_t *out, size_t n);
+}
+using namespace h2;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+// op: 0 mul_c, 1 mul_col, 2 mul(per-product asm), 3 add, 4 sub, 5 inv
+template <int F> __global__ void k_ops(const u32 *a, const u32 *b, u32 *out, int n, int op) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe x = fe_load(a + 8 * i), y = fe_load(b + 8 * i), r;
+    switch (op) {
+        case 0: r = fe_mul_c<F>(x, y); break;
+        case 1: r = fe_mul_col<F>(x, y); break;
+        case 2: r = fe_mul<F>(x, y); break;
+        case 3: r = fe_add<F>(x, y); break;
+        case 4: r = fe_sub<F>(x, y); break;
+        default: r = fe_inv<F>(x); break;
+    }
+    fe_store(out + 8 * i, r);
+}
+
+template <int F, int IMPL> __global__ void __launch_bounds__(256) k_chain(const u32 *a, u32 *out, int iters) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    fe x = fe_load(a + 8 * (i & 1023)), y = fe_load(a + 8 * ((i + 7) & 1023));
+    fe z = y, w = x;
+    for (int it = 0; it < iters; ++it) {
+        if (IMPL == 0) { x = fe_mul_c<F>(x, y); z = fe_mul_c<F>(z, w); }
+        if (IMPL == 1) { x = fe_mul_col<F>(x, y); z = fe_mul_col<F>(z, w); }
+        if (IMPL == 2) { x = fe_mul<F>(x, y); z = fe_mul<F>(z, w); }
+    }
+    fe_store(out + 8 * i, fe_add<F>(x, z));
+}
+
+template <int F> int run_field() {
+    const int n = 1 << 14;
+    std::vector<uint64_t> a(4 * n), b(4 * n), want(4 * n), got(4 * n);
+    orc_random_field(F, 11 + F, a.data(), n);
+    orc_random_field(F, 23 + F, b.data(), n);
+    // edge cases: 0, 1 (canonical one, not Montgomery), p-1, equal operands
+    const uint64_t P[2][4] = {{0x992d30ed00000001ULL, 0x224698fc094cf91bULL, 0, 0x4000000000000000ULL},
+                              {0x8c46eb2100000001ULL, 0x224698fc0994a8ddULL, 0, 0x4000000000000000ULL}};
+    memset(&a[0], 0, 32);
+    memset(&a[4], 0, 32); a[4] = 1;
+    memcpy(&a[8], P[F], 32); a[8] -= 1;
+    memcpy(&b[8], P[F], 32); b[8] -= 1;
+    memcpy(&a[12], &b[12], 32);
+    memcpy(&b[16], P[F], 32); b[16] -= 1; memset(&a[16], 0, 32); a[16] = 1;
+    u32 *da, *db, *dout;
+    CK(hipMalloc(&da, 32 * n)); CK(hipMalloc(&db, 32 * n)); CK(hipMalloc(&dout, 32 * n));
+    CK(hipMemcpy(da, a.data(), 32 * n, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, b.data(), 32 * n, hipMemcpyHostToDevice));
+    const char *names[] = {"mul_c", "mul_col", "mul_asm", "add", "sub", "inv"};
+    int fails = 0;
+    for (int op = 0; op < 6; ++op) {
+        int cnt = op == 5 ? 256 : n;
+        hipLaunchKernelGGL((k_ops<F>), dim3((cnt + 255) / 256), dim3(256), 0, 0, da, db, dout, cnt, op);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(got.data(), dout, 32 * cnt, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int i = 0; i < cnt; ++i) {
+            uint64_t w[4];
+            if (op <= 2) orc_f_mul(F, w, &a[4 * i], &b[4 * i]);
+            else if (op == 3) orc_f_add(F, w, &a[4 * i], &b[4 * i]);
+            else if (op == 4) orc_f_sub(F, w, &a[4 * i], &b[4 * i]);
+            else orc_f_inv(F, w, &a[4 * i]);
+            if (memcmp(w, &got[4 * i], 32)) { if (!bad) printf("  first mismatch op %s idx %d\n", names[op], i); bad++; }
+        }
+        printf("field %d %-8s: %d/%d mismatches\n", F, names[op], bad, cnt);
+        fails += bad;
+    }
+    CK(hipFree(da)); CK(hipFree(db)); CK(hipFree(dout));
+    return fails;
+}
+
+template <int IMPL> int bench(const char *name, int blocks_per_cu) {
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    int blocks = prop.multiProcessorCount * blocks_per_cu;
+    std::vector<uint64_t> a(4 * 1024);
+    orc_random_field(0, 5, a.data(), 1024);
+    u32 *da, *dout;
+    CK(hipMalloc(&da, 32 * 1024)); CK(hipMalloc(&dout, (size_t)32 * blocks * 256));
+    CK(hipMemcpy(da, a.data(), 32 * 1024, hipMemcpyHostToDevice));
+    const int iters = 2000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_chain<FP, IMPL>), dim3(blocks), dim3(256), 0, 0, da, dout, 10);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_chain<FP, IMPL>), dim3(blocks), dim3(256), 0, 0, da, dout, iters);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double muls = (double)blocks * 256 * iters * 2;
+    printf("%-8s waves/SIMD %d: %8.3f ms  %8.2f G modmul/s\n", name, blocks_per_cu, ms, muls / (ms * 1e-3) / 1e9);
+    CK(hipFree(da)); CK(hipFree(dout));
+    return 0;
+}
+
+int main() {
+    int fails = run_field<FP>() + run_field<FQ>();
+    for (int w : {1, 2, 4, 8}) {
+        bench<0>("mul_c", w); bench<1>("mul_col", w); bench<2>("mul_asm", w);
+    }
+    printf(fails ? "FIELD CHECK FAILED\n" : "FIELD CHECK OK\n");
+    return fails ? 1 : 0;
+}

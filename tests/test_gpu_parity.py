@@ -1,0 +1,248 @@
+"""Parity of the HIP path (through the C ABI) against the oracle on seeded inputs.  Bit-exact bar:
+identical canonical affine (x, y) for MSM results, identical field elements at every index for NTTs.
+Runs only on a real MI355X (`-m gpu`)."""
+import numpy as np
+import pytest
+
+import halo2_amd as h
+from halo2_amd import fields
+from oracle import c_oracle as co
+from oracle import pasta as o
+
+pytestmark = pytest.mark.gpu
+
+
+def mont(field, v):
+    return fields.scalar_limbs(v, field, True)
+
+
+def affine_of(curve, out):
+    """Jacobian (12,) or affine (8,) Montgomery limbs -> canonical (x, y) / None, via the oracle."""
+    out = np.ascontiguousarray(out, dtype=np.uint64)
+    return co.jac_to_affine_ints(curve, out) if out.shape[0] == 12 else co.affine_to_ints(curve, out)
+
+
+# ------------------------------------------------------------------ NTT
+@pytest.mark.parametrize("field", [h.FP, h.FQ])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 8, 9, 10, 13, 16, 17])
+def test_best_fft_matches_oracle(field, log_n):
+    m = fields.MODULUS[field]
+    a = co.random_field(field, 900 + log_n, 1 << log_n)
+    omega = mont(field, o.omega_for(m, log_n))
+    want = co.best_fft(field, a, omega, log_n)
+    got = h.best_fft(a.copy(), omega, log_n, field)
+    assert np.array_equal(got, want)
+
+
+def test_best_fft_canonical_form_and_nonroot_omega():
+    field, m, log_n = h.FP, o.P, 11
+    a = co.random_field(field, 77, 1 << log_n)
+    w = 0x1234567 % m                           # benches/fft.rs:17 style arbitrary omega
+    want = co.best_fft(field, a, mont(field, w), log_n)
+    got = h.best_fft(a.copy(), mont(field, w), log_n, field)
+    assert np.array_equal(got, want)
+    # canonical-form buffers in, canonical out
+    a_can = co.from_mont(field, a)
+    got_can = h.best_fft(a_can.copy(), fields.scalar_limbs(w, field, False), log_n, field, form=h.FORM_CANONICAL)
+    assert np.array_equal(got_can, co.from_mont(field, want))
+
+
+def test_best_fft_rejects_bad_length():
+    a = co.random_field(h.FP, 1, 12)
+    with pytest.raises(ValueError):
+        h.best_fft(a, mont(h.FP, 1), 4, h.FP)
+
+
+@pytest.mark.parametrize("field,j,k", [(h.FP, 3, 6), (h.FP, 5, 9), (h.FQ, 3, 10), (h.FP, 4, 12)])
+def test_domain_transforms_match_oracle(field, j, k):
+    dom = h.EvaluationDomain(j, k, field)
+    ref = o.EvaluationDomain(j, k, fields.MODULUS[field])
+    assert (dom.extended_k, dom.omega, dom.extended_omega, dom.g_coset) == (ref.extended_k, ref.omega, ref.extended_omega, ref.g_coset)
+    assert dom.t_evaluations == ref.t_evaluations
+    a = co.random_field(field, 5 * k + j, dom.n)
+    coeff_want = co.ifft(field, a, mont(field, ref.omega_inv), k, mont(field, ref.ifft_divisor))
+    coeff = dom.lagrange_to_coeff(a.copy())
+    assert np.array_equal(coeff, coeff_want)
+    ext_want = co.coeff_to_extended(field, coeff_want, k, ref.extended_k, mont(field, ref.g_coset), mont(field, ref.g_coset_inv),
+                                    mont(field, ref.extended_omega))
+    ext = dom.coeff_to_extended(coeff)
+    assert np.array_equal(ext, ext_want)
+    back_want = co.extended_to_coeff(field, ext_want, ref.extended_k, mont(field, ref.g_coset), mont(field, ref.g_coset_inv),
+                                     mont(field, ref.extended_omega_inv), mont(field, ref.extended_ifft_divisor))
+    back = dom.extended_to_coeff(ext.copy())
+    assert np.array_equal(back, back_want[: dom.n * dom.quotient_poly_degree])
+    assert np.array_equal(back[: dom.n], coeff_want)          # round trip
+
+
+def test_fft_roundtrip_2_22():
+    """BASELINE config 3: 2^22 Fp forward + inverse returns the input (size-independent property);
+    forward checked elementwise against the oracle at 2^18."""
+    field, m = h.FP, o.P
+    for log_n, check_oracle in ((18, True), (22, False)):
+        a = co.random_field(field, 4000 + log_n, 1 << log_n)
+        omega = o.omega_for(m, log_n)
+        fwd = h.best_fft(a.copy(), mont(field, omega), log_n, field)
+        if check_oracle:
+            assert np.array_equal(fwd, co.best_fft(field, a, mont(field, omega), log_n))
+        dom_div = pow(1 << log_n, -1, m)
+        back = h.best_fft(fwd.copy(), mont(field, pow(omega, -1, m)), log_n, field)
+        lib = h.lib()
+        # scale by 1/n through the fused entry point as well
+        from halo2_amd.arithmetic import _p
+        fused = fwd.copy()
+        assert lib.h2_ifft(field, _p(fused), log_n, _p(mont(field, pow(omega, -1, m))), _p(mont(field, dom_div)), h.FORM_MONTGOMERY) == 0
+        assert np.array_equal(fused, a)
+        # unscaled inverse equals n * a: check a sample through the oracle's field mul
+        idx = [0, 1, 12345 % (1 << log_n), (1 << log_n) - 1]
+        got = fields.from_limbs(back[idx], field)
+        want = [(v << log_n) % m for v in fields.from_limbs(a[idx], field)]
+        assert got == want
+
+
+# ------------------------------------------------------------------ MSM
+SIZES = [0, 1, 2, 3, 4, 31, 32, 33, 255, 256, 257, 1000, 4096, 65537]
+
+
+@pytest.mark.parametrize("curve", [h.PALLAS, h.VESTA])
+def test_best_multiexp_matches_oracle(curve):
+    """arithmetic.rs:440-458 test_multiexp, with the oracle's best_multiexp as the expected value."""
+    sf = co.field_of_curve(curve, "scalar")
+    for n in SIZES:
+        scal = co.random_field(sf, 1000 + n, n)
+        bases = co.generate_bases(curve, 5000 + n, n)
+        want = co.jac_to_affine_ints(curve, co.best_multiexp(curve, scal, bases))
+        got = h.best_multiexp(scal, bases, curve)
+        assert affine_of(curve, got) == want, n
+        got_aff = h.best_multiexp(scal, bases, curve, affine=True)
+        assert affine_of(curve, got_aff) == want, n
+        if n:
+            assert co.lib().orc_point_on_curve(curve, co._p(np.ascontiguousarray(got_aff))) == 1
+
+
+def test_best_multiexp_rejects_length_mismatch():
+    with pytest.raises(ValueError):
+        h.best_multiexp(np.zeros((4, 4), np.uint64), np.zeros((5, 8), np.uint64), h.PALLAS)
+
+
+def test_msm_edge_cases():
+    """zero scalars, q-1, identity bases, duplicate bases, a base with its negation, sparse columns."""
+    curve = h.PALLAS
+    bm, sm = o.CURVES[curve]
+    sf = co.field_of_curve(curve, "scalar")
+    n = 600
+    bases = co.generate_bases(curve, 31337, n)
+    b_int = [co.affine_to_ints(curve, bases[i]) for i in range(n)]
+    b_int[3] = None
+    b_int[5] = b_int[4]
+    b_int[7] = o.ec_neg(b_int[6], bm)
+    for i in range(100, 140):
+        b_int[i] = b_int[100]                    # 40 copies of one base
+    bases = co.points_to_mont(curve, b_int)
+    s_int = co.limbs_to_ints(co.from_mont(sf, co.random_field(sf, 4242, n)))
+    s_int[0] = 0
+    s_int[1] = sm - 1
+    s_int[4] = s_int[5] = 12345
+    s_int[6] = s_int[7] = 777
+    for i in range(100, 140):
+        s_int[i] = 99                            # same digit everywhere -> one heavy bucket, P + P path
+    for i in range(200, 600):
+        s_int[i] = 0 if i % 10 else s_int[i]     # 90 % zeros
+    scal = co.to_mont(sf, co.ints_to_limbs(s_int))
+    want = co.jac_to_affine_ints(curve, co.best_multiexp(curve, scal, bases))
+    assert affine_of(curve, h.best_multiexp(scal, bases, curve)) == want
+    # all scalars equal + all bases equal -> n * s * B
+    s_same = co.to_mont(sf, co.ints_to_limbs([9] * n))
+    b_same = co.points_to_mont(curve, [b_int[0]] * n)
+    assert affine_of(curve, h.best_multiexp(s_same, b_same, curve)) == o.ec_mul(9 * n, b_int[0], bm)
+    # everything cancels
+    half = n // 2
+    b_pm = co.points_to_mont(curve, b_int[8:8 + half] + [o.ec_neg(p, bm) for p in b_int[8:8 + half]])
+    s_pm = co.to_mont(sf, co.ints_to_limbs(s_int[8:8 + half] * 2))
+    out = h.best_multiexp(s_pm, b_pm, curve)
+    assert affine_of(curve, out) is None and not out[8:].any()
+    # canonical form in / out
+    got = h.best_multiexp(co.from_mont(sf, scal), co.from_mont(co.field_of_curve(curve, "base"), bases.reshape(-1, 4)).reshape(-1, 8),
+                          curve, form=h.FORM_CANONICAL, affine=True)
+    assert (fields.from_limbs(got.reshape(2, 4), montgomery=False)[0], fields.from_limbs(got.reshape(2, 4), montgomery=False)[1]) == want
+
+
+def test_msm_linearity_and_split_2_20():
+    """BASELINE config 2 size: properties that do not need the oracle at full size -- linearity in the
+    scalars and split-and-sum over 8 ranges (the multi-GPU partition) -- plus the oracle on a 2^16 prefix."""
+    curve = h.PALLAS
+    sf = co.field_of_curve(curve, "scalar")
+    n = 1 << 20
+    bases = co.generate_bases(curve, 20, n)
+    a = co.random_field(sf, 21, n)
+    b = co.random_field(sf, 22, n)
+    # linearity MSM(a) + MSM(b) == MSM(a + b) on the first 2^14 entries (a + b formed with Python ints)
+    m_ = 1 << 14
+    ai = fields.from_limbs(a[:m_], sf)
+    bi = fields.from_limbs(b[:m_], sf)
+    s = fields.to_limbs([(x + y) % fields.MODULUS[sf] for x, y in zip(ai, bi)], sf)
+    ra = h.best_multiexp(a[:m_], bases[:m_], curve)
+    rb = h.best_multiexp(b[:m_], bases[:m_], curve)
+    rs = h.best_multiexp(s, bases[:m_], curve)
+    assert affine_of(curve, h.points_sum(np.stack([ra, rb]), curve)) == affine_of(curve, rs)
+    # full size: whole == sum of 8 contiguous range partials
+    whole = h.best_multiexp(a, bases, curve)
+    parts = [h.best_multiexp(a[i * n // 8:(i + 1) * n // 8], bases[i * n // 8:(i + 1) * n // 8], curve) for i in range(8)]
+    assert affine_of(curve, h.points_sum(np.stack(parts), curve)) == affine_of(curve, whole)
+    # oracle on a 2^16 prefix
+    k = 1 << 16
+    assert affine_of(curve, h.best_multiexp(a[:k], bases[:k], curve)) == co.jac_to_affine_ints(curve, co.best_multiexp(curve, a[:k], bases[:k]))
+
+
+@pytest.mark.parametrize("curve", [h.PALLAS, h.VESTA])
+def test_params_commit_matches_oracle(curve):
+    """Params::commit / commit_lagrange with the blind term (poly/commitment.rs:119-150) and
+    test_commit_lagrange (:258-302): commit(iFFT(a)) == commit_lagrange(a)."""
+    k = 5
+    n = 1 << k
+    bm, sm = o.CURVES[curve]
+    sf = co.field_of_curve(curve, "scalar")
+    g = co.generate_bases(curve, 2024 + curve, n)
+    g_int = [co.affine_to_ints(curve, g[i]) for i in range(n)]
+    w_int = o.ec_mul(424242, (bm - 1, 2), bm)
+    u_int = o.ec_mul(171717, (bm - 1, 2), bm)
+    dom = h.EvaluationDomain(1, k, sf)
+    g_lag = []
+    for i in range(n):
+        acc = None
+        for j in range(n):
+            acc = o.ec_add(acc, o.ec_mul(pow(dom.omega_inv, i * j, sm) * dom.ifft_divisor % sm, g_int[j], bm), bm)
+        g_lag.append(acc)
+    params = h.Params.from_generators(curve, k, g, co.points_to_mont(curve, g_lag), co.points_to_mont(curve, [w_int])[0],
+                                      co.points_to_mont(curve, [u_int])[0])
+    a = co.random_field(sf, 31, n)
+    blind = h.Blind(fields.scalar_limbs(987654321, sf))
+    coeff = dom.lagrange_to_coeff(a.copy())
+    c1 = params.commit(coeff, blind)
+    c2 = params.commit_lagrange(a, blind)
+    want = co.jac_to_affine_ints(curve, co.commit(curve, g, co.points_to_mont(curve, [w_int])[0], coeff, blind.value))
+    assert affine_of(curve, c1) == want
+    assert affine_of(curve, c2) == want
+    assert affine_of(curve, params.commit(coeff, h.Blind(field=sf), affine=True)) == co.jac_to_affine_ints(
+        curve, co.commit(curve, g, co.points_to_mont(curve, [w_int])[0], coeff, fields.scalar_limbs(1, sf)))
+    params.close()
+
+
+def test_device_resident_path():
+    """torch CUDA tensors in, device tensors out, on torch's current stream."""
+    torch = pytest.importorskip("torch")
+    curve, n = h.VESTA, 1 << 12
+    sf = co.field_of_curve(curve, "scalar")
+    scal = co.random_field(sf, 1, n)
+    bases = co.generate_bases(curve, 2, n)
+    d_s = torch.from_numpy(scal.view(np.int64)).cuda()
+    d_b = torch.from_numpy(bases.view(np.int64)).cuda()
+    out = h.best_multiexp(d_s, d_b, curve)
+    torch.cuda.synchronize()
+    assert affine_of(curve, out.cpu().numpy().view(np.uint64)) == co.jac_to_affine_ints(curve, co.best_multiexp(curve, scal, bases))
+    field, log_n = h.FP, 12
+    a = co.random_field(field, 3, 1 << log_n)
+    omega = mont(field, o.omega_for(o.P, log_n))
+    d_a = torch.from_numpy(a.view(np.int64)).cuda()
+    h.best_fft(d_a, omega, log_n, field)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_a.cpu().numpy().view(np.uint64), co.best_fft(field, a, omega, log_n))
