@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Pallas MSM M scalar-mults/s (+ Fp NTT G butterflies/s) at k = 20 on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   -> ONE JSON line on rank 0.
+
+  step      one pass of the hot path over one batch = one 2^20-point Pallas `best_multiexp`
+            (a column commit, BASELINE.json configs[1]); scalars are seeded synthetic columns already
+            resident in HBM, the basis is registered once (Params::g stays on the device).
+  N > 1     independent column commits, one stream of columns per GPU (weak scaling, no data-path
+            collective -- SURVEY.md section 8e); launched by torch.distributed.run, one rank per GPU.
+            After the timed region the ranks also run one range-split MSM and sum the 96-byte
+            partials exchanged with a single RCCL all_gather (verification, not timed).
+  value     total scalar-mults of all ranks / max-over-ranks wall time of the K steps.
+  roofline  dominant kernel = msm_accumulate; achieved = algorithmic bytes per launch (96 B per
+            (scalar, base) pair) / its average duration measured with HIP events on
+            the launching stream inside the timed region (h2_profile_*).
+  cpu_baseline  the C restatement of the reference's best_multiexp (oracle/, "port") timed on the host
+            cores of this box on the same 2^20 workload (1 run), rank 0 at N = 1 only.
+The oracle is used here only as the timed CPU baseline and to generate inputs -- never in the GPU path.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K_LOG = 20
+ALGO_BYTES_PER_PAIR = 96          # 32 B scalar + 64 B affine base, read once
+HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=K_LOG, help="override the MSM size (parity/debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--columns", type=int, default=4, help="distinct scalar columns resident in HBM")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import halo2_amd as h
+    from halo2_amd import fields, parallel
+    from halo2_amd._lib import check
+    from oracle import c_oracle as co     # input generation + CPU baseline only
+
+    lib = h.lib()
+    check(lib.h2_init(local_rank), "h2_init")
+    curve = h.PALLAS
+    sf = co.field_of_curve(curve, "scalar")
+    n = 1 << args.log_n
+    dev = torch.device("cuda", local_rank)
+
+    # ---- synthetic inputs (seeded; identical on every rank except the per-rank columns) ----
+    t0 = time.time()
+    bases = co.generate_bases(curve, 0x48414C4F32, n)
+    cols = [co.random_field(sf, 1000 + 97 * rank + c, n) for c in range(args.columns)]
+    gen_s = time.time() - t0
+    params_g = C.c_uint64(0)
+    from halo2_amd.arithmetic import _p
+    check(lib.h2_bases_register(curve, _p(bases), n, h.FORM_MONTGOMERY, C.byref(params_g)), "h2_bases_register")
+    d_cols = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]
+    d_out = torch.zeros((max(args.steps, 1), 12), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+
+    def step(i):
+        rc = lib.h2_commit_device(params_g, d_cols[i % len(d_cols)].data_ptr(), n, None, None, h.FORM_MONTGOMERY,
+                                  0, d_out[i % d_out.shape[0]].data_ptr(), sp)
+        check(rc, "h2_commit_device")
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    lib.h2_profile_enable(1)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = {}
+    for name, slot in (("msm_accumulate", 0), ("msm_sort", 2), ("msm_reduce", 3)):
+        ms, cnt = C.c_double(0), C.c_uint64(0)
+        lib.h2_profile_read(slot, C.byref(ms), C.byref(cnt))
+        prof[name] = (ms.value, cnt.value)
+    lib.h2_profile_enable(0)
+
+    # ---- parity spot check of the timed outputs (rank 0: first column vs the split-and-sum identity) ----
+    first = d_out[0].cpu().numpy().view(np.uint64)
+    parts = [h.best_multiexp(cols[0][i * n // 4:(i + 1) * n // 4], bases[i * n // 4:(i + 1) * n // 4], curve) for i in range(4)]
+    split_ok = co.jac_to_affine_ints(curve, h.points_sum(np.stack(parts), curve)) == co.jac_to_affine_ints(curve, first)
+
+    # ---- multi-GPU exchange step: one range-split MSM, partials all-gathered over RCCL, summed locally ----
+    split_msm_ok = None
+    if world > 1:
+        shared = co.random_field(sf, 4242, n)           # same column on every rank
+        total = parallel.split_msm(shared, bases, curve, rank, world, device=dev)
+        whole = h.best_multiexp(shared, bases, curve) if rank == 0 else None
+        if rank == 0:
+            split_msm_ok = co.jac_to_affine_ints(curve, total) == co.jac_to_affine_ints(curve, whole)
+
+    # ---- NTT leg (reported beside the headline value; Fp, k = 20 and 2^22 round trip) ----
+    ntt = {}
+    if rank == 0:
+        from oracle import pasta
+        for log_n in (20, 22):
+            a = co.random_field(h.FP, 7 + log_n, 1 << log_n)
+            d_a = torch.from_numpy(a.view(np.int64)).to(dev)
+            omega = fields.scalar_limbs(pasta.omega_for(pasta.P, log_n), h.FP)
+            for _ in range(2):
+                h.best_fft(d_a, omega, log_n, h.FP)
+            torch.cuda.synchronize()
+            reps = 10
+            lib.h2_profile_enable(1)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                h.best_fft(d_a, omega, log_n, h.FP)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / reps
+            ms, cnt = C.c_double(0), C.c_uint64(0)
+            lib.h2_profile_read(1, C.byref(ms), C.byref(cnt))
+            lib.h2_profile_enable(0)
+            bf = (1 << (log_n - 1)) * log_n
+            ntt[f"2^{log_n}"] = {"ms": round(dt * 1e3, 4), "Gbutterflies_per_s": round(bf / dt / 1e9, 3),
+                                 "kernel_ms": round(ms.value / reps, 4), "passes": int(cnt.value // reps),
+                                 "algorithmic_GBps": round(64.0 * (1 << log_n) / dt / 1e9, 1)}
+            del d_a
+
+    # ---- CPU baseline: C restatement of the reference algorithm on this box's host cores ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cores = co.lib().orc_get_threads()
+        t1 = time.perf_counter()
+        ref = co.best_multiexp(curve, cols[0], bases)
+        cpu_s = time.perf_counter() - t1
+        cpu_ok = co.jac_to_affine_ints(curve, ref) == co.jac_to_affine_ints(curve, first)
+        c = co.lib().orc_window_bits(n)
+        cpu = {"value": round(n / cpu_s / 1e6, 4), "unit": "Mscalar-mults/s", "cores": int(min(cores, 256 // c + 1)),
+               "host_cores": int(cores), "kind": "port",
+               "sample": f"1 run of the same 2^{args.log_n}-point Pallas best_multiexp (c={c}, {256 // c + 1} window tasks), "
+                         f"{cpu_s:.2f} s wall; C restatement of arithmetic.rs:143-180, not the Rust reference",
+               "bit_exact_vs_gpu": bool(cpu_ok)}
+
+    if rank == 0:
+        total_mults = float(n) * args.steps * world
+        value = total_mults / elapsed / 1e6
+        acc_ms, acc_cnt = prof["msm_accumulate"]
+        avg_ms = acc_ms / max(acc_cnt, 1)
+        achieved = ALGO_BYTES_PER_PAIR * n / (avg_ms * 1e-3) / 1e9 if acc_cnt else None
+        out = {
+            "metric": "Pallas MSM Mscalar-mults/s (+ Fp NTT Gbutterflies/s) at k=20",
+            "value": round(value, 3), "unit": "Mscalar-mults/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u256 (8x32-bit Montgomery limbs)",
+            "data": "synthetic",
+            "config": {"workload": f"2^{args.log_n}-point Pallas best_multiexp, uniform random Fq scalars, "
+                                   "bases resident (Params::g registered), one column commit per step per GPU",
+                       "window_bits": h.msm_window_bits(n), "columns_resident": args.columns,
+                       "parallelism": f"{world} independent column streams"},
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 2) if achieved else None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
+                         "traffic": None, "avg_kernel_ms": round(avg_ms, 4), "launches": int(acc_cnt),
+                         "note": "VALU integer-multiply bound, not HBM bound: see DESIGN.md (modmul/s vs measured peak)"},
+            "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()},
+            "ntt": ntt, "cpu_baseline": cpu,
+            "checks": {"split_sum_identity": bool(split_ok), "split_msm_allgather": split_msm_ok},
+            "input_gen_s": round(gen_s, 2),
+        }
+        print(json.dumps(out))
+    lib.h2_bases_free(params_g)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

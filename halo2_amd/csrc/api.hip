@@ -2,6 +2,8 @@
 // The MSM entry points live in msm.hip, the NTT entry points in ntt.hip (see include/halo2_mi355x.h).
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -39,7 +41,68 @@ int ensure_device() {
     return H2_OK;
 }
 
+// ---- event profiler ---------------------------------------------------------------------------
+struct ProfState {
+    std::mutex mu;
+    bool on = false;
+    struct Pair { hipEvent_t a, b; };
+    std::vector<Pair> pending[PROF_SLOTS];
+    hipEvent_t open[PROF_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    double total_ms[PROF_SLOTS] = {0, 0, 0, 0};
+    uint64_t count[PROF_SLOTS] = {0, 0, 0, 0};
+};
+static ProfState g_prof;
+bool prof_enabled() { return g_prof.on; }
+void prof_begin(int slot, hipStream_t st) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    g_prof.open[slot] = e;
+}
+void prof_end(int slot, hipStream_t st) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (!g_prof.open[slot]) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    g_prof.pending[slot].push_back({g_prof.open[slot], e});
+    g_prof.open[slot] = nullptr;
+}
+
 }  // namespace h2
+
+extern "C" int h2_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(h2::g_prof.mu);
+    h2::g_prof.on = on != 0;
+    if (on) {
+        for (int s = 0; s < h2::PROF_SLOTS; ++s) {
+            h2::g_prof.total_ms[s] = 0;
+            h2::g_prof.count[s] = 0;
+        }
+    }
+    return H2_OK;
+}
+
+extern "C" int h2_profile_read(int slot, double *total_ms, uint64_t *launches) {
+    if (slot < 0 || slot >= h2::PROF_SLOTS || !total_ms || !launches) return H2_ERR_ARGS;
+    std::lock_guard<std::mutex> lk(h2::g_prof.mu);
+    for (auto &pr : h2::g_prof.pending[slot]) {
+        float ms = 0;
+        if (hipEventSynchronize(pr.b) == hipSuccess && hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) {
+            h2::g_prof.total_ms[slot] += ms;
+            h2::g_prof.count[slot] += 1;
+        }
+        (void)hipEventDestroy(pr.a);
+        (void)hipEventDestroy(pr.b);
+    }
+    h2::g_prof.pending[slot].clear();
+    *total_ms = h2::g_prof.total_ms[slot];
+    *launches = h2::g_prof.count[slot];
+    return H2_OK;
+}
 
 extern "C" int h2_device_count(void) {
     int count = 0;

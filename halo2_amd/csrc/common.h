@@ -48,6 +48,13 @@ struct DevBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(ptr); }
 };
 
+// Optional kernel timing with HIP events on the launching stream (h2_profile_enable): bench.py uses it to
+// measure the dominant kernels' average duration live, inside the timed region.
+enum ProfSlot { PROF_MSM_ACCUMULATE = 0, PROF_NTT_PASS = 1, PROF_MSM_SORT = 2, PROF_MSM_REDUCE = 3, PROF_SLOTS = 4 };
+bool prof_enabled();
+void prof_begin(int slot, hipStream_t st);
+void prof_end(int slot, hipStream_t st);
+
 // Confirms a usable gfx950 device exists; every entry point calls this first so a missing GPU or
 // runtime fails loudly (H2_ERR_NODEV) instead of silently doing nothing.
 int ensure_device();

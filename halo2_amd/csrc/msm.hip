@@ -374,6 +374,7 @@ static int msm_launch(MsmContext &cx, const void *d_scalars, const void *d_bases
         cx.attr_set = true;
     }
     const u32 n32 = (u32)n;
+    prof_begin(PROF_MSM_SORT, st);
     hipLaunchKernelGGL((msm_recode<FS>), dim3((n32 + 255) / 256), dim3(256), 0, st, (const u32 *)d_scalars,
                        (const u32 *)d_extra_scalar, cx.digits.as<uint16_t>(), n32, sh.c, sh.W,
                        form == H2_FORM_MONTGOMERY);
@@ -385,15 +386,20 @@ static int msm_launch(MsmContext &cx, const void *d_scalars, const void *d_bases
                        total_buckets);
     hipLaunchKernelGGL(msm_scatter, dim3(sh.B, sh.W), dim3(1024), sh.NB * 4, st, cx.digits.as<uint16_t>(),
                        cx.hist.as<u32>(), cx.starts.as<u32>(), cx.entries.as<u32>(), n32, sh.chunk, sh.NB);
+    prof_end(PROF_MSM_SORT, st);
+    prof_begin(PROF_MSM_ACCUMULATE, st);
     hipLaunchKernelGGL((msm_accumulate<FB>), dim3((total_buckets + 255) / 256), dim3(256), 0, st, (const u32 *)d_bases,
                        (const u32 *)d_extra_base, d_extra_base ? (u32)n_in : 0xFFFFFFFFu, cx.entries.as<u32>(),
                        cx.starts.as<u32>(), cx.counts.as<u32>(), cx.buckets.as<u32>(), total_buckets);
+    prof_end(PROF_MSM_ACCUMULATE, st);
+    prof_begin(PROF_MSM_REDUCE, st);
     hipLaunchKernelGGL((msm_reduce_segments<FB>), dim3((segs + 255) / 256), dim3(256), 0, st, cx.buckets.as<u32>(),
                        cx.partial.as<u32>(), sh.NB, segs);
     hipLaunchKernelGGL((msm_sum_window<FB>), dim3(sh.W), dim3(256), 256 * 128, st, cx.partial.as<u32>(),
                        cx.wsums.as<u32>(), sh.NB / kSeg);
     hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, cx.wsums.as<u32>(), sh.W, sh.c, d_extra,
                        (u32 *)d_out, out_kind, form == H2_FORM_MONTGOMERY);
+    prof_end(PROF_MSM_REDUCE, st);
     H2_HIP(hipGetLastError());
     return H2_OK;
 }

@@ -433,12 +433,14 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
         if (threads < 64) threads = 64;
         size_t tiles = n >> (A.r + A.logT);
         size_t lds = ((size_t)32 << A.r) << A.logT;
+        prof_begin(PROF_NTT_PASS, st);
         if (J.field == H2_FP)
             hipLaunchKernelGGL((ntt_pass<FP>), dim3((unsigned)tiles), dim3(threads), lds, st, (const u32 *)src, (u32 *)dst,
                                (const u32 *)tw->d, A);
         else
             hipLaunchKernelGGL((ntt_pass<FQ>), dim3((unsigned)tiles), dim3(threads), lds, st, (const u32 *)src, (u32 *)dst,
                                (const u32 *)tw->d, A);
+        prof_end(PROF_NTT_PASS, st);
         s0 += A.r;
     }
     H2_HIP(hipGetLastError());

@@ -128,6 +128,17 @@ int h2_extended_to_coeff_device(int field, void *d_a, unsigned ext_k, const uint
  * point.  The local step after the 96-byte all-gather of a range-split MSM (one partial per GPU). */
 int h2_points_sum(int curve, const uint64_t *points_xyz, size_t count, uint64_t *out_xyz);
 
+/* ---- measurement aid (no reference counterpart) ------------------------------------------------ */
+/* When enabled, the library brackets its dominant kernels with HIP events on the launching stream.
+ * h2_profile_read drains them: slot 0 = MSM bucket accumulation, 1 = NTT passes (sum over the passes
+ * of one transform counts as several launches), 2 = MSM recode+sort, 3 = MSM reduce+combine. */
+#define H2_PROF_MSM_ACCUMULATE 0
+#define H2_PROF_NTT_PASS 1
+#define H2_PROF_MSM_SORT 2
+#define H2_PROF_MSM_REDUCE 3
+int h2_profile_enable(int on);
+int h2_profile_read(int slot, double *total_ms, uint64_t *launches);
+
 #ifdef __cplusplus
 }
 #endif

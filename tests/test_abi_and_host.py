@@ -1,0 +1,110 @@
+"""CPU-only checks of the drop-in boundary and the host logic: the C-ABI library loads, exports every
+symbol include/halo2_mi355x.h declares, validates arguments without a GPU, fails loudly (no CPU fallback)
+when no device is present; EvaluationDomain constants match the reference's pinned values."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import halo2_amd as h
+from halo2_amd import fields
+from halo2_amd import _lib
+from oracle import pasta as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "halo2_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(h2_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    lib = h.lib()
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in the header but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
+    # and nothing bound that the header does not declare
+    assert sorted(_lib.SIGNATURES) == syms
+    out = subprocess.check_output(["nm", "-D", "--defined-only", h.LIB_PATH], text=True)
+    exported = set(re.findall(r"\bT (h2_[a-z0-9_]+)", out))
+    assert exported == set(syms)
+
+
+def test_no_torch_types_in_abi():
+    text = open(os.path.join(ROOT, "include", "halo2_mi355x.h")).read()
+    assert "torch" not in text.lower() and "at::" not in text
+
+
+def test_argument_validation_without_gpu():
+    lib = h.lib()
+    z4 = np.zeros((4, 4), np.uint64)
+    z8 = np.zeros((4, 8), np.uint64)
+    out = np.zeros(12, np.uint64)
+    p = lambda a: a.ctypes.data_as(_lib.u64p)
+    assert lib.h2_msm(7, p(z4), p(z8), 4, 1, 0, p(out)) == _lib.H2_ERR_ARGS          # bad curve
+    assert lib.h2_msm(0, p(z4), p(z8), 4, 9, 0, p(out)) == _lib.H2_ERR_ARGS          # bad form
+    assert lib.h2_msm(0, None, p(z8), 4, 1, 0, p(out)) == _lib.H2_ERR_ARGS           # null scalars
+    assert lib.h2_ntt(0, p(z4), 33, p(z4[0]), 1) == _lib.H2_ERR_ARGS                 # log_n > 32
+    assert lib.h2_ntt(3, p(z4), 2, p(z4[0]), 1) == _lib.H2_ERR_ARGS                  # bad field
+    assert lib.h2_bases_free(123456) == _lib.H2_ERR_HANDLE
+    with pytest.raises(ValueError):                                                   # arithmetic.rs:144
+        h.best_multiexp(z4, np.zeros((5, 8), np.uint64), h.PALLAS)
+    with pytest.raises(ValueError):                                                   # arithmetic.rs:205
+        h.best_fft(z4, z4[0], 3, h.FP)
+
+
+def test_fails_loudly_without_device():
+    """The product path has no CPU fallback: on a box without a GPU every compute call errors out."""
+    if h.lib().h2_device_count() > 0:
+        pytest.skip("a GPU is present")
+    z4 = np.zeros((4, 4), np.uint64)
+    with pytest.raises(h.H2Error, match="no MI355X device|no HIP device"):
+        h.best_multiexp(z4, np.zeros((4, 8), np.uint64), h.PALLAS)
+    with pytest.raises(h.H2Error):
+        h.best_fft(z4, z4[0], 2, h.FP)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "halo2_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h", ".inc")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("Python oracle", "").replace("inject the oracle", ""), f
+
+
+def test_domain_constants_match_reference_pins(golden_dir):
+    vks = json.load(open(os.path.join(golden_dir, "pinned_vk.json")))
+    for v in vks:
+        # tests/plonk_api.rs:593-597 and circuit_data/vk_*.rdata:4-8: k, extended_k, omega
+        j = 5 if v["k"] == 5 else None
+        for cs_degree in range(2, 12):
+            d = h.EvaluationDomain(cs_degree, v["k"], h.FP)
+            if d.extended_k == v["extended_k"]:
+                assert d.omega == int(v["omega"], 16)
+                break
+        else:
+            raise AssertionError("no degree reproduces extended_k")
+    d = h.EvaluationDomain(3, 20, h.FP)        # simple-example at k = 20
+    assert d.extended_k == 21 and len(d.t_evaluations) == 2
+    d5 = h.EvaluationDomain(5, 8, h.FP)        # benches/plonk.rs at k = 8
+    assert d5.extended_k == 10
+    ref = o.EvaluationDomain(5, 8, o.P)
+    assert (d5.omega, d5.extended_omega, d5.g_coset, d5.g_coset_inv, d5.ifft_divisor, d5.extended_ifft_divisor,
+            d5.t_evaluations) == (ref.omega, ref.extended_omega, ref.g_coset, ref.g_coset_inv, ref.ifft_divisor,
+                                  ref.extended_ifft_divisor, ref.t_evaluations)
+    assert pow(d5.g_coset, 3, o.P) == 1 and d5.g_coset != 1
+
+
+def test_limb_encoding_roundtrip():
+    vals = [0, 1, o.P - 1, 0x123456789ABCDEF0123456789ABCDEF]
+    a = fields.to_limbs(vals, h.FP)
+    assert fields.from_limbs(a, h.FP) == vals
+    assert fields.from_limbs(fields.to_limbs(vals, None, montgomery=False), None, montgomery=False) == vals
