@@ -1,25 +1,37 @@
 // Pippenger multi-scalar multiplication for Pallas / Vesta on gfx950.
 //
 // Replaces the body of `best_multiexp` (halo2_proofs/src/arithmetic.rs:143-180) and `Buckets::sum`
-// (:74-93).  The reference runs one CPU task per c-bit window, each re-streaming all n (scalar, base)
-// pairs; the result is a group element, so any window width / digit encoding gives the same answer
-// (SURVEY.md appendix A.1 item 7).  This implementation is organised for the GPU instead:
+// (:74-93), and -- for bases registered once per `Params` -- `Params::commit` / `commit_lagrange`
+// (poly/commitment.rs:119-150).  The reference runs one CPU task per c-bit window, each re-streaming
+// all n (scalar, base) pairs; the result is a group element, so window width, digit encoding and
+// summation order are free.  Organised for the GPU instead:
 //
-//   recode      one thread per scalar: Montgomery -> canonical once (the reference redoes `to_repr`
-//               per window, :77), then W signed c-bit digits -> u16 codes, window-major        [HBM]
-//   count       per (window, chunk) workgroup: 2^(c-1)-bin histogram in LDS (128 KiB at c = 16;
-//               global atomics measured 20x slower), written out as per-chunk prefix slices    [LDS]
-//   scan        per-bucket totals + exclusive offsets over all W * 2^(c-1) buckets
-//   scatter     same workgroups: offsets in LDS, LDS atomics hand out slots; point index | sign
+//   recode      one lane per scalar: Montgomery -> canonical once (the reference redoes `to_repr` per
+//               window, :77), W signed c-bit digits -> u16 codes, window-major                 [HBM]
+//   count       per (slice, chunk) workgroup: 2^(c-1)-bin histogram in LDS (128 KiB at c = 16; global
+//               atomics measured 20x slower), written out as per-chunk slices                   [LDS]
+//   scan        chunk prefixes, then a three-kernel exclusive scan giving every bucket its entry
+//               offset and the offsets of its fixed-size work parts
+//   scatter     same workgroups: offsets in LDS, LDS atomics hand out slots; base index | sign
 //               lands in the bucket-sorted entry list                                           [LDS]
-//   accumulate  one thread per bucket: gather 64-B affine bases (MALL-resident at k = 20), mixed
-//               XYZZ additions in registers -- the hot kernel, ~90 % of the modular multiplies  [VALU]
-//   reduce      running-sum fold (:86-92) restructured as 8-bucket segments + a 15-bit scalar
-//               multiple per segment, then a tree sum per window
+//   accumulate  the hot kernel: the sorted entry list is cut into PARTS of <= 64 entries of one
+//               bucket; one lane per part gathers 64-B affine bases and does XYZZ mixed additions in
+//               registers.  Every lane does the same amount of work whatever the digit distribution
+//               (heavy buckets -- repeated scalars, tiny scalars -- just own more parts)          [VALU]
+//   fold        parts -> buckets: 32-way partial sums, then a per-bucket finisher
+//   reduce      running-sum fold (:86-92) restructured as 8-bucket segments + a small scalar
+//               multiple per segment, then a tree sum per slice
 //   combine     Horner over windows (:169-178) on one lane; emits Jacobian or affine
 //
+// Two shapes share these kernels:
+//   generic     (h2_msm) W slices of 2^(c-1) buckets, one per window; combine does the c*i doublings.
+//   registered  (h2_bases_register / h2_commit) the table [W][n+1] of 2^(c*w) * P_i is precomputed in
+//               HBM (1 GiB at k = 20 -- nothing next to 288 GB), so all windows share ONE slice of
+//               buckets: 16x fewer buckets to reduce and no doubling chain at all.  Column n holds the
+//               blind's base `w` (poly/commitment.rs:127).
+//
 // No MFMA anywhere: this is modular-integer arithmetic.  Bound by VALU integer-multiply issue, not
-// HBM: algorithmic traffic is 96 B per (scalar, base) pair against ~1.9e2 modular multiplies.
+// HBM: algorithmic traffic is 96 B per (scalar, base) pair against ~1.8e2 modular multiplies.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -34,34 +46,46 @@ namespace h2 {
 
 static constexpr int kMaxC = 16;
 static constexpr u32 kZeroCode = 0xFFFFu;
-static constexpr int kSeg = 8;  // buckets per reduce segment
+static constexpr int kSeg = 8;     // buckets per reduce segment
+static constexpr u32 kPart1 = 64;  // entries per accumulate part
+static constexpr u32 kPart2 = 32;  // parts per fold part
+static constexpr u32 kScanBlock = 1024;
 
 struct MsmShape {
-    size_t n;
-    int c;        // window bits
-    int W;        // windows
-    u32 NB;       // buckets per window = 2^(c-1)
-    u32 B;        // chunks
-    u32 chunk;    // scalars per chunk
+    int c, W;
+    u32 NB;          // buckets per slice = 2^(c-1)
+    u32 slices;      // generic: W; registered (precomputed table): 1
+    size_t m;        // digit columns per window = points used + (blind ? 1 : 0)
+    size_t items;    // digit codes per slice: generic m, registered W*m
+    u32 B, chunk;    // chunks per slice, codes per chunk
+    u32 total_buckets;
 };
 
-static MsmShape msm_shape(size_t n) {
-    MsmShape s;
-    s.n = n;
+// window width: minimise mixed adds + reduce work.  `shared_buckets`: registered bases (one slice).
+static int choose_c(size_t n, bool shared_buckets) {
     double best = 1e300;
     int bc = 4;
     for (int c = 4; c <= kMaxC; ++c) {
         int W = 255 / c + 1;
-        double cost = (double)W * ((double)n * 10.5 + (double)(1u << (c - 1)) * 40.0);
+        double buckets = (double)(1u << (c - 1)) * (shared_buckets ? 1 : W);
+        double cost = (double)W * (double)n * 10.5 + buckets * 60.0;
         if (cost < best) { best = cost; bc = c; }
     }
-    s.c = bc;
-    s.W = 255 / bc + 1;
-    s.NB = 1u << (bc - 1);
-    u32 B = (u32)((n + 65535) / 65536);
-    if (B < 1) B = 1;
-    s.B = B;
-    s.chunk = (u32)((n + B - 1) / B);
+    return bc;
+}
+
+static MsmShape make_shape(size_t m, int c, bool shared_buckets) {
+    MsmShape s;
+    s.c = c;
+    s.W = 255 / c + 1;
+    s.NB = 1u << (c - 1);
+    s.slices = shared_buckets ? 1 : (u32)s.W;
+    s.m = m;
+    s.items = shared_buckets ? (size_t)s.W * m : m;
+    u32 B = (u32)((s.items + 65535) / 65536);
+    s.B = B < 1 ? 1 : B;
+    s.chunk = (u32)((s.items + s.B - 1) / s.B);
+    s.total_buckets = s.slices * s.NB;
     return s;
 }
 
@@ -73,14 +97,14 @@ __device__ __forceinline__ u32 limb_at(const fe &s, int idx) {
 }
 
 // ---- recode: scalars -> signed window digits -------------------------------------------------
-// code = 0xFFFF for digit 0, else (|d| - 1) | (d < 0 ? 0x8000 : 0);  digits[w * n + i]
+// code = 0xFFFF for digit 0, else (|d| - 1) | (d < 0 ? 0x8000 : 0);  digits[w * m + i]
 template <int FS>
 __global__ void __launch_bounds__(256) msm_recode(const u32 *__restrict__ scalars, const u32 *__restrict__ extra_scalar,
-                                                  uint16_t *__restrict__ digits, u32 n, int c, int W, int mont) {
-    // n counts the optional extra (blind) scalar, which is element n - 1 and lives in its own buffer
+                                                  uint16_t *__restrict__ digits, u32 m, int c, int W, int mont) {
+    // m counts the optional extra (blind) scalar, which is column m - 1 and lives in its own buffer
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    fe s = (extra_scalar && i == n - 1) ? fe_load(extra_scalar) : fe_load(scalars + 8 * (size_t)i);
+    if (i >= m) return;
+    fe s = (extra_scalar && i == m - 1) ? fe_load(extra_scalar) : fe_load(scalars + 8 * (size_t)i);
     if (mont) s = fe_from_mont<FS>(s);
     u32 carry = 0;
     const u32 mask = (1u << c) - 1, half = 1u << (c - 1);
@@ -91,30 +115,30 @@ __global__ void __launch_bounds__(256) msm_recode(const u32 *__restrict__ scalar
         u32 code;
         if (raw > half) {
             carry = 1;
-            code = ((1u << c) - raw - 1) | 0x8000u;   // d = raw - 2^c < 0, |d| - 1
+            code = ((1u << c) - raw - 1) | 0x8000u;   // d = raw - 2^c <= 0: |d| - 1 (d = 0 wraps to 0xFFFF)
         } else {
             carry = 0;
             code = raw ? raw - 1 : kZeroCode;
         }
-        digits[(size_t)w * n + i] = (uint16_t)code;
+        digits[(size_t)w * m + i] = (uint16_t)code;
     }
 }
 
-// ---- count: LDS histogram per (window, chunk) --------------------------------------------------
-__global__ void __launch_bounds__(1024) msm_count(const uint16_t *__restrict__ digits, u32 *__restrict__ hist, u32 n,
-                                                  u32 chunk, u32 NB) {
+// ---- count: LDS histogram per (slice, chunk) ---------------------------------------------------
+__global__ void __launch_bounds__(1024) msm_count(const uint16_t *__restrict__ digits, u32 *__restrict__ hist,
+                                                  size_t items, u32 chunk, u32 NB) {
     extern __shared__ __attribute__((aligned(16))) u32 h[];
-    const u32 b = blockIdx.x, w = blockIdx.y, B = gridDim.x;
+    const u32 b = blockIdx.x, sl = blockIdx.y, B = gridDim.x;
     for (u32 j = threadIdx.x; j < NB; j += blockDim.x) h[j] = 0;
     __syncthreads();
-    u32 lo = b * chunk, hi = min(n, lo + chunk);
-    const uint16_t *d = digits + (size_t)w * n;
-    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    size_t lo = (size_t)b * chunk, hi = min(items, lo + chunk);
+    const uint16_t *d = digits + (size_t)sl * items;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         u32 code = d[i];
         if (code != kZeroCode) atomicAdd(&h[code & 0x7FFFu], 1u);
     }
     __syncthreads();
-    u32 *dst = hist + ((size_t)w * B + b) * NB;
+    u32 *dst = hist + ((size_t)sl * B + b) * NB;
     for (u32 j = threadIdx.x; j < NB; j += blockDim.x) dst[j] = h[j];
 }
 
@@ -123,10 +147,10 @@ __global__ void __launch_bounds__(256) msm_chunk_prefix(u32 *__restrict__ hist, 
                                                         u32 B, u32 total_buckets) {
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total_buckets) return;
-    u32 w = g / NB, j = g % NB;
+    u32 sl = g / NB, j = g % NB;
     u32 run = 0;
     for (u32 b = 0; b < B; ++b) {
-        size_t k = ((size_t)w * B + b) * NB + j;
+        size_t k = ((size_t)sl * B + b) * NB + j;
         u32 t = hist[k];
         hist[k] = run;
         run += t;
@@ -134,70 +158,179 @@ __global__ void __launch_bounds__(256) msm_chunk_prefix(u32 *__restrict__ hist, 
     counts[g] = run;
 }
 
-// ---- scan b: exclusive scan of bucket totals (single workgroup) --------------------------------
-__global__ void __launch_bounds__(1024) msm_scan_counts(const u32 *__restrict__ counts, u32 *__restrict__ starts,
-                                                        u32 total) {
-    __shared__ u32 part[1024];
+// ---- scan b: three exclusive scans over the buckets in one sweep ---------------------------------
+//   starts  : entry offsets          (scan of cnt)
+//   pstarts : accumulate-part offsets (scan of ceil(cnt / kPart1))
+//   fstarts : fold-part offsets       (scan of ceil(ceil(cnt / kPart1) / kPart2))
+// arrays have total + 1 entries (last = grand total).  Three kernels: block sums, scan of block sums, apply.
+__device__ __forceinline__ void scan_terms(u32 cnt, u32 &p1, u32 &p2) {
+    p1 = (cnt + kPart1 - 1) / kPart1;
+    p2 = (p1 + kPart2 - 1) / kPart2;
+}
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *sh, u32 &total) {
+    // blockDim.x == kScanBlock
     const u32 t = threadIdx.x;
-    u32 per = (total + 1023) / 1024;
-    u32 lo = t * per, hi = min(total, lo + per);
-    u32 s = 0;
-    for (u32 i = lo; i < hi; ++i) s += counts[i];
-    part[t] = s;
+    sh[t] = v;
     __syncthreads();
-    for (u32 off = 1; off < 1024; off <<= 1) {
-        u32 v = t >= off ? part[t - off] : 0;
+    for (u32 off = 1; off < kScanBlock; off <<= 1) {
+        u32 x = t >= off ? sh[t - off] : 0;
         __syncthreads();
-        part[t] += v;
+        sh[t] += x;
         __syncthreads();
     }
-    u32 run = part[t] - s;
-    for (u32 i = lo; i < hi; ++i) {
-        starts[i] = run;
-        run += counts[i];
+    total = sh[kScanBlock - 1];
+    u32 r = sh[t] - v;
+    __syncthreads();
+    return r;
+}
+__global__ void __launch_bounds__(kScanBlock) msm_scan_blocksums(const u32 *__restrict__ counts, u32 *__restrict__ bsums,
+                                                                 u32 total, u32 nblocks) {
+    __shared__ u32 sh[kScanBlock];
+    u32 g = blockIdx.x * kScanBlock + threadIdx.x;
+    u32 cnt = g < total ? counts[g] : 0, p1, p2, tot;
+    scan_terms(cnt, p1, p2);
+    (void)block_excl_scan(cnt, sh, tot);
+    if (threadIdx.x == 0) bsums[blockIdx.x] = tot;
+    (void)block_excl_scan(p1, sh, tot);
+    if (threadIdx.x == 0) bsums[nblocks + blockIdx.x] = tot;
+    (void)block_excl_scan(p2, sh, tot);
+    if (threadIdx.x == 0) bsums[2 * nblocks + blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(kScanBlock) msm_scan_top(u32 *__restrict__ bsums, u32 nblocks, u32 *__restrict__ totals) {
+    __shared__ u32 sh[kScanBlock];
+    for (int k = 0; k < 3; ++k) {
+        u32 carry = 0;
+        for (u32 base = 0; base < nblocks; base += kScanBlock) {
+            u32 i = base + threadIdx.x;
+            u32 v = i < nblocks ? bsums[k * nblocks + i] : 0, tot;
+            u32 ex = block_excl_scan(v, sh, tot);
+            if (i < nblocks) bsums[k * nblocks + i] = carry + ex;
+            carry += tot;
+        }
+        if (threadIdx.x == 0) totals[k] = carry;
+    }
+}
+__global__ void __launch_bounds__(kScanBlock) msm_scan_apply(const u32 *__restrict__ counts, const u32 *__restrict__ bsums,
+                                                             const u32 *__restrict__ totals, u32 *__restrict__ starts,
+                                                             u32 *__restrict__ pstarts, u32 *__restrict__ fstarts, u32 total,
+                                                             u32 nblocks) {
+    __shared__ u32 sh[kScanBlock];
+    u32 g = blockIdx.x * kScanBlock + threadIdx.x;
+    u32 cnt = g < total ? counts[g] : 0, p1, p2, tot;
+    scan_terms(cnt, p1, p2);
+    u32 a = block_excl_scan(cnt, sh, tot) + bsums[blockIdx.x];
+    u32 b = block_excl_scan(p1, sh, tot) + bsums[nblocks + blockIdx.x];
+    u32 c = block_excl_scan(p2, sh, tot) + bsums[2 * nblocks + blockIdx.x];
+    if (g < total) {
+        starts[g] = a;
+        pstarts[g] = b;
+        fstarts[g] = c;
+    }
+    if (g == 0) {
+        starts[total] = totals[0];
+        pstarts[total] = totals[1];
+        fstarts[total] = totals[2];
     }
 }
 
 // ---- scatter: bucket-sorted entry list ----------------------------------------------------------
+// entry = base index | sign << 31.  generic: base index = column (column m-1 of a blinded commit maps to
+// `extra_col`); registered: base index = w * stride + column, straight into the precomputed table.
 __global__ void __launch_bounds__(1024) msm_scatter(const uint16_t *__restrict__ digits, const u32 *__restrict__ hist,
-                                                    const u32 *__restrict__ starts, u32 *__restrict__ entries, u32 n,
-                                                    u32 chunk, u32 NB) {
+                                                    const u32 *__restrict__ starts, u32 *__restrict__ entries,
+                                                    size_t items, u32 chunk, u32 NB, u32 m, u32 stride, u32 extra_col,
+                                                    int table) {
     extern __shared__ __attribute__((aligned(16))) u32 off[];
-    const u32 b = blockIdx.x, w = blockIdx.y, B = gridDim.x;
-    const u32 *src = hist + ((size_t)w * B + b) * NB;
-    const u32 *st = starts + (size_t)w * NB;
+    const u32 b = blockIdx.x, sl = blockIdx.y, B = gridDim.x;
+    const u32 *src = hist + ((size_t)sl * B + b) * NB;
+    const u32 *st = starts + (size_t)sl * NB;
     for (u32 j = threadIdx.x; j < NB; j += blockDim.x) off[j] = st[j] + src[j];
     __syncthreads();
-    u32 lo = b * chunk, hi = min(n, lo + chunk);
-    const uint16_t *d = digits + (size_t)w * n;
-    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    size_t lo = (size_t)b * chunk, hi = min(items, lo + chunk);
+    const uint16_t *d = digits + (size_t)sl * items;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         u32 code = d[i];
         if (code != kZeroCode) {
             u32 pos = atomicAdd(&off[code & 0x7FFFu], 1u);
-            entries[pos] = i | ((code & 0x8000u) << 16);
+            const u32 i32 = (u32)i;  // items < 2^31
+            u32 w = table ? i32 / m : 0, col = table ? i32 % m : i32;
+            if (col == m - 1 && extra_col != 0xFFFFFFFFu) col = extra_col;
+            entries[pos] = (w * stride + col) | ((code & 0x8000u) << 16);
         }
     }
 }
 
-// ---- accumulate: one thread per bucket -----------------------------------------------------------
+// largest b in [0, n) with arr[b] <= t  (arr non-decreasing, arr[0] = 0)
+__device__ __forceinline__ u32 upper_bucket(const u32 *__restrict__ arr, u32 n, u32 t) {
+    u32 lo = 0, hi = n;  // invariant: arr[lo] <= t < arr[hi]  (arr[n] = total > t)
+    while (hi - lo > 1) {
+        u32 mid = (lo + hi) >> 1;
+        if (arr[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ---- accumulate: one lane per part of <= kPart1 entries of one bucket ------------------------------
 template <int FB>
 __global__ void __launch_bounds__(256) msm_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
                                                       u32 extra_index, const u32 *__restrict__ entries,
-                                                      const u32 *__restrict__ starts, const u32 *__restrict__ counts,
-                                                      u32 *__restrict__ buckets, u32 total_buckets) {
-    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total_buckets) return;
-    u32 s = starts[g], cnt = counts[g];
+                                                      const u32 *__restrict__ starts, const u32 *__restrict__ pstarts,
+                                                      u32 *__restrict__ parts, u32 total_buckets) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pstarts[total_buckets]) return;
+    const u32 b = upper_bucket(pstarts, total_buckets, t);
+    const u32 k = t - pstarts[b];
+    const u32 lo = starts[b] + k * kPart1, hi = min(starts[b + 1], lo + kPart1);
     xyzz<FB> acc = xyzz_identity<FB>();
-    for (u32 k = 0; k < cnt; ++k) {
-        u32 e = entries[s + k];
-        u32 idx = e & 0x7FFFFFFFu;
-        // the blind's base `w` (Params::commit, poly/commitment.rs:127) is element n, in its own buffer
-        affine<FB> p = aff_load<FB>(idx == extra_index ? extra_base : bases + 16 * (size_t)idx);
-        if (e >> 31) p.y = fe_neg<FB>(p.y);
+    u32 e = entries[lo];
+    u32 idx = e & 0x7FFFFFFFu;
+    // the blind's base `w` (Params::commit, poly/commitment.rs:127) may live in its own buffer
+    affine<FB> nxt = aff_load<FB>(idx == extra_index ? extra_base : bases + 16 * (size_t)idx);
+    for (u32 i = lo; i < hi; ++i) {
+        affine<FB> p = nxt;
+        const u32 neg = e >> 31;
+        if (i + 1 < hi) {  // fetch the next base while this one is being added
+            e = entries[i + 1];
+            idx = e & 0x7FFFFFFFu;
+            nxt = aff_load<FB>(idx == extra_index ? extra_base : bases + 16 * (size_t)idx);
+        }
+        if (neg) p.y = fe_neg<FB>(p.y);
         xyzz_madd<FB>(acc, p);
     }
-    xyzz_store<FB>(buckets + 32 * (size_t)g, acc);
+    xyzz_store<FB>(parts + 32 * (size_t)t, acc);
+}
+
+// ---- fold level: one lane per group of <= kPart2 parts of one bucket --------------------------------
+template <int FB>
+__global__ void __launch_bounds__(256) msm_fold_parts(const u32 *__restrict__ parts, const u32 *__restrict__ pstarts,
+                                                      const u32 *__restrict__ fstarts, u32 *__restrict__ folded,
+                                                      u32 total_buckets) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= fstarts[total_buckets]) return;
+    const u32 b = upper_bucket(fstarts, total_buckets, t);
+    const u32 k = t - fstarts[b];
+    const u32 lo = pstarts[b] + k * kPart2, hi = min(pstarts[b + 1], lo + kPart2);
+    xyzz<FB> acc = xyzz_load<FB>(parts + 32 * (size_t)lo);
+    for (u32 i = lo + 1; i < hi; ++i) {
+        xyzz<FB> p = xyzz_load<FB>(parts + 32 * (size_t)i);
+        xyzz_add<FB>(acc, p);
+    }
+    xyzz_store<FB>(folded + 32 * (size_t)t, acc);
+}
+
+// ---- finisher: one lane per bucket sums what is left (one element unless the bucket is enormous) -----
+template <int FB>
+__global__ void __launch_bounds__(256) msm_finish_buckets(const u32 *__restrict__ folded, const u32 *__restrict__ fstarts,
+                                                          u32 *__restrict__ buckets, u32 total_buckets) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= total_buckets) return;
+    const u32 lo = fstarts[b], hi = fstarts[b + 1];
+    xyzz<FB> acc = xyzz_identity<FB>();
+    for (u32 i = lo; i < hi; ++i) {
+        xyzz<FB> p = xyzz_load<FB>(folded + 32 * (size_t)i);
+        xyzz_add<FB>(acc, p);
+    }
+    xyzz_store<FB>(buckets + 32 * (size_t)b, acc);
 }
 
 // k * p for a small k (bucket index offsets, < 2^16): MSB-first double-and-add
@@ -216,9 +349,9 @@ __global__ void __launch_bounds__(256) msm_reduce_segments(const u32 *__restrict
                                                            u32 NB, u32 total_segments) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total_segments) return;
-    u32 segs_per_window = NB / kSeg;
-    u32 w = t / segs_per_window, sg = t % segs_per_window;
-    const u32 *base = buckets + 32 * ((size_t)w * NB + (size_t)sg * kSeg);
+    u32 segs_per_slice = NB / kSeg;
+    u32 sl = t / segs_per_slice, sg = t % segs_per_slice;
+    const u32 *base = buckets + 32 * ((size_t)sl * NB + (size_t)sg * kSeg);
     xyzz<FB> run = xyzz_identity<FB>(), acc = xyzz_identity<FB>();
     for (int j = kSeg - 1; j >= 0; --j) {
         xyzz<FB> bk = xyzz_load<FB>(base + 32 * j);
@@ -231,15 +364,15 @@ __global__ void __launch_bounds__(256) msm_reduce_segments(const u32 *__restrict
     xyzz_store<FB>(partial + 32 * (size_t)t, acc);
 }
 
-// ---- reduce level 2: tree sum of a window's partials ----------------------------------------------
+// ---- reduce level 2: tree sum of a slice's partials ------------------------------------------------
 template <int FB>
-__global__ void __launch_bounds__(256) msm_sum_window(const u32 *__restrict__ partial, u32 *__restrict__ window_sums,
-                                                      u32 per_window) {
+__global__ void __launch_bounds__(256) msm_sum_slice(const u32 *__restrict__ partial, u32 *__restrict__ slice_sums,
+                                                     u32 per_slice) {
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
-    const u32 w = blockIdx.x, t = threadIdx.x;
-    const u32 *src = partial + 32 * (size_t)w * per_window;
+    const u32 sl = blockIdx.x, t = threadIdx.x;
+    const u32 *src = partial + 32 * (size_t)sl * per_slice;
     xyzz<FB> acc = xyzz_identity<FB>();
-    for (u32 i = t; i < per_window; i += blockDim.x) {
+    for (u32 i = t; i < per_slice; i += blockDim.x) {
         xyzz<FB> p = xyzz_load<FB>(src + 32 * (size_t)i);
         xyzz_add<FB>(acc, p);
     }
@@ -255,25 +388,21 @@ __global__ void __launch_bounds__(256) msm_sum_window(const u32 *__restrict__ pa
     }
     if (t == 0) {
         xyzz<FB> r = xyzz_load<FB>(sh);
-        xyzz_store<FB>(window_sums + 32 * (size_t)w, r);
+        xyzz_store<FB>(slice_sums + 32 * (size_t)sl, r);
     }
 }
 
-// ---- combine: Horner over windows (+ optional blind term), emit Jacobian / affine -----------------
-// extra: optional XYZZ point added at the end (the blind*w term of Params::commit)
+// ---- combine: Horner over slices (windows), emit Jacobian / affine ---------------------------------
 template <int FB>
-__global__ void msm_combine(const u32 *__restrict__ window_sums, int W, int c, const u32 *__restrict__ extra,
-                            u32 *__restrict__ out, int out_kind, int out_mont) {
+__global__ void msm_combine(const u32 *__restrict__ slice_sums, int slices, int c, u32 *__restrict__ out, int out_kind,
+                            int out_mont) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     xyzz<FB> r = xyzz_identity<FB>();
-    for (int w = W - 1; w >= 0; --w) {
-        for (int k = 0; k < c; ++k) r = xyzz_dbl<FB>(r);
-        xyzz<FB> s = xyzz_load<FB>(window_sums + 32 * (size_t)w);
+    for (int w = slices - 1; w >= 0; --w) {
+        if (w != slices - 1)
+            for (int k = 0; k < c; ++k) r = xyzz_dbl<FB>(r);
+        xyzz<FB> s = xyzz_load<FB>(slice_sums + 32 * (size_t)w);
         xyzz_add<FB>(r, s);
-    }
-    if (extra) {
-        xyzz<FB> e = xyzz_load<FB>(extra);
-        xyzz_add<FB>(r, e);
     }
     if (out_kind == H2_OUT_AFFINE) {
         affine<FB> a = xyzz_to_affine<FB>(r);
@@ -288,6 +417,72 @@ __global__ void msm_combine(const u32 *__restrict__ window_sums, int W, int c, c
         fe_store(out + 8, Y);
         fe_store(out + 16, Z);
     }
+}
+
+// ---- precomputed table for registered bases: row w holds 2^(c*w) * P_i as affine points --------------
+// chain: one lane per point walks w = 1 .. W-1 with c doublings each, parking XYZZ in `tmp`
+template <int FB>
+__global__ void __launch_bounds__(256) msm_table_chain(const u32 *__restrict__ row0, u32 *__restrict__ tmp, u32 count,
+                                                       u32 first, u32 stride, int c, int W) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    affine<FB> p = aff_load<FB>(row0 + 16 * (size_t)(first + i));
+    xyzz<FB> r = xyzz_identity<FB>();
+    xyzz_madd<FB>(r, p);
+    for (int w = 1; w < W; ++w) {
+        for (int k = 0; k < c; ++k) r = xyzz_dbl<FB>(r);
+        xyzz_store<FB>(tmp + 32 * ((size_t)(w - 1) * count + i), r);
+    }
+    (void)stride;
+}
+// blind base: column `col` of the table must hold the multiples of `w`.  One lane compares w with what row 0
+// already holds; only when it differs does it store w, redo the chain into `tmp` and raise `flag` so that
+// msm_blind_normalise refreshes rows 1..W-1.  Entirely on the stream: no host round trip per commit.
+template <int FB>
+__global__ void msm_blind_chain(u32 *__restrict__ table, const u32 *__restrict__ w_xy, u32 *__restrict__ tmp,
+                                u32 *__restrict__ flag, u32 col, u32 stride, int c, int W) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    affine<FB> p = aff_load<FB>(w_xy);
+    affine<FB> cur = aff_load<FB>(table + 16 * (size_t)col);
+    if (fe_eq(p.x, cur.x) && fe_eq(p.y, cur.y)) {
+        *flag = 0;
+        return;
+    }
+    fe_store(table + 16 * (size_t)col, p.x);
+    fe_store(table + 16 * (size_t)col + 8, p.y);
+    xyzz<FB> r = xyzz_identity<FB>();
+    xyzz_madd<FB>(r, p);
+    for (int w = 1; w < W; ++w) {
+        for (int k = 0; k < c; ++k) r = xyzz_dbl<FB>(r);
+        xyzz_store<FB>(tmp + 32 * (size_t)(w - 1), r);
+    }
+    *flag = 1;
+    (void)stride;
+}
+template <int FB>
+__global__ void msm_blind_normalise(const u32 *__restrict__ tmp, u32 *__restrict__ table, const u32 *__restrict__ flag,
+                                    u32 col, u32 stride, int W) {
+    u32 w = threadIdx.x + 1;
+    if (*flag != 1 || (int)w >= W) return;
+    xyzz<FB> r = xyzz_load<FB>(tmp + 32 * (size_t)(w - 1));
+    affine<FB> a = xyzz_to_affine<FB>(r);
+    u32 *dst = table + 16 * ((size_t)w * stride + col);
+    fe_store(dst, a.x);
+    fe_store(dst + 8, a.y);
+}
+
+// normalise: one lane per (w, i): XYZZ -> affine into table row w
+template <int FB>
+__global__ void __launch_bounds__(256) msm_table_normalise(const u32 *__restrict__ tmp, u32 *__restrict__ table, u32 count,
+                                                           u32 first, u32 stride, int W) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)count * (W - 1)) return;
+    u32 w = (u32)(t / count) + 1, i = (u32)(t % count);
+    xyzz<FB> r = xyzz_load<FB>(tmp + 32 * t);
+    affine<FB> a = xyzz_to_affine<FB>(r);
+    u32 *dst = table + 16 * ((size_t)w * stride + first + i);
+    fe_store(dst, a.x);
+    fe_store(dst + 8, a.y);
 }
 
 // ---- small helpers -----------------------------------------------------------------------------
@@ -325,7 +520,8 @@ __global__ void k_points_sum(const u32 *__restrict__ pts, u32 count, u32 *__rest
 // ---- host orchestration ----------------------------------------------------------------------------
 struct MsmContext {
     std::mutex mu;
-    DevBuf digits, hist, counts, starts, entries, buckets, partial, wsums, extra, stage_s, stage_b, out, small;
+    DevBuf digits, hist, counts, starts, pstarts, fstarts, bsums, entries, parts, folded, buckets, partial, ssums,
+        stage_s, stage_b, out, small;
     bool attr_set = false;
 };
 
@@ -341,81 +537,117 @@ static MsmContext &msm_ctx(hipStream_t st = nullptr) {
     return *slot;
 }
 
-template <int FB, int FS>
-static int msm_launch(MsmContext &cx, const void *d_scalars, const void *d_bases, size_t n_in, int form,
-                      const void *d_extra_scalar, const void *d_extra_base, int out_kind, void *d_out, hipStream_t st) {
-    const u32 *d_extra = nullptr;
-    const size_t n = n_in + (d_extra_scalar ? 1 : 0);
-    if (n == 0) {
-        // identity (+ extra)
-        int rc;
-        if ((rc = cx.wsums.reserve(128)) != H2_OK) return rc;
-        H2_HIP(hipMemsetAsync(cx.wsums.ptr, 0, 128, st));
-        hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, cx.wsums.as<u32>(), 1, 1, d_extra, (u32 *)d_out,
-                           out_kind, form == H2_FORM_MONTGOMERY);
+struct MsmArgs {
+    const void *d_scalars;       // n_used scalars
+    const void *d_extra_scalar;  // blind or null
+    const void *d_bases;         // generic: n_used affine points; registered: table [W][stride]
+    const void *d_extra_base;    // generic + blind: w's buffer; else null
+    size_t n_used;
+    bool table;                  // registered (precomputed) shape
+    int c;                       // window bits (fixed by the table when `table`)
+    u32 stride;                  // table row stride (n_registered + 1)
+    u32 extra_col;               // table column of the blind's base; 0xFFFFFFFF when unused
+    int form, out_kind;
+    void *d_out;
+};
+
+template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a, hipStream_t st) {
+    const size_t m = a.n_used + (a.d_extra_scalar ? 1 : 0);
+    int rc;
+    if (m == 0) {
+        if ((rc = cx.ssums.reserve(128)) != H2_OK) return rc;
+        H2_HIP(hipMemsetAsync(cx.ssums.ptr, 0, 128, st));
+        hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, cx.ssums.as<u32>(), 1, 0, (u32 *)a.d_out, a.out_kind,
+                           a.form == H2_FORM_MONTGOMERY);
         H2_HIP(hipGetLastError());
         return H2_OK;
     }
-    MsmShape sh = msm_shape(n);
-    const u32 total_buckets = (u32)sh.W * sh.NB;
-    const u32 segs = total_buckets / kSeg;
-    int rc;
-    if ((rc = cx.digits.reserve((size_t)sh.W * n * 2)) != H2_OK) return rc;
-    if ((rc = cx.hist.reserve((size_t)sh.W * sh.B * sh.NB * 4)) != H2_OK) return rc;
-    if ((rc = cx.counts.reserve((size_t)total_buckets * 4)) != H2_OK) return rc;
-    if ((rc = cx.starts.reserve((size_t)total_buckets * 4)) != H2_OK) return rc;
-    if ((rc = cx.entries.reserve((size_t)sh.W * n * 4)) != H2_OK) return rc;
-    if ((rc = cx.buckets.reserve((size_t)total_buckets * 128)) != H2_OK) return rc;
+    const MsmShape sh = make_shape(m, a.c, a.table);
+    const u32 tb = sh.total_buckets, segs = tb / kSeg;
+    const size_t all_items = (size_t)sh.W * m;
+    const size_t max_parts = all_items / kPart1 + tb + 1, max_folds = max_parts / kPart2 + tb + 1;
+    const u32 nblocks = (tb + kScanBlock - 1) / kScanBlock;
+    if ((rc = cx.digits.reserve(all_items * 2)) != H2_OK) return rc;
+    if ((rc = cx.hist.reserve((size_t)sh.slices * sh.B * sh.NB * 4)) != H2_OK) return rc;
+    if ((rc = cx.counts.reserve((size_t)tb * 4)) != H2_OK) return rc;
+    if ((rc = cx.starts.reserve((size_t)(tb + 1) * 4)) != H2_OK) return rc;
+    if ((rc = cx.pstarts.reserve((size_t)(tb + 1) * 4)) != H2_OK) return rc;
+    if ((rc = cx.fstarts.reserve((size_t)(tb + 1) * 4)) != H2_OK) return rc;
+    if ((rc = cx.bsums.reserve((size_t)(3 * nblocks + 4) * 4)) != H2_OK) return rc;
+    if ((rc = cx.entries.reserve(all_items * 4)) != H2_OK) return rc;
+    if ((rc = cx.parts.reserve(max_parts * 128)) != H2_OK) return rc;
+    if ((rc = cx.folded.reserve(max_folds * 128)) != H2_OK) return rc;
+    if ((rc = cx.buckets.reserve((size_t)tb * 128)) != H2_OK) return rc;
     if ((rc = cx.partial.reserve((size_t)segs * 128)) != H2_OK) return rc;
-    if ((rc = cx.wsums.reserve((size_t)sh.W * 128)) != H2_OK) return rc;
+    if ((rc = cx.ssums.reserve((size_t)sh.slices * 128)) != H2_OK) return rc;
     if (!cx.attr_set) {
         H2_HIP(hipFuncSetAttribute((const void *)msm_count, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         H2_HIP(hipFuncSetAttribute((const void *)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         cx.attr_set = true;
     }
-    const u32 n32 = (u32)n;
+    const u32 m32 = (u32)m;
+    u32 *totals = cx.bsums.as<u32>() + 3 * nblocks;
     prof_begin(PROF_MSM_SORT, st);
-    hipLaunchKernelGGL((msm_recode<FS>), dim3((n32 + 255) / 256), dim3(256), 0, st, (const u32 *)d_scalars,
-                       (const u32 *)d_extra_scalar, cx.digits.as<uint16_t>(), n32, sh.c, sh.W,
-                       form == H2_FORM_MONTGOMERY);
-    hipLaunchKernelGGL(msm_count, dim3(sh.B, sh.W), dim3(1024), sh.NB * 4, st, cx.digits.as<uint16_t>(),
-                       cx.hist.as<u32>(), n32, sh.chunk, sh.NB);
-    hipLaunchKernelGGL(msm_chunk_prefix, dim3((total_buckets + 255) / 256), dim3(256), 0, st, cx.hist.as<u32>(),
-                       cx.counts.as<u32>(), sh.NB, sh.B, total_buckets);
-    hipLaunchKernelGGL(msm_scan_counts, dim3(1), dim3(1024), 0, st, cx.counts.as<u32>(), cx.starts.as<u32>(),
-                       total_buckets);
-    hipLaunchKernelGGL(msm_scatter, dim3(sh.B, sh.W), dim3(1024), sh.NB * 4, st, cx.digits.as<uint16_t>(),
-                       cx.hist.as<u32>(), cx.starts.as<u32>(), cx.entries.as<u32>(), n32, sh.chunk, sh.NB);
+    hipLaunchKernelGGL((msm_recode<FS>), dim3((m32 + 255) / 256), dim3(256), 0, st, (const u32 *)a.d_scalars,
+                       (const u32 *)a.d_extra_scalar, cx.digits.as<uint16_t>(), m32, sh.c, sh.W,
+                       a.form == H2_FORM_MONTGOMERY);
+    hipLaunchKernelGGL(msm_count, dim3(sh.B, sh.slices), dim3(1024), sh.NB * 4, st, cx.digits.as<uint16_t>(),
+                       cx.hist.as<u32>(), sh.items, sh.chunk, sh.NB);
+    hipLaunchKernelGGL(msm_chunk_prefix, dim3((tb + 255) / 256), dim3(256), 0, st, cx.hist.as<u32>(), cx.counts.as<u32>(),
+                       sh.NB, sh.B, tb);
+    hipLaunchKernelGGL(msm_scan_blocksums, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), tb,
+                       nblocks);
+    hipLaunchKernelGGL(msm_scan_top, dim3(1), dim3(kScanBlock), 0, st, cx.bsums.as<u32>(), nblocks, totals);
+    hipLaunchKernelGGL(msm_scan_apply, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), totals,
+                       cx.starts.as<u32>(), cx.pstarts.as<u32>(), cx.fstarts.as<u32>(), tb, nblocks);
+    const u32 extra_col = a.d_extra_scalar ? (a.table ? a.extra_col : (u32)a.n_used) : 0xFFFFFFFFu;
+    hipLaunchKernelGGL(msm_scatter, dim3(sh.B, sh.slices), dim3(1024), sh.NB * 4, st, cx.digits.as<uint16_t>(),
+                       cx.hist.as<u32>(), cx.starts.as<u32>(), cx.entries.as<u32>(), sh.items, sh.chunk, sh.NB, m32,
+                       a.table ? a.stride : 0u, extra_col, a.table ? 1 : 0);
     prof_end(PROF_MSM_SORT, st);
     prof_begin(PROF_MSM_ACCUMULATE, st);
-    hipLaunchKernelGGL((msm_accumulate<FB>), dim3((total_buckets + 255) / 256), dim3(256), 0, st, (const u32 *)d_bases,
-                       (const u32 *)d_extra_base, d_extra_base ? (u32)n_in : 0xFFFFFFFFu, cx.entries.as<u32>(),
-                       cx.starts.as<u32>(), cx.counts.as<u32>(), cx.buckets.as<u32>(), total_buckets);
+    hipLaunchKernelGGL((msm_accumulate<FB>), dim3((unsigned)((max_parts + 255) / 256)), dim3(256), 0, st,
+                       (const u32 *)a.d_bases, (const u32 *)a.d_extra_base,
+                       (!a.table && a.d_extra_base) ? (u32)a.n_used : 0xFFFFFFFFu, cx.entries.as<u32>(), cx.starts.as<u32>(),
+                       cx.pstarts.as<u32>(), cx.parts.as<u32>(), tb);
     prof_end(PROF_MSM_ACCUMULATE, st);
     prof_begin(PROF_MSM_REDUCE, st);
+    hipLaunchKernelGGL((msm_fold_parts<FB>), dim3((unsigned)((max_folds + 255) / 256)), dim3(256), 0, st, cx.parts.as<u32>(),
+                       cx.pstarts.as<u32>(), cx.fstarts.as<u32>(), cx.folded.as<u32>(), tb);
+    hipLaunchKernelGGL((msm_finish_buckets<FB>), dim3((tb + 255) / 256), dim3(256), 0, st, cx.folded.as<u32>(),
+                       cx.fstarts.as<u32>(), cx.buckets.as<u32>(), tb);
     hipLaunchKernelGGL((msm_reduce_segments<FB>), dim3((segs + 255) / 256), dim3(256), 0, st, cx.buckets.as<u32>(),
                        cx.partial.as<u32>(), sh.NB, segs);
-    hipLaunchKernelGGL((msm_sum_window<FB>), dim3(sh.W), dim3(256), 256 * 128, st, cx.partial.as<u32>(),
-                       cx.wsums.as<u32>(), sh.NB / kSeg);
-    hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, cx.wsums.as<u32>(), sh.W, sh.c, d_extra,
-                       (u32 *)d_out, out_kind, form == H2_FORM_MONTGOMERY);
+    hipLaunchKernelGGL((msm_sum_slice<FB>), dim3(sh.slices), dim3(256), 256 * 128, st, cx.partial.as<u32>(),
+                       cx.ssums.as<u32>(), sh.NB / kSeg);
+    hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, cx.ssums.as<u32>(), (int)sh.slices, sh.c, (u32 *)a.d_out,
+                       a.out_kind, a.form == H2_FORM_MONTGOMERY);
     prof_end(PROF_MSM_REDUCE, st);
     H2_HIP(hipGetLastError());
     return H2_OK;
 }
 
-static int msm_dispatch(MsmContext &cx, int curve, const void *d_scalars, const void *d_bases, size_t n, int form,
-                        const void *d_extra_scalar, const void *d_extra_base, int out_kind, void *d_out, hipStream_t st) {
-    if (curve == H2_PALLAS)
-        return msm_launch<FP, FQ>(cx, d_scalars, d_bases, n, form, d_extra_scalar, d_extra_base, out_kind, d_out, st);
-    return msm_launch<FQ, FP>(cx, d_scalars, d_bases, n, form, d_extra_scalar, d_extra_base, out_kind, d_out, st);
+static int msm_dispatch(MsmContext &cx, int curve, const MsmArgs &a, hipStream_t st) {
+    if (curve == H2_PALLAS) return msm_launch<FP, FQ>(cx, a, st);
+    return msm_launch<FQ, FP>(cx, a, st);
+}
+
+static void to_mont_async(int curve, u32 *d, size_t field_elems, hipStream_t st) {
+    if (!field_elems) return;
+    dim3 grid((unsigned)((field_elems + 255) / 256)), block(256);
+    if (curve == H2_PALLAS) hipLaunchKernelGGL((k_to_mont<FP>), grid, block, 0, st, d, field_elems);
+    else hipLaunchKernelGGL((k_to_mont<FQ>), grid, block, 0, st, d, field_elems);
 }
 
 // ---- registered bases -------------------------------------------------------------------------------
 struct Bases {
-    int curve;
-    size_t n;
-    void *d_xy;  // Montgomery affine, n * 64 B
+    std::mutex mu;
+    int curve = 0;
+    size_t n = 0;
+    int c = 16, W = 16;
+    u32 stride = 0;            // n + 1: column n is the blind's base
+    void *d_table = nullptr;   // [W][stride] affine Montgomery points, row w = 2^(c*w) * P
+    void *d_blind_tmp = nullptr;  // (W-1) XYZZ + flag word, scratch of msm_blind_chain
 };
 static std::mutex g_bases_mu;
 static std::map<h2_bases_t, std::shared_ptr<Bases>> g_bases;
@@ -432,21 +664,57 @@ static bool bad_common(int curve, int form, int out_kind) {
            (out_kind != H2_OUT_JACOBIAN && out_kind != H2_OUT_AFFINE);
 }
 
-// device-side commit core: optional (blind, w) pair rides along as element n; bases Montgomery on device
-static int commit_core(MsmContext &cx, int curve, const void *d_scalars, const void *d_bases, size_t n, int form,
-                       const void *d_w, const void *d_blind, int out_kind, void *d_out, hipStream_t st) {
-    return msm_dispatch(cx, curve, d_scalars, d_bases, n, form, d_blind, d_w, out_kind, d_out, st);
+// fills rows 1..W-1 of the table for columns [first, first + count) from row 0
+static int table_fill(Bases &b, u32 first, u32 count, hipStream_t st) {
+    if (!count || b.W <= 1) return H2_OK;
+    void *tmp = nullptr;
+    // worked in slabs so the XYZZ staging stays modest
+    const u32 slab = 1u << 18;
+    H2_HIP(hipMalloc(&tmp, (size_t)std::min(count, slab) * (b.W - 1) * 128));
+    for (u32 off = 0; off < count; off += slab) {
+        u32 cnt = std::min(slab, count - off);
+        dim3 g1((cnt + 255) / 256), blk(256);
+        size_t tot = (size_t)cnt * (b.W - 1);
+        dim3 g2((unsigned)((tot + 255) / 256));
+        if (b.curve == H2_PALLAS) {
+            hipLaunchKernelGGL((msm_table_chain<FP>), g1, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.stride, b.c, b.W);
+            hipLaunchKernelGGL((msm_table_normalise<FP>), g2, blk, 0, st, (const u32 *)tmp, (u32 *)b.d_table, cnt, first + off, b.stride, b.W);
+        } else {
+            hipLaunchKernelGGL((msm_table_chain<FQ>), g1, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.stride, b.c, b.W);
+            hipLaunchKernelGGL((msm_table_normalise<FQ>), g2, blk, 0, st, (const u32 *)tmp, (u32 *)b.d_table, cnt, first + off, b.stride, b.W);
+        }
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) { set_last_hip_error(e, __FILE__, __LINE__); return H2_ERR_HIP; }
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
+// makes column n of the table hold the multiples of `w` (device pointer, Montgomery), asynchronously on `st`.
+// A handle serves ONE blind base at a time (Params::w is fixed per Params, poly/commitment.rs:26-33).
+static int ensure_blind_base(Bases &b, const void *d_w_mont, hipStream_t st) {
+    u32 *tmp = (u32 *)b.d_blind_tmp, *flag = tmp + 32 * (size_t)b.W;
+    if (b.curve == H2_PALLAS) {
+        hipLaunchKernelGGL((msm_blind_chain<FP>), dim3(1), dim3(64), 0, st, (u32 *)b.d_table, (const u32 *)d_w_mont, tmp, flag, (u32)b.n, b.stride, b.c, b.W);
+        hipLaunchKernelGGL((msm_blind_normalise<FP>), dim3(1), dim3(64), 0, st, tmp, (u32 *)b.d_table, flag, (u32)b.n, b.stride, b.W);
+    } else {
+        hipLaunchKernelGGL((msm_blind_chain<FQ>), dim3(1), dim3(64), 0, st, (u32 *)b.d_table, (const u32 *)d_w_mont, tmp, flag, (u32)b.n, b.stride, b.c, b.W);
+        hipLaunchKernelGGL((msm_blind_normalise<FQ>), dim3(1), dim3(64), 0, st, tmp, (u32 *)b.d_table, flag, (u32)b.n, b.stride, b.W);
+    }
+    H2_HIP(hipGetLastError());
+    return H2_OK;
 }
 
 }  // namespace h2
 
 using namespace h2;
 
-extern "C" int h2_msm_window_bits(size_t n) { return msm_shape(n ? n : 1).c; }
+extern "C" int h2_msm_window_bits(size_t n) { return choose_c(n ? n : 1, false); }
 
 extern "C" int h2_msm_device(int curve, const void *d_scalars, const void *d_bases_xy, size_t n, int form, int out_kind,
                              void *d_out, void *stream) {
-    if (bad_common(curve, form, out_kind) || !d_out || (n && (!d_scalars || !d_bases_xy)) || n > 0x7FFFFFFFu)
+    if (bad_common(curve, form, out_kind) || !d_out || (n && (!d_scalars || !d_bases_xy)) || n > 0x7FFFFFF0u)
         return H2_ERR_ARGS;
     int rc = ensure_device();
     if (rc != H2_OK) return rc;
@@ -454,73 +722,65 @@ extern "C" int h2_msm_device(int curve, const void *d_scalars, const void *d_bas
     MsmContext &cx = msm_ctx(st);
     std::lock_guard<std::mutex> lk(cx.mu);
     const void *bases = d_bases_xy;
-    if (form == H2_FORM_CANONICAL && n) {
-        // bases arrive canonical: convert a private copy to Montgomery
+    if (form == H2_FORM_CANONICAL && n) {  // bases arrive canonical: convert a private copy to Montgomery
         if ((rc = cx.stage_b.reserve(n * 64)) != H2_OK) return rc;
         H2_HIP(hipMemcpyAsync(cx.stage_b.ptr, d_bases_xy, n * 64, hipMemcpyDeviceToDevice, st));
-        size_t cnt = n * 2;
-        if (curve == H2_PALLAS)
-            hipLaunchKernelGGL((k_to_mont<FP>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, cx.stage_b.as<u32>(), cnt);
-        else
-            hipLaunchKernelGGL((k_to_mont<FQ>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, cx.stage_b.as<u32>(), cnt);
+        to_mont_async(curve, cx.stage_b.as<u32>(), n * 2, st);
         bases = cx.stage_b.ptr;
     }
-    return msm_dispatch(cx, curve, d_scalars, bases, n, form, nullptr, nullptr, out_kind, d_out, st);
+    MsmArgs a{d_scalars, nullptr, bases, nullptr, n, false, choose_c(n ? n : 1, false), 0, 0xFFFFFFFFu, form, out_kind, d_out};
+    return msm_dispatch(cx, curve, a, st);
 }
 
 extern "C" int h2_msm(int curve, const uint64_t *scalars, const uint64_t *bases_xy, size_t n, int form, int out_kind,
                       uint64_t *out) {
-    if (bad_common(curve, form, out_kind) || !out || (n && (!scalars || !bases_xy)) || n > 0x7FFFFFFFu) return H2_ERR_ARGS;
+    if (bad_common(curve, form, out_kind) || !out || (n && (!scalars || !bases_xy)) || n > 0x7FFFFFF0u) return H2_ERR_ARGS;
     int rc = ensure_device();
     if (rc != H2_OK) return rc;
     MsmContext &cx = msm_ctx();
     const size_t out_bytes = out_kind == H2_OUT_AFFINE ? 64 : 96;
-    {
-        std::lock_guard<std::mutex> lk(cx.mu);
-        if ((rc = cx.stage_s.reserve(n * 32 + 32)) != H2_OK) return rc;
-        if ((rc = cx.stage_b.reserve(n * 64 + 64)) != H2_OK) return rc;
-        if ((rc = cx.out.reserve(128)) != H2_OK) return rc;
-        if (n) {
-            H2_HIP(hipMemcpyAsync(cx.stage_s.ptr, scalars, n * 32, hipMemcpyHostToDevice, 0));
-            H2_HIP(hipMemcpyAsync(cx.stage_b.ptr, bases_xy, n * 64, hipMemcpyHostToDevice, 0));
-            if (form == H2_FORM_CANONICAL) {
-                size_t cnt = n * 2;
-                if (curve == H2_PALLAS)
-                    hipLaunchKernelGGL((k_to_mont<FP>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, 0, cx.stage_b.as<u32>(), cnt);
-                else
-                    hipLaunchKernelGGL((k_to_mont<FQ>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, 0, cx.stage_b.as<u32>(), cnt);
-            }
-        }
-        rc = msm_dispatch(cx, curve, cx.stage_s.ptr, cx.stage_b.ptr, n, form, nullptr, nullptr, out_kind, cx.out.ptr, 0);
-        if (rc != H2_OK) return rc;
-        H2_HIP(hipMemcpyAsync(out, cx.out.ptr, out_bytes, hipMemcpyDeviceToHost, 0));
-        H2_HIP(hipStreamSynchronize(0));
+    std::lock_guard<std::mutex> lk(cx.mu);
+    if ((rc = cx.stage_s.reserve(n * 32 + 32)) != H2_OK) return rc;
+    if ((rc = cx.stage_b.reserve(n * 64 + 64)) != H2_OK) return rc;
+    if ((rc = cx.out.reserve(128)) != H2_OK) return rc;
+    if (n) {
+        H2_HIP(hipMemcpyAsync(cx.stage_s.ptr, scalars, n * 32, hipMemcpyHostToDevice, 0));
+        H2_HIP(hipMemcpyAsync(cx.stage_b.ptr, bases_xy, n * 64, hipMemcpyHostToDevice, 0));
+        if (form == H2_FORM_CANONICAL) to_mont_async(curve, cx.stage_b.as<u32>(), n * 2, 0);
     }
+    MsmArgs a{cx.stage_s.ptr, nullptr, cx.stage_b.ptr, nullptr, n, false, choose_c(n ? n : 1, false), 0, 0xFFFFFFFFu, form,
+              out_kind, cx.out.ptr};
+    if ((rc = msm_dispatch(cx, curve, a, 0)) != H2_OK) return rc;
+    H2_HIP(hipMemcpyAsync(out, cx.out.ptr, out_bytes, hipMemcpyDeviceToHost, 0));
+    H2_HIP(hipStreamSynchronize(0));
     return H2_OK;
 }
 
 extern "C" int h2_bases_register(int curve, const uint64_t *bases_xy, size_t n, int form, h2_bases_t *handle) {
     if ((curve != H2_PALLAS && curve != H2_VESTA) || (form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY) ||
-        !handle || (n && !bases_xy) || n > 0x7FFFFFFEu)
+        !handle || (n && !bases_xy) || n > (1u << 26))
         return H2_ERR_ARGS;
     int rc = ensure_device();
     if (rc != H2_OK) return rc;
     auto b = std::make_shared<Bases>();
     b->curve = curve;
     b->n = n;
-    b->d_xy = nullptr;
-    H2_HIP(hipMalloc(&b->d_xy, n * 64 + 64));
+    b->c = choose_c(n ? n : 1, true);
+    b->W = 255 / b->c + 1;
+    b->stride = (u32)n + 1;
+    H2_HIP(hipMalloc(&b->d_table, (size_t)b->W * b->stride * 64));
+    H2_HIP(hipMemsetAsync(b->d_table, 0, (size_t)b->W * b->stride * 64, 0));
+    H2_HIP(hipMalloc(&b->d_blind_tmp, (size_t)b->W * 128 + 64));
+    H2_HIP(hipMemsetAsync(b->d_blind_tmp, 0, (size_t)b->W * 128 + 64, 0));
     if (n) {
-        H2_HIP(hipMemcpy(b->d_xy, bases_xy, n * 64, hipMemcpyHostToDevice));
-        if (form == H2_FORM_CANONICAL) {
-            size_t cnt = n * 2;
-            if (curve == H2_PALLAS)
-                hipLaunchKernelGGL((k_to_mont<FP>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, 0, (u32 *)b->d_xy, cnt);
-            else
-                hipLaunchKernelGGL((k_to_mont<FQ>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, 0, (u32 *)b->d_xy, cnt);
-            H2_HIP(hipStreamSynchronize(0));
+        H2_HIP(hipMemcpyAsync(b->d_table, bases_xy, n * 64, hipMemcpyHostToDevice, 0));
+        if (form == H2_FORM_CANONICAL) to_mont_async(curve, (u32 *)b->d_table, n * 2, 0);
+        if ((rc = table_fill(*b, 0, (u32)n, 0)) != H2_OK) {
+            (void)hipFree(b->d_table);
+            return rc;
         }
     }
+    H2_HIP(hipStreamSynchronize(0));
     std::lock_guard<std::mutex> lk(g_bases_mu);
     h2_bases_t h = g_next_handle++;
     g_bases[h] = b;
@@ -537,7 +797,11 @@ extern "C" int h2_bases_free(h2_bases_t handle) {
         b = it->second;
         g_bases.erase(it);
     }
-    if (b->d_xy) H2_HIP(hipFree(b->d_xy));
+    if (b->d_table) {
+        H2_HIP(hipDeviceSynchronize());
+        H2_HIP(hipFree(b->d_table));
+        if (b->d_blind_tmp) H2_HIP(hipFree(b->d_blind_tmp));
+    }
     return H2_OK;
 }
 
@@ -552,15 +816,19 @@ extern "C" int h2_commit_device(h2_bases_t g, const void *d_scalars, size_t n, c
     hipStream_t st = (hipStream_t)stream;
     MsmContext &cx = msm_ctx(st);
     std::lock_guard<std::mutex> lk(cx.mu);
-    const void *w = d_w_xy;
-    if (d_w_xy && form == H2_FORM_CANONICAL) {
-        if ((rc = cx.small.reserve(64)) != H2_OK) return rc;
-        H2_HIP(hipMemcpyAsync(cx.small.ptr, d_w_xy, 64, hipMemcpyDeviceToDevice, st));
-        if (b->curve == H2_PALLAS) hipLaunchKernelGGL((k_to_mont<FP>), dim3(1), dim3(256), 0, st, cx.small.as<u32>(), (size_t)2);
-        else hipLaunchKernelGGL((k_to_mont<FQ>), dim3(1), dim3(256), 0, st, cx.small.as<u32>(), (size_t)2);
-        w = cx.small.ptr;
+    if (d_w_xy) {
+        const void *w = d_w_xy;
+        if (form == H2_FORM_CANONICAL) {
+            if ((rc = cx.small.reserve(64)) != H2_OK) return rc;
+            H2_HIP(hipMemcpyAsync(cx.small.ptr, d_w_xy, 64, hipMemcpyDeviceToDevice, st));
+            to_mont_async(b->curve, cx.small.as<u32>(), 2, st);
+            w = cx.small.ptr;
+        }
+        std::lock_guard<std::mutex> bl(b->mu);
+        if ((rc = ensure_blind_base(*b, w, st)) != H2_OK) return rc;
     }
-    return commit_core(cx, b->curve, d_scalars, b->d_xy, n, form, w, d_blind, out_kind, d_out, st);
+    MsmArgs a{d_scalars, d_blind, b->d_table, nullptr, n, true, b->c, b->stride, (u32)b->n, form, out_kind, d_out};
+    return msm_dispatch(cx, b->curve, a, st);
 }
 
 extern "C" int h2_commit(h2_bases_t g, const uint64_t *scalars, size_t n, const uint64_t *w_xy, const uint64_t *blind,
@@ -578,19 +846,17 @@ extern "C" int h2_commit(h2_bases_t g, const uint64_t *scalars, size_t n, const 
     if ((rc = cx.small.reserve(64 + 32)) != H2_OK) return rc;
     if ((rc = cx.out.reserve(128)) != H2_OK) return rc;
     if (n) H2_HIP(hipMemcpyAsync(cx.stage_s.ptr, scalars, n * 32, hipMemcpyHostToDevice, 0));
-    const void *d_w = nullptr, *d_bl = nullptr;
+    const void *d_bl = nullptr;
     if (w_xy) {
         H2_HIP(hipMemcpyAsync(cx.small.ptr, w_xy, 64, hipMemcpyHostToDevice, 0));
         H2_HIP(hipMemcpyAsync((char *)cx.small.ptr + 64, blind, 32, hipMemcpyHostToDevice, 0));
-        if (form == H2_FORM_CANONICAL) {
-            if (b->curve == H2_PALLAS) hipLaunchKernelGGL((k_to_mont<FP>), dim3(1), dim3(256), 0, 0, cx.small.as<u32>(), (size_t)2);
-            else hipLaunchKernelGGL((k_to_mont<FQ>), dim3(1), dim3(256), 0, 0, cx.small.as<u32>(), (size_t)2);
-        }
-        d_w = cx.small.ptr;
+        if (form == H2_FORM_CANONICAL) to_mont_async(b->curve, cx.small.as<u32>(), 2, 0);
         d_bl = (char *)cx.small.ptr + 64;
+        std::lock_guard<std::mutex> bl(b->mu);
+        if ((rc = ensure_blind_base(*b, cx.small.ptr, 0)) != H2_OK) return rc;
     }
-    rc = commit_core(cx, b->curve, cx.stage_s.ptr, b->d_xy, n, form, d_w, d_bl, out_kind, cx.out.ptr, 0);
-    if (rc != H2_OK) return rc;
+    MsmArgs a{cx.stage_s.ptr, d_bl, b->d_table, nullptr, n, true, b->c, b->stride, (u32)b->n, form, out_kind, cx.out.ptr};
+    if ((rc = msm_dispatch(cx, b->curve, a, 0)) != H2_OK) return rc;
     H2_HIP(hipMemcpyAsync(out, cx.out.ptr, out_bytes, hipMemcpyDeviceToHost, 0));
     H2_HIP(hipStreamSynchronize(0));
     return H2_OK;

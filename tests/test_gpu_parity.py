@@ -227,6 +227,58 @@ def test_params_commit_matches_oracle(curve):
     params.close()
 
 
+def test_registered_bases_prefix_blind_and_skew():
+    """h2_commit on a registered (precomputed-table) basis: full commits with two different blind bases,
+    prefix MSMs over the first n' bases (IPA rounds, poly/commitment/prover.rs:107-108), and heavily
+    skewed columns (all-equal scalars, tiny scalars, 99 % zeros) -- the work partition must not care."""
+    import ctypes as C
+    from halo2_amd.arithmetic import _p
+    curve = h.VESTA
+    bm, sm = o.CURVES[curve]
+    sf = co.field_of_curve(curve, "scalar")
+    n = 3000
+    g = co.generate_bases(curve, 777, n)
+    lib = h.lib()
+    hd = C.c_uint64(0)
+    assert lib.h2_bases_register(curve, _p(g), n, h.FORM_MONTGOMERY, C.byref(hd)) == 0
+    out = np.zeros(12, np.uint64)
+    cols = {
+        "uniform": co.random_field(sf, 1, n),
+        "all_equal": co.to_mont(sf, co.ints_to_limbs([0xDEADBEEFCAFE] * n)),
+        "tiny": co.to_mont(sf, co.ints_to_limbs([i % 7 for i in range(n)])),
+        "sparse": co.to_mont(sf, co.ints_to_limbs([0 if i % 100 else (i * 7919 + 1) for i in range(n)])),
+        "max": co.to_mont(sf, co.ints_to_limbs([sm - 1 - i for i in range(n)])),
+    }
+    w1 = co.points_to_mont(curve, [o.ec_mul(5, (bm - 1, 2), bm)])[0]
+    w2 = co.points_to_mont(curve, [o.ec_mul(7, (bm - 1, 2), bm)])[0]
+    blind = fields.scalar_limbs(123456789, sf)
+    for name, col in cols.items():
+        for w in (w1, w2, w1):
+            assert lib.h2_commit(hd, _p(col), n, _p(w), _p(blind), h.FORM_MONTGOMERY, 0, _p(out)) == 0
+            want = co.jac_to_affine_ints(curve, co.commit(curve, g, w, col, blind))
+            assert affine_of(curve, out) == want, name
+        for n_used in (0, 1, 17, 1500, n):
+            assert lib.h2_commit(hd, _p(col), n_used, None, None, h.FORM_MONTGOMERY, 0, _p(out)) == 0
+            want = co.jac_to_affine_ints(curve, co.best_multiexp(curve, col[:n_used], g[:n_used]))
+            assert affine_of(curve, out) == want, (name, n_used)
+    assert lib.h2_commit(hd, _p(cols["uniform"]), n + 1, None, None, h.FORM_MONTGOMERY, 0, _p(out)) == 1   # more than registered
+    assert lib.h2_bases_free(hd) == 0
+    assert lib.h2_bases_free(hd) == 4
+
+
+def test_generic_msm_skewed_large():
+    """2^17 points, every scalar identical (one bucket per window owns everything) and all < 2^16."""
+    curve = h.PALLAS
+    bm, sm = o.CURVES[curve]
+    sf = co.field_of_curve(curve, "scalar")
+    n = 1 << 17
+    bases = co.generate_bases(curve, 99, n)
+    same = co.to_mont(sf, co.ints_to_limbs([0x1234567] * n))
+    assert affine_of(curve, h.best_multiexp(same, bases, curve)) == co.jac_to_affine_ints(curve, co.best_multiexp(curve, same, bases))
+    small = co.to_mont(sf, co.ints_to_limbs([(i * 2654435761) & 0xFFFF for i in range(n)]))
+    assert affine_of(curve, h.best_multiexp(small, bases, curve)) == co.jac_to_affine_ints(curve, co.best_multiexp(curve, small, bases))
+
+
 def test_device_resident_path():
     """torch CUDA tensors in, device tensors out, on torch's current stream."""
     torch = pytest.importorskip("torch")
