@@ -173,6 +173,13 @@ template <int F> __device__ __forceinline__ fe fe_mul_col(const fe &a, const fe 
     return fe_reduce_once<F>(r);
 }
 
+// Variant: the whole multiplication as ONE asm statement with the accumulator in pinned VGPRs
+// (generated, see gen_field_mul.py block_multiplier): no compiler glue between columns.
+template <int F> __device__ __forceinline__ fe fe_mul_blk(const fe &a, const fe &b) {
+#include "field_mul_blk.inc"
+    return fe_reduce_once<F>(r);
+}
+
 // Variant: plain C operand-scanning (CIOS); the compiler picks the instructions.  Kept as the
 // readable specification of the multiplier and as an A/B baseline for the asm variants.
 template <int F> __device__ __forceinline__ fe fe_mul_c(const fe &a, const fe &b) {
@@ -213,6 +220,8 @@ template <int F> __device__ __forceinline__ fe fe_mulx(const fe &a, const fe &b)
     return fe_mul_c<F>(a, b);
 #elif H2_MUL_IMPL == 1
     return fe_mul_col<F>(a, b);
+#elif H2_MUL_IMPL == 3
+    return fe_mul_blk<F>(a, b);
 #else
     return fe_mul<F>(a, b);
 #endif

@@ -14,11 +14,11 @@
 //               offset and the offsets of its fixed-size work parts
 //   scatter     same workgroups: offsets in LDS, LDS atomics hand out slots; base index | sign
 //               lands in the bucket-sorted entry list                                           [LDS]
-//   accumulate  the hot kernel: the sorted entry list is cut into PARTS of <= 64 entries of one
-//               bucket; one lane per part gathers 64-B affine bases and does XYZZ mixed additions in
-//               registers.  Every lane does the same amount of work whatever the digit distribution
-//               (heavy buckets -- repeated scalars, tiny scalars -- just own more parts)          [VALU]
-//   fold        parts -> buckets: 32-way partial sums, then a per-bucket finisher
+//   accumulate  the hot kernel: the sorted entry list is cut into T EQUAL ranges, T = the lanes the chip
+//               keeps resident; each lane gathers 64-B affine bases and does XYZZ mixed additions in
+//               registers, flushing a segment whenever its range crosses a bucket boundary.  Every lane
+//               does the same work whatever the digit distribution (repeated or tiny scalars)      [VALU]
+//   finish      bucket = its own segment + the heads of the ranges that begin inside it
 //   reduce      running-sum fold (:86-92) restructured as 8-bucket segments + a small scalar
 //               multiple per segment, then a tree sum per slice
 //   combine     Horner over windows (:169-178) on one lane; emits Jacobian or affine
@@ -47,8 +47,6 @@ namespace h2 {
 static constexpr int kMaxC = 16;
 static constexpr u32 kZeroCode = 0xFFFFu;
 static constexpr int kSeg = 8;     // buckets per reduce segment
-static constexpr u32 kPart1 = 64;  // entries per accumulate part
-static constexpr u32 kPart2 = 32;  // parts per fold part
 static constexpr u32 kScanBlock = 1024;
 
 struct MsmShape {
@@ -158,15 +156,8 @@ __global__ void __launch_bounds__(256) msm_chunk_prefix(u32 *__restrict__ hist, 
     counts[g] = run;
 }
 
-// ---- scan b: three exclusive scans over the buckets in one sweep ---------------------------------
-//   starts  : entry offsets          (scan of cnt)
-//   pstarts : accumulate-part offsets (scan of ceil(cnt / kPart1))
-//   fstarts : fold-part offsets       (scan of ceil(ceil(cnt / kPart1) / kPart2))
-// arrays have total + 1 entries (last = grand total).  Three kernels: block sums, scan of block sums, apply.
-__device__ __forceinline__ void scan_terms(u32 cnt, u32 &p1, u32 &p2) {
-    p1 = (cnt + kPart1 - 1) / kPart1;
-    p2 = (p1 + kPart2 - 1) / kPart2;
-}
+// ---- scan b: exclusive scan of the bucket totals -> entry offsets (starts[total] = M) ----------------
+// three kernels: block sums, scan of block sums, apply.
 __device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *sh, u32 &total) {
     // blockDim.x == kScanBlock
     const u32 t = threadIdx.x;
@@ -184,53 +175,34 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *sh, u32 &total) {
     return r;
 }
 __global__ void __launch_bounds__(kScanBlock) msm_scan_blocksums(const u32 *__restrict__ counts, u32 *__restrict__ bsums,
-                                                                 u32 total, u32 nblocks) {
+                                                                 u32 total) {
     __shared__ u32 sh[kScanBlock];
     u32 g = blockIdx.x * kScanBlock + threadIdx.x;
-    u32 cnt = g < total ? counts[g] : 0, p1, p2, tot;
-    scan_terms(cnt, p1, p2);
-    (void)block_excl_scan(cnt, sh, tot);
+    u32 tot;
+    (void)block_excl_scan(g < total ? counts[g] : 0, sh, tot);
     if (threadIdx.x == 0) bsums[blockIdx.x] = tot;
-    (void)block_excl_scan(p1, sh, tot);
-    if (threadIdx.x == 0) bsums[nblocks + blockIdx.x] = tot;
-    (void)block_excl_scan(p2, sh, tot);
-    if (threadIdx.x == 0) bsums[2 * nblocks + blockIdx.x] = tot;
 }
-__global__ void __launch_bounds__(kScanBlock) msm_scan_top(u32 *__restrict__ bsums, u32 nblocks, u32 *__restrict__ totals) {
+__global__ void __launch_bounds__(kScanBlock) msm_scan_top(u32 *__restrict__ bsums, u32 nblocks, u32 *__restrict__ grand) {
     __shared__ u32 sh[kScanBlock];
-    for (int k = 0; k < 3; ++k) {
-        u32 carry = 0;
-        for (u32 base = 0; base < nblocks; base += kScanBlock) {
-            u32 i = base + threadIdx.x;
-            u32 v = i < nblocks ? bsums[k * nblocks + i] : 0, tot;
-            u32 ex = block_excl_scan(v, sh, tot);
-            if (i < nblocks) bsums[k * nblocks + i] = carry + ex;
-            carry += tot;
-        }
-        if (threadIdx.x == 0) totals[k] = carry;
+    u32 carry = 0;
+    for (u32 base = 0; base < nblocks; base += kScanBlock) {
+        u32 i = base + threadIdx.x;
+        u32 v = i < nblocks ? bsums[i] : 0, tot;
+        u32 ex = block_excl_scan(v, sh, tot);
+        if (i < nblocks) bsums[i] = carry + ex;
+        carry += tot;
     }
+    if (threadIdx.x == 0) *grand = carry;
 }
 __global__ void __launch_bounds__(kScanBlock) msm_scan_apply(const u32 *__restrict__ counts, const u32 *__restrict__ bsums,
-                                                             const u32 *__restrict__ totals, u32 *__restrict__ starts,
-                                                             u32 *__restrict__ pstarts, u32 *__restrict__ fstarts, u32 total,
-                                                             u32 nblocks) {
+                                                             const u32 *__restrict__ grand, u32 *__restrict__ starts,
+                                                             u32 total) {
     __shared__ u32 sh[kScanBlock];
     u32 g = blockIdx.x * kScanBlock + threadIdx.x;
-    u32 cnt = g < total ? counts[g] : 0, p1, p2, tot;
-    scan_terms(cnt, p1, p2);
-    u32 a = block_excl_scan(cnt, sh, tot) + bsums[blockIdx.x];
-    u32 b = block_excl_scan(p1, sh, tot) + bsums[nblocks + blockIdx.x];
-    u32 c = block_excl_scan(p2, sh, tot) + bsums[2 * nblocks + blockIdx.x];
-    if (g < total) {
-        starts[g] = a;
-        pstarts[g] = b;
-        fstarts[g] = c;
-    }
-    if (g == 0) {
-        starts[total] = totals[0];
-        pstarts[total] = totals[1];
-        fstarts[total] = totals[2];
-    }
+    u32 tot;
+    u32 a = block_excl_scan(g < total ? counts[g] : 0, sh, tot) + bsums[blockIdx.x];
+    if (g < total) starts[g] = a;
+    if (g == 0) starts[total] = *grand;
 }
 
 // ---- scatter: bucket-sorted entry list ----------------------------------------------------------
@@ -270,67 +242,116 @@ __device__ __forceinline__ u32 upper_bucket(const u32 *__restrict__ arr, u32 n, 
     return lo;
 }
 
-// ---- accumulate: one lane per part of <= kPart1 entries of one bucket ------------------------------
+// ---- accumulate: exact static partition of the sorted entry list ------------------------------------
+// The M sorted entries are cut into T equal ranges, T = the number of lanes the chip keeps resident for
+// this kernel, so every lane does the same number of mixed additions and the launch is ONE full round
+// (bucket-aligned parts left a 25 % tail: 1.5 rounds of work dispatched as 2).  A lane's range may span
+// several buckets: its first segment -- the bucket already open at the range start -- goes to
+// heads[t]; every later segment starts a new bucket and is that bucket's only non-head segment, stored
+// straight into buckets[b] (zeroed beforehand).  bucket b = buckets[b] + sum of heads[t] for
+// ceil(start_b / chunk) <= t < ceil(start_{b+1} / chunk), which msm_finish_buckets adds up.
 template <int FB>
 __global__ void __launch_bounds__(256) msm_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
                                                       u32 extra_index, const u32 *__restrict__ entries,
-                                                      const u32 *__restrict__ starts, const u32 *__restrict__ pstarts,
-                                                      u32 *__restrict__ parts, u32 total_buckets) {
+                                                      const u32 *__restrict__ starts, u32 *__restrict__ heads,
+                                                      u32 *__restrict__ buckets, u32 total_buckets, u32 T) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= pstarts[total_buckets]) return;
-    const u32 b = upper_bucket(pstarts, total_buckets, t);
-    const u32 k = t - pstarts[b];
-    const u32 lo = starts[b] + k * kPart1, hi = min(starts[b + 1], lo + kPart1);
+    if (t >= T) return;
+    const u32 M = starts[total_buckets];
+    const u32 chunk = (M + T - 1) / T;
+    const u32 lo = min(M, t * chunk), hi = min(M, lo + chunk);
     xyzz<FB> acc = xyzz_identity<FB>();
-    u32 e = entries[lo];
-    u32 idx = e & 0x7FFFFFFFu;
-    // the blind's base `w` (Params::commit, poly/commitment.rs:127) may live in its own buffer
-    affine<FB> nxt = aff_load<FB>(idx == extra_index ? extra_base : bases + 16 * (size_t)idx);
-    for (u32 i = lo; i < hi; ++i) {
-        affine<FB> p = nxt;
-        const u32 neg = e >> 31;
-        if (i + 1 < hi) {  // fetch the next base while this one is being added
-            e = entries[i + 1];
-            idx = e & 0x7FFFFFFFu;
-            nxt = aff_load<FB>(idx == extra_index ? extra_base : bases + 16 * (size_t)idx);
+    if (lo < hi) {
+        u32 b = upper_bucket(starts, total_buckets, lo);
+        u32 bend = starts[b + 1];
+        bool first = true;
+        u32 e0 = entries[lo], e1 = lo + 1 < hi ? entries[lo + 1] : 0;
+        u32 idx = e0 & 0x7FFFFFFFu;
+        // the blind's base `w` (Params::commit, poly/commitment.rs:127) may live in its own buffer
+        affine<FB> nxt = aff_load<FB>(idx == extra_index ? extra_base : bases + 16 * (size_t)idx);
+        for (u32 i = lo; i < hi; ++i) {
+            affine<FB> p = nxt;
+            const u32 neg = e0 >> 31;
+            // software pipeline: entry i+2 and base i+1 are in flight while point i is added
+            const u32 e2 = i + 2 < hi ? entries[i + 2] : 0;
+            if (i + 1 < hi) {
+                idx = e1 & 0x7FFFFFFFu;
+                nxt = aff_load<FB>(idx == extra_index ? extra_base : bases + 16 * (size_t)idx);
+            }
+            e0 = e1;
+            e1 = e2;
+            if (neg) p.y = fe_neg<FB>(p.y);
+            xyzz_madd<FB>(acc, p);
+            if (i + 1 == bend && i + 1 < hi) {  // bucket b ends inside the range: flush, open the next non-empty bucket
+                xyzz_store<FB>(first ? heads + 32 * (size_t)t : buckets + 32 * (size_t)b, acc);
+                first = false;
+                acc = xyzz_identity<FB>();
+                do { ++b; bend = starts[b + 1]; } while (bend <= i + 1);
+            }
         }
-        if (neg) p.y = fe_neg<FB>(p.y);
-        xyzz_madd<FB>(acc, p);
+        xyzz_store<FB>(first ? heads + 32 * (size_t)t : buckets + 32 * (size_t)b, acc);
+        if (first) return;
+        acc = xyzz_identity<FB>();
     }
-    xyzz_store<FB>(parts + 32 * (size_t)t, acc);
+    if (lo >= hi) xyzz_store<FB>(heads + 32 * (size_t)t, acc);
 }
 
-// ---- fold level: one lane per group of <= kPart2 parts of one bucket --------------------------------
+// ---- finisher: bucket b = its own non-head segment + the heads of the ranges that begin inside it -----
+// Buckets owning more than kHeavy heads (scalars repeated thousands of times) are parked on a list and summed
+// by a whole workgroup each in msm_finish_heavy.
+static constexpr u32 kHeavy = 64;
 template <int FB>
-__global__ void __launch_bounds__(256) msm_fold_parts(const u32 *__restrict__ parts, const u32 *__restrict__ pstarts,
-                                                      const u32 *__restrict__ fstarts, u32 *__restrict__ folded,
-                                                      u32 total_buckets) {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= fstarts[total_buckets]) return;
-    const u32 b = upper_bucket(fstarts, total_buckets, t);
-    const u32 k = t - fstarts[b];
-    const u32 lo = pstarts[b] + k * kPart2, hi = min(pstarts[b + 1], lo + kPart2);
-    xyzz<FB> acc = xyzz_load<FB>(parts + 32 * (size_t)lo);
-    for (u32 i = lo + 1; i < hi; ++i) {
-        xyzz<FB> p = xyzz_load<FB>(parts + 32 * (size_t)i);
-        xyzz_add<FB>(acc, p);
-    }
-    xyzz_store<FB>(folded + 32 * (size_t)t, acc);
-}
-
-// ---- finisher: one lane per bucket sums what is left (one element unless the bucket is enormous) -----
-template <int FB>
-__global__ void __launch_bounds__(256) msm_finish_buckets(const u32 *__restrict__ folded, const u32 *__restrict__ fstarts,
-                                                          u32 *__restrict__ buckets, u32 total_buckets) {
+__global__ void __launch_bounds__(256) msm_finish_buckets(const u32 *__restrict__ heads, const u32 *__restrict__ starts,
+                                                          u32 *__restrict__ buckets, u32 *__restrict__ heavy,
+                                                          u32 total_buckets, u32 T) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= total_buckets) return;
-    const u32 lo = fstarts[b], hi = fstarts[b + 1];
-    xyzz<FB> acc = xyzz_identity<FB>();
-    for (u32 i = lo; i < hi; ++i) {
-        xyzz<FB> p = xyzz_load<FB>(folded + 32 * (size_t)i);
+    const u32 M = starts[total_buckets];
+    const u32 chunk = max(1u, (M + T - 1) / T);
+    const u32 h0 = (starts[b] + chunk - 1) / chunk, h1 = (starts[b + 1] + chunk - 1) / chunk;
+    if (h1 <= h0) return;
+    if (h1 - h0 > kHeavy) {
+        u32 slot = atomicAdd(&heavy[0], 1u);
+        heavy[1 + slot] = b;
+        return;
+    }
+    xyzz<FB> acc = xyzz_load<FB>(buckets + 32 * (size_t)b);
+    for (u32 t = h0; t < h1; ++t) {
+        xyzz<FB> p = xyzz_load<FB>(heads + 32 * (size_t)t);
         xyzz_add<FB>(acc, p);
     }
     xyzz_store<FB>(buckets + 32 * (size_t)b, acc);
+}
+template <int FB>
+__global__ void __launch_bounds__(256) msm_finish_heavy(const u32 *__restrict__ heads, const u32 *__restrict__ starts,
+                                                        u32 *__restrict__ buckets, const u32 *__restrict__ heavy,
+                                                        u32 total_buckets, u32 T) {
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    if (blockIdx.x >= heavy[0]) return;
+    const u32 b = heavy[1 + blockIdx.x], t = threadIdx.x;
+    const u32 M = starts[total_buckets];
+    const u32 chunk = max(1u, (M + T - 1) / T);
+    const u32 h0 = (starts[b] + chunk - 1) / chunk, h1 = (starts[b + 1] + chunk - 1) / chunk;
+    xyzz<FB> acc = xyzz_identity<FB>();
+    if (t == 0) acc = xyzz_load<FB>(buckets + 32 * (size_t)b);
+    for (u32 i = h0 + t; i < h1; i += blockDim.x) {
+        xyzz<FB> p = xyzz_load<FB>(heads + 32 * (size_t)i);
+        xyzz_add<FB>(acc, p);
+    }
+    xyzz_store<FB>(sh + 32 * t, acc);
+    __syncthreads();
+    for (u32 off = blockDim.x / 2; off > 0; off >>= 1) {
+        if (t < off) {
+            xyzz<FB> x = xyzz_load<FB>(sh + 32 * t), y = xyzz_load<FB>(sh + 32 * (t + off));
+            xyzz_add<FB>(x, y);
+            xyzz_store<FB>(sh + 32 * t, x);
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        xyzz<FB> r = xyzz_load<FB>(sh);
+        xyzz_store<FB>(buckets + 32 * (size_t)b, r);
+    }
 }
 
 // k * p for a small k (bucket index offsets, < 2^16): MSB-first double-and-add
@@ -520,9 +541,10 @@ __global__ void k_points_sum(const u32 *__restrict__ pts, u32 count, u32 *__rest
 // ---- host orchestration ----------------------------------------------------------------------------
 struct MsmContext {
     std::mutex mu;
-    DevBuf digits, hist, counts, starts, pstarts, fstarts, bsums, entries, parts, folded, buckets, partial, ssums,
-        stage_s, stage_b, out, small;
+    DevBuf digits, hist, counts, starts, bsums, entries, heads, heavy, buckets, partial, ssums, stage_s, stage_b, out,
+        small;
     bool attr_set = false;
+    u32 lanes[2] = {0, 0};  // resident lanes of msm_accumulate<FP>, <FQ> on this device
 };
 
 // One workspace per (device, stream): calls enqueued on different streams never share scratch.
@@ -565,28 +587,36 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     const MsmShape sh = make_shape(m, a.c, a.table);
     const u32 tb = sh.total_buckets, segs = tb / kSeg;
     const size_t all_items = (size_t)sh.W * m;
-    const size_t max_parts = all_items / kPart1 + tb + 1, max_folds = max_parts / kPart2 + tb + 1;
     const u32 nblocks = (tb + kScanBlock - 1) / kScanBlock;
-    if ((rc = cx.digits.reserve(all_items * 2)) != H2_OK) return rc;
-    if ((rc = cx.hist.reserve((size_t)sh.slices * sh.B * sh.NB * 4)) != H2_OK) return rc;
-    if ((rc = cx.counts.reserve((size_t)tb * 4)) != H2_OK) return rc;
-    if ((rc = cx.starts.reserve((size_t)(tb + 1) * 4)) != H2_OK) return rc;
-    if ((rc = cx.pstarts.reserve((size_t)(tb + 1) * 4)) != H2_OK) return rc;
-    if ((rc = cx.fstarts.reserve((size_t)(tb + 1) * 4)) != H2_OK) return rc;
-    if ((rc = cx.bsums.reserve((size_t)(3 * nblocks + 4) * 4)) != H2_OK) return rc;
-    if ((rc = cx.entries.reserve(all_items * 4)) != H2_OK) return rc;
-    if ((rc = cx.parts.reserve(max_parts * 128)) != H2_OK) return rc;
-    if ((rc = cx.folded.reserve(max_folds * 128)) != H2_OK) return rc;
-    if ((rc = cx.buckets.reserve((size_t)tb * 128)) != H2_OK) return rc;
-    if ((rc = cx.partial.reserve((size_t)segs * 128)) != H2_OK) return rc;
-    if ((rc = cx.ssums.reserve((size_t)sh.slices * 128)) != H2_OK) return rc;
     if (!cx.attr_set) {
         H2_HIP(hipFuncSetAttribute((const void *)msm_count, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         H2_HIP(hipFuncSetAttribute((const void *)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         cx.attr_set = true;
     }
+    u32 &lanes = cx.lanes[FB];
+    if (!lanes) {  // how many lanes of the accumulate kernel the chip holds at once
+        int dev = 0, cus = 0, per_cu = 0;
+        H2_HIP(hipGetDevice(&dev));
+        H2_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB>, 256, 0));
+        lanes = (u32)cus * (u32)std::max(per_cu, 1) * 256u;
+    }
+    // one round of resident lanes; small problems use fewer lanes so a range keeps >= 16 entries
+    u32 T = (u32)std::min<size_t>(lanes, std::max<size_t>(256, (all_items / 16 + 255) / 256 * 256));
+    const u32 max_heavy = T / kHeavy + 2;
+    if ((rc = cx.digits.reserve(all_items * 2)) != H2_OK) return rc;
+    if ((rc = cx.hist.reserve((size_t)sh.slices * sh.B * sh.NB * 4)) != H2_OK) return rc;
+    if ((rc = cx.counts.reserve((size_t)tb * 4)) != H2_OK) return rc;
+    if ((rc = cx.starts.reserve((size_t)(tb + 1) * 4)) != H2_OK) return rc;
+    if ((rc = cx.bsums.reserve((size_t)(nblocks + 4) * 4)) != H2_OK) return rc;
+    if ((rc = cx.entries.reserve(all_items * 4)) != H2_OK) return rc;
+    if ((rc = cx.heads.reserve((size_t)T * 128)) != H2_OK) return rc;
+    if ((rc = cx.heavy.reserve((size_t)(max_heavy + 1) * 4)) != H2_OK) return rc;
+    if ((rc = cx.buckets.reserve((size_t)tb * 128)) != H2_OK) return rc;
+    if ((rc = cx.partial.reserve((size_t)segs * 128)) != H2_OK) return rc;
+    if ((rc = cx.ssums.reserve((size_t)sh.slices * 128)) != H2_OK) return rc;
     const u32 m32 = (u32)m;
-    u32 *totals = cx.bsums.as<u32>() + 3 * nblocks;
+    u32 *grand = cx.bsums.as<u32>() + nblocks;
     prof_begin(PROF_MSM_SORT, st);
     hipLaunchKernelGGL((msm_recode<FS>), dim3((m32 + 255) / 256), dim3(256), 0, st, (const u32 *)a.d_scalars,
                        (const u32 *)a.d_extra_scalar, cx.digits.as<uint16_t>(), m32, sh.c, sh.W,
@@ -595,27 +625,27 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                        cx.hist.as<u32>(), sh.items, sh.chunk, sh.NB);
     hipLaunchKernelGGL(msm_chunk_prefix, dim3((tb + 255) / 256), dim3(256), 0, st, cx.hist.as<u32>(), cx.counts.as<u32>(),
                        sh.NB, sh.B, tb);
-    hipLaunchKernelGGL(msm_scan_blocksums, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), tb,
-                       nblocks);
-    hipLaunchKernelGGL(msm_scan_top, dim3(1), dim3(kScanBlock), 0, st, cx.bsums.as<u32>(), nblocks, totals);
-    hipLaunchKernelGGL(msm_scan_apply, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), totals,
-                       cx.starts.as<u32>(), cx.pstarts.as<u32>(), cx.fstarts.as<u32>(), tb, nblocks);
+    hipLaunchKernelGGL(msm_scan_blocksums, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), tb);
+    hipLaunchKernelGGL(msm_scan_top, dim3(1), dim3(kScanBlock), 0, st, cx.bsums.as<u32>(), nblocks, grand);
+    hipLaunchKernelGGL(msm_scan_apply, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), grand,
+                       cx.starts.as<u32>(), tb);
     const u32 extra_col = a.d_extra_scalar ? (a.table ? a.extra_col : (u32)a.n_used) : 0xFFFFFFFFu;
     hipLaunchKernelGGL(msm_scatter, dim3(sh.B, sh.slices), dim3(1024), sh.NB * 4, st, cx.digits.as<uint16_t>(),
                        cx.hist.as<u32>(), cx.starts.as<u32>(), cx.entries.as<u32>(), sh.items, sh.chunk, sh.NB, m32,
                        a.table ? a.stride : 0u, extra_col, a.table ? 1 : 0);
+    H2_HIP(hipMemsetAsync(cx.buckets.ptr, 0, (size_t)tb * 128, st));
+    H2_HIP(hipMemsetAsync(cx.heavy.ptr, 0, 4, st));
     prof_end(PROF_MSM_SORT, st);
     prof_begin(PROF_MSM_ACCUMULATE, st);
-    hipLaunchKernelGGL((msm_accumulate<FB>), dim3((unsigned)((max_parts + 255) / 256)), dim3(256), 0, st,
-                       (const u32 *)a.d_bases, (const u32 *)a.d_extra_base,
-                       (!a.table && a.d_extra_base) ? (u32)a.n_used : 0xFFFFFFFFu, cx.entries.as<u32>(), cx.starts.as<u32>(),
-                       cx.pstarts.as<u32>(), cx.parts.as<u32>(), tb);
+    hipLaunchKernelGGL((msm_accumulate<FB>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases,
+                       (const u32 *)a.d_extra_base, (!a.table && a.d_extra_base) ? (u32)a.n_used : 0xFFFFFFFFu,
+                       cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T);
     prof_end(PROF_MSM_ACCUMULATE, st);
     prof_begin(PROF_MSM_REDUCE, st);
-    hipLaunchKernelGGL((msm_fold_parts<FB>), dim3((unsigned)((max_folds + 255) / 256)), dim3(256), 0, st, cx.parts.as<u32>(),
-                       cx.pstarts.as<u32>(), cx.fstarts.as<u32>(), cx.folded.as<u32>(), tb);
-    hipLaunchKernelGGL((msm_finish_buckets<FB>), dim3((tb + 255) / 256), dim3(256), 0, st, cx.folded.as<u32>(),
-                       cx.fstarts.as<u32>(), cx.buckets.as<u32>(), tb);
+    hipLaunchKernelGGL((msm_finish_buckets<FB>), dim3((tb + 255) / 256), dim3(256), 0, st, cx.heads.as<u32>(),
+                       cx.starts.as<u32>(), cx.buckets.as<u32>(), cx.heavy.as<u32>(), tb, T);
+    hipLaunchKernelGGL((msm_finish_heavy<FB>), dim3(max_heavy), dim3(256), 256 * 128, st, cx.heads.as<u32>(),
+                       cx.starts.as<u32>(), cx.buckets.as<u32>(), cx.heavy.as<u32>(), tb, T);
     hipLaunchKernelGGL((msm_reduce_segments<FB>), dim3((segs + 255) / 256), dim3(256), 0, st, cx.buckets.as<u32>(),
                        cx.partial.as<u32>(), sh.NB, segs);
     hipLaunchKernelGGL((msm_sum_slice<FB>), dim3(sh.slices), dim3(256), 256 * 128, st, cx.partial.as<u32>(),
