@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=K_LOG, help="override the MSM size (parity/debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--columns", type=int, default=4, help="distinct scalar columns resident in HBM")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("H2_BENCH_STREAMS", "1")),
+                    help="HIP streams the independent column commits are spread over (per GPU)")
     args = ap.parse_args()
 
     import torch
@@ -83,12 +85,13 @@ def main():
     check(lib.h2_bases_register(curve, _p(bases), n, h.FORM_MONTGOMERY, C.byref(params_g)), "h2_bases_register")
     d_cols = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]
     d_out = torch.zeros((max(args.steps, 1), 12), dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream()
-    sp = C.c_void_p(stream.cuda_stream)
+    streams = [torch.cuda.current_stream()] if args.streams <= 1 else [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
+    sps = [C.c_void_p(s_.cuda_stream) for s_ in streams]
 
     def step(i):
+        # consecutive column commits are independent (plonk/prover.rs:305-309): round-robin them over the streams
         rc = lib.h2_commit_device(params_g, d_cols[i % len(d_cols)].data_ptr(), n, None, None, h.FORM_MONTGOMERY,
-                                  0, d_out[i % d_out.shape[0]].data_ptr(), sp)
+                                  0, d_out[i % d_out.shape[0]].data_ptr(), sps[i % len(sps)])
         check(rc, "h2_commit_device")
 
     def sync_all():
@@ -191,7 +194,7 @@ def main():
             "config": {"workload": f"2^{args.log_n}-point Pallas best_multiexp, uniform random Fq scalars, "
                                    "bases resident (Params::g registered), one column commit per step per GPU",
                        "window_bits": h.msm_window_bits(n), "columns_resident": args.columns,
-                       "parallelism": f"{world} independent column streams"},
+                       "parallelism": f"{world} GPU(s) x {len(streams)} stream(s) of independent column commits"},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 2) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
                          "traffic": None, "avg_kernel_ms": round(avg_ms, 4), "launches": int(acc_cnt),

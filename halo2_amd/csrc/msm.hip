@@ -34,6 +34,7 @@
 // HBM: algorithmic traffic is 96 B per (scalar, base) pair against ~1.8e2 modular multiplies.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -600,6 +601,12 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         H2_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB>, 256, 0));
         lanes = (u32)cus * (u32)std::max(per_cu, 1) * 256u;
+        // H2_MSM_LANES_FRAC < 1 leaves wave slots free so that the latency-bound sort / reduce kernels of a
+        // commit running on ANOTHER stream can overlap this kernel (independent column commits)
+        if (const char *f = getenv("H2_MSM_LANES_FRAC")) {
+            double frac = atof(f);
+            if (frac > 0.1 && frac <= 1.0) lanes = std::max(256u, (u32)(lanes * frac) / 256u * 256u);
+        }
     }
     // one round of resident lanes; small problems use fewer lanes so a range keeps >= 16 entries
     u32 T = (u32)std::min<size_t>(lanes, std::max<size_t>(256, (all_items / 16 + 255) / 256 * 256));
