@@ -141,12 +141,15 @@ struct PassArgs {
     feparam k0, k1, k2;     // store multipliers
 };
 
-// LDS planes: lo16[slot], hi16[slot], slot = mid * T + col
-template <int F>
+// LDS planes: lo16[slot], hi16[slot], slot = mid * T + col.
+// R = stages in the pass (compile time, so the twiddles of all R stages can sit in registers: their loads
+// are issued together with the tile load instead of one L2 round trip per stage).
+template <int F, int R, bool FIRST>
 __global__ void __launch_bounds__(1024) ntt_pass(const u32 *__restrict__ in, u32 *__restrict__ out,
                                                  const u32 *__restrict__ tw, PassArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-    const int r = A.r, logT = A.logT, L = A.L, s0 = A.s0;
+    constexpr int r = R;
+    const int logT = A.logT, L = A.L, s0 = A.s0;
     const u32 T = 1u << logT, rows = 1u << r, tile = rows << logT;
     uint4 *lo16 = lds, *hi16 = lds + tile;
     const u32 tid = threadIdx.x, nthr = blockDim.x;
@@ -154,7 +157,7 @@ __global__ void __launch_bounds__(1024) ntt_pass(const u32 *__restrict__ in, u32
     // tile coordinates
     size_t hi_idx = 0, lo0 = 0;   // general pass: x = hi_idx * 2^(s0+r) + mid * 2^s0 + lo0 + col
     u32 c0 = 0;                   // first pass: columns c0 .. c0 + T - 1 of the 2^(L-r) column space
-    if (A.first) {
+    if (FIRST) {
         c0 = blockIdx.x << logT;
     } else {
         u32 tiles_per_hi = 1u << (s0 - logT);
@@ -162,8 +165,22 @@ __global__ void __launch_bounds__(1024) ntt_pass(const u32 *__restrict__ in, u32
         lo0 = (size_t)(blockIdx.x % tiles_per_hi) << logT;
     }
 
+    // ---- twiddles of this lane's butterfly in every stage (independent of the data: issue first) ----
+    fe w[R];
+    {
+        const u32 col = tid & (T - 1), q = tid >> logT;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int t = s0 + u;
+            u32 mid0 = ((q >> u) << (u + 1)) | (q & ((1u << u) - 1));
+            size_t xm = ((size_t)(mid0 & ((1u << u) - 1)) << s0) + (FIRST ? 0 : (lo0 + col));
+            size_t e = xm << (L - t - 1);
+            if (!(FIRST && u == 0) && tid < (tile >> 1)) w[u] = fe_load(tw + 8 * e);
+        }
+    }
+
     // ---- load ----
-    if (A.first) {
+    if (FIRST) {
         const int cb = L - r;  // column bits
         for (u32 e = tid; e < tile; e += nthr) {
             u32 col = e & (T - 1), row = e >> logT;
@@ -198,24 +215,19 @@ __global__ void __launch_bounds__(1024) ntt_pass(const u32 *__restrict__ in, u32
     }
     __syncthreads();
 
-    // ---- r butterfly stages, one butterfly per lane (loop if the tile has more than nthr butterflies) ----
+    // ---- R butterfly stages, one butterfly per lane, one barrier per stage ----
     const u32 nbf = tile >> 1;
-    for (int u = 0; u < r; ++u) {
-        const int t = s0 + u;
-        for (u32 bfl = tid; bfl < nbf; bfl += nthr) {
-            u32 col = bfl & (T - 1), q = bfl >> logT;
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        if (tid < nbf) {
+            u32 col = tid & (T - 1), q = tid >> logT;
             u32 mid0 = ((q >> u) << (u + 1)) | (q & ((1u << u) - 1));
             u32 s_a = (mid0 << logT) + col, s_b = s_a + (T << u);
-            // twiddle exponent: (x mod 2^t) * 2^(L - t - 1)
-            size_t xm = ((size_t)(mid0 & ((1u << u) - 1)) << s0) + (A.first ? 0 : (lo0 + col));
-            size_t e = xm << (L - t - 1);
             uint4 al = lo16[s_a], ah = hi16[s_a], bl = lo16[s_b], bh = hi16[s_b];
             fe a{{al.x, al.y, al.z, al.w, ah.x, ah.y, ah.z, ah.w}};
             fe b{{bl.x, bl.y, bl.z, bl.w, bh.x, bh.y, bh.z, bh.w}};
-            if (e != 0) {
-                fe w = fe_load(tw + 8 * e);
-                b = fe_mulx<F>(b, w);
-            }
+            // twiddle omega^((x mod 2^t) * 2^(L-t-1)); the bit-reversed first stage has twiddle 1 throughout
+            if (!(FIRST && u == 0)) b = fe_mulx<F>(b, w[u]);
             fe s = fe_add<F>(a, b), d = fe_sub<F>(a, b);
             lo16[s_a] = make_uint4(s.v[0], s.v[1], s.v[2], s.v[3]);
             hi16[s_a] = make_uint4(s.v[4], s.v[5], s.v[6], s.v[7]);
@@ -229,7 +241,7 @@ __global__ void __launch_bounds__(1024) ntt_pass(const u32 *__restrict__ in, u32
     for (u32 e = tid; e < tile; e += nthr) {
         u32 col, mid;
         size_t x;
-        if (A.first) {
+        if (FIRST) {
             mid = e & (rows - 1);
             col = e >> r;
             x = ((size_t)bitrev(c0 + col, L - r) << r) + mid;
@@ -344,6 +356,41 @@ static int get_twiddles(NttContext &cx, int field, int L, const u64 omega_m[4], 
     return H2_OK;
 }
 
+template <int F, int R, bool FIRST>
+static int launch_pass_t(const PassArgs &A, unsigned tiles, u32 threads, size_t lds, hipStream_t st, const u32 *src, u32 *dst,
+                         const u32 *tw) {
+    static bool attr = false;  // raise the dynamic-LDS cap once per instantiation
+    if (!attr) {
+        H2_HIP(hipFuncSetAttribute((const void *)ntt_pass<F, R, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        attr = true;
+    }
+    hipLaunchKernelGGL((ntt_pass<F, R, FIRST>), dim3(tiles), dim3(threads), lds, st, src, dst, tw, A);
+    return H2_OK;
+}
+template <int F, bool FIRST>
+static int launch_pass_r(const PassArgs &A, unsigned tiles, u32 threads, size_t lds, hipStream_t st, const u32 *src, u32 *dst,
+                         const u32 *tw) {
+    switch (A.r) {
+        case 1: return launch_pass_t<F, 1, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
+        case 2: return launch_pass_t<F, 2, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
+        case 3: return launch_pass_t<F, 3, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
+        case 4: return launch_pass_t<F, 4, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
+        case 5: return launch_pass_t<F, 5, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
+        case 6: return launch_pass_t<F, 6, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
+        case 7: return launch_pass_t<F, 7, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
+        case 8: return launch_pass_t<F, 8, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
+    }
+    return H2_ERR_ARGS;
+}
+static int launch_pass(int field, const PassArgs &A, unsigned tiles, u32 threads, size_t lds, hipStream_t st, const u32 *src,
+                       u32 *dst, const u32 *tw) {
+    if (field == H2_FP)
+        return A.first ? launch_pass_r<FP, true>(A, tiles, threads, lds, st, src, dst, tw)
+                       : launch_pass_r<FP, false>(A, tiles, threads, lds, st, src, dst, tw);
+    return A.first ? launch_pass_r<FQ, true>(A, tiles, threads, lds, st, src, dst, tw)
+                   : launch_pass_r<FQ, false>(A, tiles, threads, lds, st, src, dst, tw);
+}
+
 struct NttJob {
     int field;
     unsigned L;
@@ -360,8 +407,6 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
     NttContext &cx = ntt_ctx();
     std::lock_guard<std::mutex> lk(cx.mu);
     if (!cx.attr_set) {
-        H2_HIP(hipFuncSetAttribute((const void *)ntt_pass<FP>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        H2_HIP(hipFuncSetAttribute((const void *)ntt_pass<FQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         cx.attr_set = true;
     }
     const int L = (int)J.L;
@@ -434,12 +479,8 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
         size_t tiles = n >> (A.r + A.logT);
         size_t lds = ((size_t)32 << A.r) << A.logT;
         prof_begin(PROF_NTT_PASS, st);
-        if (J.field == H2_FP)
-            hipLaunchKernelGGL((ntt_pass<FP>), dim3((unsigned)tiles), dim3(threads), lds, st, (const u32 *)src, (u32 *)dst,
-                               (const u32 *)tw->d, A);
-        else
-            hipLaunchKernelGGL((ntt_pass<FQ>), dim3((unsigned)tiles), dim3(threads), lds, st, (const u32 *)src, (u32 *)dst,
-                               (const u32 *)tw->d, A);
+        if ((rc = launch_pass(J.field, A, (unsigned)tiles, threads, lds, st, (const u32 *)src, (u32 *)dst, (const u32 *)tw->d)) != H2_OK)
+            return rc;
         prof_end(PROF_NTT_PASS, st);
         s0 += A.r;
     }
@@ -450,7 +491,6 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
 static bool bad_field(int field, int form) {
     return (field != H2_FP && field != H2_FQ) || (form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY);
 }
-static const u64 kZero4[4] = {0, 0, 0, 0};
 
 static int job_ntt(NttJob &J, int field, void *d_a, unsigned log_n, const u64 *omega, int form) {
     memset(&J, 0, sizeof J);
