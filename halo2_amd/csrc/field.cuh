@@ -63,15 +63,19 @@ __device__ __forceinline__ bool fe_eq(const fe &a, const fe &b) {
     return d == 0;
 }
 
+// Carry chains are written with __builtin_addc / __builtin_subc: they lower to v_add_co_u32 / v_addc_co_u32
+// (one instruction per limb).  Spelling them with 64-bit temporaries makes hipcc emit v_lshl_add_u64 + v_mov
+// shuffles instead -- ~5 instructions per limb, which made add/sub cost half a multiplication.
+
 // r = a - p if a >= p else a          (a < 2p)
 template <int F> __device__ __forceinline__ fe fe_reduce_once(const fe &a) {
     fe d;
-    u64 br = 0;
+    u32 br = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        u64 t = (u64)a.v[i] - mod_limb<F>(i) - br;
-        d.v[i] = (u32)t;
-        br = (t >> 32) & 1;
+        u32 bo;
+        d.v[i] = __builtin_subc(a.v[i], mod_limb<F>(i), br, &bo);
+        br = bo;
     }
     fe r;
 #pragma unroll
@@ -81,34 +85,34 @@ template <int F> __device__ __forceinline__ fe fe_reduce_once(const fe &a) {
 
 template <int F> __device__ __forceinline__ fe fe_add(const fe &a, const fe &b) {
     fe s;
-    u64 c = 0;
+    u32 c = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        c += (u64)a.v[i] + b.v[i];
-        s.v[i] = (u32)c;
-        c >>= 32;
+        u32 co;
+        s.v[i] = __builtin_addc(a.v[i], b.v[i], c, &co);
+        c = co;
     }
     return fe_reduce_once<F>(s);  // a + b < 2p < 2^256: no carry out of limb 7
 }
 
 template <int F> __device__ __forceinline__ fe fe_sub(const fe &a, const fe &b) {
     fe d;
-    u64 br = 0;
+    u32 br = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        u64 t = (u64)a.v[i] - b.v[i] - br;
-        d.v[i] = (u32)t;
-        br = (t >> 32) & 1;
+        u32 bo;
+        d.v[i] = __builtin_subc(a.v[i], b.v[i], br, &bo);
+        br = bo;
     }
     // add p back when the subtraction borrowed
-    u32 mask = 0u - (u32)br;
+    const u32 mask = 0u - br;
     fe r;
-    u64 c = 0;
+    u32 c = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        c += (u64)d.v[i] + (mod_limb<F>(i) & mask);
-        r.v[i] = (u32)c;
-        c >>= 32;
+        u32 co;
+        r.v[i] = __builtin_addc(d.v[i], mod_limb<F>(i) & mask, c, &co);
+        c = co;
     }
     return r;
 }

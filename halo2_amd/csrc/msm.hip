@@ -33,6 +33,7 @@
 // No MFMA anywhere: this is modular-integer arithmetic.  Bound by VALU integer-multiply issue, not
 // HBM: algorithmic traffic is 96 B per (scalar, base) pair against ~1.8e2 modular multiplies.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -45,6 +46,7 @@
 
 namespace h2 {
 
+static std::atomic<double> g_lane_fraction{1.0};
 static constexpr int kMaxC = 16;
 static constexpr u32 kZeroCode = 0xFFFFu;
 static constexpr int kSeg = 8;     // buckets per reduce segment
@@ -601,15 +603,12 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         H2_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB>, 256, 0));
         lanes = (u32)cus * (u32)std::max(per_cu, 1) * 256u;
-        // H2_MSM_LANES_FRAC < 1 leaves wave slots free so that the latency-bound sort / reduce kernels of a
-        // commit running on ANOTHER stream can overlap this kernel (independent column commits)
-        if (const char *f = getenv("H2_MSM_LANES_FRAC")) {
-            double frac = atof(f);
-            if (frac > 0.1 && frac <= 1.0) lanes = std::max(256u, (u32)(lanes * frac) / 256u * 256u);
-        }
     }
     // one round of resident lanes; small problems use fewer lanes so a range keeps >= 16 entries
-    u32 T = (u32)std::min<size_t>(lanes, std::max<size_t>(256, (all_items / 16 + 255) / 256 * 256));
+    // a lane fraction < 1 (h2_set_option) leaves wave slots free so that the latency-bound sort / reduce kernels
+    // of a commit running on ANOTHER stream can overlap this kernel (independent column commits)
+    const u32 usable = std::max(256u, (u32)(lanes * g_lane_fraction.load()) / 256u * 256u);
+    u32 T = (u32)std::min<size_t>(usable, std::max<size_t>(256, (all_items / 16 + 255) / 256 * 256));
     const u32 max_heavy = T / kHeavy + 2;
     if ((rc = cx.digits.reserve(all_items * 2)) != H2_OK) return rc;
     if ((rc = cx.hist.reserve((size_t)sh.slices * sh.B * sh.NB * 4)) != H2_OK) return rc;
@@ -748,6 +747,16 @@ static int ensure_blind_base(Bases &b, const void *d_w_mont, hipStream_t st) {
 using namespace h2;
 
 extern "C" int h2_msm_window_bits(size_t n) { return choose_c(n ? n : 1, false); }
+
+extern "C" int h2_set_option(const char *key, double value) {
+    if (!key) return H2_ERR_ARGS;
+    if (strcmp(key, "msm_lane_fraction") == 0) {
+        if (!(value > 0.05 && value <= 1.0)) return H2_ERR_ARGS;
+        g_lane_fraction.store(value);
+        return H2_OK;
+    }
+    return H2_ERR_ARGS;
+}
 
 extern "C" int h2_msm_device(int curve, const void *d_scalars, const void *d_bases_xy, size_t n, int form, int out_kind,
                              void *d_out, void *stream) {

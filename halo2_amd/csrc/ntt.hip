@@ -21,6 +21,7 @@
 //
 // Cost model: (n/2) log n butterflies = 1 modular multiply + add + sub each; ~1.2e3 VALU cycles per
 // wave-butterfly against ~100 cycles of LDS + L2 traffic: VALU-bound, like the MSM.  No MFMA.
+#include <cstdlib>
 #include <cstring>
 #include <list>
 #include <map>
@@ -165,20 +166,6 @@ __global__ void __launch_bounds__(1024) ntt_pass(const u32 *__restrict__ in, u32
         lo0 = (size_t)(blockIdx.x % tiles_per_hi) << logT;
     }
 
-    // ---- twiddles of this lane's butterfly in every stage (independent of the data: issue first) ----
-    fe w[R];
-    {
-        const u32 col = tid & (T - 1), q = tid >> logT;
-#pragma unroll
-        for (int u = 0; u < R; ++u) {
-            const int t = s0 + u;
-            u32 mid0 = ((q >> u) << (u + 1)) | (q & ((1u << u) - 1));
-            size_t xm = ((size_t)(mid0 & ((1u << u) - 1)) << s0) + (FIRST ? 0 : (lo0 + col));
-            size_t e = xm << (L - t - 1);
-            if (!(FIRST && u == 0) && tid < (tile >> 1)) w[u] = fe_load(tw + 8 * e);
-        }
-    }
-
     // ---- load ----
     if (FIRST) {
         const int cb = L - r;  // column bits
@@ -215,22 +202,70 @@ __global__ void __launch_bounds__(1024) ntt_pass(const u32 *__restrict__ in, u32
     }
     __syncthreads();
 
-    // ---- R butterfly stages, one butterfly per lane, one barrier per stage ----
-    const u32 nbf = tile >> 1;
+    // ---- R butterfly stages as radix-4 rounds (two stages per LDS round trip and per barrier; LDS writes
+    //      are the slow direction on gfx950), plus one radix-2 round when R is odd.  One lane owns one radix-4
+    //      group: elements mid00, mid00 | 2^u, mid00 | 2^(u+1), mid00 | 2^u | 2^(u+1).
+    const size_t lo_x = FIRST ? 0 : (lo0 + (tid & (T - 1)));
+    const u32 ngrp = tile >> 2;
 #pragma unroll
-    for (int u = 0; u < R; ++u) {
-        if (tid < nbf) {
-            u32 col = tid & (T - 1), q = tid >> logT;
-            u32 mid0 = ((q >> u) << (u + 1)) | (q & ((1u << u) - 1));
-            u32 s_a = (mid0 << logT) + col, s_b = s_a + (T << u);
+    for (int u = 0; u + 1 < R; u += 2) {
+        if (tid < ngrp) {
+            const int t = s0 + u;
+            const u32 col = tid & (T - 1), q = tid >> logT;
+            const u32 low = q & ((1u << u) - 1);
+            const u32 mid00 = ((q >> u) << (u + 2)) | low;
+            const u32 s00 = (mid00 << logT) + col, s01 = s00 + (T << u), s10 = s00 + (T << (u + 1)), s11 = s10 + (T << u);
+            // twiddle exponents (x mod 2^t) * 2^(L-t-1): stage t shares one twiddle between its two butterflies,
+            // stage t+1 needs two (the second is n/4 further on)
+            const size_t xm = ((size_t)low << s0) + lo_x;
+            const size_t eA = xm << (L - t - 1), eB0 = xm << (L - t - 2), eB1 = eB0 + ((size_t)1 << (L - 2));
+            fe wA, wB0, wB1;
+            if (!(FIRST && u == 0)) wA = fe_load(tw + 8 * eA);
+            wB0 = fe_load(tw + 8 * eB0);
+            wB1 = fe_load(tw + 8 * eB1);
+            uint4 l0 = lo16[s00], h0 = hi16[s00], l1 = lo16[s01], h1 = hi16[s01];
+            uint4 l2 = lo16[s10], h2 = hi16[s10], l3 = lo16[s11], h3 = hi16[s11];
+            fe e0{{l0.x, l0.y, l0.z, l0.w, h0.x, h0.y, h0.z, h0.w}}, e1{{l1.x, l1.y, l1.z, l1.w, h1.x, h1.y, h1.z, h1.w}};
+            fe e2{{l2.x, l2.y, l2.z, l2.w, h2.x, h2.y, h2.z, h2.w}}, e3{{l3.x, l3.y, l3.z, l3.w, h3.x, h3.y, h3.z, h3.w}};
+            if (!(FIRST && u == 0)) {
+                e1 = fe_mulx<F>(e1, wA);
+                e3 = fe_mulx<F>(e3, wA);
+            }
+            fe a0 = fe_add<F>(e0, e1), a1 = fe_sub<F>(e0, e1), a2 = fe_add<F>(e2, e3), a3 = fe_sub<F>(e2, e3);
+            a2 = fe_mulx<F>(a2, wB0);
+            a3 = fe_mulx<F>(a3, wB1);
+            e0 = fe_add<F>(a0, a2);
+            e2 = fe_sub<F>(a0, a2);
+            e1 = fe_add<F>(a1, a3);
+            e3 = fe_sub<F>(a1, a3);
+            lo16[s00] = make_uint4(e0.v[0], e0.v[1], e0.v[2], e0.v[3]);
+            hi16[s00] = make_uint4(e0.v[4], e0.v[5], e0.v[6], e0.v[7]);
+            lo16[s01] = make_uint4(e1.v[0], e1.v[1], e1.v[2], e1.v[3]);
+            hi16[s01] = make_uint4(e1.v[4], e1.v[5], e1.v[6], e1.v[7]);
+            lo16[s10] = make_uint4(e2.v[0], e2.v[1], e2.v[2], e2.v[3]);
+            hi16[s10] = make_uint4(e2.v[4], e2.v[5], e2.v[6], e2.v[7]);
+            lo16[s11] = make_uint4(e3.v[0], e3.v[1], e3.v[2], e3.v[3]);
+            hi16[s11] = make_uint4(e3.v[4], e3.v[5], e3.v[6], e3.v[7]);
+        }
+        __syncthreads();
+    }
+    if (R & 1) {  // leftover radix-2 stage: tile/2 butterflies over tile/4 lanes
+        constexpr int u = R - 1;
+        const int t = s0 + u;
+        const u32 nbf = tile >> 1;
+        for (u32 bfl = tid; bfl < nbf; bfl += nthr) {
+            const u32 col = bfl & (T - 1), q = bfl >> logT;
+            const u32 low = q & ((1u << u) - 1);
+            const u32 mid0 = ((q >> u) << (u + 1)) | low;
+            const u32 s_a = (mid0 << logT) + col, s_b = s_a + (T << u);
+            const size_t xm = ((size_t)low << s0) + (FIRST ? 0 : (lo0 + col));
             uint4 al = lo16[s_a], ah = hi16[s_a], bl = lo16[s_b], bh = hi16[s_b];
             fe a{{al.x, al.y, al.z, al.w, ah.x, ah.y, ah.z, ah.w}};
             fe b{{bl.x, bl.y, bl.z, bl.w, bh.x, bh.y, bh.z, bh.w}};
-            // twiddle omega^((x mod 2^t) * 2^(L-t-1)); the bit-reversed first stage has twiddle 1 throughout
-            if (!(FIRST && u == 0)) b = fe_mulx<F>(b, w[u]);
-            fe s = fe_add<F>(a, b), d = fe_sub<F>(a, b);
-            lo16[s_a] = make_uint4(s.v[0], s.v[1], s.v[2], s.v[3]);
-            hi16[s_a] = make_uint4(s.v[4], s.v[5], s.v[6], s.v[7]);
+            if (!(FIRST && u == 0)) b = fe_mulx<F>(b, fe_load(tw + 8 * (xm << (L - t - 1))));
+            fe sm = fe_add<F>(a, b), d = fe_sub<F>(a, b);
+            lo16[s_a] = make_uint4(sm.v[0], sm.v[1], sm.v[2], sm.v[3]);
+            hi16[s_a] = make_uint4(sm.v[4], sm.v[5], sm.v[6], sm.v[7]);
             lo16[s_b] = make_uint4(d.v[0], d.v[1], d.v[2], d.v[3]);
             hi16[s_b] = make_uint4(d.v[4], d.v[5], d.v[6], d.v[7]);
         }
@@ -379,6 +414,8 @@ static int launch_pass_r(const PassArgs &A, unsigned tiles, u32 threads, size_t 
         case 6: return launch_pass_t<F, 6, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
         case 7: return launch_pass_t<F, 7, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
         case 8: return launch_pass_t<F, 8, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
+        case 9: return launch_pass_t<F, 9, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
+        case 10: return launch_pass_t<F, 10, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
     }
     return H2_ERR_ARGS;
 }
@@ -422,9 +459,11 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
     int rc = get_twiddles(cx, J.field, L, J.omega, st, tw);
     if (rc != H2_OK) return rc;
 
-    // pass plan: ceil(L / 8) passes, stages spread evenly
-    const int P = (L + 7) / 8;
-    int stages[8];
+    // pass plan: ceil(L / maxr) passes, stages spread evenly (H2_NTT_MAXR / H2_NTT_LOGT: tuning sweeps only)
+    static const int maxr = [] { const char *e = getenv("H2_NTT_MAXR"); int v = e ? atoi(e) : 8; return v >= 1 && v <= 10 ? v : 8; }();
+    static const int want_logT = [] { const char *e = getenv("H2_NTT_LOGT"); int v = e ? atoi(e) : 3; return v >= 0 && v <= 5 ? v : 3; }();
+    const int P = (L + maxr - 1) / maxr;
+    int stages[40];
     for (int i = 0; i < P; ++i) stages[i] = L / P + (i < L % P ? 1 : 0);
     const size_t n = (size_t)1 << L;
     int dev = 0;
@@ -446,9 +485,10 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
         A.n_in = J.n_in;
         const bool last = i == P - 1;
         int colbits = A.first ? (L - A.r) : s0;
-        A.logT = std::min(3, colbits);
+        A.logT = std::min(want_logT, colbits);
+        while (A.logT > 0 && ((32u << A.r) << A.logT) > 65536) A.logT--;
         // keep >= 256 lanes per workgroup when the pass is narrow
-        while (A.logT < colbits && ((1 << (A.r - 1)) << A.logT) < 256 && ((32u << A.r) << (A.logT + 1)) <= 65536) A.logT++;
+        while (A.logT < colbits && ((1 << A.r) << A.logT) < 1024 && ((32u << A.r) << (A.logT + 1)) <= 65536) A.logT++;
         if (A.first) {
             A.load_mode = J.load_mode;
             A.lk0 = to_param(J.lk0);
@@ -474,8 +514,8 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
             src = A.first ? J.d_in : tmp;
             dst = last ? J.d_out : tmp;
         }
-        u32 threads = (u32)std::min<size_t>(1024, (size_t)(1u << (A.r - 1)) << A.logT);
-        if (threads < 64) threads = 64;
+        // one lane per radix-4 group (tile / 4); a 1-stage pass needs tile / 2 butterflies, looped
+        u32 threads = (u32)std::min<size_t>(1024, std::max<size_t>(64, ((size_t)1 << A.r << A.logT) / 4));
         size_t tiles = n >> (A.r + A.logT);
         size_t lds = ((size_t)32 << A.r) << A.logT;
         prof_begin(PROF_NTT_PASS, st);

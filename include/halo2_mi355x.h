@@ -63,6 +63,9 @@ int h2_init(int device);
 const char *h2_last_error(void);
 /* Window width the MSM would use for n points (informational; the result does not depend on it). */
 int h2_msm_window_bits(size_t n);
+/* Tuning knobs (never change results).  "msm_lane_fraction" in (0.05, 1]: share of the resident wave slots
+ * one bucket-accumulation launch claims; < 1 lets commits issued on other streams overlap it (default 1). */
+int h2_set_option(const char *key, double value);
 
 /* ---- MSM: replaces best_multiexp (halo2_proofs/src/arithmetic.rs:143-180) -------------------- */
 /* out = sum_i scalars[i] * bases[i].  n may be 0 (identity).  `out_kind` selects 12- or 8-limb output. */
