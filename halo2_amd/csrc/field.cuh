@@ -184,6 +184,14 @@ template <int F> __device__ __forceinline__ fe fe_mul_blk(const fe &a, const fe 
     return fe_reduce_once<F>(r);
 }
 
+// Variant: ONE asm statement, list-scheduled by gen_field_mul.py so that every carry (an SGPR written by a
+// VALU instruction) is read no sooner than three instructions later -- the gfx940/gfx950 "VALU writes SGPR ->
+// VALU reads it" hazard (2 wait states), which hipcc pads in its own code but cannot see inside asm text.
+template <int F> __device__ __forceinline__ fe fe_mul_sched(const fe &a, const fe &b) {
+#include "field_mul_sched.inc"
+    return fe_reduce_once<F>(r);
+}
+
 // Variant: plain C operand-scanning (CIOS); the compiler picks the instructions.  Kept as the
 // readable specification of the multiplier and as an A/B baseline for the asm variants.
 template <int F> __device__ __forceinline__ fe fe_mul_c(const fe &a, const fe &b) {
@@ -217,7 +225,7 @@ template <int F> __device__ __forceinline__ fe fe_mul_c(const fe &a, const fe &b
 }
 
 #ifndef H2_MUL_IMPL
-#define H2_MUL_IMPL 1
+#define H2_MUL_IMPL 4
 #endif
 template <int F> __device__ __forceinline__ fe fe_mulx(const fe &a, const fe &b) {
 #if H2_MUL_IMPL == 0
@@ -226,6 +234,8 @@ template <int F> __device__ __forceinline__ fe fe_mulx(const fe &a, const fe &b)
     return fe_mul_col<F>(a, b);
 #elif H2_MUL_IMPL == 3
     return fe_mul_blk<F>(a, b);
+#elif H2_MUL_IMPL == 4
+    return fe_mul_sched<F>(a, b);
 #else
     return fe_mul<F>(a, b);
 #endif

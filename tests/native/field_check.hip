@@ -30,6 +30,7 @@ template <int F> __global__ void k_ops(const u32 *a, const u32 *b, u32 *out, int
         case 3: r = fe_add<F>(x, y); break;
         case 4: r = fe_sub<F>(x, y); break;
         case 6: r = fe_mul_blk<F>(x, y); break;
+        case 7: r = fe_mul_sched<F>(x, y); break;
         default: r = fe_inv<F>(x); break;
     }
     fe_store(out + 8 * i, r);
@@ -44,6 +45,7 @@ template <int F, int IMPL> __global__ void __launch_bounds__(256) k_chain(const 
         if (IMPL == 1) { x = fe_mul_col<F>(x, y); z = fe_mul_col<F>(z, w); }
         if (IMPL == 2) { x = fe_mul<F>(x, y); z = fe_mul<F>(z, w); }
         if (IMPL == 3) { x = fe_mul_blk<F>(x, y); z = fe_mul_blk<F>(z, w); }
+        if (IMPL == 4) { x = fe_mul_sched<F>(x, y); z = fe_mul_sched<F>(z, w); }
     }
     fe_store(out + 8 * i, fe_add<F>(x, z));
 }
@@ -66,9 +68,9 @@ template <int F> int run_field() {
     CK(hipMalloc(&da, 32 * n)); CK(hipMalloc(&db, 32 * n)); CK(hipMalloc(&dout, 32 * n));
     CK(hipMemcpy(da, a.data(), 32 * n, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, b.data(), 32 * n, hipMemcpyHostToDevice));
-    const char *names[] = {"mul_c", "mul_col", "mul_asm", "add", "sub", "inv", "mul_blk"};
+    const char *names[] = {"mul_c", "mul_col", "mul_asm", "add", "sub", "inv", "mul_blk", "mul_sched"};
     int fails = 0;
-    for (int op = 0; op < 7; ++op) {
+    for (int op = 0; op < 8; ++op) {
         int cnt = op == 5 ? 256 : n;
         hipLaunchKernelGGL((k_ops<F>), dim3((cnt + 255) / 256), dim3(256), 0, 0, da, db, dout, cnt, op);
         CK(hipDeviceSynchronize());
@@ -76,7 +78,7 @@ template <int F> int run_field() {
         int bad = 0;
         for (int i = 0; i < cnt; ++i) {
             uint64_t w[4];
-            if (op <= 2 || op == 6) orc_f_mul(F, w, &a[4 * i], &b[4 * i]);
+            if (op <= 2 || op >= 6) orc_f_mul(F, w, &a[4 * i], &b[4 * i]);
             else if (op == 3) orc_f_add(F, w, &a[4 * i], &b[4 * i]);
             else if (op == 4) orc_f_sub(F, w, &a[4 * i], &b[4 * i]);
             else orc_f_inv(F, w, &a[4 * i]);
@@ -115,7 +117,7 @@ template <int IMPL> int bench(const char *name, int blocks_per_cu) {
 int main() {
     int fails = run_field<FP>() + run_field<FQ>();
     for (int w : {1, 2, 4, 8}) {
-        bench<1>("mul_col", w); bench<3>("mul_blk", w);
+        bench<1>("mul_col", w); bench<3>("mul_blk", w); bench<4>("mul_sched", w);
     }
     printf(fails ? "FIELD CHECK FAILED\n" : "FIELD CHECK OK\n");
     return fails ? 1 : 0;
