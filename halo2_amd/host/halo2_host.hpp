@@ -1,0 +1,201 @@
+// halo2_host.hpp -- C++ mirror of the reference's interface for the hot path, on top of the C ABI
+// (include/halo2_mi355x.h).  The reference's host language is Rust (no toolchain in this image), so this
+// header plays the role the Rust shim of INTEGRATION.md would: same names, argument meaning and error
+// behaviour as
+//     arithmetic::best_multiexp / best_fft            halo2_proofs/src/arithmetic.rs:143, :192
+//     EvaluationDomain::{new, lagrange_to_coeff, coeff_to_extended, extended_to_coeff}
+//                                                     halo2_proofs/src/poly/domain.rs:40, :227, :241, :303
+//     Params::{commit, commit_lagrange}, Blind        halo2_proofs/src/poly/commitment.rs:119, :135, :208
+// Where the reference panics (assert_eq! on lengths) these throw std::invalid_argument; HIP / device
+// failures throw std::runtime_error with h2_last_error().  All compute happens in libhalo2_mi355x.so.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/halo2_mi355x.h"
+
+namespace halo2 {
+
+using Fe = std::array<uint64_t, 4>;        // field element, Montgomery limbs (what Rust's Fp/Fq holds)
+using Affine = std::array<uint64_t, 8>;    // {x, y}; identity = all zero
+using Jacobian = std::array<uint64_t, 12>; // {X, Y, Z}; identity: Z = 0
+
+inline void check(int rc, const char *what) {
+    if (rc == H2_OK) return;
+    if (rc == H2_ERR_ARGS) throw std::invalid_argument(std::string(what) + ": bad arguments");
+    throw std::runtime_error(std::string(what) + ": " + h2_last_error());
+}
+
+// ---- host-side Pasta field arithmetic (constants only; pasta_curves supplies these to the reference) ------
+namespace field {
+typedef unsigned __int128 u128;
+struct Params { uint64_t p[4], inv, r2[4], one[4]; };
+inline const Params &params(int f) {
+    static const Params P[2] = {
+        {{0x992d30ed00000001ULL, 0x224698fc094cf91bULL, 0, 0x4000000000000000ULL}, 0x992d30ecffffffffULL,
+         {0x8c78ecb30000000fULL, 0xd7d30dbd8b0de0e7ULL, 0x7797a99bc3c95d18ULL, 0x096d41af7b9cb714ULL},
+         {0x34786d38fffffffdULL, 0x992c350be41914adULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL}},
+        {{0x8c46eb2100000001ULL, 0x224698fc0994a8ddULL, 0, 0x4000000000000000ULL}, 0x8c46eb20ffffffffULL,
+         {0xfc9678ff0000000fULL, 0x67bb433d891a16e3ULL, 0x7fae231004ccf590ULL, 0x096d41af7ccfdaa9ULL},
+         {0x5b2b3e9cfffffffdULL, 0x992c350be3420567ULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL}}};
+    return P[f];
+}
+inline Fe mul(int f, const Fe &a, const Fe &b) {   // Montgomery product
+    const Params &F = params(f);
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { c += (u128)a[j] * b[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+        uint64_t m = t[0] * F.inv;
+        c = ((u128)m * F.p[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; j++) { c += (u128)m * F.p[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    bool ge = t[4] != 0;
+    if (!ge) { ge = true; for (int i = 3; i >= 0; i--) { if (t[i] > F.p[i]) break; if (t[i] < F.p[i]) { ge = false; break; } } }
+    if (ge) { u128 br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)t[i] - F.p[i] - (uint64_t)br; t[i] = (uint64_t)d; br = (d >> 64) & 1; } }
+    return Fe{t[0], t[1], t[2], t[3]};
+}
+inline Fe one(int f) { const Params &F = params(f); return Fe{F.one[0], F.one[1], F.one[2], F.one[3]}; }
+inline Fe from_u64(int f, uint64_t v) { const Params &F = params(f); return mul(f, Fe{v, 0, 0, 0}, Fe{F.r2[0], F.r2[1], F.r2[2], F.r2[3]}); }
+inline Fe pow(int f, Fe base, const uint64_t e[4]) {
+    Fe acc = one(f);
+    for (int i = 0; i < 256; i++) { if ((e[i / 64] >> (i % 64)) & 1) acc = mul(f, acc, base); base = mul(f, base, base); }
+    return acc;
+}
+inline Fe inv(int f, const Fe &a) {   // a^(p-2)
+    const Params &F = params(f);
+    uint64_t e[4] = {F.p[0] - 2, F.p[1], F.p[2], F.p[3]};
+    return pow(f, a, e);
+}
+inline Fe sub(int f, const Fe &a, const Fe &b) {
+    const Params &F = params(f);
+    uint64_t t[4]; u128 br = 0;
+    for (int i = 0; i < 4; i++) { u128 d = (u128)a[i] - b[i] - (uint64_t)br; t[i] = (uint64_t)d; br = (d >> 64) & 1; }
+    if (br) { u128 c = 0; for (int i = 0; i < 4; i++) { c += (u128)t[i] + F.p[i]; t[i] = (uint64_t)c; c >>= 64; } }
+    return Fe{t[0], t[1], t[2], t[3]};
+}
+// ROOT_OF_UNITY = 5^((p-1)/2^32): multiplicative generator 5, S = 32 for both fields
+inline Fe root_of_unity(int f) {
+    const Params &F = params(f);
+    uint64_t e[4] = {(F.p[0] >> 32) | (F.p[1] << 32), (F.p[1] >> 32) | (F.p[2] << 32), (F.p[2] >> 32) | (F.p[3] << 32), F.p[3] >> 32};
+    return pow(f, from_u64(f, 5), e);   // (p - 1) >> 32 == p >> 32 because p = 1 mod 2^32
+}
+// ZETA: primitive cube root of unity (pasta_curves): Fp (5^((p-1)/3))^2, Fq 5^((q-1)/3)
+inline Fe zeta(int f) {
+    const Params &F = params(f);
+    // (p - 1) / 3 by long division on the limbs
+    uint64_t n[4] = {F.p[0] - 1, F.p[1], F.p[2], F.p[3]}, q[4];
+    u128 rem = 0;
+    for (int i = 3; i >= 0; i--) { u128 cur = (rem << 64) | n[i]; q[i] = (uint64_t)(cur / 3); rem = cur % 3; }
+    Fe z = pow(f, from_u64(f, 5), q);
+    return f == H2_FP ? mul(f, z, z) : z;
+}
+}  // namespace field
+
+// ---- arithmetic.rs ----------------------------------------------------------------------------------------
+template <int CURVE>
+inline Jacobian best_multiexp(const std::vector<Fe> &coeffs, const std::vector<Affine> &bases) {
+    if (coeffs.size() != bases.size()) throw std::invalid_argument("best_multiexp: coeffs.len() != bases.len()");   // arithmetic.rs:144
+    Jacobian out{};
+    check(h2_msm(CURVE, coeffs.empty() ? nullptr : coeffs[0].data(), bases.empty() ? nullptr : bases[0].data(), coeffs.size(),
+                 H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, out.data()), "h2_msm");
+    return out;
+}
+template <int FIELD> inline void best_fft(std::vector<Fe> &a, const Fe &omega, uint32_t log_n) {
+    if (a.size() != ((size_t)1 << log_n)) throw std::invalid_argument("best_fft: a.len() != 1 << log_n");       // arithmetic.rs:205
+    check(h2_ntt(FIELD, a[0].data(), log_n, omega.data(), H2_FORM_MONTGOMERY), "h2_ntt");
+}
+
+// ---- poly/domain.rs ------------------------------------------------------------------------------------------
+template <int FIELD> class EvaluationDomain {
+  public:
+    uint32_t k, extended_k;
+    uint64_t n, quotient_poly_degree;
+    Fe omega, omega_inv, extended_omega, extended_omega_inv, g_coset, g_coset_inv, ifft_divisor, extended_ifft_divisor;
+    std::vector<Fe> t_evaluations;
+
+    EvaluationDomain(uint32_t j, uint32_t k_) : k(k_), n((uint64_t)1 << k_), quotient_poly_degree(j - 1) {   // domain.rs:40
+        extended_k = k;
+        while (((uint64_t)1 << extended_k) < n * quotient_poly_degree) extended_k++;
+        if (extended_k > 32) throw std::invalid_argument("EvaluationDomain: extended_k > S");                // domain.rs:56
+        extended_omega = field::root_of_unity(FIELD);
+        for (uint32_t i = extended_k; i < 32; i++) extended_omega = field::mul(FIELD, extended_omega, extended_omega);
+        omega = extended_omega;
+        for (uint32_t i = k; i < extended_k; i++) omega = field::mul(FIELD, omega, omega);
+        omega_inv = field::inv(FIELD, omega);
+        extended_omega_inv = field::inv(FIELD, extended_omega);
+        g_coset = field::zeta(FIELD);
+        g_coset_inv = field::mul(FIELD, g_coset, g_coset);
+        ifft_divisor = field::inv(FIELD, field::from_u64(FIELD, (uint64_t)1 << k));
+        extended_ifft_divisor = field::inv(FIELD, field::from_u64(FIELD, (uint64_t)1 << extended_k));
+        uint64_t e[4] = {n, 0, 0, 0};
+        Fe orig = field::pow(FIELD, g_coset, e), step = field::pow(FIELD, extended_omega, e), cur = orig;
+        do {                                                                                                   // domain.rs:85-110
+            t_evaluations.push_back(field::inv(FIELD, field::sub(FIELD, cur, field::one(FIELD))));
+            cur = field::mul(FIELD, cur, step);
+        } while (cur != orig);
+    }
+    size_t extended_len() const { return (size_t)1 << extended_k; }
+
+    std::vector<Fe> lagrange_to_coeff(std::vector<Fe> a) const {                                                // domain.rs:227
+        if (a.size() != n) throw std::invalid_argument("lagrange_to_coeff: wrong length");
+        check(h2_ifft(FIELD, a[0].data(), k, omega_inv.data(), ifft_divisor.data(), H2_FORM_MONTGOMERY), "h2_ifft");
+        return a;
+    }
+    std::vector<Fe> coeff_to_extended(const std::vector<Fe> &a) const {                                         // domain.rs:241
+        if (a.size() != n) throw std::invalid_argument("coeff_to_extended: wrong length");
+        std::vector<Fe> out(extended_len());
+        check(h2_coeff_to_extended(FIELD, a[0].data(), out[0].data(), k, extended_k, g_coset.data(), g_coset_inv.data(),
+                                   extended_omega.data(), H2_FORM_MONTGOMERY), "h2_coeff_to_extended");
+        return out;
+    }
+    std::vector<Fe> extended_to_coeff(std::vector<Fe> a) const {                                                // domain.rs:303
+        if (a.size() != extended_len()) throw std::invalid_argument("extended_to_coeff: wrong length");
+        check(h2_extended_to_coeff(FIELD, a[0].data(), extended_k, g_coset.data(), g_coset_inv.data(), extended_omega_inv.data(),
+                                   extended_ifft_divisor.data(), H2_FORM_MONTGOMERY), "h2_extended_to_coeff");
+        a.resize(n * quotient_poly_degree);
+        return a;
+    }
+};
+
+// ---- poly/commitment.rs ------------------------------------------------------------------------------------------
+template <int CURVE> struct Blind { Fe value; };
+
+template <int CURVE> class Params {
+  public:
+    uint32_t k;
+    uint64_t n;
+    std::vector<Affine> g, g_lagrange;
+    Affine w, u;
+    // what Params::read (commitment.rs:184) ends with: generators in hand; `new`'s hash-to-curve is upstream of the hot path
+    Params(uint32_t k_, std::vector<Affine> g_, std::vector<Affine> g_lagrange_, const Affine &w_, const Affine &u_)
+        : k(k_), n((uint64_t)1 << k_), g(std::move(g_)), g_lagrange(std::move(g_lagrange_)), w(w_), u(u_) {
+        if (g.size() != n || g_lagrange.size() != n) throw std::invalid_argument("Params: need 2^k generators");
+        check(h2_bases_register(CURVE, g[0].data(), n, H2_FORM_MONTGOMERY, &h_g), "h2_bases_register");
+        check(h2_bases_register(CURVE, g_lagrange[0].data(), n, H2_FORM_MONTGOMERY, &h_gl), "h2_bases_register");
+    }
+    ~Params() { if (h_g) h2_bases_free(h_g); if (h_gl) h2_bases_free(h_gl); }
+    Params(const Params &) = delete;
+    Params &operator=(const Params &) = delete;
+
+    Jacobian commit(const std::vector<Fe> &poly, const Blind<CURVE> &r) const { return run(h_g, poly, r); }            // :119
+    Jacobian commit_lagrange(const std::vector<Fe> &poly, const Blind<CURVE> &r) const { return run(h_gl, poly, r); }  // :135
+    std::vector<Affine> get_g() const { return g; }
+
+  private:
+    h2_bases_t h_g = 0, h_gl = 0;
+    Jacobian run(h2_bases_t h, const std::vector<Fe> &poly, const Blind<CURVE> &r) const {
+        if (poly.size() != n) throw std::invalid_argument("commit: poly.len() != n");
+        Jacobian out{};
+        check(h2_commit(h, poly[0].data(), n, w.data(), r.value.data(), H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, out.data()), "h2_commit");
+        return out;
+    }
+};
+
+}  // namespace halo2

@@ -1,0 +1,99 @@
+// C++ parity test of the host mirror (halo2_amd/host/halo2_host.hpp) through the C ABI, against the C oracle.
+// Written the way the reference's own tests read (arithmetic.rs:440 test_multiexp, commitment.rs:258
+// test_commit_lagrange, domain.rs iFFT checks).  TEST CODE: links oracle/h2_oracle.c as the checker.
+// Build: g++ -O2 -std=c++17 tests/native/host_mirror_check.cpp -Lhalo2_amd -lhalo2_mi355x -Loracle -lh2oracle (see __graft_entry__.build)
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../halo2_amd/host/halo2_host.hpp"
+
+extern "C" {
+void orc_random_field(int field, uint64_t seed, uint64_t *out, size_t n);
+void orc_generate_bases(int curve, const uint64_t *g_xy, uint64_t seed, uint64_t *out_xy, size_t n);
+int orc_best_multiexp(int curve, const uint64_t *scalars, const uint64_t *bases, size_t n, uint64_t *out_xyz);
+int orc_commit(int curve, const uint64_t *g, const uint64_t *w, const uint64_t *poly, const uint64_t *blind, size_t n, uint64_t *out_xyz);
+void orc_point_to_affine(int curve, uint64_t *out_xy, const uint64_t *in_xyz);
+int orc_best_fft(int field, uint64_t *a, const uint64_t *omega, unsigned log_n);
+int orc_ifft(int field, uint64_t *a, const uint64_t *omega_inv, unsigned log_n, const uint64_t *divisor);
+int orc_coeff_to_extended(int field, uint64_t *a_ext, unsigned k, unsigned ext_k, const uint64_t *g_coset, const uint64_t *g_coset_inv, const uint64_t *extended_omega);
+void orc_to_mont(int field, uint64_t *a, size_t n);
+}
+using namespace halo2;
+
+static int fails = 0;
+#define EXPECT(cond, msg) do { if (!(cond)) { printf("FAIL: %s\n", msg); fails++; } else printf("ok: %s\n", msg); } while (0)
+
+static bool same_point(int curve, const Jacobian &a, const uint64_t *b_xyz) {
+    uint64_t x[8], y[8];
+    orc_point_to_affine(curve, x, a.data());
+    orc_point_to_affine(curve, y, b_xyz);
+    return memcmp(x, y, 64) == 0;
+}
+
+int main() {
+    if (h2_device_count() <= 0) { printf("no GPU: host mirror check needs an MI355X\n"); return 2; }
+    constexpr int CURVE = H2_VESTA, FIELD = H2_FP;   // every proof in the reference runs on Vesta / Fp
+    const uint32_t k = 8;
+    const size_t n = (size_t)1 << k;
+    // generators: seeded multiples of (-1, 2) (pinned on-curve point, poly/commitment/msm.rs:181)
+    uint64_t gen[8] = {0}; {
+        const auto &Fq = field::params(H2_FQ);
+        uint64_t m1[4] = {Fq.p[0] - 1, Fq.p[1], Fq.p[2], Fq.p[3]}, two[4] = {2, 0, 0, 0};
+        memcpy(gen, m1, 32); memcpy(gen + 4, two, 32);
+        orc_to_mont(H2_FQ, gen, 2);
+    }
+    std::vector<Affine> g(n), gl(n);
+    orc_generate_bases(CURVE, gen, 11, g[0].data(), n);
+    orc_generate_bases(CURVE, gen, 12, gl[0].data(), n);
+    Affine w, u;
+    orc_generate_bases(CURVE, gen, 13, w.data(), 1);
+    orc_generate_bases(CURVE, gen, 14, u.data(), 1);
+
+    // test_multiexp (arithmetic.rs:440-458)
+    std::vector<Fe> coeffs(n);
+    orc_random_field(FIELD, 21, coeffs[0].data(), n);
+    Jacobian got = best_multiexp<CURVE>(coeffs, g);
+    uint64_t want[12];
+    orc_best_multiexp(CURVE, coeffs[0].data(), g[0].data(), n, want);
+    EXPECT(same_point(CURVE, got, want), "best_multiexp == oracle (k = 8, Vesta)");
+    bool threw = false;
+    try { std::vector<Fe> c2(n - 1); best_multiexp<CURVE>(c2, g); } catch (const std::invalid_argument &) { threw = true; }
+    EXPECT(threw, "best_multiexp rejects mismatched lengths (arithmetic.rs:144)");
+
+    // Params::commit / commit_lagrange with a blind (commitment.rs:119-150)
+    Params<CURVE> params(k, g, gl, w, u);
+    Blind<CURVE> r{field::from_u64(FIELD, 987654321)};
+    orc_commit(CURVE, g[0].data(), w.data(), coeffs[0].data(), r.value.data(), n, want);
+    EXPECT(same_point(CURVE, params.commit(coeffs, r), want), "Params::commit == oracle");
+    orc_commit(CURVE, gl[0].data(), w.data(), coeffs[0].data(), r.value.data(), n, want);
+    EXPECT(same_point(CURVE, params.commit_lagrange(coeffs, r), want), "Params::commit_lagrange == oracle");
+
+    // EvaluationDomain (domain.rs): constants, iFFT, coset FFT, round trip
+    EvaluationDomain<FIELD> dom(5, k);     // benches/plonk.rs: cs_degree 5 -> extended_k = k + 2
+    EXPECT(dom.extended_k == 10 && dom.t_evaluations.size() == 4, "EvaluationDomain::new(5, 8): extended_k = 10, 4 t_evaluations");
+    Fe w3 = field::mul(FIELD, field::mul(FIELD, dom.g_coset, dom.g_coset), dom.g_coset);
+    EXPECT(w3 == field::one(FIELD) && dom.g_coset != field::one(FIELD), "zeta^3 = 1, zeta != 1");
+    std::vector<Fe> a(n);
+    orc_random_field(FIELD, 31, a[0].data(), n);
+    std::vector<Fe> ref = a;
+    orc_ifft(FIELD, ref[0].data(), dom.omega_inv.data(), k, dom.ifft_divisor.data());
+    std::vector<Fe> coeff = dom.lagrange_to_coeff(a);
+    EXPECT(coeff == ref, "lagrange_to_coeff == oracle ifft");
+    std::vector<Fe> ext_ref(dom.extended_len());
+    memcpy(ext_ref[0].data(), ref[0].data(), n * 32);
+    orc_coeff_to_extended(FIELD, ext_ref[0].data(), k, dom.extended_k, dom.g_coset.data(), dom.g_coset_inv.data(), dom.extended_omega.data());
+    std::vector<Fe> ext = dom.coeff_to_extended(coeff);
+    EXPECT(ext == ext_ref, "coeff_to_extended == oracle");
+    std::vector<Fe> back = dom.extended_to_coeff(ext);
+    bool rt = back.size() == n * dom.quotient_poly_degree && std::equal(coeff.begin(), coeff.end(), back.begin());
+    for (size_t i = n; i < back.size(); i++) rt = rt && back[i] == Fe{0, 0, 0, 0};
+    EXPECT(rt, "extended_to_coeff(coeff_to_extended(p)) == p, zero padded to n * (degree - 1)");
+    std::vector<Fe> f = a;
+    best_fft<FIELD>(f, dom.omega, k);
+    std::vector<Fe> fref = a;
+    orc_best_fft(FIELD, fref[0].data(), dom.omega.data(), k);
+    EXPECT(f == fref, "best_fft == oracle");
+    printf(fails ? "HOST MIRROR CHECK FAILED (%d)\n" : "HOST MIRROR CHECK OK\n", fails);
+    return fails ? 1 : 0;
+}

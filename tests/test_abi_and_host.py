@@ -108,3 +108,11 @@ def test_limb_encoding_roundtrip():
     a = fields.to_limbs(vals, h.FP)
     assert fields.from_limbs(a, h.FP) == vals
     assert fields.from_limbs(fields.to_limbs(vals, None, montgomery=False), None, montgomery=False) == vals
+
+
+def test_cpp_host_mirror_header_compiles():
+    """The C++ mirror of the reference interface is self-contained: it compiles against the C header alone."""
+    src = '#include "halo2_amd/host/halo2_host.hpp"\nint main() { halo2::EvaluationDomain<H2_FP> d(3, 4); return d.extended_k == 5 ? 0 : 1; }\n'
+    out = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", ROOT, "-x", "c++", "-"], input=src, text=True,
+                         capture_output=True, cwd=ROOT)
+    assert out.returncode == 0, out.stderr

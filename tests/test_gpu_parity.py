@@ -298,3 +298,17 @@ def test_device_resident_path():
     h.best_fft(d_a, omega, log_n, field)
     torch.cuda.synchronize()
     assert np.array_equal(d_a.cpu().numpy().view(np.uint64), co.best_fft(field, a, omega, log_n))
+
+
+@pytest.mark.parametrize("binary,marker", [("field_check", "FIELD CHECK OK"), ("host_mirror_check", "HOST MIRROR CHECK OK")])
+def test_native_drivers(binary, marker):
+    """tests/native/*: the gfx950 field arithmetic (every multiplier variant, add, sub, inverse; both moduli; edge
+    values) against the C oracle, and the C++ host mirror (halo2_amd/host/halo2_host.hpp) through the C ABI from a
+    plain g++ program -- no Python, no torch in the process.  Built by __graft_entry__.build()."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", binary)
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} not built (run __graft_entry__.build())")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and marker in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
