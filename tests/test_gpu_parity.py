@@ -312,3 +312,21 @@ def test_native_drivers(binary, marker):
         pytest.skip(f"{exe} not built (run __graft_entry__.build())")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and marker in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("config,k", [("plonk-bench", 8), ("simple-example", 10)])
+def test_create_proof_trace_replay(config, k):
+    """BASELINE configs[0] / configs[3] at test size: the whole MSM / FFT call trace of one create_proof
+    (bench/replay_create_proof.py), every output compared with the oracle."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "replay", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench", "replay_create_proof.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.run_trace(config, k, check=True)
+    assert res["mismatches"] == [], res
+    lag = mod.CONFIGS[config]["lagrange_columns"]
+    assert res["ops"] == 3 * lag + 1 + 1 + mod.CONFIGS[config]["h_pieces"] + 2 + 2 * k
+    if config == "plonk-bench":
+        assert (res["msm_full"], res["ipa_msm"], res["extended_k"]) == (11, 16, 10)   # SURVEY.md section 3.2 config 1
