@@ -330,3 +330,35 @@ def test_create_proof_trace_replay(config, k):
     assert res["ops"] == 3 * lag + 1 + 1 + mod.CONFIGS[config]["h_pieces"] + 2 + 2 * k
     if config == "plonk-bench":
         assert (res["msm_full"], res["ipa_msm"], res["extended_k"]) == (11, 16, 10)
+
+
+def test_concurrent_streams_and_lane_fraction():
+    """bench.py spreads independent column commits over several HIP streams with a reduced accumulate lane
+    fraction: every commit must still be bit-exact (per-(device, stream) workspaces, one shared table)."""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    from halo2_amd.arithmetic import _p
+    curve, n, ncols = h.PALLAS, 1 << 14, 9
+    sf = co.field_of_curve(curve, "scalar")
+    lib = h.lib()
+    g = co.generate_bases(curve, 55, n)
+    hd = C.c_uint64(0)
+    assert lib.h2_bases_register(curve, _p(g), n, h.FORM_MONTGOMERY, C.byref(hd)) == 0
+    cols = [co.random_field(sf, 600 + i, n) for i in range(ncols)]
+    d_cols = [torch.from_numpy(c.view(np.int64)).cuda() for c in cols]
+    d_out = torch.zeros((ncols, 12), dtype=torch.int64, device="cuda")
+    assert lib.h2_set_option(b"msm_lane_fraction", 0.5) == 0
+    assert lib.h2_set_option(b"msm_lane_fraction", 7.0) == 1 and lib.h2_set_option(b"no_such_option", 1.0) == 1
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for i in range(ncols):
+            rc = lib.h2_commit_device(hd, d_cols[i].data_ptr(), n, None, None, h.FORM_MONTGOMERY, 0, d_out[i].data_ptr(),
+                                      C.c_void_p(streams[i % 3].cuda_stream))
+            assert rc == 0
+    torch.cuda.synchronize()
+    assert lib.h2_set_option(b"msm_lane_fraction", 1.0) == 0
+    res = d_out.cpu().numpy().view(np.uint64)
+    for i in range(ncols):
+        assert affine_of(curve, res[i]) == co.jac_to_affine_ints(curve, co.best_multiexp(curve, cols[i], g)), i
+    assert lib.h2_bases_free(hd) == 0
