@@ -42,7 +42,7 @@
 #include <vector>
 
 #include "common.h"
-#include "curve.cuh"
+#include "curve_wide.cuh"
 
 namespace h2 {
 
@@ -357,21 +357,14 @@ __global__ void __launch_bounds__(256) msm_finish_heavy(const u32 *__restrict__ 
     }
 }
 
-// k * p for a small k (bucket index offsets, < 2^16): MSB-first double-and-add
-template <int FB> __device__ xyzz<FB> xyzz_mul_small(const xyzz<FB> &p, u32 k) {
-    xyzz<FB> r = xyzz_identity<FB>();
-    for (int b = 31 - __clz(k | 1); b >= 0; --b) {
-        r = xyzz_dbl<FB>(r);
-        if ((k >> b) & 1) xyzz_add<FB>(r, p);
-    }
-    return k ? r : xyzz_identity<FB>();
-}
+// The three tail kernels below run each logical lane as a quad of 4 hardware lanes (curve_wide.cuh): the chip
+// is nearly idle here, so lanes are free and the dependent-multiply depth per point operation drops 3x.
 
 // ---- reduce level 1: segment of kSeg buckets -> sum_j (j+1) * B_j restricted to the segment ------
 template <int FB>
 __global__ void __launch_bounds__(256) msm_reduce_segments(const u32 *__restrict__ buckets, u32 *__restrict__ partial,
                                                            u32 NB, u32 total_segments) {
-    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 t = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
     if (t >= total_segments) return;
     u32 segs_per_slice = NB / kSeg;
     u32 sl = t / segs_per_slice, sg = t % segs_per_slice;
@@ -379,55 +372,58 @@ __global__ void __launch_bounds__(256) msm_reduce_segments(const u32 *__restrict
     xyzz<FB> run = xyzz_identity<FB>(), acc = xyzz_identity<FB>();
     for (int j = kSeg - 1; j >= 0; --j) {
         xyzz<FB> bk = xyzz_load<FB>(base + 32 * j);
-        xyzz_add<FB>(run, bk);
-        xyzz_add<FB>(acc, run);
+        xyzz_add_wide<FB>(run, bk);
+        xyzz_add_wide<FB>(acc, run);
     }
     // buckets of this segment carry weights sg*kSeg + (j+1): add (sg*kSeg) * run
-    xyzz<FB> sh = xyzz_mul_small<FB>(run, sg * kSeg);
-    xyzz_add<FB>(acc, sh);
-    xyzz_store<FB>(partial + 32 * (size_t)t, acc);
+    xyzz<FB> sh = xyzz_mul_small_wide<FB>(run, sg * kSeg);
+    xyzz_add_wide<FB>(acc, sh);
+    if ((threadIdx.x & (kGroup - 1)) == 0) xyzz_store<FB>(partial + 32 * (size_t)t, acc);
 }
 
-// ---- reduce level 2: tree sum of a slice's partials ------------------------------------------------
+// ---- reduce level 2: tree sum of a slice's partials (1024 hardware lanes = 256 logical lanes) ----------
 template <int FB>
-__global__ void __launch_bounds__(256) msm_sum_slice(const u32 *__restrict__ partial, u32 *__restrict__ slice_sums,
-                                                     u32 per_slice) {
+__global__ void __launch_bounds__(1024) msm_sum_slice(const u32 *__restrict__ partial, u32 *__restrict__ slice_sums,
+                                                      u32 per_slice) {
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
-    const u32 sl = blockIdx.x, t = threadIdx.x;
+    const u32 sl = blockIdx.x, t = threadIdx.x / kGroup, nl = blockDim.x / kGroup;
+    const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
     const u32 *src = partial + 32 * (size_t)sl * per_slice;
     xyzz<FB> acc = xyzz_identity<FB>();
-    for (u32 i = t; i < per_slice; i += blockDim.x) {
+    for (u32 i = t; i < per_slice; i += nl) {
         xyzz<FB> p = xyzz_load<FB>(src + 32 * (size_t)i);
-        xyzz_add<FB>(acc, p);
+        xyzz_add_wide<FB>(acc, p);
     }
-    xyzz_store<FB>(sh + 32 * t, acc);
+    if (lead) xyzz_store<FB>(sh + 32 * t, acc);
     __syncthreads();
-    for (u32 off = blockDim.x / 2; off > 0; off >>= 1) {
+    for (u32 off = nl / 2; off > 0; off >>= 1) {
         if (t < off) {
             xyzz<FB> a = xyzz_load<FB>(sh + 32 * t), b = xyzz_load<FB>(sh + 32 * (t + off));
-            xyzz_add<FB>(a, b);
-            xyzz_store<FB>(sh + 32 * t, a);
+            xyzz_add_wide<FB>(a, b);
+            __builtin_amdgcn_wave_barrier();
+            if (lead) xyzz_store<FB>(sh + 32 * t, a);
         }
         __syncthreads();
     }
-    if (t == 0) {
+    if (threadIdx.x == 0) {
         xyzz<FB> r = xyzz_load<FB>(sh);
         xyzz_store<FB>(slice_sums + 32 * (size_t)sl, r);
     }
 }
 
-// ---- combine: Horner over slices (windows), emit Jacobian / affine ---------------------------------
+// ---- combine: Horner over slices (windows), emit Jacobian / affine; one quad of lanes ---------------
 template <int FB>
-__global__ void msm_combine(const u32 *__restrict__ slice_sums, int slices, int c, u32 *__restrict__ out, int out_kind,
-                            int out_mont) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void __launch_bounds__(64) msm_combine(const u32 *__restrict__ slice_sums, int slices, int c, u32 *__restrict__ out,
+                                                  int out_kind, int out_mont) {
+    if (blockIdx.x != 0 || threadIdx.x >= kGroup) return;
     xyzz<FB> r = xyzz_identity<FB>();
     for (int w = slices - 1; w >= 0; --w) {
         if (w != slices - 1)
-            for (int k = 0; k < c; ++k) r = xyzz_dbl<FB>(r);
+            for (int k = 0; k < c; ++k) r = xyzz_dbl_wide<FB>(r);
         xyzz<FB> s = xyzz_load<FB>(slice_sums + 32 * (size_t)w);
-        xyzz_add<FB>(r, s);
+        xyzz_add_wide<FB>(r, s);
     }
+    if (threadIdx.x != 0) return;
     if (out_kind == H2_OUT_AFFINE) {
         affine<FB> a = xyzz_to_affine<FB>(r);
         if (!out_mont) { a.x = fe_from_mont<FB>(a.x); a.y = fe_from_mont<FB>(a.y); }
@@ -652,9 +648,9 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                        cx.starts.as<u32>(), cx.buckets.as<u32>(), cx.heavy.as<u32>(), tb, T);
     hipLaunchKernelGGL((msm_finish_heavy<FB>), dim3(max_heavy), dim3(256), 256 * 128, st, cx.heads.as<u32>(),
                        cx.starts.as<u32>(), cx.buckets.as<u32>(), cx.heavy.as<u32>(), tb, T);
-    hipLaunchKernelGGL((msm_reduce_segments<FB>), dim3((segs + 255) / 256), dim3(256), 0, st, cx.buckets.as<u32>(),
+    hipLaunchKernelGGL((msm_reduce_segments<FB>), dim3((segs * kGroup + 255) / 256), dim3(256), 0, st, cx.buckets.as<u32>(),
                        cx.partial.as<u32>(), sh.NB, segs);
-    hipLaunchKernelGGL((msm_sum_slice<FB>), dim3(sh.slices), dim3(256), 256 * 128, st, cx.partial.as<u32>(),
+    hipLaunchKernelGGL((msm_sum_slice<FB>), dim3(sh.slices), dim3(1024), (1024 / kGroup) * 128, st, cx.partial.as<u32>(),
                        cx.ssums.as<u32>(), sh.NB / kSeg);
     hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, cx.ssums.as<u32>(), (int)sh.slices, sh.c, (u32 *)a.d_out,
                        a.out_kind, a.form == H2_FORM_MONTGOMERY);
