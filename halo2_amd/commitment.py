@@ -77,6 +77,33 @@ class Params:
                               out_kind, _p(out)), "h2_commit")
         return out
 
+    def commit_batch(self, polys, blinds, lagrange: bool = False, affine: bool = False):
+        """The independent column commits of one prover phase (plonk/prover.rs:305-313) in one call: device
+        tensors in, one (len, 12|8) device tensor out; columns overlap on internal streams."""
+        import torch
+        if len(polys) != len(blinds):
+            raise ValueError("commit_batch: polys and blinds differ in length")
+        if not polys:
+            return None
+        dev = polys[0].device
+        out_len = 8 if affine else 12
+        out = torch.empty((len(polys), out_len), dtype=torch.int64, device=dev)
+        if self._w_dev is None or self._w_dev.device != dev:
+            self._w_dev = torch.from_numpy(self.w.view(np.int64)).to(dev)
+        d_bl = torch.from_numpy(np.stack([np.ascontiguousarray(b.value) for b in blinds]).view(np.int64)).to(dev)
+        n_ = len(polys)
+        arr = C.c_void_p * n_
+        for p_ in polys:
+            if p_.shape[0] != self.n:
+                raise ValueError("commit_batch: polynomial length != n")
+        sc = arr(*[p_.data_ptr() for p_ in polys])
+        bl = arr(*[d_bl[i].data_ptr() for i in range(n_)])
+        outs = arr(*[out[i].data_ptr() for i in range(n_)])
+        check(lib().h2_commit_batch_device(self._h_gl if lagrange else self._h_g, sc, n_, self.n, self._w_dev.data_ptr(), bl,
+                                           FORM_MONTGOMERY, OUT_AFFINE if affine else OUT_JACOBIAN, outs, _stream_ptr()),
+              "h2_commit_batch_device")
+        return out
+
     def commit(self, poly, r: Blind, affine: bool = False):
         """commitment.rs:119-130: sum poly[i] * g[i] + r * w."""
         return self._commit(self._h_g, poly, r, affine)

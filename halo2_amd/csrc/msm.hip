@@ -586,6 +586,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     const MsmShape sh = make_shape(m, a.c, a.table);
     const u32 tb = sh.total_buckets, segs = tb / kSeg;
     const size_t all_items = (size_t)sh.W * m;
+    if (all_items >= ((size_t)1 << 31)) return H2_ERR_ARGS;  // entry = table index | sign << 31
     const u32 nblocks = (tb + kScanBlock - 1) / kScanBlock;
     if (!cx.attr_set) {
         H2_HIP(hipFuncSetAttribute((const void *)msm_count, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
@@ -680,6 +681,9 @@ struct Bases {
     u32 stride = 0;            // n + 1: column n is the blind's base
     void *d_table = nullptr;   // [W][stride] affine Montgomery points, row w = 2^(c*w) * P
     void *d_blind_tmp = nullptr;  // (W-1) XYZZ + flag word, scratch of msm_blind_chain
+    // blind-base maintenance is serialised on one stream of its own, whatever streams the commits come from
+    hipStream_t maint = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
 };
 static std::mutex g_bases_mu;
 static std::map<h2_bases_t, std::shared_ptr<Bases>> g_bases;
@@ -723,18 +727,31 @@ static int table_fill(Bases &b, u32 first, u32 count, hipStream_t st) {
     return H2_OK;
 }
 
-// makes column n of the table hold the multiples of `w` (device pointer, Montgomery), asynchronously on `st`.
-// A handle serves ONE blind base at a time (Params::w is fixed per Params, poly/commitment.rs:26-33).
+// makes column n of the table hold the multiples of `w` (device pointer, Montgomery).  Asynchronous: the check /
+// recompute kernels run on the handle's maintenance stream (so concurrent commits on different streams cannot
+// interleave them), ordered after `st` (which produced w) and before whatever `st` does next.
+// A handle serves ONE blind base at a time (Params::w is fixed per Params, poly/commitment.rs:26-33): switching
+// to a different w while commits with the old one are still in flight is not supported.
 static int ensure_blind_base(Bases &b, const void *d_w_mont, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(b.mu);
+    if (!b.maint) {
+        H2_HIP(hipStreamCreateWithFlags(&b.maint, hipStreamNonBlocking));
+        H2_HIP(hipEventCreateWithFlags(&b.ev_in, hipEventDisableTiming));
+        H2_HIP(hipEventCreateWithFlags(&b.ev_out, hipEventDisableTiming));
+    }
+    H2_HIP(hipEventRecord(b.ev_in, st));
+    H2_HIP(hipStreamWaitEvent(b.maint, b.ev_in, 0));
     u32 *tmp = (u32 *)b.d_blind_tmp, *flag = tmp + 32 * (size_t)b.W;
     if (b.curve == H2_PALLAS) {
-        hipLaunchKernelGGL((msm_blind_chain<FP>), dim3(1), dim3(64), 0, st, (u32 *)b.d_table, (const u32 *)d_w_mont, tmp, flag, (u32)b.n, b.stride, b.c, b.W);
-        hipLaunchKernelGGL((msm_blind_normalise<FP>), dim3(1), dim3(64), 0, st, tmp, (u32 *)b.d_table, flag, (u32)b.n, b.stride, b.W);
+        hipLaunchKernelGGL((msm_blind_chain<FP>), dim3(1), dim3(64), 0, b.maint, (u32 *)b.d_table, (const u32 *)d_w_mont, tmp, flag, (u32)b.n, b.stride, b.c, b.W);
+        hipLaunchKernelGGL((msm_blind_normalise<FP>), dim3(1), dim3(64), 0, b.maint, tmp, (u32 *)b.d_table, flag, (u32)b.n, b.stride, b.W);
     } else {
-        hipLaunchKernelGGL((msm_blind_chain<FQ>), dim3(1), dim3(64), 0, st, (u32 *)b.d_table, (const u32 *)d_w_mont, tmp, flag, (u32)b.n, b.stride, b.c, b.W);
-        hipLaunchKernelGGL((msm_blind_normalise<FQ>), dim3(1), dim3(64), 0, st, tmp, (u32 *)b.d_table, flag, (u32)b.n, b.stride, b.W);
+        hipLaunchKernelGGL((msm_blind_chain<FQ>), dim3(1), dim3(64), 0, b.maint, (u32 *)b.d_table, (const u32 *)d_w_mont, tmp, flag, (u32)b.n, b.stride, b.c, b.W);
+        hipLaunchKernelGGL((msm_blind_normalise<FQ>), dim3(1), dim3(64), 0, b.maint, tmp, (u32 *)b.d_table, flag, (u32)b.n, b.stride, b.W);
     }
     H2_HIP(hipGetLastError());
+    H2_HIP(hipEventRecord(b.ev_out, b.maint));
+    H2_HIP(hipStreamWaitEvent(st, b.ev_out, 0));
     return H2_OK;
 }
 
@@ -843,12 +860,25 @@ extern "C" int h2_bases_free(h2_bases_t handle) {
         H2_HIP(hipDeviceSynchronize());
         H2_HIP(hipFree(b->d_table));
         if (b->d_blind_tmp) H2_HIP(hipFree(b->d_blind_tmp));
+        if (b->maint) {
+            (void)hipStreamDestroy(b->maint);
+            (void)hipEventDestroy(b->ev_in);
+            (void)hipEventDestroy(b->ev_out);
+        }
     }
     return H2_OK;
 }
 
+static int commit_device_impl(h2_bases_t g, const void *d_scalars, size_t n, const void *d_w_xy, const void *d_blind, int form,
+                              int out_kind, void *d_out, void *stream, bool blind_base_ready);
+
 extern "C" int h2_commit_device(h2_bases_t g, const void *d_scalars, size_t n, const void *d_w_xy, const void *d_blind,
                                 int form, int out_kind, void *d_out, void *stream) {
+    return commit_device_impl(g, d_scalars, n, d_w_xy, d_blind, form, out_kind, d_out, stream, false);
+}
+
+static int commit_device_impl(h2_bases_t g, const void *d_scalars, size_t n, const void *d_w_xy, const void *d_blind, int form,
+                              int out_kind, void *d_out, void *stream, bool blind_base_ready) {
     auto b = find_bases(g);
     if (!b) return H2_ERR_HANDLE;
     if (bad_common(b->curve, form, out_kind) || !d_out || (n && !d_scalars) || n > b->n || ((d_w_xy == nullptr) != (d_blind == nullptr)))
@@ -858,7 +888,7 @@ extern "C" int h2_commit_device(h2_bases_t g, const void *d_scalars, size_t n, c
     hipStream_t st = (hipStream_t)stream;
     MsmContext &cx = msm_ctx(st);
     std::lock_guard<std::mutex> lk(cx.mu);
-    if (d_w_xy) {
+    if (d_w_xy && !blind_base_ready) {
         const void *w = d_w_xy;
         if (form == H2_FORM_CANONICAL) {
             if ((rc = cx.small.reserve(64)) != H2_OK) return rc;
@@ -866,11 +896,76 @@ extern "C" int h2_commit_device(h2_bases_t g, const void *d_scalars, size_t n, c
             to_mont_async(b->curve, cx.small.as<u32>(), 2, st);
             w = cx.small.ptr;
         }
-        std::lock_guard<std::mutex> bl(b->mu);
         if ((rc = ensure_blind_base(*b, w, st)) != H2_OK) return rc;
     }
     MsmArgs a{d_scalars, d_blind, b->d_table, nullptr, n, true, b->c, b->stride, (u32)b->n, form, out_kind, d_out};
     return msm_dispatch(cx, b->curve, a, st);
+}
+
+// ---- batched commits: the columns of one prover phase (plonk/prover.rs:93-101, 301-313; vanishing/prover.rs:96-108)
+// are independent; spread them over internal streams so one column's latency-bound sort / reduce kernels run beside
+// another's accumulate, then join on the caller's stream.
+namespace {
+struct BatchStreams {
+    std::mutex mu;
+    std::vector<hipStream_t> s;
+    std::vector<hipEvent_t> done;
+    hipEvent_t fork = nullptr;
+};
+BatchStreams &batch_streams() {
+    static BatchStreams b[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return b[dev & 15];
+}
+}  // namespace
+
+extern "C" int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars, size_t count, size_t n, const void *d_w_xy,
+                                      const void *const *d_blinds, int form, int out_kind, void *const *d_outs, void *stream) {
+    if (!d_scalars || !d_outs || (d_w_xy && !d_blinds)) return H2_ERR_ARGS;
+    if (count == 0) return H2_OK;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    BatchStreams &bs = batch_streams();
+    std::lock_guard<std::mutex> lk(bs.mu);
+    const size_t want = std::min<size_t>(3, count);
+    while (bs.s.size() < want) {
+        hipStream_t st;
+        hipEvent_t ev;
+        H2_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        H2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        bs.s.push_back(st);
+        bs.done.push_back(ev);
+    }
+    if (!bs.fork) H2_HIP(hipEventCreateWithFlags(&bs.fork, hipEventDisableTiming));
+    hipStream_t user = (hipStream_t)stream;
+    if (d_w_xy) {  // bring the blind base up to date ONCE, on the caller's stream, before forking
+        auto b = find_bases(g);
+        if (!b) return H2_ERR_HANDLE;
+        if (form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY) return H2_ERR_ARGS;
+        const void *w = d_w_xy;
+        MsmContext &cx = msm_ctx(user);
+        std::lock_guard<std::mutex> cl(cx.mu);
+        if (form == H2_FORM_CANONICAL) {
+            if ((rc = cx.small.reserve(64)) != H2_OK) return rc;
+            H2_HIP(hipMemcpyAsync(cx.small.ptr, d_w_xy, 64, hipMemcpyDeviceToDevice, user));
+            to_mont_async(b->curve, cx.small.as<u32>(), 2, user);
+            w = cx.small.ptr;
+        }
+        if ((rc = ensure_blind_base(*b, w, user)) != H2_OK) return rc;
+    }
+    const double saved = g_lane_fraction.load();
+    if (want > 1) g_lane_fraction.store(std::min(saved, 0.67));
+    H2_HIP(hipEventRecord(bs.fork, user));
+    for (size_t i = 0; i < want; ++i) H2_HIP(hipStreamWaitEvent(bs.s[i], bs.fork, 0));
+    for (size_t i = 0; i < count && rc == H2_OK; ++i)
+        rc = commit_device_impl(g, d_scalars[i], n, d_w_xy, d_w_xy ? d_blinds[i] : nullptr, form, out_kind, d_outs[i], bs.s[i % want], true);
+    g_lane_fraction.store(saved);
+    for (size_t i = 0; i < want; ++i) {
+        H2_HIP(hipEventRecord(bs.done[i], bs.s[i]));
+        H2_HIP(hipStreamWaitEvent(user, bs.done[i], 0));
+    }
+    return rc;
 }
 
 extern "C" int h2_commit(h2_bases_t g, const uint64_t *scalars, size_t n, const uint64_t *w_xy, const uint64_t *blind,
@@ -894,7 +989,6 @@ extern "C" int h2_commit(h2_bases_t g, const uint64_t *scalars, size_t n, const 
         H2_HIP(hipMemcpyAsync((char *)cx.small.ptr + 64, blind, 32, hipMemcpyHostToDevice, 0));
         if (form == H2_FORM_CANONICAL) to_mont_async(b->curve, cx.small.as<u32>(), 2, 0);
         d_bl = (char *)cx.small.ptr + 64;
-        std::lock_guard<std::mutex> bl(b->mu);
         if ((rc = ensure_blind_base(*b, cx.small.ptr, 0)) != H2_OK) return rc;
     }
     MsmArgs a{cx.stage_s.ptr, d_bl, b->d_table, nullptr, n, true, b->c, b->stride, (u32)b->n, form, out_kind, cx.out.ptr};

@@ -117,6 +117,13 @@ int h2_msm_device(int curve, const void *d_scalars, const void *d_bases_xy, size
                   int out_kind, void *d_out, void *stream);
 int h2_commit_device(h2_bases_t g, const void *d_scalars, size_t n, const void *d_w_xy,
                      const void *d_blind, int form, int out_kind, void *d_out, void *stream);
+/* `count` independent commits over one registered basis -- the column commits of a prover phase
+ * (plonk/prover.rs:93-101, 301-313; vanishing/prover.rs:96-108).  d_scalars[i] / d_blinds[i] / d_outs[i] are
+ * device pointers held in HOST arrays; the commits are spread over internal streams (one column's latency-bound
+ * sort/reduce kernels overlap another's accumulate) and joined on `stream`.  d_w_xy NULL: no blind term. */
+int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars, size_t count, size_t n,
+                           const void *d_w_xy, const void *const *d_blinds, int form, int out_kind,
+                           void *const *d_outs, void *stream);
 int h2_ntt_device(int field, void *d_a, unsigned log_n, const uint64_t *omega, int form, void *stream);
 int h2_ifft_device(int field, void *d_a, unsigned log_n, const uint64_t *omega_inv,
                    const uint64_t *divisor, int form, void *stream);

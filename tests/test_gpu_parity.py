@@ -362,3 +362,26 @@ def test_concurrent_streams_and_lane_fraction():
     for i in range(ncols):
         assert affine_of(curve, res[i]) == co.jac_to_affine_ints(curve, co.best_multiexp(curve, cols[i], g)), i
     assert lib.h2_bases_free(hd) == 0
+
+
+def test_commit_batch_matches_oracle():
+    """h2_commit_batch_device: the independent column commits of a prover phase in one call (internal streams)."""
+    torch = pytest.importorskip("torch")
+    curve, k = h.VESTA, 12
+    n = 1 << k
+    sf = co.field_of_curve(curve, "scalar")
+    g = co.generate_bases(curve, 901, n)
+    gl = co.generate_bases(curve, 902, n)
+    w = co.generate_bases(curve, 903, 1)[0]
+    u = co.generate_bases(curve, 904, 1)[0]
+    params = h.Params.from_generators(curve, k, g, gl, w, u)
+    cols = [co.random_field(sf, 910 + i, n) for i in range(7)]
+    blinds = [h.Blind(co.random_field(sf, 920 + i, 1)[0]) for i in range(7)]
+    d_cols = [torch.from_numpy(c.view(np.int64)).cuda() for c in cols]
+    for lagrange, basis in ((True, gl), (False, g)):
+        out = params.commit_batch(d_cols, blinds, lagrange=lagrange)
+        torch.cuda.synchronize()
+        res = out.cpu().numpy().view(np.uint64)
+        for i in range(7):
+            assert affine_of(curve, res[i]) == co.jac_to_affine_ints(curve, co.commit(curve, basis, w, cols[i], blinds[i].value)), (lagrange, i)
+    params.close()
