@@ -60,10 +60,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("H2_BENCH_BACKEND", "nccl")      # "gloo": exercise the N > 1 code path on a 1-GPU box
+    if backend == "gloo":
+        local_rank %= max(ndev, 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import halo2_amd as h
     from halo2_amd import fields, parallel
@@ -116,8 +123,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = {}
@@ -153,7 +161,7 @@ def main():
     split_msm_ok = None
     if world > 1:
         shared = co.random_field(sf, 4242, n)           # same column on every rank
-        total = parallel.split_msm(shared, bases, curve, rank, world, device=dev)
+        total = parallel.split_msm(shared, bases, curve, rank, world, device=comm_dev)
         whole = h.best_multiexp(shared, bases, curve) if rank == 0 else None
         if rank == 0:
             split_msm_ok = co.jac_to_affine_ints(curve, total) == co.jac_to_affine_ints(curve, whole)

@@ -21,7 +21,11 @@ _lib = None
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "h2_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libh2oracle.so"])
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lk:    # several ranks may arrive here at once
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+                subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libh2oracle.so"])
     return _SO
 
 
