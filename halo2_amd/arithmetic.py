@@ -86,3 +86,36 @@ def points_sum(points_xyz, curve: int) -> np.ndarray:
 
 def msm_window_bits(n: int) -> int:
     return lib().h2_msm_window_bits(n)
+
+
+def parallel_generator_collapse(g, challenge, curve: int, form: int = FORM_MONTGOMERY):
+    """`parallel_generator_collapse` (poly/commitment/prover.rs:154-166): g[i] <- g[i] + [challenge] * g[half + i] for the
+    first half of `g` (2 * half affine points), normalised to affine.  Returns the collapsed half (the reference
+    truncates, :137).  numpy in -> numpy out; torch CUDA tensor in -> in place, a view of the first half out."""
+    challenge = np.ascontiguousarray(challenge, dtype=np.uint64).reshape(4)
+    if g.shape[0] % 2:
+        raise ValueError("parallel_generator_collapse: odd length")
+    half = g.shape[0] // 2
+    if _is_torch(g):
+        assert g.is_cuda and g.is_contiguous()
+        check(lib().h2_generator_collapse_device(curve, g.data_ptr(), half, _p(challenge), form, _stream_ptr()),
+              "h2_generator_collapse_device")
+        return g[:half]
+    g = _np(g, 8).copy()
+    check(lib().h2_generator_collapse(curve, _p(g), half, _p(challenge), form), "h2_generator_collapse")
+    return g[:half]
+
+
+def fold_scalars(a, factor, field: int, form: int = FORM_MONTGOMERY):
+    """The p' / b collapse of an IPA round (poly/commitment/prover.rs:128-131): a[i] += a[half + i] * factor."""
+    factor = np.ascontiguousarray(factor, dtype=np.uint64).reshape(4)
+    if a.shape[0] % 2:
+        raise ValueError("fold_scalars: odd length")
+    half = a.shape[0] // 2
+    if _is_torch(a):
+        assert a.is_cuda and a.is_contiguous()
+        check(lib().h2_fold_scalars_device(field, a.data_ptr(), half, _p(factor), form, _stream_ptr()), "h2_fold_scalars_device")
+        return a[:half]
+    a = _np(a, 4).copy()
+    check(lib().h2_fold_scalars(field, _p(a), half, _p(factor), form), "h2_fold_scalars")
+    return a[:half]

@@ -1,0 +1,78 @@
+// Host-side Pasta field arithmetic for the handful of constants a call needs (twiddle steps, fused scale factors,
+// challenge recoding).  4 x 64-bit Montgomery limbs, R = 2^256 -- same values as field.cuh's device constants.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/halo2_mi355x.h"
+
+namespace h2 {
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+struct HostField {
+    u64 p[4], inv, r2[4], one[4];
+};
+static const HostField kHostField[2] = {
+    {{0x992d30ed00000001ULL, 0x224698fc094cf91bULL, 0, 0x4000000000000000ULL}, 0x992d30ecffffffffULL,
+     {0x8c78ecb30000000fULL, 0xd7d30dbd8b0de0e7ULL, 0x7797a99bc3c95d18ULL, 0x096d41af7b9cb714ULL},
+     {0x34786d38fffffffdULL, 0x992c350be41914adULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL}},
+    {{0x8c46eb2100000001ULL, 0x224698fc0994a8ddULL, 0, 0x4000000000000000ULL}, 0x8c46eb20ffffffffULL,
+     {0xfc9678ff0000000fULL, 0x67bb433d891a16e3ULL, 0x7fae231004ccf590ULL, 0x096d41af7ccfdaa9ULL},
+     {0x5b2b3e9cfffffffdULL, 0x992c350be3420567ULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL}},
+};
+static void host_mul(int f, u64 r[4], const u64 a[4], const u64 b[4]) {
+    const HostField &F = kHostField[f];
+    u64 t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) {
+            c += (u128)a[j] * b[i] + t[j];
+            t[j] = (u64)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (u64)c;
+        t[5] = (u64)(c >> 64);
+        u64 m = t[0] * F.inv;
+        c = ((u128)m * F.p[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; j++) {
+            c += (u128)m * F.p[j] + t[j];
+            t[j - 1] = (u64)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (u64)c;
+        t[4] = t[5] + (u64)(c >> 64);
+    }
+    bool ge = t[4] != 0;
+    if (!ge) {
+        ge = true;
+        for (int i = 3; i >= 0; i--) {
+            if (t[i] > F.p[i]) break;
+            if (t[i] < F.p[i]) { ge = false; break; }
+        }
+    }
+    if (ge) {
+        u128 br = 0;
+        for (int i = 0; i < 4; i++) {
+            u128 d = (u128)t[i] - F.p[i] - (u64)br;
+            t[i] = (u64)d;
+            br = (d >> 64) & 1;
+        }
+    }
+    memcpy(r, t, 32);
+}
+// bring a caller-supplied constant into Montgomery form
+static void host_to_mont(int f, u64 r[4], const u64 *a, int form) {
+    if (form == H2_FORM_MONTGOMERY) memcpy(r, a, 32);
+    else host_mul(f, r, a, kHostField[f].r2);
+}
+
+// Montgomery -> canonical
+static inline void host_from_mont(int f, u64 r[4], const u64 a[4]) {
+    const u64 one[4] = {1, 0, 0, 0};
+    host_mul(f, r, a, one);
+}
+
+}  // namespace h2

@@ -138,6 +138,17 @@ int h2_extended_to_coeff_device(int field, void *d_a, unsigned ext_k, const uint
  * point.  The local step after the 96-byte all-gather of a range-split MSM (one partial per GPU). */
 int h2_points_sum(int curve, const uint64_t *points_xyz, size_t count, uint64_t *out_xyz);
 
+/* ---- IPA round kernels (next to the MSMs inside commitment::create_proof) ----------------------- */
+/* replaces parallel_generator_collapse (halo2_proofs/src/poly/commitment/prover.rs:154-166):
+ * g holds 2*half affine points; on return g[i] = g[i] + [challenge] * g[half + i] for i < half, affine
+ * (the caller truncates to `half`, :137).  `challenge` is a scalar-field element in `form`. */
+int h2_generator_collapse(int curve, uint64_t *g_xy, size_t half, const uint64_t *challenge, int form);
+int h2_generator_collapse_device(int curve, void *d_g_xy, size_t half, const uint64_t *challenge, int form,
+                                 void *stream);
+/* replaces the p' / b collapse loop (prover.rs:128-131): a[i] += a[half + i] * factor for i < half. */
+int h2_fold_scalars(int field, uint64_t *a, size_t half, const uint64_t *factor, int form);
+int h2_fold_scalars_device(int field, void *d_a, size_t half, const uint64_t *factor, int form, void *stream);
+
 /* ---- measurement aid (no reference counterpart) ------------------------------------------------ */
 /* When enabled, the library brackets its dominant kernels with HIP events on the launching stream.
  * h2_profile_read drains them: slot 0 = MSM bucket accumulation, 1 = NTT passes (sum over the passes

@@ -61,6 +61,8 @@ def lib():
             "orc_random_field": ([C.c_int, C.c_uint64, u64p, C.c_size_t], None),
             "orc_generate_bases": ([C.c_int, u64p, C.c_uint64, u64p, C.c_size_t], None),
             "orc_msm_naive": ([C.c_int, u64p, u64p, C.c_size_t, u64p], C.c_int),
+            "orc_generator_collapse": ([C.c_int, u64p, C.c_size_t, u64p], None),
+            "orc_fold_scalars": ([C.c_int, u64p, C.c_size_t, u64p], None),
         }
         for name, (args, res) in sig.items():
             fn = getattr(_lib, name)
@@ -224,3 +226,18 @@ def generate_bases(curve: int, seed: int, n: int) -> np.ndarray:
     g = generator(curve)
     lib().orc_generate_bases(curve, _p(g), seed, _p(out), n)
     return out
+
+
+def generator_collapse(curve: int, g: np.ndarray, challenge: np.ndarray) -> np.ndarray:
+    """parallel_generator_collapse (poly/commitment/prover.rs:154-166): returns the collapsed first half."""
+    g = np.ascontiguousarray(g, dtype=np.uint64).copy()
+    half = g.shape[0] // 2
+    lib().orc_generator_collapse(curve, _p(g), half, _p(np.ascontiguousarray(challenge, dtype=np.uint64)))
+    return g[:half]
+
+
+def fold_scalars(field: int, a: np.ndarray, factor: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+    half = a.shape[0] // 2
+    lib().orc_fold_scalars(field, _p(a), half, _p(np.ascontiguousarray(factor, dtype=np.uint64)))
+    return a[:half]

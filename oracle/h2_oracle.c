@@ -12,6 +12,8 @@
  *   orc_extended_to_coeff  halo2_proofs/src/poly/domain.rs:303-325
  *   orc_divide_by_vanishing_poly  halo2_proofs/src/poly/domain.rs:329-348
  *   orc_commit             halo2_proofs/src/poly/commitment.rs:119-150
+ *   orc_generator_collapse halo2_proofs/src/poly/commitment/prover.rs:154-166
+ *   orc_fold_scalars       halo2_proofs/src/poly/commitment/prover.rs:128-131
  * Field and curve arithmetic (pasta_curves 0.5.1, Cargo.lock:1303, not vendored in the
  * reference tree) is restated from the definition: p, q below; y^2 = x^3 + 5;
  * Montgomery form with R = 2^256; Jacobian projective coordinates.
@@ -764,4 +766,32 @@ int orc_msm_naive(int curve, const u64 *scalars, const u64 *bases, size_t n, u64
     }
     memcpy(out_xyz, &acc, sizeof acc);
     return 0;
+}
+
+/* ------------------------------------------------------------------ IPA round pieces */
+/* parallel_generator_collapse, poly/commitment/prover.rs:154-166: g_lo[i] = g_lo[i] + g_hi[i] * challenge, normalised.
+ * g: 2*half affine points (Montgomery); challenge: scalar-field element (Montgomery). */
+typedef struct { int curve; u64 *g; size_t half; u64 k[4]; } collapse_ctx;
+static void collapse_task(void *vctx, size_t i) {
+    collapse_ctx *c = (collapse_ctx *)vctx;
+    const field_t *bf = base_field(c->curve);
+    jac_t t, lo;
+    jac_mul(bf, &t, (const aff_t *)(c->g + 8 * (c->half + i)), c->k);
+    jac_from_aff(bf, &lo, (const aff_t *)(c->g + 8 * i));
+    jac_add(bf, &t, &lo, &t);
+    jac_to_affine(bf, (aff_t *)(c->g + 8 * i), &t);
+}
+void orc_generator_collapse(int curve, u64 *g, size_t half, const u64 *challenge) {
+    collapse_ctx c = {curve, g, half, {0, 0, 0, 0}};
+    f_from_mont(scalar_field(curve), c.k, challenge);
+    parallel_for(half, collapse_task, &c);
+}
+/* prover.rs:128-131: a[i] = a[i] + a[i + half] * factor */
+void orc_fold_scalars(int field, u64 *a, size_t half, const u64 *factor) {
+    const field_t *f = &FIELDS[field];
+    for (size_t i = 0; i < half; i++) {
+        u64 t[4];
+        f_mul(f, t, a + 4 * (half + i), factor);
+        f_add(f, a + 4 * i, a + 4 * i, t);
+    }
 }

@@ -385,3 +385,38 @@ def test_commit_batch_matches_oracle():
         for i in range(7):
             assert affine_of(curve, res[i]) == co.jac_to_affine_ints(curve, co.commit(curve, basis, w, cols[i], blinds[i].value)), (lagrange, i)
     params.close()
+
+
+@pytest.mark.parametrize("curve", [h.PALLAS, h.VESTA])
+def test_ipa_round_kernels_match_oracle(curve):
+    """parallel_generator_collapse (poly/commitment/prover.rs:154-166) and the p'/b fold (:128-131), run for every
+    round of a k = 9 argument with the vectors kept on the device, against the oracle's restatement."""
+    torch = pytest.importorskip("torch")
+    bm, sm = o.CURVES[curve]
+    sf = co.field_of_curve(curve, "scalar")
+    k = 9
+    n = 1 << k
+    g = co.generate_bases(curve, 77 + curve, n)
+    g[5] = 0                                            # an identity generator must survive the collapse
+    p_vec = co.random_field(sf, 78, n)
+    challenges = [fields.scalar_limbs(v, sf) for v in (0, 1, sm - 1, 2)] + [co.random_field(sf, 80 + j, 1)[0] for j in range(k - 4)]
+    d_g = torch.from_numpy(g.view(np.int64)).cuda()
+    d_p = torch.from_numpy(p_vec.view(np.int64)).cuda()
+    ref_g, ref_p = g, p_vec
+    for j, u in enumerate(challenges):
+        ref_g = co.generator_collapse(curve, ref_g, u)
+        ref_p = co.fold_scalars(sf, ref_p, u)
+        d_g = h.parallel_generator_collapse(d_g, u, curve).contiguous()
+        d_p = h.fold_scalars(d_p, u, sf).contiguous()
+        torch.cuda.synchronize()
+        assert np.array_equal(d_g.cpu().numpy().view(np.uint64), ref_g), j
+        assert np.array_equal(d_p.cpu().numpy().view(np.uint64), ref_p), j
+    assert ref_g.shape[0] == 1
+    # host-pointer + canonical-form entry points
+    bf = co.field_of_curve(curve, "base")
+    g_can = co.from_mont(bf, g.reshape(-1, 4)).reshape(-1, 8)
+    u = co.random_field(sf, 99, 1)[0]
+    got = h.parallel_generator_collapse(g_can, co.from_mont(sf, u.reshape(1, 4))[0], curve, form=h.FORM_CANONICAL)
+    assert np.array_equal(co.to_mont(bf, got.reshape(-1, 4)).reshape(-1, 8), co.generator_collapse(curve, g, u))
+    with pytest.raises(ValueError):
+        h.parallel_generator_collapse(g[:3], u, curve)
