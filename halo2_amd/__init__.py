@@ -5,5 +5,5 @@ of the reference's interface; all compute is hand-written HIP in halo2_amd/csrc/
 from ._lib import (FORM_CANONICAL, FORM_MONTGOMERY, FP, FQ, LIB_PATH, PALLAS, VESTA, H2Error, lib)  # noqa: F401
 from .arithmetic import (best_fft, best_multiexp, fold_scalars, msm_window_bits, parallel_generator_collapse,  # noqa: F401
                          points_sum)
-from .commitment import Blind, Params  # noqa: F401
+from .commitment import Blind, Params, lagrange_basis  # noqa: F401
 from .domain import EvaluationDomain  # noqa: F401

@@ -48,6 +48,8 @@ SIGNATURES = {
     "h2_generator_collapse_device": ([C.c_int, vp, C.c_size_t, u64p, C.c_int, vp], C.c_int),
     "h2_fold_scalars": ([C.c_int, u64p, C.c_size_t, u64p, C.c_int], C.c_int),
     "h2_fold_scalars_device": ([C.c_int, vp, C.c_size_t, u64p, C.c_int, vp], C.c_int),
+    "h2_lagrange_basis": ([C.c_int, u64p, u64p, C.c_uint, C.c_int], C.c_int),
+    "h2_lagrange_basis_device": ([C.c_int, vp, vp, C.c_uint, C.c_int, vp], C.c_int),
     "h2_profile_enable": ([C.c_int], C.c_int),
     "h2_profile_read": ([C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),
 }

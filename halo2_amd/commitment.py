@@ -22,6 +22,16 @@ class Blind:
         self.value = fields.scalar_limbs(1, field, True) if value is None else np.ascontiguousarray(value, dtype=np.uint64)
 
 
+def lagrange_basis(g, curve: int, k: int, form: int = FORM_MONTGOMERY) -> np.ndarray:
+    """The point FFT of `Params::new` (commitment.rs:77-100): g_lagrange from g, on the device."""
+    g = _np(g, 8)
+    if g.shape[0] != 1 << k:
+        raise ValueError("lagrange_basis: need 2^k generators")
+    out = np.empty_like(g)
+    check(lib().h2_lagrange_basis(curve, _p(g), _p(out), k, form), "h2_lagrange_basis")
+    return out
+
+
 class Params:
     def __init__(self, curve: int, k: int, g, g_lagrange, w, u):
         self.curve, self.k, self.n = curve, k, 1 << k
@@ -40,6 +50,9 @@ class Params:
 
     @classmethod
     def from_generators(cls, curve: int, k: int, g, g_lagrange, w, u) -> "Params":
+        """g_lagrange=None: derive it from g with the device point FFT, as Params::new does (:77-100)."""
+        if g_lagrange is None:
+            g_lagrange = lagrange_basis(g, curve, k)
         return cls(curve, k, g, g_lagrange, w, u)
 
     def close(self):

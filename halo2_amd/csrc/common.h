@@ -55,6 +55,10 @@ bool prof_enabled();
 void prof_begin(int slot, hipStream_t st);
 void prof_end(int slot, hipStream_t st);
 
+// Device table omega^0 .. omega^(2^(L-1) - 1) (Montgomery, 32 B each) from the NTT's per-(field, omega, log n) cache
+// (ntt.hip); built on `st` when missing.  Shared with the curve-point FFT (ecfft.hip).
+int ntt_twiddle_table(int field, int L, const uint64_t omega_mont[4], hipStream_t st, const uint32_t **d_tw);
+
 // Confirms a usable gfx950 device exists; every entry point calls this first so a missing GPU or
 // runtime fails loudly (H2_ERR_NODEV) instead of silently doing nothing.
 int ensure_device();

@@ -368,6 +368,16 @@ static int launch_pass(int field, const PassArgs &A, unsigned tiles, u32 threads
                    : launch_pass_r<FQ, false>(A, tiles, threads, lds, st, src, dst, tw);
 }
 
+int ntt_twiddle_table(int field, int L, const uint64_t omega_mont[4], hipStream_t st, const uint32_t **d_tw) {
+    NttContext &cx = ntt_ctx();
+    std::lock_guard<std::mutex> lk(cx.mu);
+    std::shared_ptr<TwEntry> tw;
+    int rc = get_twiddles(cx, field, L, omega_mont, st, tw);
+    if (rc != H2_OK) return rc;
+    *d_tw = (const uint32_t *)tw->d;   // stays alive in the cache (evicted only beyond 6 GiB of tables)
+    return H2_OK;
+}
+
 struct NttJob {
     int field;
     unsigned L;

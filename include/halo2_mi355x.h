@@ -149,6 +149,13 @@ int h2_generator_collapse_device(int curve, void *d_g_xy, size_t half, const uin
 int h2_fold_scalars(int field, uint64_t *a, size_t half, const uint64_t *factor, int form);
 int h2_fold_scalars_device(int field, void *d_a, size_t half, const uint64_t *factor, int form, void *stream);
 
+/* ---- Params set-up: Lagrange basis by an FFT over curve points -------------------------------- */
+/* replaces the point FFT + 2^-k scaling + batch_normalize of Params::new
+ * (halo2_proofs/src/poly/commitment.rs:77-100): out[j] = 2^-k * sum_i alpha_inv^(i*j) * g[i], affine, where
+ * alpha_inv is the inverse 2^k-th root of unity of the curve's scalar field.  g and out hold 2^k points. */
+int h2_lagrange_basis(int curve, const uint64_t *g_xy, uint64_t *out_xy, unsigned k, int form);
+int h2_lagrange_basis_device(int curve, const void *d_g_xy, void *d_out_xy, unsigned k, int form, void *stream);
+
 /* ---- measurement aid (no reference counterpart) ------------------------------------------------ */
 /* When enabled, the library brackets its dominant kernels with HIP events on the launching stream.
  * h2_profile_read drains them: slot 0 = MSM bucket accumulation, 1 = NTT passes (sum over the passes

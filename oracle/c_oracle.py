@@ -62,6 +62,7 @@ def lib():
             "orc_generate_bases": ([C.c_int, u64p, C.c_uint64, u64p, C.c_size_t], None),
             "orc_msm_naive": ([C.c_int, u64p, u64p, C.c_size_t, u64p], C.c_int),
             "orc_generator_collapse": ([C.c_int, u64p, C.c_size_t, u64p], None),
+            "orc_lagrange_basis": ([C.c_int, u64p, C.c_uint, u64p], C.c_int),
             "orc_fold_scalars": ([C.c_int, u64p, C.c_size_t, u64p], None),
         }
         for name, (args, res) in sig.items():
@@ -241,3 +242,11 @@ def fold_scalars(field: int, a: np.ndarray, factor: np.ndarray) -> np.ndarray:
     half = a.shape[0] // 2
     lib().orc_fold_scalars(field, _p(a), half, _p(np.ascontiguousarray(factor, dtype=np.uint64)))
     return a[:half]
+
+
+def lagrange_basis(curve: int, g: np.ndarray, k: int) -> np.ndarray:
+    """g_lagrange of Params::new (poly/commitment.rs:77-100) from g."""
+    g = np.ascontiguousarray(g, dtype=np.uint64)
+    out = np.zeros_like(g)
+    assert lib().orc_lagrange_basis(curve, _p(g), k, _p(out)) == 0
+    return out

@@ -12,6 +12,7 @@
  *   orc_extended_to_coeff  halo2_proofs/src/poly/domain.rs:303-325
  *   orc_divide_by_vanishing_poly  halo2_proofs/src/poly/domain.rs:329-348
  *   orc_commit             halo2_proofs/src/poly/commitment.rs:119-150
+ *   orc_lagrange_basis     halo2_proofs/src/poly/commitment.rs:77-100 (point FFT of Params::new)
  *   orc_generator_collapse halo2_proofs/src/poly/commitment/prover.rs:154-166
  *   orc_fold_scalars       halo2_proofs/src/poly/commitment/prover.rs:128-131
  * Field and curve arithmetic (pasta_curves 0.5.1, Cargo.lock:1303, not vendored in the
@@ -794,4 +795,74 @@ void orc_fold_scalars(int field, u64 *a, size_t half, const u64 *factor) {
         f_mul(f, t, a + 4 * (half + i), factor);
         f_add(f, a + 4 * i, a + 4 * i, t);
     }
+}
+
+/* ------------------------------------------------------------------ Params::new: Lagrange basis */
+/* poly/commitment.rs:77-100: best_fft over curve points with alpha_inv = ROOT_OF_UNITY_INV^(2^(S-k)), then every point
+ * times 2^-k, then normalise.  best_fft's generic G = C::Curve instance (arithmetic.rs:192-255, iterative form). */
+typedef struct { int curve; jac_t *a; size_t n; size_t chunk, twiddle_chunk; const u64 *tw_canon; } ecfft_ctx;
+static void ecfft_block_task(void *vctx, size_t blk) {
+    ecfft_ctx *c = (ecfft_ctx *)vctx;
+    const field_t *bf = base_field(c->curve);
+    jac_t *left = c->a + blk * c->chunk, *right = left + c->chunk / 2;
+    for (size_t i = 0; i < c->chunk / 2; i++) {
+        jac_t t = right[i], neg;
+        if (i != 0) {                                   /* twiddle factor one for i == 0 (:232-238) */
+            aff_t ta;
+            jac_to_affine(bf, &ta, &right[i]);
+            jac_mul(bf, &t, &ta, c->tw_canon + 4 * (i * c->twiddle_chunk));
+        }
+        neg = t;
+        f_neg(bf, neg.y, t.y);
+        right[i] = left[i];
+        jac_add(bf, &left[i], &left[i], &t);
+        jac_add(bf, &right[i], &right[i], &neg);
+    }
+}
+int orc_lagrange_basis(int curve, const u64 *g, unsigned k, u64 *out) {
+    if (k >= 32) return -1;
+    const field_t *bf = base_field(curve), *sf = scalar_field(curve);
+    size_t n = (size_t)1 << k;
+    /* alpha_inv */
+    u64 five[4] = {5, 0, 0, 0}, e[4], root[4], inv[4];
+    f_to_mont(sf, five, five);
+    e[0] = (sf->p[0] >> 32) | (sf->p[1] << 32); e[1] = (sf->p[1] >> 32) | (sf->p[2] << 32);
+    e[2] = (sf->p[2] >> 32) | (sf->p[3] << 32); e[3] = sf->p[3] >> 32;     /* (p - 1) / 2^32 */
+    f_pow(sf, root, five, e);
+    for (unsigned i = k; i < 32; i++) f_sqr(sf, root, root);
+    f_inv(sf, inv, root);
+    jac_t *a = (jac_t *)malloc(n * sizeof(jac_t));
+    for (size_t i = 0; i < n; i++) jac_from_aff(bf, &a[i], (const aff_t *)(g + 8 * i));
+    for (size_t x = 0; x < n; x++) {                                       /* bit reversal :207-212 */
+        size_t rx = bitreverse(x, k);
+        if (x < rx) { jac_t t = a[x]; a[x] = a[rx]; a[rx] = t; }
+    }
+    size_t half = n / 2;
+    u64 *tw = (u64 *)malloc((half ? half : 1) * 32), w[4];
+    memcpy(w, sf->r, 32);
+    for (size_t j = 0; j < half; j++) { f_from_mont(sf, tw + 4 * j, w); f_mul(sf, w, w, inv); }
+    ecfft_ctx c = {curve, a, n, 2, n / 2, tw};
+    for (unsigned s = 0; s < k; s++) {
+        parallel_for(n / c.chunk, ecfft_block_task, &c);
+        c.chunk *= 2;
+        c.twiddle_chunk /= 2;
+    }
+    /* g *= TWO_INV^k (:83-88), normalise (:90-100) */
+    u64 two[4] = {2, 0, 0, 0}, minv[4], minv_c[4], acc[4];
+    f_to_mont(sf, two, two);
+    f_inv(sf, two, two);
+    memcpy(acc, sf->r, 32);
+    for (unsigned i = 0; i < k; i++) f_mul(sf, acc, acc, two);
+    memcpy(minv, acc, 32);
+    f_from_mont(sf, minv_c, minv);
+    for (size_t i = 0; i < n; i++) {
+        aff_t p;
+        jac_t r;
+        jac_to_affine(bf, &p, &a[i]);
+        jac_mul(bf, &r, &p, minv_c);
+        jac_to_affine(bf, (aff_t *)(out + 8 * i), &r);
+    }
+    free(tw);
+    free(a);
+    return 0;
 }

@@ -420,3 +420,41 @@ def test_ipa_round_kernels_match_oracle(curve):
     assert np.array_equal(co.to_mont(bf, got.reshape(-1, 4)).reshape(-1, 8), co.generator_collapse(curve, g, u))
     with pytest.raises(ValueError):
         h.parallel_generator_collapse(g[:3], u, curve)
+
+
+@pytest.mark.parametrize("curve", [h.PALLAS, h.VESTA])
+def test_lagrange_basis_and_commit_lagrange_identity(curve):
+    """Params::new's point FFT (poly/commitment.rs:77-100) on the device vs the oracle's restatement, then the
+    reference's own test_commit_lagrange_{epaffine,eqaffine} (:258-302) at k = 6:
+    commit(lagrange_to_coeff(a)) == commit_lagrange(a), which ties the MSM, the field iFFT and the point FFT together."""
+    sf = co.field_of_curve(curve, "scalar")
+    for k in (0, 1, 3, 6):
+        g = co.generate_bases(curve, 300 + k, 1 << k)
+        assert np.array_equal(h.lagrange_basis(g, curve, k), co.lagrange_basis(curve, g, k)), k
+    k = 6
+    n = 1 << k
+    g = co.generate_bases(curve, 306, n)
+    w = co.generate_bases(curve, 307, 1)[0]
+    u = co.generate_bases(curve, 308, 1)[0]
+    params = h.Params.from_generators(curve, k, g, None, w, u)
+    dom = h.EvaluationDomain(1, k, sf)
+    a = co.random_field(sf, 309, n)
+    alpha = h.Blind(co.random_field(sf, 310, 1)[0])
+    b = dom.lagrange_to_coeff(a.copy())
+    assert affine_of(curve, params.commit(b, alpha)) == affine_of(curve, params.commit_lagrange(a, alpha))
+    params.close()
+
+
+def test_lagrange_basis_k12_properties():
+    """Larger point FFT without the oracle: sum_j g_lagrange[j] = g[0] (all Lagrange polynomials sum to 1) and
+    commit_lagrange of the evaluations of X^3 equals g[3]."""
+    curve, k = h.VESTA, 12
+    n = 1 << k
+    sf = co.field_of_curve(curve, "scalar")
+    g = co.generate_bases(curve, 400, n)
+    gl = h.lagrange_basis(g, curve, k)
+    ones = np.tile(fields.scalar_limbs(1, sf), (n, 1))
+    assert affine_of(curve, h.best_multiexp(ones, gl, curve)) == co.affine_to_ints(curve, g[0])
+    dom = h.EvaluationDomain(1, k, sf)
+    evals = fields.to_limbs([pow(dom.omega, 3 * i, dom.m) for i in range(n)], sf)
+    assert affine_of(curve, h.best_multiexp(evals, gl, curve)) == co.affine_to_ints(curve, g[3])
