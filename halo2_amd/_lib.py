@@ -35,6 +35,8 @@ SIGNATURES = {
     "h2_ifft": ([C.c_int, u64p, C.c_uint, u64p, u64p, C.c_int], C.c_int),
     "h2_coeff_to_extended": ([C.c_int, u64p, u64p, C.c_uint, C.c_uint, u64p, u64p, u64p, C.c_int], C.c_int),
     "h2_extended_to_coeff": ([C.c_int, u64p, C.c_uint, u64p, u64p, u64p, u64p, C.c_int], C.c_int),
+    "h2_divide_by_vanishing_poly": ([C.c_int, u64p, C.c_uint, u64p, C.c_size_t, C.c_int], C.c_int),
+    "h2_divide_by_vanishing_poly_device": ([C.c_int, vp, C.c_uint, u64p, C.c_size_t, C.c_int, vp], C.c_int),
     "h2_msm_device": ([C.c_int, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp], C.c_int),
     "h2_commit_device": ([C.c_uint64, vp, C.c_size_t, vp, vp, C.c_int, C.c_int, vp, vp], C.c_int),
     "h2_commit_batch_device": ([C.c_uint64, C.POINTER(vp), C.c_size_t, C.c_size_t, vp, C.POINTER(vp), C.c_int, C.c_int,

@@ -557,6 +557,39 @@ extern "C" int h2_extended_to_coeff_device(int field, void *d_a, unsigned ext_k,
     return ntt_run(J, (hipStream_t)stream);
 }
 
+// ---- divide_by_vanishing_poly (poly/domain.rs:329-348): a[i] *= t_evaluations[i mod nt] ----------------------------
+template <int F>
+__global__ void __launch_bounds__(256) k_mul_periodic(u32 *__restrict__ a, const u32 *__restrict__ t, size_t n, u32 nt) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_store(a + 8 * i, fe_mulx<F>(fe_load(a + 8 * i), fe_load(t + 8 * (size_t)(i % nt))));
+}
+
+extern "C" int h2_divide_by_vanishing_poly_device(int field, void *d_a, unsigned ext_k, const uint64_t *t_evaluations, size_t nt, int form,
+                                                  void *stream) {
+    if (bad_field(field, form) || !d_a || !t_evaluations || nt == 0 || nt > 4096 || ext_k > 32) return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    NttContext &cx = ntt_ctx();
+    std::lock_guard<std::mutex> lk(cx.mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    DevBuf &tb = cx.stage[std::make_pair(dev * 4 + 2, st)];
+    if ((rc = tb.reserve(nt * 32)) != H2_OK) return rc;
+    std::vector<u64> tm(nt * 4);
+    for (size_t i = 0; i < nt; ++i) host_to_mont(field, &tm[4 * i], t_evaluations + 4 * i, form);   // Montgomery factors work for either data form
+    H2_HIP(hipStreamSynchronize(st));   // the small table buffer is reused across calls
+    H2_HIP(hipMemcpyAsync(tb.ptr, tm.data(), nt * 32, hipMemcpyHostToDevice, st));
+    H2_HIP(hipStreamSynchronize(st));   // tm goes out of scope
+    const size_t n = (size_t)1 << ext_k;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (field == H2_FP) hipLaunchKernelGGL((k_mul_periodic<FP>), grid, block, 0, st, (u32 *)d_a, tb.as<u32>(), n, (u32)nt);
+    else hipLaunchKernelGGL((k_mul_periodic<FQ>), grid, block, 0, st, (u32 *)d_a, tb.as<u32>(), n, (u32)nt);
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
 // ---- host-pointer variants: stage through a per-stream device buffer --------------------------------
 namespace {
 struct Staged {
@@ -624,6 +657,21 @@ extern "C" int h2_coeff_to_extended(int field, const uint64_t *a, uint64_t *out,
     if ((rc = h2_coeff_to_extended_device(field, si.d, so.d, k, ext_k, g_coset, g_coset_inv, extended_omega, form, nullptr)) != H2_OK)
         return rc;
     H2_HIP(hipMemcpyAsync(out, so.d, out_bytes, hipMemcpyDeviceToHost, 0));
+    H2_HIP(hipStreamSynchronize(0));
+    return H2_OK;
+}
+
+extern "C" int h2_divide_by_vanishing_poly(int field, uint64_t *a, unsigned ext_k, const uint64_t *t_evaluations, size_t nt, int form) {
+    if (bad_field(field, form) || !a || !t_evaluations || nt == 0 || nt > 4096 || ext_k > 32) return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    size_t bytes = (size_t)32 << ext_k;
+    Staged s = stage_buffer(bytes, 0);
+    if (s.rc != H2_OK) return s.rc;
+    H2_HIP(hipMemcpyAsync(s.d, a, bytes, hipMemcpyHostToDevice, 0));
+    if ((rc = h2_divide_by_vanishing_poly_device(field, s.d, ext_k, t_evaluations, nt, form, nullptr)) != H2_OK) return rc;
+    H2_HIP(hipMemcpyAsync(a, s.d, bytes, hipMemcpyDeviceToHost, 0));
     H2_HIP(hipStreamSynchronize(0));
     return H2_OK;
 }

@@ -105,3 +105,17 @@ class EvaluationDomain:
         check(lib().h2_extended_to_coeff(self.field, _p(a), self.extended_k, *args, FORM_MONTGOMERY),
               "h2_extended_to_coeff")
         return a[:keep]
+
+    # -- domain.rs:329-348
+    def divide_by_vanishing_poly(self, a):
+        if a.shape[0] != self.extended_len():
+            raise ValueError("divide_by_vanishing_poly: wrong length")
+        t = fields.to_limbs(self.t_evaluations, self.field, True)
+        if _is_torch(a):
+            check(lib().h2_divide_by_vanishing_poly_device(self.field, a.data_ptr(), self.extended_k, _p(t), t.shape[0],
+                                                           FORM_MONTGOMERY, _stream_ptr()), "h2_divide_by_vanishing_poly_device")
+            return a
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        check(lib().h2_divide_by_vanishing_poly(self.field, _p(a), self.extended_k, _p(t), t.shape[0], FORM_MONTGOMERY),
+              "h2_divide_by_vanishing_poly")
+        return a

@@ -110,6 +110,11 @@ int h2_extended_to_coeff(int field, uint64_t *a, unsigned ext_k, const uint64_t 
                          const uint64_t *g_coset_inv, const uint64_t *extended_omega_inv,
                          const uint64_t *extended_ifft_divisor, int form);
 
+/* replaces EvaluationDomain::divide_by_vanishing_poly (poly/domain.rs:329-348): a[i] *= t_evaluations[i mod nt]
+ * over the extended domain (nt = 2^(ext_k - k) <= 4096 inverse vanishing-polynomial values, host memory). */
+int h2_divide_by_vanishing_poly(int field, uint64_t *a, unsigned ext_k, const uint64_t *t_evaluations,
+                                size_t nt, int form);
+
 /* ---- device-resident variants (data already in HBM; `stream` is a hipStream_t or NULL) -------- */
 /* Same contracts as above with device pointers; asynchronous on `stream`; outputs land in device
  * memory.  Used by batched provers and by bench.py (inputs resident in HBM before timing starts). */
@@ -133,6 +138,9 @@ int h2_coeff_to_extended_device(int field, const void *d_a, void *d_out, unsigne
 int h2_extended_to_coeff_device(int field, void *d_a, unsigned ext_k, const uint64_t *g_coset,
                                 const uint64_t *g_coset_inv, const uint64_t *extended_omega_inv,
                                 const uint64_t *extended_ifft_divisor, int form, void *stream);
+
+int h2_divide_by_vanishing_poly_device(int field, void *d_a, unsigned ext_k, const uint64_t *t_evaluations,
+                                       size_t nt, int form, void *stream);
 
 /* Sum of `count` Jacobian points laid out contiguously (12 limbs each, Montgomery) -> one Jacobian
  * point.  The local step after the 96-byte all-gather of a range-split MSM (one partial per GPU). */

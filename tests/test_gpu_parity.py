@@ -72,6 +72,8 @@ def test_domain_transforms_match_oracle(field, j, k):
     back = dom.extended_to_coeff(ext.copy())
     assert np.array_equal(back, back_want[: dom.n * dom.quotient_poly_degree])
     assert np.array_equal(back[: dom.n], coeff_want)          # round trip
+    t = co.to_mont(field, co.ints_to_limbs(ref.t_evaluations))
+    assert np.array_equal(dom.divide_by_vanishing_poly(ext.copy()), co.divide_by_vanishing_poly(field, ext_want, ref.extended_k, t))
 
 
 def test_fft_roundtrip_2_22():
