@@ -254,7 +254,7 @@ __device__ __forceinline__ u32 upper_bucket(const u32 *__restrict__ arr, u32 n, 
 // straight into buckets[b] (zeroed beforehand).  bucket b = buckets[b] + sum of heads[t] for
 // ceil(start_b / chunk) <= t < ceil(start_{b+1} / chunk), which msm_finish_buckets adds up.
 template <int FB>
-__global__ void __launch_bounds__(256) msm_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
+__global__ void __launch_bounds__(256, 4) msm_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
                                                       u32 extra_index, const u32 *__restrict__ entries,
                                                       const u32 *__restrict__ starts, u32 *__restrict__ heads,
                                                       u32 *__restrict__ buckets, u32 total_buckets, u32 T) {
@@ -307,23 +307,29 @@ template <int FB>
 __global__ void __launch_bounds__(256) msm_finish_buckets(const u32 *__restrict__ heads, const u32 *__restrict__ starts,
                                                           u32 *__restrict__ buckets, u32 *__restrict__ heavy,
                                                           u32 total_buckets, u32 T) {
-    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    // one quad of lanes per bucket (curve_wide.cuh)
+    const u32 b = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
     if (b >= total_buckets) return;
+    const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
     const u32 M = starts[total_buckets];
     const u32 chunk = max(1u, (M + T - 1) / T);
     const u32 h0 = (starts[b] + chunk - 1) / chunk, h1 = (starts[b + 1] + chunk - 1) / chunk;
     if (h1 <= h0) return;
     if (h1 - h0 > kHeavy) {
-        u32 slot = atomicAdd(&heavy[0], 1u);
-        heavy[1 + slot] = b;
+        if (lead) {
+            u32 slot = atomicAdd(&heavy[0], 1u);
+            heavy[1 + slot] = b;
+        }
         return;
     }
     xyzz<FB> acc = xyzz_load<FB>(buckets + 32 * (size_t)b);
+    xyzz<FB> nxt = xyzz_load<FB>(heads + 32 * (size_t)h0);
     for (u32 t = h0; t < h1; ++t) {
-        xyzz<FB> p = xyzz_load<FB>(heads + 32 * (size_t)t);
-        xyzz_add<FB>(acc, p);
+        xyzz<FB> p = nxt;
+        if (t + 1 < h1) nxt = xyzz_load<FB>(heads + 32 * (size_t)(t + 1));
+        xyzz_add_wide<FB>(acc, p);
     }
-    xyzz_store<FB>(buckets + 32 * (size_t)b, acc);
+    if (lead) xyzz_store<FB>(buckets + 32 * (size_t)b, acc);
 }
 template <int FB>
 __global__ void __launch_bounds__(256) msm_finish_heavy(const u32 *__restrict__ heads, const u32 *__restrict__ starts,
@@ -381,16 +387,18 @@ __global__ void __launch_bounds__(256) msm_reduce_segments(const u32 *__restrict
     if ((threadIdx.x & (kGroup - 1)) == 0) xyzz_store<FB>(partial + 32 * (size_t)t, acc);
 }
 
-// ---- reduce level 2: tree sum of a slice's partials (1024 hardware lanes = 256 logical lanes) ----------
+// ---- reduce level 2: tree sum of a slice's partials, in two launches (many workgroups, then one per slice) --------
+// grid (blocks_per_slice, slices); block j of slice s sums partial[s][j * share .. (j + 1) * share) into out[s][j]
 template <int FB>
-__global__ void __launch_bounds__(1024) msm_sum_slice(const u32 *__restrict__ partial, u32 *__restrict__ slice_sums,
-                                                      u32 per_slice) {
+__global__ void __launch_bounds__(256) msm_sum_slice(const u32 *__restrict__ partial, u32 *__restrict__ out, u32 per_slice,
+                                                     u32 share) {
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
-    const u32 sl = blockIdx.x, t = threadIdx.x / kGroup, nl = blockDim.x / kGroup;
+    const u32 sl = blockIdx.y, blk = blockIdx.x, t = threadIdx.x / kGroup, nl = blockDim.x / kGroup;
     const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
+    const u32 lo = blk * share, hi = min(per_slice, lo + share);
     const u32 *src = partial + 32 * (size_t)sl * per_slice;
     xyzz<FB> acc = xyzz_identity<FB>();
-    for (u32 i = t; i < per_slice; i += nl) {
+    for (u32 i = lo + t; i < hi; i += nl) {
         xyzz<FB> p = xyzz_load<FB>(src + 32 * (size_t)i);
         xyzz_add_wide<FB>(acc, p);
     }
@@ -400,14 +408,13 @@ __global__ void __launch_bounds__(1024) msm_sum_slice(const u32 *__restrict__ pa
         if (t < off) {
             xyzz<FB> a = xyzz_load<FB>(sh + 32 * t), b = xyzz_load<FB>(sh + 32 * (t + off));
             xyzz_add_wide<FB>(a, b);
-            __builtin_amdgcn_wave_barrier();
             if (lead) xyzz_store<FB>(sh + 32 * t, a);
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         xyzz<FB> r = xyzz_load<FB>(sh);
-        xyzz_store<FB>(slice_sums + 32 * (size_t)sl, r);
+        xyzz_store<FB>(out + 32 * ((size_t)sl * gridDim.x + blk), r);
     }
 }
 
@@ -613,7 +620,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     if ((rc = cx.starts.reserve((size_t)(tb + 1) * 4)) != H2_OK) return rc;
     if ((rc = cx.bsums.reserve((size_t)(nblocks + 4) * 4)) != H2_OK) return rc;
     if ((rc = cx.entries.reserve(all_items * 4)) != H2_OK) return rc;
-    if ((rc = cx.heads.reserve((size_t)T * 128)) != H2_OK) return rc;
+    if ((rc = cx.heads.reserve((size_t)std::max<size_t>(T, (size_t)sh.slices * 32) * 128)) != H2_OK) return rc;
     if ((rc = cx.heavy.reserve((size_t)(max_heavy + 1) * 4)) != H2_OK) return rc;
     if ((rc = cx.buckets.reserve((size_t)tb * 128)) != H2_OK) return rc;
     if ((rc = cx.partial.reserve((size_t)segs * 128)) != H2_OK) return rc;
@@ -645,14 +652,26 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                        cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T);
     prof_end(PROF_MSM_ACCUMULATE, st);
     prof_begin(PROF_MSM_REDUCE, st);
-    hipLaunchKernelGGL((msm_finish_buckets<FB>), dim3((tb + 255) / 256), dim3(256), 0, st, cx.heads.as<u32>(),
+    hipLaunchKernelGGL((msm_finish_buckets<FB>), dim3((tb * kGroup + 255) / 256), dim3(256), 0, st, cx.heads.as<u32>(),
                        cx.starts.as<u32>(), cx.buckets.as<u32>(), cx.heavy.as<u32>(), tb, T);
     hipLaunchKernelGGL((msm_finish_heavy<FB>), dim3(max_heavy), dim3(256), 256 * 128, st, cx.heads.as<u32>(),
                        cx.starts.as<u32>(), cx.buckets.as<u32>(), cx.heavy.as<u32>(), tb, T);
     hipLaunchKernelGGL((msm_reduce_segments<FB>), dim3((segs * kGroup + 255) / 256), dim3(256), 0, st, cx.buckets.as<u32>(),
                        cx.partial.as<u32>(), sh.NB, segs);
-    hipLaunchKernelGGL((msm_sum_slice<FB>), dim3(sh.slices), dim3(1024), (1024 / kGroup) * 128, st, cx.partial.as<u32>(),
-                       cx.ssums.as<u32>(), sh.NB / kSeg);
+    {   // 64 logical lanes per workgroup; first level leaves <= 32 block sums per slice
+        const u32 per_slice = sh.NB / kSeg, nl = 256 / kGroup;
+        const u32 bps = std::max(1u, std::min(32u, per_slice / (2 * nl)));
+        const u32 share = (per_slice + bps - 1) / bps;
+        if (bps > 1) {
+            hipLaunchKernelGGL((msm_sum_slice<FB>), dim3(bps, sh.slices), dim3(256), nl * 128, st, cx.partial.as<u32>(),
+                               cx.heads.as<u32>(), per_slice, share);     // heads[] is free again: reuse as level-1 output
+            hipLaunchKernelGGL((msm_sum_slice<FB>), dim3(1, sh.slices), dim3(256), nl * 128, st, cx.heads.as<u32>(),
+                               cx.ssums.as<u32>(), bps, bps);
+        } else {
+            hipLaunchKernelGGL((msm_sum_slice<FB>), dim3(1, sh.slices), dim3(256), nl * 128, st, cx.partial.as<u32>(),
+                               cx.ssums.as<u32>(), per_slice, per_slice);
+        }
+    }
     hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, cx.ssums.as<u32>(), (int)sh.slices, sh.c, (u32 *)a.d_out,
                        a.out_kind, a.form == H2_FORM_MONTGOMERY);
     prof_end(PROF_MSM_REDUCE, st);
