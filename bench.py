@@ -45,10 +45,10 @@ def main():
     ap.add_argument("--log-n", type=int, default=K_LOG, help="override the MSM size (parity/debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--columns", type=int, default=4, help="distinct scalar columns resident in HBM")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("H2_BENCH_STREAMS", "3")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("H2_BENCH_STREAMS", "2")),
                     help="HIP streams the independent column commits are spread over (per GPU)")
     ap.add_argument("--lane-fraction", type=float, default=None,
-                    help="share of the wave slots one accumulate launch claims (default 0.67 with >1 stream, else 1)")
+                    help="share of the wave slots one accumulate launch claims (default 1)")
     args = ap.parse_args()
 
     import torch
@@ -79,7 +79,7 @@ def main():
 
     lib = h.lib()
     check(lib.h2_init(local_rank), "h2_init")
-    lane_fraction = args.lane_fraction if args.lane_fraction else (0.67 if args.streams > 1 else 1.0)
+    lane_fraction = args.lane_fraction if args.lane_fraction else 1.0
     check(lib.h2_set_option(b"msm_lane_fraction", lane_fraction), "h2_set_option")
     curve = h.PALLAS
     sf = co.field_of_curve(curve, "scalar")

@@ -64,6 +64,10 @@ struct MsmShape {
 
 // window width: minimise mixed adds + reduce work.  `shared_buckets`: registered bases (one slice).
 static int choose_c(size_t n, bool shared_buckets) {
+    if (const char *e = getenv("H2_MSM_C")) {   // tuning sweeps only
+        int v = atoi(e);
+        if (v >= 4 && v <= kMaxC) return v;
+    }
     double best = 1e300;
     int bc = 4;
     for (int c = 4; c <= kMaxC; ++c) {
@@ -947,7 +951,7 @@ extern "C" int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars
     if (rc != H2_OK) return rc;
     BatchStreams &bs = batch_streams();
     std::lock_guard<std::mutex> lk(bs.mu);
-    const size_t want = std::min<size_t>(3, count);
+    const size_t want = std::min<size_t>(2, count);
     while (bs.s.size() < want) {
         hipStream_t st;
         hipEvent_t ev;
@@ -973,13 +977,10 @@ extern "C" int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars
         }
         if ((rc = ensure_blind_base(*b, w, user)) != H2_OK) return rc;
     }
-    const double saved = g_lane_fraction.load();
-    if (want > 1) g_lane_fraction.store(std::min(saved, 0.67));
     H2_HIP(hipEventRecord(bs.fork, user));
     for (size_t i = 0; i < want; ++i) H2_HIP(hipStreamWaitEvent(bs.s[i], bs.fork, 0));
     for (size_t i = 0; i < count && rc == H2_OK; ++i)
         rc = commit_device_impl(g, d_scalars[i], n, d_w_xy, d_w_xy ? d_blinds[i] : nullptr, form, out_kind, d_outs[i], bs.s[i % want], true);
-    g_lane_fraction.store(saved);
     for (size_t i = 0; i < want; ++i) {
         H2_HIP(hipEventRecord(bs.done[i], bs.s[i]));
         H2_HIP(hipStreamWaitEvent(user, bs.done[i], 0));
