@@ -152,8 +152,33 @@ def main():
         lib.h2_profile_enable(0)
         check(lib.h2_set_option(b"msm_lane_fraction", lane_fraction), "h2_set_option")
 
+    first = d_out[0].cpu().numpy().view(np.uint64).copy()   # output of timed step 0, before d_out is reused below
+
+    # ---- skewed columns: 90 % zeros, and every scalar < 2^16 -- same kernels, same partition ----
+    skew = {}
+    if rank == 0:
+        z = cols[0].copy()
+        z[np.arange(n) % 10 != 0] = 0
+        small = fields.to_limbs([((i * 2654435761) & 0xFFFF) for i in range(1 << 12)], sf)
+        small = np.tile(small, (n >> 12, 1)) if n >= (1 << 12) else small[:n]
+        for name, col in (("zeros90", z), ("below_2^16", np.ascontiguousarray(small))):
+            d_c = torch.from_numpy(col.view(np.int64)).to(dev)
+            for rep_ in range(3):
+                if rep_ == 1:
+                    torch.cuda.synchronize()
+                    t4 = time.perf_counter()
+                check(lib.h2_commit_device(params_g, d_c.data_ptr(), n, None, None, h.FORM_MONTGOMERY, 0, d_out[0].data_ptr(), sps[0]),
+                      "h2_commit_device")
+            torch.cuda.synchronize()
+            skew[name] = {"ms": round((time.perf_counter() - t4) / 2 * 1e3, 4)}
+            if name == "zeros90" and args.log_n <= 20:
+                got = d_out[0].cpu().numpy().view(np.uint64)
+                nz = np.arange(n) % 10 == 0
+                want = h.best_multiexp(np.ascontiguousarray(col[nz]), np.ascontiguousarray(bases[nz]), curve)
+                skew[name]["equals_dense_msm_over_nonzeros"] = bool(co.jac_to_affine_ints(curve, got) == co.jac_to_affine_ints(curve, want))
+            del d_c
+
     # ---- parity spot check of the timed outputs (rank 0: first column vs the split-and-sum identity) ----
-    first = d_out[0].cpu().numpy().view(np.uint64)
     parts = [h.best_multiexp(cols[0][i * n // 4:(i + 1) * n // 4], bases[i * n // 4:(i + 1) * n // 4], curve) for i in range(4)]
     split_ok = co.jac_to_affine_ints(curve, h.points_sum(np.stack(parts), curve)) == co.jac_to_affine_ints(curve, first)
 
@@ -215,7 +240,23 @@ def main():
                 torch.cuda.synchronize()
                 ms_dt = (time.perf_counter() - t3) / len(d_cols_ntt)
                 del d_cols_ntt
-            ntt[f"2^{log_n}"] = {"ms": round(dt * 1e3, 4), "Gbutterflies_per_s": round(bf / dt / 1e9, 3), "cpu_baseline": cpu_ntt,
+            rt_ms = None
+            if log_n == 22:   # BASELINE configs[2]: forward + inverse round trip
+                omega_inv = fields.scalar_limbs(pow(pasta.omega_for(pasta.P, log_n), -1, pasta.P), h.FP)
+                divisor = fields.scalar_limbs(pow(1 << log_n, -1, pasta.P), h.FP)
+                d_rt = torch.from_numpy(a.view(np.int64)).to(dev)
+                for rep_ in range(3):
+                    if rep_ == 1:
+                        torch.cuda.synchronize()
+                        t5 = time.perf_counter()
+                    h.best_fft(d_rt, omega, log_n, h.FP)
+                    check(lib.h2_ifft_device(h.FP, d_rt.data_ptr(), log_n, _p(omega_inv), _p(divisor), h.FORM_MONTGOMERY,
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "h2_ifft_device")
+                torch.cuda.synchronize()
+                rt_ms = {"ms": round((time.perf_counter() - t5) / 2 * 1e3, 4),
+                         "returns_input": bool(np.array_equal(d_rt.cpu().numpy().view(np.uint64), a))}
+                del d_rt
+            ntt[f"2^{log_n}"] = {"ms": round(dt * 1e3, 4), "forward_inverse_roundtrip": rt_ms, "Gbutterflies_per_s": round(bf / dt / 1e9, 3), "cpu_baseline": cpu_ntt,
                                  "kernel_ms": round(ms.value / reps, 4), "passes": int(cnt.value // reps),
                                  "independent_columns": None if ms_dt is None else {
                                      "streams": len(streams), "ms_per_fft": round(ms_dt * 1e3, 4), "Gbutterflies_per_s": round(bf / ms_dt / 1e9, 3)},
@@ -276,7 +317,7 @@ def main():
                                  "the registered-bases path, which gathers 16 precomputed multiples per point from a 1 GiB table by design"},
             "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()},
             "kernel_ms_isolated": iso,
-            "ntt": ntt, "cpu_baseline": cpu,
+            "skewed_columns": skew, "ntt": ntt, "cpu_baseline": cpu,
             "checks": {"split_sum_identity": bool(split_ok), "split_msm_allgather": split_msm_ok},
             "input_gen_s": round(gen_s, 2),
         }

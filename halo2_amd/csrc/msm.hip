@@ -239,6 +239,10 @@ __global__ void __launch_bounds__(1024) msm_scatter(const uint16_t *__restrict__
     }
 }
 
+// lanes actually used for M sorted entries: the launch is sized for the worst case (no zero digits); sparse or tiny
+// columns use fewer lanes so that a lane's range keeps >= 16 entries
+__device__ __forceinline__ u32 eff_lanes(u32 M, u32 T) { return min(T, max(256u, (M + 15) / 16)); }
+
 // largest b in [0, n) with arr[b] <= t  (arr non-decreasing, arr[0] = 0)
 __device__ __forceinline__ u32 upper_bucket(const u32 *__restrict__ arr, u32 n, u32 t) {
     u32 lo = 0, hi = n;  // invariant: arr[lo] <= t < arr[hi]  (arr[n] = total > t)
@@ -263,8 +267,9 @@ __global__ void __launch_bounds__(256, 4) msm_accumulate(const u32 *__restrict__
                                                       const u32 *__restrict__ starts, u32 *__restrict__ heads,
                                                       u32 *__restrict__ buckets, u32 total_buckets, u32 T) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
     const u32 M = starts[total_buckets];
+    T = eff_lanes(M, T);
+    if (t >= T) return;
     const u32 chunk = (M + T - 1) / T;
     const u32 lo = min(M, t * chunk), hi = min(M, lo + chunk);
     xyzz<FB> acc = xyzz_identity<FB>();
@@ -307,6 +312,7 @@ __global__ void __launch_bounds__(256, 4) msm_accumulate(const u32 *__restrict__
 // Buckets owning more than kHeavy heads (scalars repeated thousands of times) are parked on a list and summed
 // by a whole workgroup each in msm_finish_heavy.
 static constexpr u32 kHeavy = 64;
+static constexpr u32 kMaxHeavy = 512;   // heavy buckets handed to the workgroup path; any beyond that are summed in place
 template <int FB>
 __global__ void __launch_bounds__(256) msm_finish_buckets(const u32 *__restrict__ heads, const u32 *__restrict__ starts,
                                                           u32 *__restrict__ buckets, u32 *__restrict__ heavy,
@@ -316,15 +322,21 @@ __global__ void __launch_bounds__(256) msm_finish_buckets(const u32 *__restrict_
     if (b >= total_buckets) return;
     const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
     const u32 M = starts[total_buckets];
+    T = eff_lanes(M, T);
     const u32 chunk = max(1u, (M + T - 1) / T);
     const u32 h0 = (starts[b] + chunk - 1) / chunk, h1 = (starts[b + 1] + chunk - 1) / chunk;
     if (h1 <= h0) return;
     if (h1 - h0 > kHeavy) {
-        if (lead) {
-            u32 slot = atomicAdd(&heavy[0], 1u);
-            heavy[1 + slot] = b;
+        u32 slot = 0;
+        if (lead) slot = atomicAdd(&heavy[1], 1u);
+        slot = (u32)__builtin_amdgcn_mov_dpp((int)slot, 0, 0xf, 0xf, false);   // quad lane 0's ticket
+        if (slot < kMaxHeavy) {
+            if (lead) {
+                heavy[2 + slot] = b;
+                atomicAdd(&heavy[0], 1u);
+            }
+            return;
         }
-        return;
     }
     xyzz<FB> acc = xyzz_load<FB>(buckets + 32 * (size_t)b);
     xyzz<FB> nxt = xyzz_load<FB>(heads + 32 * (size_t)h0);
@@ -335,36 +347,54 @@ __global__ void __launch_bounds__(256) msm_finish_buckets(const u32 *__restrict_
     }
     if (lead) xyzz_store<FB>(buckets + 32 * (size_t)b, acc);
 }
+// heavy buckets: kHeavyBlocks workgroups share one bucket's heads (quad-wide adds), then msm_finish_heavy2 folds
+// their partial sums and the bucket's own segment
+static constexpr u32 kHeavyBlocks = 32;
 template <int FB>
 __global__ void __launch_bounds__(256) msm_finish_heavy(const u32 *__restrict__ heads, const u32 *__restrict__ starts,
-                                                        u32 *__restrict__ buckets, const u32 *__restrict__ heavy,
+                                                        u32 *__restrict__ scratch, const u32 *__restrict__ heavy,
                                                         u32 total_buckets, u32 T) {
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
-    if (blockIdx.x >= heavy[0]) return;
-    const u32 b = heavy[1 + blockIdx.x], t = threadIdx.x;
+    if (blockIdx.y >= min(heavy[1], kMaxHeavy)) return;
+    const u32 b = heavy[2 + blockIdx.y], t = threadIdx.x / kGroup, nl = blockDim.x / kGroup;
+    const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
     const u32 M = starts[total_buckets];
+    T = eff_lanes(M, T);
     const u32 chunk = max(1u, (M + T - 1) / T);
     const u32 h0 = (starts[b] + chunk - 1) / chunk, h1 = (starts[b + 1] + chunk - 1) / chunk;
+    const u32 share = (h1 - h0 + kHeavyBlocks - 1) / kHeavyBlocks;
+    const u32 lo = h0 + blockIdx.x * share, hi = min(h1, lo + share);
     xyzz<FB> acc = xyzz_identity<FB>();
-    if (t == 0) acc = xyzz_load<FB>(buckets + 32 * (size_t)b);
-    for (u32 i = h0 + t; i < h1; i += blockDim.x) {
+    for (u32 i = lo + t; i < hi; i += nl) {
         xyzz<FB> p = xyzz_load<FB>(heads + 32 * (size_t)i);
-        xyzz_add<FB>(acc, p);
+        xyzz_add_wide<FB>(acc, p);
     }
-    xyzz_store<FB>(sh + 32 * t, acc);
+    if (lead) xyzz_store<FB>(sh + 32 * t, acc);
     __syncthreads();
-    for (u32 off = blockDim.x / 2; off > 0; off >>= 1) {
+    for (u32 off = nl / 2; off > 0; off >>= 1) {
         if (t < off) {
             xyzz<FB> x = xyzz_load<FB>(sh + 32 * t), y = xyzz_load<FB>(sh + 32 * (t + off));
-            xyzz_add<FB>(x, y);
-            xyzz_store<FB>(sh + 32 * t, x);
+            xyzz_add_wide<FB>(x, y);
+            if (lead) xyzz_store<FB>(sh + 32 * t, x);
         }
         __syncthreads();
     }
-    if (t == 0) {
+    if (threadIdx.x == 0) {
         xyzz<FB> r = xyzz_load<FB>(sh);
-        xyzz_store<FB>(buckets + 32 * (size_t)b, r);
+        xyzz_store<FB>(scratch + 32 * ((size_t)blockIdx.y * kHeavyBlocks + blockIdx.x), r);
     }
+}
+template <int FB>
+__global__ void __launch_bounds__(64) msm_finish_heavy2(const u32 *__restrict__ scratch, u32 *__restrict__ buckets,
+                                                        const u32 *__restrict__ heavy) {
+    if (blockIdx.x >= min(heavy[1], kMaxHeavy) || threadIdx.x >= kGroup) return;
+    const u32 b = heavy[2 + blockIdx.x];
+    xyzz<FB> acc = xyzz_load<FB>(buckets + 32 * (size_t)b);
+    for (u32 i = 0; i < kHeavyBlocks; ++i) {
+        xyzz<FB> p = xyzz_load<FB>(scratch + 32 * ((size_t)blockIdx.x * kHeavyBlocks + i));
+        xyzz_add_wide<FB>(acc, p);
+    }
+    if (threadIdx.x == 0) xyzz_store<FB>(buckets + 32 * (size_t)b, acc);
 }
 
 // The three tail kernels below run each logical lane as a quad of 4 hardware lanes (curve_wide.cuh): the chip
@@ -551,8 +581,8 @@ __global__ void k_points_sum(const u32 *__restrict__ pts, u32 count, u32 *__rest
 // ---- host orchestration ----------------------------------------------------------------------------
 struct MsmContext {
     std::mutex mu;
-    DevBuf digits, hist, counts, starts, bsums, entries, heads, heavy, buckets, partial, ssums, stage_s, stage_b, out,
-        small;
+    DevBuf digits, hist, counts, starts, bsums, entries, heads, heavy, hscratch, buckets, partial, ssums, stage_s, stage_b,
+        out, small;
     bool attr_set = false;
     u32 lanes[2] = {0, 0};  // resident lanes of msm_accumulate<FP>, <FQ> on this device
 };
@@ -617,7 +647,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     // of a commit running on ANOTHER stream can overlap this kernel (independent column commits)
     const u32 usable = std::max(256u, (u32)(lanes * g_lane_fraction.load()) / 256u * 256u);
     u32 T = (u32)std::min<size_t>(usable, std::max<size_t>(256, (all_items / 16 + 255) / 256 * 256));
-    const u32 max_heavy = T / kHeavy + 2;
+    const u32 max_heavy = kMaxHeavy;
     if ((rc = cx.digits.reserve(all_items * 2)) != H2_OK) return rc;
     if ((rc = cx.hist.reserve((size_t)sh.slices * sh.B * sh.NB * 4)) != H2_OK) return rc;
     if ((rc = cx.counts.reserve((size_t)tb * 4)) != H2_OK) return rc;
@@ -625,7 +655,8 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     if ((rc = cx.bsums.reserve((size_t)(nblocks + 4) * 4)) != H2_OK) return rc;
     if ((rc = cx.entries.reserve(all_items * 4)) != H2_OK) return rc;
     if ((rc = cx.heads.reserve((size_t)std::max<size_t>(T, (size_t)sh.slices * 32) * 128)) != H2_OK) return rc;
-    if ((rc = cx.heavy.reserve((size_t)(max_heavy + 1) * 4)) != H2_OK) return rc;
+    if ((rc = cx.heavy.reserve((size_t)(max_heavy + 2) * 4)) != H2_OK) return rc;
+    if ((rc = cx.hscratch.reserve((size_t)max_heavy * kHeavyBlocks * 128)) != H2_OK) return rc;
     if ((rc = cx.buckets.reserve((size_t)tb * 128)) != H2_OK) return rc;
     if ((rc = cx.partial.reserve((size_t)segs * 128)) != H2_OK) return rc;
     if ((rc = cx.ssums.reserve((size_t)sh.slices * 128)) != H2_OK) return rc;
@@ -648,7 +679,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                        cx.hist.as<u32>(), cx.starts.as<u32>(), cx.entries.as<u32>(), sh.items, sh.chunk, sh.NB, m32,
                        a.table ? a.stride : 0u, extra_col, a.table ? 1 : 0);
     H2_HIP(hipMemsetAsync(cx.buckets.ptr, 0, (size_t)tb * 128, st));
-    H2_HIP(hipMemsetAsync(cx.heavy.ptr, 0, 4, st));
+    H2_HIP(hipMemsetAsync(cx.heavy.ptr, 0, 8, st));
     prof_end(PROF_MSM_SORT, st);
     prof_begin(PROF_MSM_ACCUMULATE, st);
     hipLaunchKernelGGL((msm_accumulate<FB>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases,
@@ -658,8 +689,10 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     prof_begin(PROF_MSM_REDUCE, st);
     hipLaunchKernelGGL((msm_finish_buckets<FB>), dim3((tb * kGroup + 255) / 256), dim3(256), 0, st, cx.heads.as<u32>(),
                        cx.starts.as<u32>(), cx.buckets.as<u32>(), cx.heavy.as<u32>(), tb, T);
-    hipLaunchKernelGGL((msm_finish_heavy<FB>), dim3(max_heavy), dim3(256), 256 * 128, st, cx.heads.as<u32>(),
-                       cx.starts.as<u32>(), cx.buckets.as<u32>(), cx.heavy.as<u32>(), tb, T);
+    hipLaunchKernelGGL((msm_finish_heavy<FB>), dim3(kHeavyBlocks, max_heavy), dim3(256), (256 / kGroup) * 128, st,
+                       cx.heads.as<u32>(), cx.starts.as<u32>(), cx.hscratch.as<u32>(), cx.heavy.as<u32>(), tb, T);
+    hipLaunchKernelGGL((msm_finish_heavy2<FB>), dim3(max_heavy), dim3(64), 0, st, cx.hscratch.as<u32>(), cx.buckets.as<u32>(),
+                       cx.heavy.as<u32>());
     hipLaunchKernelGGL((msm_reduce_segments<FB>), dim3((segs * kGroup + 255) / 256), dim3(256), 0, st, cx.buckets.as<u32>(),
                        cx.partial.as<u32>(), sh.NB, segs);
     {   // 64 logical lanes per workgroup; first level leaves <= 32 block sums per slice

@@ -460,3 +460,26 @@ def test_lagrange_basis_k12_properties():
     dom = h.EvaluationDomain(1, k, sf)
     evals = fields.to_limbs([pow(dom.omega, 3 * i, dom.m) for i in range(n)], sf)
     assert affine_of(curve, h.best_multiexp(evals, gl, curve)) == co.affine_to_ints(curve, g[3])
+
+
+def test_registered_heavy_buckets_2_16():
+    """Registered-bases path with 2^16 identical scalars (a handful of buckets own everything: the workgroup-per-bucket
+    finisher) and with more heavy buckets than the finisher's list holds (falls back to in-place sums)."""
+    import ctypes as C
+    from halo2_amd.arithmetic import _p
+    curve = h.PALLAS
+    bm, sm = o.CURVES[curve]
+    sf = co.field_of_curve(curve, "scalar")
+    n = 1 << 16
+    g = co.generate_bases(curve, 1234, n)
+    lib = h.lib()
+    hd = C.c_uint64(0)
+    assert lib.h2_bases_register(curve, _p(g), n, h.FORM_MONTGOMERY, C.byref(hd)) == 0
+    out = np.zeros(12, np.uint64)
+    same = co.to_mont(sf, co.ints_to_limbs([0x0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF] * n))
+    assert lib.h2_commit(hd, _p(same), n, None, None, h.FORM_MONTGOMERY, 0, _p(out)) == 0
+    assert affine_of(curve, out) == co.jac_to_affine_ints(curve, co.best_multiexp(curve, same, g))
+    few = co.to_mont(sf, co.ints_to_limbs([(i % 3 + 1) * 0x0001000100010001000100010001000100010001000100010001000100010001 % sm for i in range(n)]))
+    assert lib.h2_commit(hd, _p(few), n, None, None, h.FORM_MONTGOMERY, 0, _p(out)) == 0
+    assert affine_of(curve, out) == co.jac_to_affine_ints(curve, co.best_multiexp(curve, few, g))
+    assert lib.h2_bases_free(hd) == 0
