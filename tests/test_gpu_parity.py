@@ -482,4 +482,8 @@ def test_registered_heavy_buckets_2_16():
     few = co.to_mont(sf, co.ints_to_limbs([(i % 3 + 1) * 0x0001000100010001000100010001000100010001000100010001000100010001 % sm for i in range(n)]))
     assert lib.h2_commit(hd, _p(few), n, None, None, h.FORM_MONTGOMERY, 0, _p(out)) == 0
     assert affine_of(curve, out) == co.jac_to_affine_ints(curve, co.best_multiexp(curve, few, g))
+    rep = 0x0001000100010001000100010001000100010001000100010001000100010001
+    many = co.to_mont(sf, co.ints_to_limbs([(((i * 2654435761) >> 7) % 600 + 1) * rep % sm for i in range(n)]))   # ~600 heavy buckets > the finisher's list
+    assert lib.h2_commit(hd, _p(many), n, None, None, h.FORM_MONTGOMERY, 0, _p(out)) == 0
+    assert affine_of(curve, out) == co.jac_to_affine_ints(curve, co.best_multiexp(curve, many, g))
     assert lib.h2_bases_free(hd) == 0
