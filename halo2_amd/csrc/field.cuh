@@ -121,6 +121,10 @@ template <int F> __device__ __forceinline__ fe fe_neg(const fe &a) { return fe_s
 template <int F> __device__ __forceinline__ fe fe_dbl(const fe &a) { return fe_add<F>(a, a); }
 
 // ---- Montgomery multiplication ------------------------------------------------------------
+#ifdef H2_FIELD_EXPERIMENTS
+// Earlier multiplier variants, compiled only into tests/native/field_check.hip for A/B measurements.  They issue
+// v_mad_u64_u32 -> v_addc_co_u32 back to back inside asm text, i.e. they lean on hardware interlocks for the
+// gfx940/gfx950 "VALU writes SGPR -> VALU reads it" hazard; the shipped multiplier (fe_mul_sched) does not.
 // 96-bit column accumulator step: {acc, hi} += x * y
 __device__ __forceinline__ void mac96(u64 &acc, u32 &hi, u32 x, u32 y) {
     asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
@@ -177,12 +181,17 @@ template <int F> __device__ __forceinline__ fe fe_mul_col(const fe &a, const fe 
     return fe_reduce_once<F>(r);
 }
 
+#ifdef H2_FIELD_EXPERIMENTS
 // Variant: the whole multiplication as ONE asm statement with the accumulator in pinned VGPRs
 // (generated, see gen_field_mul.py block_multiplier): no compiler glue between columns.
 template <int F> __device__ __forceinline__ fe fe_mul_blk(const fe &a, const fe &b) {
 #include "field_mul_blk.inc"
     return fe_reduce_once<F>(r);
 }
+
+#endif  // H2_FIELD_EXPERIMENTS
+
+#endif  // H2_FIELD_EXPERIMENTS
 
 // Variant: ONE asm statement, list-scheduled by gen_field_mul.py so that every carry (an SGPR written by a
 // VALU instruction) is read no sooner than three instructions later -- the gfx940/gfx950 "VALU writes SGPR ->
@@ -230,14 +239,8 @@ template <int F> __device__ __forceinline__ fe fe_mul_c(const fe &a, const fe &b
 template <int F> __device__ __forceinline__ fe fe_mulx(const fe &a, const fe &b) {
 #if H2_MUL_IMPL == 0
     return fe_mul_c<F>(a, b);
-#elif H2_MUL_IMPL == 1
-    return fe_mul_col<F>(a, b);
-#elif H2_MUL_IMPL == 3
-    return fe_mul_blk<F>(a, b);
-#elif H2_MUL_IMPL == 4
-    return fe_mul_sched<F>(a, b);
 #else
-    return fe_mul<F>(a, b);
+    return fe_mul_sched<F>(a, b);
 #endif
 }
 

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <vector>
+#define H2_FIELD_EXPERIMENTS 1
 #include "../../halo2_amd/csrc/field.cuh"
 
 extern "C" {

@@ -1,0 +1,62 @@
+"""bench.py's driver contract, on a real GPU: one JSON line with the required keys (incl. `roofline` and
+`cpu_baseline`), and the N > 1 path (torch.distributed.run, one rank per GPU) exercised with two ranks over gloo
+on whatever GPUs the box has."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _last_json(out: str):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"] and "2^20" in d["config"]["workload"]
+    assert abs(d["ms_per_step"] * 1e-3 * d["value"] * 1e6 - (1 << 20)) / (1 << 20) < 0.02     # value == n / time per step
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["kernel"] == "msm_accumulate"
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["bit_exact_vs_gpu"] is True
+    assert d["value"] > 10 * c["value"]                                   # north star: >= 10x the host CPU, bit-exact
+    assert d["checks"]["split_sum_identity"] is True
+    assert d["ntt"]["2^22"]["forward_inverse_roundtrip"]["returns_input"] is True
+
+
+def test_bench_two_ranks_gloo():
+    env = dict(os.environ, H2_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                          "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["checks"]["split_msm_allgather"] is True and d["checks"]["split_sum_identity"] is True
+    # whole-job aggregate: both ranks' scalar-mults over the max-over-ranks time
+    assert abs(d["ms_per_step"] * 1e-3 * d["value"] * 1e6 - 2 * (1 << 20)) / (2 << 20) < 0.02
