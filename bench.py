@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=K_LOG, help="override the MSM size (parity/debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--columns", type=int, default=4, help="distinct scalar columns resident in HBM")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("H2_BENCH_STREAMS", "2")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("H2_BENCH_STREAMS", "3")),
                     help="HIP streams the independent column commits are spread over (per GPU)")
     ap.add_argument("--lane-fraction", type=float, default=None,
                     help="share of the wave slots one accumulate launch claims (default 1)")
@@ -110,6 +110,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for i in range(len(sps)):     # one untimed commit per stream: each (device, stream) pair owns a workspace that is
+        step(i)                   # allocated on first use (hipMalloc synchronises the device)
+    sync_all()
     for i in range(args.warmup):
         step(i)
     sync_all()

@@ -101,11 +101,17 @@ __device__ __forceinline__ u32 limb_at(const fe &s, int idx) {
     return v;
 }
 
+// The sort and tail stages are short dependent chains; when another stream's msm_accumulate shares the SIMDs they
+// must win issue arbitration or they stretch 3-4x and the stream they belong to feeds the chip late (timeline in
+// DESIGN.md section 5).  msm_accumulate stays at priority 0.
+#define H2_LATENCY_STAGE() __builtin_amdgcn_s_setprio(3)
+
 // ---- recode: scalars -> signed window digits -------------------------------------------------
 // code = 0xFFFF for digit 0, else (|d| - 1) | (d < 0 ? 0x8000 : 0);  digits[w * m + i]
 template <int FS>
 __global__ void __launch_bounds__(256) msm_recode(const u32 *__restrict__ scalars, const u32 *__restrict__ extra_scalar,
                                                   uint16_t *__restrict__ digits, u32 m, int c, int W, int mont) {
+    H2_LATENCY_STAGE();
     // m counts the optional extra (blind) scalar, which is column m - 1 and lives in its own buffer
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
@@ -132,6 +138,7 @@ __global__ void __launch_bounds__(256) msm_recode(const u32 *__restrict__ scalar
 // ---- count: LDS histogram per (slice, chunk) ---------------------------------------------------
 __global__ void __launch_bounds__(1024) msm_count(const uint16_t *__restrict__ digits, u32 *__restrict__ hist,
                                                   size_t items, u32 chunk, u32 NB) {
+    H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 h[];
     const u32 b = blockIdx.x, sl = blockIdx.y, B = gridDim.x;
     for (u32 j = threadIdx.x; j < NB; j += blockDim.x) h[j] = 0;
@@ -150,6 +157,7 @@ __global__ void __launch_bounds__(1024) msm_count(const uint16_t *__restrict__ d
 // ---- scan a: per-bucket totals, chunk slices become exclusive prefixes -------------------------
 __global__ void __launch_bounds__(256) msm_chunk_prefix(u32 *__restrict__ hist, u32 *__restrict__ counts, u32 NB,
                                                         u32 B, u32 total_buckets) {
+    H2_LATENCY_STAGE();
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total_buckets) return;
     u32 sl = g / NB, j = g % NB;
@@ -183,6 +191,7 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *sh, u32 &total) {
 }
 __global__ void __launch_bounds__(kScanBlock) msm_scan_blocksums(const u32 *__restrict__ counts, u32 *__restrict__ bsums,
                                                                  u32 total) {
+    H2_LATENCY_STAGE();
     __shared__ u32 sh[kScanBlock];
     u32 g = blockIdx.x * kScanBlock + threadIdx.x;
     u32 tot;
@@ -190,6 +199,7 @@ __global__ void __launch_bounds__(kScanBlock) msm_scan_blocksums(const u32 *__re
     if (threadIdx.x == 0) bsums[blockIdx.x] = tot;
 }
 __global__ void __launch_bounds__(kScanBlock) msm_scan_top(u32 *__restrict__ bsums, u32 nblocks, u32 *__restrict__ grand) {
+    H2_LATENCY_STAGE();
     __shared__ u32 sh[kScanBlock];
     u32 carry = 0;
     for (u32 base = 0; base < nblocks; base += kScanBlock) {
@@ -204,6 +214,7 @@ __global__ void __launch_bounds__(kScanBlock) msm_scan_top(u32 *__restrict__ bsu
 __global__ void __launch_bounds__(kScanBlock) msm_scan_apply(const u32 *__restrict__ counts, const u32 *__restrict__ bsums,
                                                              const u32 *__restrict__ grand, u32 *__restrict__ starts,
                                                              u32 total) {
+    H2_LATENCY_STAGE();
     __shared__ u32 sh[kScanBlock];
     u32 g = blockIdx.x * kScanBlock + threadIdx.x;
     u32 tot;
@@ -219,6 +230,7 @@ __global__ void __launch_bounds__(1024) msm_scatter(const uint16_t *__restrict__
                                                     const u32 *__restrict__ starts, u32 *__restrict__ entries,
                                                     size_t items, u32 chunk, u32 NB, u32 m, u32 stride, u32 extra_col,
                                                     int table) {
+    H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 off[];
     const u32 b = blockIdx.x, sl = blockIdx.y, B = gridDim.x;
     const u32 *src = hist + ((size_t)sl * B + b) * NB;
@@ -317,6 +329,7 @@ template <int FB>
 __global__ void __launch_bounds__(256) msm_finish_buckets(const u32 *__restrict__ heads, const u32 *__restrict__ starts,
                                                           u32 *__restrict__ buckets, u32 *__restrict__ heavy,
                                                           u32 total_buckets, u32 T) {
+    H2_LATENCY_STAGE();
     // one quad of lanes per bucket (curve_wide.cuh)
     const u32 b = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
     if (b >= total_buckets) return;
@@ -354,6 +367,7 @@ template <int FB>
 __global__ void __launch_bounds__(256) msm_finish_heavy(const u32 *__restrict__ heads, const u32 *__restrict__ starts,
                                                         u32 *__restrict__ scratch, const u32 *__restrict__ heavy,
                                                         u32 total_buckets, u32 T) {
+    H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
     if (blockIdx.y >= min(heavy[1], kMaxHeavy)) return;
     const u32 b = heavy[2 + blockIdx.y], t = threadIdx.x / kGroup, nl = blockDim.x / kGroup;
@@ -387,6 +401,7 @@ __global__ void __launch_bounds__(256) msm_finish_heavy(const u32 *__restrict__ 
 template <int FB>
 __global__ void __launch_bounds__(64) msm_finish_heavy2(const u32 *__restrict__ scratch, u32 *__restrict__ buckets,
                                                         const u32 *__restrict__ heavy) {
+    H2_LATENCY_STAGE();
     if (blockIdx.x >= min(heavy[1], kMaxHeavy) || threadIdx.x >= kGroup) return;
     const u32 b = heavy[2 + blockIdx.x];
     xyzz<FB> acc = xyzz_load<FB>(buckets + 32 * (size_t)b);
@@ -404,6 +419,7 @@ __global__ void __launch_bounds__(64) msm_finish_heavy2(const u32 *__restrict__ 
 template <int FB>
 __global__ void __launch_bounds__(256) msm_reduce_segments(const u32 *__restrict__ buckets, u32 *__restrict__ partial,
                                                            u32 NB, u32 total_segments) {
+    H2_LATENCY_STAGE();
     const u32 t = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
     if (t >= total_segments) return;
     u32 segs_per_slice = NB / kSeg;
@@ -426,6 +442,7 @@ __global__ void __launch_bounds__(256) msm_reduce_segments(const u32 *__restrict
 template <int FB>
 __global__ void __launch_bounds__(256) msm_sum_slice(const u32 *__restrict__ partial, u32 *__restrict__ out, u32 per_slice,
                                                      u32 share) {
+    H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
     const u32 sl = blockIdx.y, blk = blockIdx.x, t = threadIdx.x / kGroup, nl = blockDim.x / kGroup;
     const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
@@ -456,6 +473,7 @@ __global__ void __launch_bounds__(256) msm_sum_slice(const u32 *__restrict__ par
 template <int FB>
 __global__ void __launch_bounds__(64) msm_combine(const u32 *__restrict__ slice_sums, int slices, int c, u32 *__restrict__ out,
                                                   int out_kind, int out_mont) {
+    H2_LATENCY_STAGE();
     if (blockIdx.x != 0 || threadIdx.x >= kGroup) return;
     xyzz<FB> r = xyzz_identity<FB>();
     for (int w = slices - 1; w >= 0; --w) {
@@ -578,6 +596,32 @@ __global__ void k_points_sum(const u32 *__restrict__ pts, u32 count, u32 *__rest
     fe_store(out + 16, Z);
 }
 
+// ---- debug timeline (H2_TIMELINE=1): one-lane stamp kernels between the stages of a commit record the device wall
+// clock; h2_debug_timeline drains them.  Used to see how commits on different streams interleave on the chip.
+__global__ void msm_stamp(unsigned long long *buf, u32 *count, u32 tag, u32 cap) {
+    u32 i = atomicAdd(count, 1u);
+    if (i < cap) {
+        buf[2 * i] = wall_clock64();
+        buf[2 * i + 1] = tag;
+    }
+}
+static unsigned long long *g_tl_buf = nullptr;
+static u32 *g_tl_count = nullptr;
+static const u32 kTlCap = 1 << 16;
+static bool timeline_on() {
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("H2_TIMELINE");
+        on = e && atoi(e) ? 1 : 0;
+        if (on) {
+            if (hipMalloc(&g_tl_buf, kTlCap * 16) != hipSuccess || hipMalloc(&g_tl_count, 4) != hipSuccess) on = 0;
+            else (void)hipMemset(g_tl_count, 0, 4);
+        }
+    }
+    return on == 1;
+}
+#define TL_STAMP(tag) do { if (timeline_on()) hipLaunchKernelGGL(msm_stamp, dim3(1), dim3(1), 0, st, g_tl_buf, g_tl_count, (u32)(tag), kTlCap); } while (0)
+
 // ---- host orchestration ----------------------------------------------------------------------------
 struct MsmContext {
     std::mutex mu;
@@ -611,6 +655,7 @@ struct MsmArgs {
     u32 extra_col;               // table column of the blind's base; 0xFFFFFFFF when unused
     int form, out_kind;
     void *d_out;
+    double lane_fraction = 0.0;  // 0 = the process-wide option; the batch entry point narrows its commits
 };
 
 template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a, hipStream_t st) {
@@ -645,7 +690,8 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     // one round of resident lanes; small problems use fewer lanes so a range keeps >= 16 entries
     // a lane fraction < 1 (h2_set_option) leaves wave slots free so that the latency-bound sort / reduce kernels
     // of a commit running on ANOTHER stream can overlap this kernel (independent column commits)
-    const u32 usable = std::max(256u, (u32)(lanes * g_lane_fraction.load()) / 256u * 256u);
+    const double fraction = a.lane_fraction > 0.0 ? a.lane_fraction : g_lane_fraction.load();
+    const u32 usable = std::max(256u, (u32)(lanes * fraction) / 256u * 256u);
     u32 T = (u32)std::min<size_t>(usable, std::max<size_t>(256, (all_items / 16 + 255) / 256 * 256));
     const u32 max_heavy = kMaxHeavy;
     if ((rc = cx.digits.reserve(all_items * 2)) != H2_OK) return rc;
@@ -662,6 +708,8 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     if ((rc = cx.ssums.reserve((size_t)sh.slices * 128)) != H2_OK) return rc;
     const u32 m32 = (u32)m;
     u32 *grand = cx.bsums.as<u32>() + nblocks;
+    const u32 tl_id = (u32)(((uintptr_t)st >> 4) & 0xFFFF) << 8;
+    TL_STAMP(tl_id | 1);
     prof_begin(PROF_MSM_SORT, st);
     hipLaunchKernelGGL((msm_recode<FS>), dim3((m32 + 255) / 256), dim3(256), 0, st, (const u32 *)a.d_scalars,
                        (const u32 *)a.d_extra_scalar, cx.digits.as<uint16_t>(), m32, sh.c, sh.W,
@@ -681,11 +729,13 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     H2_HIP(hipMemsetAsync(cx.buckets.ptr, 0, (size_t)tb * 128, st));
     H2_HIP(hipMemsetAsync(cx.heavy.ptr, 0, 8, st));
     prof_end(PROF_MSM_SORT, st);
+    TL_STAMP(tl_id | 2);
     prof_begin(PROF_MSM_ACCUMULATE, st);
     hipLaunchKernelGGL((msm_accumulate<FB>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases,
                        (const u32 *)a.d_extra_base, (!a.table && a.d_extra_base) ? (u32)a.n_used : 0xFFFFFFFFu,
                        cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T);
     prof_end(PROF_MSM_ACCUMULATE, st);
+    TL_STAMP(tl_id | 3);
     prof_begin(PROF_MSM_REDUCE, st);
     hipLaunchKernelGGL((msm_finish_buckets<FB>), dim3((tb * kGroup + 255) / 256), dim3(256), 0, st, cx.heads.as<u32>(),
                        cx.starts.as<u32>(), cx.buckets.as<u32>(), cx.heavy.as<u32>(), tb, T);
@@ -712,6 +762,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, cx.ssums.as<u32>(), (int)sh.slices, sh.c, (u32 *)a.d_out,
                        a.out_kind, a.form == H2_FORM_MONTGOMERY);
     prof_end(PROF_MSM_REDUCE, st);
+    TL_STAMP(tl_id | 4);
     H2_HIP(hipGetLastError());
     return H2_OK;
 }
@@ -816,6 +867,17 @@ static int ensure_blind_base(Bases &b, const void *d_w_mont, hipStream_t st) {
 using namespace h2;
 
 extern "C" int h2_msm_window_bits(size_t n) { return choose_c(n ? n : 1, false); }
+
+// debug only (not in the public header): copies up to `cap` {clock, tag} pairs recorded under H2_TIMELINE=1
+extern "C" int h2_debug_timeline(unsigned long long *out, unsigned cap) {
+    if (!timeline_on() || !out) return -1;
+    u32 n = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&n, g_tl_count, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    n = std::min(std::min(n, kTlCap), cap);
+    if (hipMemcpy(out, g_tl_buf, (size_t)n * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    (void)hipMemset(g_tl_count, 0, 4);
+    return (int)n;
+}
 
 extern "C" int h2_set_option(const char *key, double value) {
     if (!key) return H2_ERR_ARGS;
@@ -926,7 +988,7 @@ extern "C" int h2_bases_free(h2_bases_t handle) {
 }
 
 static int commit_device_impl(h2_bases_t g, const void *d_scalars, size_t n, const void *d_w_xy, const void *d_blind, int form,
-                              int out_kind, void *d_out, void *stream, bool blind_base_ready);
+                              int out_kind, void *d_out, void *stream, bool blind_base_ready, double lane_fraction = 0.0);
 
 extern "C" int h2_commit_device(h2_bases_t g, const void *d_scalars, size_t n, const void *d_w_xy, const void *d_blind,
                                 int form, int out_kind, void *d_out, void *stream) {
@@ -934,7 +996,7 @@ extern "C" int h2_commit_device(h2_bases_t g, const void *d_scalars, size_t n, c
 }
 
 static int commit_device_impl(h2_bases_t g, const void *d_scalars, size_t n, const void *d_w_xy, const void *d_blind, int form,
-                              int out_kind, void *d_out, void *stream, bool blind_base_ready) {
+                              int out_kind, void *d_out, void *stream, bool blind_base_ready, double lane_fraction) {
     auto b = find_bases(g);
     if (!b) return H2_ERR_HANDLE;
     if (bad_common(b->curve, form, out_kind) || !d_out || (n && !d_scalars) || n > b->n || ((d_w_xy == nullptr) != (d_blind == nullptr)))
@@ -955,12 +1017,16 @@ static int commit_device_impl(h2_bases_t g, const void *d_scalars, size_t n, con
         if ((rc = ensure_blind_base(*b, w, st)) != H2_OK) return rc;
     }
     MsmArgs a{d_scalars, d_blind, b->d_table, nullptr, n, true, b->c, b->stride, (u32)b->n, form, out_kind, d_out};
+    a.lane_fraction = lane_fraction;
     return msm_dispatch(cx, b->curve, a, st);
 }
 
 // ---- batched commits: the columns of one prover phase (plonk/prover.rs:93-101, 301-313; vanishing/prover.rs:96-108)
 // are independent; spread them over internal streams so one column's latency-bound sort / reduce kernels run beside
-// another's accumulate, then join on the caller's stream.
+// another's accumulate, then join on the caller's stream.  Measured at 2^20 (ms per commit):
+// 1 stream 1.94; 2 streams 1.64-1.70; 3 streams 1.60-1.64; 4 streams 1.56-1.75.  An accumulate launch fills the register
+// file, so the other columns' short kernels run in the gaps between accumulates; narrowing the accumulates
+// (lane fraction 0.5) lets them co-reside instead and reaches 1.52 in long runs, but drains badly on short batches.
 namespace {
 struct BatchStreams {
     std::mutex mu;
@@ -984,7 +1050,8 @@ extern "C" int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars
     if (rc != H2_OK) return rc;
     BatchStreams &bs = batch_streams();
     std::lock_guard<std::mutex> lk(bs.mu);
-    const size_t want = std::min<size_t>(2, count);
+    const size_t want = std::min<size_t>(3, count);
+    const double fraction = 0.0;  // the process-wide option
     while (bs.s.size() < want) {
         hipStream_t st;
         hipEvent_t ev;
@@ -1013,7 +1080,7 @@ extern "C" int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars
     H2_HIP(hipEventRecord(bs.fork, user));
     for (size_t i = 0; i < want; ++i) H2_HIP(hipStreamWaitEvent(bs.s[i], bs.fork, 0));
     for (size_t i = 0; i < count && rc == H2_OK; ++i)
-        rc = commit_device_impl(g, d_scalars[i], n, d_w_xy, d_w_xy ? d_blinds[i] : nullptr, form, out_kind, d_outs[i], bs.s[i % want], true);
+        rc = commit_device_impl(g, d_scalars[i], n, d_w_xy, d_w_xy ? d_blinds[i] : nullptr, form, out_kind, d_outs[i], bs.s[i % want], true, fraction);
     for (size_t i = 0; i < want; ++i) {
         H2_HIP(hipEventRecord(bs.done[i], bs.s[i]));
         H2_HIP(hipStreamWaitEvent(user, bs.done[i], 0));
