@@ -3,7 +3,8 @@ Pasta MSM (`best_multiexp`, `Params::commit*`) and NTT (`best_fft`, `EvaluationD
 C ABI (include/halo2_mi355x.h, halo2_amd/libhalo2_mi355x.so).  This package is the thin host-side mirror
 of the reference's interface; all compute is hand-written HIP in halo2_amd/csrc/."""
 from ._lib import (FORM_CANONICAL, FORM_MONTGOMERY, FP, FQ, LIB_PATH, PALLAS, VESTA, H2Error, lib)  # noqa: F401
-from .arithmetic import (best_fft, best_multiexp, fold_scalars, msm_window_bits, parallel_generator_collapse,  # noqa: F401
-                         points_sum)
+from .arithmetic import (batch_invert, best_fft, best_multiexp, compute_inner_product, eval_polynomial,  # noqa: F401
+                         fold_scalars, grand_product, kate_division, msm_window_bits, parallel_generator_collapse,
+                         points_sum, powers, scale_add, small_multiexp)
 from .commitment import Blind, Params, lagrange_basis  # noqa: F401
 from .domain import EvaluationDomain  # noqa: F401

@@ -52,8 +52,23 @@ SIGNATURES = {
     "h2_fold_scalars_device": ([C.c_int, vp, C.c_size_t, u64p, C.c_int, vp], C.c_int),
     "h2_lagrange_basis": ([C.c_int, u64p, u64p, C.c_uint, C.c_int], C.c_int),
     "h2_lagrange_basis_device": ([C.c_int, vp, vp, C.c_uint, C.c_int, vp], C.c_int),
+    "h2_eval_polynomial": ([C.c_int, u64p, C.c_size_t, u64p, C.c_int, u64p], C.c_int),
+    "h2_eval_polynomial_device": ([C.c_int, vp, C.c_size_t, u64p, C.c_int, vp, vp], C.c_int),
+    "h2_inner_product": ([C.c_int, u64p, u64p, C.c_size_t, C.c_int, u64p], C.c_int),
+    "h2_inner_product_device": ([C.c_int, vp, vp, C.c_size_t, C.c_int, vp, vp], C.c_int),
+    "h2_kate_division": ([C.c_int, u64p, C.c_size_t, u64p, C.c_int, u64p], C.c_int),
+    "h2_kate_division_device": ([C.c_int, vp, C.c_size_t, u64p, C.c_int, vp, vp], C.c_int),
+    "h2_powers": ([C.c_int, u64p, C.c_size_t, C.c_int, u64p], C.c_int),
+    "h2_powers_device": ([C.c_int, u64p, C.c_size_t, C.c_int, vp, vp], C.c_int),
+    "h2_scale_add": ([C.c_int, u64p, u64p, u64p, C.c_size_t, C.c_int], C.c_int),
+    "h2_scale_add_device": ([C.c_int, vp, u64p, vp, C.c_size_t, C.c_int, vp], C.c_int),
+    "h2_batch_invert": ([C.c_int, u64p, C.c_size_t, C.c_int], C.c_int),
+    "h2_batch_invert_device": ([C.c_int, vp, C.c_size_t, C.c_int, vp], C.c_int),
+    "h2_grand_product": ([C.c_int, u64p, C.c_size_t, u64p, C.c_int, u64p], C.c_int),
+    "h2_grand_product_device": ([C.c_int, vp, C.c_size_t, u64p, C.c_int, vp, vp], C.c_int),
     "h2_profile_enable": ([C.c_int], C.c_int),
     "h2_profile_read": ([C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),
+    "h2_debug_timeline": ([C.POINTER(C.c_ulonglong), C.c_uint], C.c_int),
 }
 
 

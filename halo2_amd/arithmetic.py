@@ -119,3 +119,121 @@ def fold_scalars(a, factor, field: int, form: int = FORM_MONTGOMERY):
     a = _np(a, 4).copy()
     check(lib().h2_fold_scalars(field, _p(a), half, _p(factor), form), "h2_fold_scalars")
     return a[:half]
+
+
+# ---- polynomial helpers of arithmetic.rs / the opening argument (numpy in -> numpy out; torch CUDA in -> torch out) ----
+def _fe(v) -> np.ndarray:
+    return np.ascontiguousarray(v, dtype=np.uint64).reshape(4)
+
+
+def _dev_vec(a):
+    assert a.is_cuda and a.is_contiguous() and a.ndim == 2 and a.shape[1] == 4
+    return a
+
+
+def small_multiexp(coeffs, bases, curve: int, form: int = FORM_MONTGOMERY):
+    """`small_multiexp` (arithmetic.rs:116-136) -- same sum as best_multiexp; on the device both are one kernel path."""
+    return best_multiexp(coeffs, bases, curve, form)
+
+
+def eval_polynomial(poly, point, field: int, form: int = FORM_MONTGOMERY):
+    """`eval_polynomial` (arithmetic.rs:298-303): sum_i poly[i] * point^i -> (4,) limbs."""
+    point = _fe(point)
+    if _is_torch(poly):
+        import torch
+        out = torch.empty(4, dtype=poly.dtype, device=poly.device)
+        check(lib().h2_eval_polynomial_device(field, _dev_vec(poly).data_ptr(), poly.shape[0], _p(point), form, out.data_ptr(),
+                                              _stream_ptr()), "h2_eval_polynomial_device")
+        return out
+    poly = _np(poly, 4)
+    out = np.zeros(4, dtype=np.uint64)
+    check(lib().h2_eval_polynomial(field, _p(poly), poly.shape[0], _p(point), form, _p(out)), "h2_eval_polynomial")
+    return out
+
+
+def compute_inner_product(a, b, field: int, form: int = FORM_MONTGOMERY):
+    """`compute_inner_product` (arithmetic.rs:308-318).  Raises ValueError on a length mismatch (the reference asserts)."""
+    if a.shape[0] != b.shape[0]:
+        raise ValueError("compute_inner_product: lengths differ")
+    if _is_torch(a):
+        import torch
+        out = torch.empty(4, dtype=a.dtype, device=a.device)
+        check(lib().h2_inner_product_device(field, _dev_vec(a).data_ptr(), _dev_vec(b).data_ptr(), a.shape[0], form, out.data_ptr(),
+                                            _stream_ptr()), "h2_inner_product_device")
+        return out
+    a, b = _np(a, 4), _np(b, 4)
+    out = np.zeros(4, dtype=np.uint64)
+    check(lib().h2_inner_product(field, _p(a), _p(b), a.shape[0], form, _p(out)), "h2_inner_product")
+    return out
+
+
+def kate_division(a, b, field: int, form: int = FORM_MONTGOMERY):
+    """`kate_division` (arithmetic.rs:322-341): a(X) / (X - b) without the remainder; len(a) - 1 coefficients."""
+    b = _fe(b)
+    if a.shape[0] == 0:
+        raise ValueError("kate_division: empty polynomial")
+    if _is_torch(a):
+        import torch
+        out = torch.empty((a.shape[0] - 1, 4), dtype=a.dtype, device=a.device)
+        check(lib().h2_kate_division_device(field, _dev_vec(a).data_ptr(), a.shape[0], _p(b), form, out.data_ptr(), _stream_ptr()),
+              "h2_kate_division_device")
+        return out
+    a = _np(a, 4)
+    out = np.zeros((a.shape[0] - 1, 4), dtype=np.uint64)
+    check(lib().h2_kate_division(field, _p(a), a.shape[0], _p(b), form, _p(out)), "h2_kate_division")
+    return out
+
+
+def powers(x, n: int, field: int, form: int = FORM_MONTGOMERY, device=None):
+    """1, x, x^2, ... x^(n-1): the `b` vector of the opening argument (poly/commitment/prover.rs:90-97).
+    `device` = a torch device for a device-resident result."""
+    x = _fe(x)
+    if device is not None:
+        import torch
+        out = torch.empty((n, 4), dtype=torch.int64, device=device)
+        check(lib().h2_powers_device(field, _p(x), n, form, out.data_ptr(), _stream_ptr()), "h2_powers_device")
+        return out
+    out = np.zeros((n, 4), dtype=np.uint64)
+    check(lib().h2_powers(field, _p(x), n, form, _p(out)), "h2_powers")
+    return out
+
+
+def scale_add(a, x, b, field: int, form: int = FORM_MONTGOMERY):
+    """a * x + b coefficient-wise (`s_poly * xi + p_poly`, poly/commitment/prover.rs:70).  torch: in place on `a`."""
+    x = _fe(x)
+    if a.shape[0] != b.shape[0]:
+        raise ValueError("scale_add: lengths differ")
+    if _is_torch(a):
+        check(lib().h2_scale_add_device(field, _dev_vec(a).data_ptr(), _p(x), _dev_vec(b).data_ptr(), a.shape[0], form, _stream_ptr()),
+              "h2_scale_add_device")
+        return a
+    a, b = _np(a, 4).copy(), _np(b, 4)
+    check(lib().h2_scale_add(field, _p(a), _p(x), _p(b), a.shape[0], form), "h2_scale_add")
+    return a
+
+
+def batch_invert(a, field: int, form: int = FORM_MONTGOMERY):
+    """ff::BatchInvert (plonk/permutation/prover.rs:118): element-wise inverse, zeros stay zero.  torch: in place."""
+    if _is_torch(a):
+        check(lib().h2_batch_invert_device(field, _dev_vec(a).data_ptr(), a.shape[0], form, _stream_ptr()), "h2_batch_invert_device")
+        return a
+    a = _np(a, 4).copy()
+    check(lib().h2_batch_invert(field, _p(a), a.shape[0], form), "h2_batch_invert")
+    return a
+
+
+def grand_product(m, n: int, init, field: int, form: int = FORM_MONTGOMERY):
+    """z[0] = init, z[i] = z[i-1] * m[i-1] for i < n (plonk/permutation/prover.rs:147-153)."""
+    init = _fe(init)
+    if m.shape[0] < n - 1:
+        raise ValueError("grand_product: need at least n - 1 factors")
+    if _is_torch(m):
+        import torch
+        z = torch.empty((n, 4), dtype=m.dtype, device=m.device)
+        check(lib().h2_grand_product_device(field, _dev_vec(m).data_ptr(), n, _p(init), form, z.data_ptr(), _stream_ptr()),
+              "h2_grand_product_device")
+        return z
+    m = _np(m, 4)
+    z = np.zeros((n, 4), dtype=np.uint64)
+    check(lib().h2_grand_product(field, _p(m), n, _p(init), form, _p(z)), "h2_grand_product")
+    return z

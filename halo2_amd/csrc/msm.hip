@@ -868,7 +868,7 @@ using namespace h2;
 
 extern "C" int h2_msm_window_bits(size_t n) { return choose_c(n ? n : 1, false); }
 
-// debug only (not in the public header): copies up to `cap` {clock, tag} pairs recorded under H2_TIMELINE=1
+// copies up to `cap` {clock, tag} pairs recorded under H2_TIMELINE=1 (measurement aid, see the header)
 extern "C" int h2_debug_timeline(unsigned long long *out, unsigned cap) {
     if (!timeline_on() || !out) return -1;
     u32 n = 0;

@@ -164,6 +164,38 @@ int h2_fold_scalars_device(int field, void *d_a, size_t half, const uint64_t *fa
 int h2_lagrange_basis(int curve, const uint64_t *g_xy, uint64_t *out_xy, unsigned k, int form);
 int h2_lagrange_basis_device(int curve, const void *d_g_xy, void *d_out_xy, unsigned k, int form, void *stream);
 
+/* ---- polynomial helpers between the commits and the transforms ------------------------------- */
+/* Each replaces one O(n) field loop of the prover so a column can stay in HBM from witness to opening.
+ * Vectors are n contiguous 32-byte elements in `form`; single field elements (`point`, `x`, `init`) are
+ * host pointers in `form`; the *_device variants take device pointers for vectors and results. */
+/* eval_polynomial (halo2_proofs/src/arithmetic.rs:298-303): out = sum_i poly[i] * point^i. */
+int h2_eval_polynomial(int field, const uint64_t *poly, size_t n, const uint64_t *point, int form, uint64_t *out);
+int h2_eval_polynomial_device(int field, const void *d_poly, size_t n, const uint64_t *point, int form, void *d_out,
+                              void *stream);
+/* compute_inner_product (arithmetic.rs:308-318): out = sum_i a[i] * b[i]; both vectors have n elements
+ * (the reference panics on a length mismatch; the caller passes one n). */
+int h2_inner_product(int field, const uint64_t *a, const uint64_t *b, size_t n, int form, uint64_t *out);
+int h2_inner_product_device(int field, const void *d_a, const void *d_b, size_t n, int form, void *d_out, void *stream);
+/* kate_division (arithmetic.rs:322-341): out[0 .. n-2] = quotient of a(X) by (X - point), remainder dropped.
+ * n >= 1 (the reference underflows on an empty input); out must not alias a. */
+int h2_kate_division(int field, const uint64_t *a, size_t n, const uint64_t *point, int form, uint64_t *out);
+int h2_kate_division_device(int field, const void *d_a, size_t n, const uint64_t *point, int form, void *d_out, void *stream);
+/* the `b` vector of the opening argument (poly/commitment/prover.rs:90-97): out[i] = x^i, i < n. */
+int h2_powers(int field, const uint64_t *x, size_t n, int form, uint64_t *out);
+int h2_powers_device(int field, const uint64_t *x, size_t n, int form, void *d_out, void *stream);
+/* `s_poly * xi + p_poly` (poly/commitment/prover.rs:70): a[i] = a[i] * x + b[i]. */
+int h2_scale_add(int field, uint64_t *a, const uint64_t *x, const uint64_t *b, size_t n, int form);
+int h2_scale_add_device(int field, void *d_a, const uint64_t *x, const void *d_b, size_t n, int form, void *stream);
+/* ff::BatchInvert as the grand products use it (plonk/permutation/prover.rs:118, plonk/lookup/prover.rs:297):
+ * a[i] = 1 / a[i]; zeros are left zero. */
+int h2_batch_invert(int field, uint64_t *a, size_t n, int form);
+int h2_batch_invert_device(int field, void *d_a, size_t n, int form, void *stream);
+/* the running product of a permutation / lookup argument (plonk/permutation/prover.rs:147-153,
+ * plonk/lookup/prover.rs:318-326): z[0] = init, z[i] = z[i-1] * m[i-1] for 0 < i < n.  m holds at least
+ * n - 1 factors; z has n elements and must not alias m. */
+int h2_grand_product(int field, const uint64_t *m, size_t n, const uint64_t *init, int form, uint64_t *z);
+int h2_grand_product_device(int field, const void *d_m, size_t n, const uint64_t *init, int form, void *d_z, void *stream);
+
 /* ---- measurement aid (no reference counterpart) ------------------------------------------------ */
 /* When enabled, the library brackets its dominant kernels with HIP events on the launching stream.
  * h2_profile_read drains them: slot 0 = MSM bucket accumulation, 1 = NTT passes (sum over the passes
@@ -174,6 +206,10 @@ int h2_lagrange_basis_device(int curve, const void *d_g_xy, void *d_out_xy, unsi
 #define H2_PROF_MSM_REDUCE 3
 int h2_profile_enable(int on);
 int h2_profile_read(int slot, double *total_ms, uint64_t *launches);
+/* With H2_TIMELINE=1 in the environment every commit stamps the device clock (100 MHz) as its sort, accumulate
+ * and reduce stages become runnable; this drains up to `cap` {clock, (stream id << 8) | stage} pairs, stage
+ * 1 = sort, 2 = accumulate, 3 = reduce, 4 = done.  Returns the pair count, or -1 when the timeline is off. */
+int h2_debug_timeline(unsigned long long *out, unsigned cap);
 
 #ifdef __cplusplus
 }

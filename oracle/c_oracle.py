@@ -58,6 +58,13 @@ def lib():
             "orc_coeff_to_extended": ([C.c_int, u64p, C.c_uint, C.c_uint, u64p, u64p, u64p], C.c_int),
             "orc_extended_to_coeff": ([C.c_int, u64p, C.c_uint, u64p, u64p, u64p, u64p], C.c_int),
             "orc_divide_by_vanishing_poly": ([C.c_int, u64p, C.c_uint, u64p, C.c_size_t], None),
+            "orc_eval_polynomial": ([C.c_int, u64p, C.c_size_t, u64p, u64p], None),
+            "orc_inner_product": ([C.c_int, u64p, u64p, C.c_size_t, u64p], None),
+            "orc_kate_division": ([C.c_int, u64p, C.c_size_t, u64p, u64p], None),
+            "orc_powers": ([C.c_int, u64p, C.c_size_t, u64p], None),
+            "orc_scale_add": ([C.c_int, u64p, u64p, u64p, C.c_size_t], None),
+            "orc_batch_invert": ([C.c_int, u64p, C.c_size_t], None),
+            "orc_grand_product": ([C.c_int, u64p, C.c_size_t, u64p, u64p], None),
             "orc_random_field": ([C.c_int, C.c_uint64, u64p, C.c_size_t], None),
             "orc_generate_bases": ([C.c_int, u64p, C.c_uint64, u64p, C.c_size_t], None),
             "orc_msm_naive": ([C.c_int, u64p, u64p, C.c_size_t, u64p], C.c_int),
@@ -242,6 +249,58 @@ def fold_scalars(field: int, a: np.ndarray, factor: np.ndarray) -> np.ndarray:
     half = a.shape[0] // 2
     lib().orc_fold_scalars(field, _p(a), half, _p(np.ascontiguousarray(factor, dtype=np.uint64)))
     return a[:half]
+
+
+def _fe(v) -> np.ndarray:
+    return np.ascontiguousarray(v, dtype=np.uint64).reshape(4)
+
+
+def eval_polynomial(field: int, poly: np.ndarray, point) -> np.ndarray:
+    poly = np.ascontiguousarray(poly, dtype=np.uint64)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().orc_eval_polynomial(field, _p(poly), poly.shape[0], _p(_fe(point)), _p(out))
+    return out
+
+
+def inner_product(field: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a, b = np.ascontiguousarray(a, dtype=np.uint64), np.ascontiguousarray(b, dtype=np.uint64)
+    assert a.shape == b.shape
+    out = np.zeros(4, dtype=np.uint64)
+    lib().orc_inner_product(field, _p(a), _p(b), a.shape[0], _p(out))
+    return out
+
+
+def kate_division(field: int, a: np.ndarray, point) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    q = np.zeros((a.shape[0] - 1, 4), dtype=np.uint64)
+    lib().orc_kate_division(field, _p(a), a.shape[0], _p(_fe(point)), _p(q))
+    return q
+
+
+def powers(field: int, x, n: int) -> np.ndarray:
+    out = np.zeros((n, 4), dtype=np.uint64)
+    lib().orc_powers(field, _p(_fe(x)), n, _p(out))
+    return out
+
+
+def scale_add(field: int, a: np.ndarray, x, b: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    lib().orc_scale_add(field, _p(a), _p(_fe(x)), _p(b), a.shape[0])
+    return a
+
+
+def batch_invert(field: int, a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+    lib().orc_batch_invert(field, _p(a), a.shape[0])
+    return a
+
+
+def grand_product(field: int, m: np.ndarray, n: int, init) -> np.ndarray:
+    m = np.ascontiguousarray(m, dtype=np.uint64)
+    z = np.zeros((n, 4), dtype=np.uint64)
+    lib().orc_grand_product(field, _p(m), n, _p(_fe(init)), _p(z))
+    return z
 
 
 def lagrange_basis(curve: int, g: np.ndarray, k: int) -> np.ndarray:

@@ -15,6 +15,13 @@
  *   orc_lagrange_basis     halo2_proofs/src/poly/commitment.rs:77-100 (point FFT of Params::new)
  *   orc_generator_collapse halo2_proofs/src/poly/commitment/prover.rs:154-166
  *   orc_fold_scalars       halo2_proofs/src/poly/commitment/prover.rs:128-131
+ *   orc_eval_polynomial    halo2_proofs/src/arithmetic.rs:298-303
+ *   orc_inner_product      halo2_proofs/src/arithmetic.rs:308-318
+ *   orc_kate_division      halo2_proofs/src/arithmetic.rs:322-341
+ *   orc_powers             halo2_proofs/src/poly/commitment/prover.rs:90-97
+ *   orc_scale_add          halo2_proofs/src/poly/commitment/prover.rs:70 (Polynomial * F, + : poly.rs)
+ *   orc_batch_invert       ff 0.13 BatchInvert (Cargo.lock:628), call sites plonk/permutation/prover.rs:118
+ *   orc_grand_product      halo2_proofs/src/plonk/permutation/prover.rs:147-153
  * Field and curve arithmetic (pasta_curves 0.5.1, Cargo.lock:1303, not vendored in the
  * reference tree) is restated from the definition: p, q below; y^2 = x^3 + 5;
  * Montgomery form with R = 2^256; Jacobian projective coordinates.
@@ -795,6 +802,86 @@ void orc_fold_scalars(int field, u64 *a, size_t half, const u64 *factor) {
         f_mul(f, t, a + 4 * (half + i), factor);
         f_add(f, a + 4 * i, a + 4 * i, t);
     }
+}
+
+/* ------------------------------------------------------------------ polynomial helpers (sequential, as written) */
+/* arithmetic.rs:298-303: fold from the top coefficient, acc = acc * point + coeff */
+void orc_eval_polynomial(int field, const u64 *poly, size_t n, const u64 *point, u64 *out) {
+    const field_t *f = &FIELDS[field];
+    u64 acc[4] = {0, 0, 0, 0};
+    for (size_t i = n; i-- > 0;) {
+        f_mul(f, acc, acc, point);
+        f_add(f, acc, acc, poly + 4 * i);
+    }
+    memcpy(out, acc, 32);
+}
+/* arithmetic.rs:308-318 */
+void orc_inner_product(int field, const u64 *a, const u64 *b, size_t n, u64 *out) {
+    const field_t *f = &FIELDS[field];
+    u64 acc[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < n; i++) {
+        u64 t[4];
+        f_mul(f, t, a + 4 * i, b + 4 * i);
+        f_add(f, acc, acc, t);
+    }
+    memcpy(out, acc, 32);
+}
+/* arithmetic.rs:322-341: b = -b; from the top: lead = a_i - tmp; q = lead; tmp = lead * b.  q has n - 1 entries */
+void orc_kate_division(int field, const u64 *a, size_t n, const u64 *point, u64 *q) {
+    const field_t *f = &FIELDS[field];
+    u64 nb[4], tmp[4] = {0, 0, 0, 0};
+    f_neg(f, nb, point);
+    for (size_t i = n; i-- > 1;) {               /* q.iter_mut().rev().zip(a.rev()): q[i-1] pairs with a[i] */
+        u64 lead[4];
+        f_sub(f, lead, a + 4 * i, tmp);
+        memcpy(q + 4 * (i - 1), lead, 32);
+        f_mul(f, tmp, lead, nb);
+    }
+}
+/* prover.rs:90-97: cur = 1; push(cur); cur *= x */
+void orc_powers(int field, const u64 *x, size_t n, u64 *out) {
+    const field_t *f = &FIELDS[field];
+    u64 cur[4];
+    memcpy(cur, f->r, 32);
+    for (size_t i = 0; i < n; i++) {
+        memcpy(out + 4 * i, cur, 32);
+        f_mul(f, cur, cur, x);
+    }
+}
+/* prover.rs:70: s_poly * xi + p_poly, coefficient-wise */
+void orc_scale_add(int field, u64 *a, const u64 *x, const u64 *b, size_t n) {
+    const field_t *f = &FIELDS[field];
+    for (size_t i = 0; i < n; i++) {
+        f_mul(f, a + 4 * i, a + 4 * i, x);
+        f_add(f, a + 4 * i, a + 4 * i, b + 4 * i);
+    }
+}
+/* ff::BatchInvert: running product over the non-zero entries, one inversion, walk back; zeros untouched */
+void orc_batch_invert(int field, u64 *a, size_t n) {
+    const field_t *f = &FIELDS[field];
+    u64 *pre = (u64 *)malloc((n ? n : 1) * 32);
+    u64 acc[4];
+    memcpy(acc, f->r, 32);
+    for (size_t i = 0; i < n; i++) {
+        memcpy(pre + 4 * i, acc, 32);
+        if (!f_is_zero(a + 4 * i)) f_mul(f, acc, acc, a + 4 * i);
+    }
+    f_inv(f, acc, acc);
+    for (size_t i = n; i-- > 0;) {
+        if (f_is_zero(a + 4 * i)) continue;
+        u64 t[4];
+        f_mul(f, t, acc, pre + 4 * i);
+        f_mul(f, acc, acc, a + 4 * i);
+        memcpy(a + 4 * i, t, 32);
+    }
+    free(pre);
+}
+/* permutation/prover.rs:147-153: z = [init]; for row in 1..n: z.push(z[row-1] * m[row-1]) */
+void orc_grand_product(int field, const u64 *m, size_t n, const u64 *init, u64 *z) {
+    const field_t *f = &FIELDS[field];
+    if (!n) return;
+    memcpy(z, init, 32);
+    for (size_t row = 1; row < n; row++) f_mul(f, z + 4 * row, z + 4 * (row - 1), m + 4 * (row - 1));
 }
 
 /* ------------------------------------------------------------------ Params::new: Lagrange basis */

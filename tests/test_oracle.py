@@ -283,3 +283,42 @@ def test_commit_lagrange_equals_commit():
     got = co.commit(curve, g, co.points_to_mont(curve, [w_int])[0], co.to_mont(sf, co.ints_to_limbs(coeff)),
                     co.to_mont(sf, co.ints_to_limbs([blind]))[0])
     assert co.jac_to_affine_ints(curve, got) == c1
+
+
+@pytest.mark.parametrize("name,fid,m", FIELDS)
+def test_poly_helpers_c_vs_python_definition(name, fid, m):
+    """The C restatements of eval_polynomial / compute_inner_product / kate_division (arithmetic.rs:298-341), the
+    powers-of-x vector (poly/commitment/prover.rs:90-97), BatchInvert and the grand product
+    (plonk/permutation/prover.rs:118,147-153) against Python big-integer arithmetic of the definitions."""
+    rng = o.SplitMix64(0x706F6C79 + fid)
+    n = 37
+    a = [rng.next() * rng.next() * rng.next() * rng.next() % m for _ in range(n)]
+    b = [rng.next() * rng.next() * rng.next() * rng.next() % m for _ in range(n)]
+    x = rng.next() * rng.next() * rng.next() % m
+    a[5] = 0
+    mont = lambda vals: co.to_mont(fid, co.ints_to_limbs(vals))
+    ints = lambda arr: co.limbs_to_ints(co.from_mont(fid, arr))
+    am, bm, xm = mont(a), mont(b), mont([x])[0]
+
+    assert ints(co.eval_polynomial(fid, am, xm)) == [sum(c * pow(x, i, m) for i, c in enumerate(a)) % m]
+    assert ints(co.inner_product(fid, am, bm)) == [sum(u * v for u, v in zip(a, b)) % m]
+    assert ints(co.powers(fid, xm, n)) == [pow(x, i, m) for i in range(n)]
+    assert ints(co.scale_add(fid, am, xm, bm)) == [(u * x + v) % m for u, v in zip(a, b)]
+
+    # kate_division: q(X) (X - x) + a(x) == a(X)
+    q = ints(co.kate_division(fid, am, xm))
+    assert len(q) == n - 1
+    ev = sum(c * pow(x, i, m) for i, c in enumerate(a)) % m
+    back = [(-x * q[0] + ev) % m] + [(q[i - 1] - x * q[i]) % m for i in range(1, n - 1)] + [q[n - 2]]
+    assert back == a
+
+    inv = ints(co.batch_invert(fid, am))
+    assert inv == [pow(v, -1, m) if v else 0 for v in a]
+
+    init = rng.next() % m
+    z = ints(co.grand_product(fid, bm, n, mont([init])[0]))
+    want, cur = [], init
+    for i in range(n):
+        want.append(cur)
+        cur = cur * b[i] % m
+    assert z == want
