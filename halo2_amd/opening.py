@@ -1,0 +1,87 @@
+"""The polynomial-commitment opening argument, `poly::commitment::prover::create_proof`
+(halo2_proofs/src/poly/commitment/prover.rs:26-151), with every vector resident in HBM.
+
+Per round the reference runs two half-size MSMs, two inner products, the p' / b folds and the generator collapse
+on the host and round-trips nothing; a naive offload would ship O(n) bytes each way 2k times.  Here p', b and G'
+live on the device for the whole argument; per round the host sees 2 x 32 bytes (the inner products), 2 x 64 bytes
+(L_j, R_j for the transcript) and sends one challenge.
+
+torch is plumbing (device buffers, slicing); all arithmetic goes through the C ABI."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import fields
+from ._lib import FORM_MONTGOMERY
+from .arithmetic import (best_multiexp, compute_inner_product, eval_polynomial, fold_scalars, parallel_generator_collapse,
+                         powers, scale_add)
+from .commitment import Blind, Params
+
+
+def _host(t) -> np.ndarray:
+    return t.cpu().numpy().view(np.uint64)
+
+
+def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, device=None) -> None:
+    """Writes the opening proof of `p_poly` at `x_3` to `transcript`.
+
+    rng(count) -> (count, 4) uniformly random scalars, Montgomery limbs (the reference draws `C::Scalar::random`
+    n + 1 + 2k times in this order: s_poly coefficients, s_poly_blind, then l_j / r_j randomness per round).
+    p_poly: (n, 4) numpy array or torch CUDA tensor; x_3: (4,) limbs."""
+    import torch
+    curve = params.curve
+    sf = fields.CURVE_FIELDS[curve][1]
+    m = fields.MODULUS[sf]
+    n, k = params.n, params.k
+    if p_poly.shape[0] != n:
+        raise ValueError("create_proof: polynomial length != params.n")                  # prover.rs:41
+    dev = p_poly.device if hasattr(p_poly, "device") and not isinstance(p_poly, np.ndarray) else torch.device(device or "cuda:0")
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64)).to(dev)
+    as_int = lambda limbs: fields.from_limbs(limbs, sf, True)[0]
+    as_limbs = lambda v: fields.scalar_limbs(v % m, sf, True)
+    d_p = p_poly if not isinstance(p_poly, np.ndarray) else to_dev(p_poly)
+    x3 = np.ascontiguousarray(x_3, dtype=np.uint64).reshape(4)
+
+    # random polynomial with a root at x_3 (prover.rs:43-53)
+    d_s = to_dev(rng(n))
+    s_at_x3 = as_int(_host(eval_polynomial(d_s, x3, sf)))
+    d_s[0] = to_dev(as_limbs(as_int(_host(d_s[0])) - s_at_x3))
+    s_blind = Blind(np.ascontiguousarray(rng(1)[0]))
+    transcript.write_point(_host(params.commit(d_s, s_blind, affine=True)))               # prover.rs:56-57
+    xi = transcript.squeeze_challenge_scalar()                                            # prover.rs:62
+    z = transcript.squeeze_challenge_scalar()                                             # prover.rs:66
+
+    # P' = P - [v] G_0 + [xi] S (prover.rs:70-73); the synthetic blind f starts as P''s blind (:74-78)
+    d_pp = scale_add(d_s, xi, d_p, sf)                                                    # in place on d_s
+    v = as_int(_host(eval_polynomial(d_pp, x3, sf)))
+    d_pp[0] = to_dev(as_limbs(as_int(_host(d_pp[0])) - v))
+    f = (as_int(s_blind.value) * as_int(xi) + as_int(p_blind.value)) % m
+    z_i = as_int(z)
+
+    d_b = powers(x3, n, sf, device=dev)                                                   # prover.rs:86-97
+    d_g = to_dev(params.g)                                                                # G' (prover.rs:101)
+    d_uw = to_dev(np.stack([params.u, params.w]))
+
+    for j in range(k):                                                                    # prover.rs:104-142
+        half = 1 << (k - j - 1)
+        lo_p, hi_p = d_pp[:half], d_pp[half:2 * half]
+        value_l = as_int(_host(compute_inner_product(hi_p.contiguous(), d_b[:half].contiguous(), sf)))
+        value_r = as_int(_host(compute_inner_product(lo_p.contiguous(), d_b[half:2 * half].contiguous(), sf)))
+        l_rand, r_rand = rng(2)
+        # L_j = <p'_hi, G'_lo> + [value_l z] U + [l_rand] W as ONE multiexp over half + 2 points (the reference's TODO, :108-110)
+        tail_l = to_dev(np.stack([as_limbs(value_l * z_i), l_rand]))
+        tail_r = to_dev(np.stack([as_limbs(value_r * z_i), r_rand]))
+        l_j = best_multiexp(torch.cat([hi_p, tail_l]), torch.cat([d_g[:half], d_uw]), curve, FORM_MONTGOMERY, affine=True)
+        r_j = best_multiexp(torch.cat([lo_p, tail_r]), torch.cat([d_g[half:2 * half], d_uw]), curve, FORM_MONTGOMERY, affine=True)
+        transcript.write_point(_host(l_j))                                                # prover.rs:121-122
+        transcript.write_point(_host(r_j))
+        u_j = transcript.squeeze_challenge_scalar()                                       # prover.rs:124
+        u_i = as_int(u_j)
+        u_inv_i = pow(u_i, -1, m)                                                         # prover.rs:125
+        d_pp = fold_scalars(d_pp[:2 * half], as_limbs(u_inv_i), sf)                       # prover.rs:128-133
+        d_b = fold_scalars(d_b[:2 * half], u_j, sf)
+        d_g = parallel_generator_collapse(d_g[:2 * half], u_j, curve)                     # prover.rs:136-137
+        f = (f + as_int(l_rand) * u_inv_i + as_int(r_rand) * u_i) % m                     # prover.rs:140-141
+
+    transcript.write_scalar(_host(d_pp[0]))                                               # c  (prover.rs:146-148)
+    transcript.write_scalar(as_limbs(f))

@@ -116,3 +116,51 @@ def test_cpp_host_mirror_header_compiles():
     out = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", ROOT, "-x", "c++", "-"], input=src, text=True,
                          capture_output=True, cwd=ROOT)
     assert out.returncode == 0, out.stderr
+
+
+def test_transcript_mirror_matches_oracle_restatement():
+    """halo2_amd.transcript (host logic) against the oracle's independent copy of transcript.rs:150-300, and the oracle's
+    opening-argument prover against its verifier (CPU only, k = 3)."""
+    import numpy as np
+    from halo2_amd import fields
+    from halo2_amd.transcript import Blake2bWrite
+    from oracle import c_oracle as co
+    from oracle import ipa
+    curve, k = 1, 3
+    n = 1 << k
+    sf = fields.CURVE_FIELDS[curve][1]
+    g = co.generate_bases(curve, 5, n)
+    w, u = co.generate_bases(curve, 6, 1)[0], co.generate_bases(curve, 7, 1)[0]
+    pt = co.affine_to_ints(curve, g[3])
+    sc = co.random_field(sf, 8, 1)[0]
+    a, b = Blake2bWrite(curve), ipa.Transcript(curve)
+    a.write_point(g[3]); b.write_point(pt)
+    assert a.squeeze_challenge() == b.squeeze_challenge()
+    a.write_scalar(sc); b.write_scalar(fields.from_limbs(sc, sf, True)[0])
+    a.common_point(g[4]); b.common_point(co.affine_to_ints(curve, g[4]))
+    assert a.squeeze_challenge() == b.squeeze_challenge()
+    assert a.finalize() == bytes(b.out) and len(a.finalize()) == 64
+    with pytest.raises(ValueError):
+        a.write_point(np.zeros(8, dtype=np.uint64))
+
+    ctr = [40]
+
+    def rng(count):
+        ctr[0] += 1
+        return co.random_field(sf, ctr[0], count)
+    px = fields.to_limbs(range(n), sf, True)
+    blind = co.random_field(sf, 9, 1)[0]
+    p = co.jac_to_affine_ints(curve, co.commit(curve, g, w, px, blind))
+    t = ipa.Transcript(curve)
+    t.write_point(p)
+    x = t.squeeze_challenge()
+    xl = fields.scalar_limbs(x, sf, True)
+    v = fields.from_limbs(co.eval_polynomial(sf, px, xl), sf, True)[0]
+    t.write_scalar(v)
+    ipa.create_proof(curve, k, g, w, u, rng, t, px, blind, xl)
+    vt = ipa.Transcript(curve, bytes(t.out))
+    assert vt.read_point() == p and vt.squeeze_challenge() == x and vt.read_scalar() == v
+    assert ipa.verify_proof(curve, k, g, w, u, vt, p, x, v)
+    vt = ipa.Transcript(curve, bytes(t.out))
+    vt.read_point(), vt.squeeze_challenge(), vt.read_scalar()
+    assert not ipa.verify_proof(curve, k, g, w, u, vt, p, x, (v + 1))

@@ -1,0 +1,74 @@
+"""The device-resident opening argument (halo2_amd/opening.py, every vector in HBM) against the oracle's sequential
+restatement of `create_proof` (oracle/ipa.py): identical proof BYTES for the same randomness, and the oracle's
+restatement of the reference verifier accepts them.  Shaped after the reference's own `test_opening_proof`
+(halo2_proofs/src/poly/commitment.rs:305-379).  Runs only on a real MI355X (`-m gpu`)."""
+import numpy as np
+import pytest
+
+import halo2_amd as h
+from halo2_amd import fields
+from halo2_amd.opening import create_proof
+from halo2_amd.transcript import Blake2bWrite
+from oracle import c_oracle as co
+from oracle import ipa
+
+pytestmark = pytest.mark.gpu
+
+
+def _rng(sf, seed):
+    ctr = [seed]
+
+    def rng(count):
+        ctr[0] += 1
+        return co.random_field(sf, ctr[0], count)
+    return rng
+
+
+@pytest.mark.parametrize("curve,k", [(h.PALLAS, 1), (h.PALLAS, 4), (h.PALLAS, 6), (h.VESTA, 6), (h.VESTA, 11)])
+def test_opening_proof_bytes_and_verification(curve, k):
+    n = 1 << k
+    sf = fields.CURVE_FIELDS[curve][1]
+    g = co.generate_bases(curve, 50 + k, n)
+    w, u = co.generate_bases(curve, 60, 1)[0], co.generate_bases(curve, 61, 1)[0]
+    params = h.Params.from_generators(curve, k, g, None, w, u)
+    px = fields.to_limbs(range(n), sf, True)                       # commitment.rs:332-334: a_i = i
+    blind = h.Blind(co.random_field(sf, 70, 1)[0])
+
+    # --- prover on the device (commitment.rs:338-351)
+    p = params.commit(px, blind, affine=True)
+    tr = Blake2bWrite(curve)
+    tr.write_point(p)
+    x = tr.squeeze_challenge_scalar()
+    v = h.eval_polynomial(px, x, sf)
+    tr.write_scalar(v)
+    create_proof(params, _rng(sf, 1000), tr, px, blind, x)
+    ch_prover = tr.squeeze_challenge()
+    proof = tr.finalize()
+    assert len(proof) == 32 + 32 + 32 + 64 * k + 64
+
+    # --- the same prover, sequential on the CPU oracle: byte-identical transcript
+    p_int = co.affine_to_ints(curve, p)
+    ot = ipa.Transcript(curve)
+    ot.write_point(p_int)
+    ox = ot.squeeze_challenge()
+    assert ox == fields.from_limbs(x, sf, True)[0]
+    ov = co.limbs_to_ints(co.from_mont(sf, co.eval_polynomial(sf, px, x)))[0]
+    ot.write_scalar(ov)
+    ipa.create_proof(curve, k, g, w, u, _rng(sf, 1000), ot, px, blind.value, x)
+    assert bytes(ot.out) == proof
+    assert ot.squeeze_challenge() == ch_prover
+
+    # --- verifier (commitment.rs:353-366), oracle restatement of verifier.rs
+    vt = ipa.Transcript(curve, proof)
+    assert vt.read_point() == p_int
+    assert vt.squeeze_challenge() == ox
+    assert vt.read_scalar() == ov
+    assert ipa.verify_proof(curve, k, g, w, u, vt, p_int, ox, ov)
+    assert vt.squeeze_challenge() == ch_prover
+    # a flipped bit in c is rejected
+    bad = bytearray(proof)
+    bad[-40] ^= 1
+    vt = ipa.Transcript(curve, bytes(bad))
+    vt.read_point(), vt.squeeze_challenge(), vt.read_scalar()
+    assert not ipa.verify_proof(curve, k, g, w, u, vt, p_int, ox, ov)
+    params.close()
