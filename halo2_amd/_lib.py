@@ -41,6 +41,8 @@ SIGNATURES = {
     "h2_commit_device": ([C.c_uint64, vp, C.c_size_t, vp, vp, C.c_int, C.c_int, vp, vp], C.c_int),
     "h2_commit_batch_device": ([C.c_uint64, C.POINTER(vp), C.c_size_t, C.c_size_t, vp, C.POINTER(vp), C.c_int, C.c_int,
                                 C.POINTER(vp), vp], C.c_int),
+    "h2_msm_batch_device": ([C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int,
+                             C.POINTER(vp), vp], C.c_int),
     "h2_ntt_device": ([C.c_int, vp, C.c_uint, u64p, C.c_int, vp], C.c_int),
     "h2_ifft_device": ([C.c_int, vp, C.c_uint, u64p, u64p, C.c_int, vp], C.c_int),
     "h2_coeff_to_extended_device": ([C.c_int, vp, vp, C.c_uint, C.c_uint, u64p, u64p, u64p, C.c_int, vp], C.c_int),

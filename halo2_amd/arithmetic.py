@@ -60,6 +60,27 @@ def best_multiexp(coeffs, bases, curve: int, form: int = FORM_MONTGOMERY, affine
     return out
 
 
+def best_multiexp_batch(pairs, curve: int, form: int = FORM_MONTGOMERY, affine: bool = False):
+    """Several independent `best_multiexp(coeffs, bases)` over device tensors in one call (the L_j / R_j pair of an
+    opening-argument round, poly/commitment/prover.rs:107-108); returns one (len, 12|8) device tensor."""
+    import torch
+    out_len = 8 if affine else 12
+    for coeffs, bases in pairs:
+        if coeffs.shape[0] != bases.shape[0]:
+            raise ValueError("best_multiexp: coeffs and bases differ in length")
+        assert coeffs.is_cuda and bases.is_cuda and coeffs.is_contiguous() and bases.is_contiguous()
+    if not pairs:
+        return None
+    out = torch.empty((len(pairs), out_len), dtype=torch.int64, device=pairs[0][0].device)
+    arr = C.c_void_p * len(pairs)
+    rc = lib().h2_msm_batch_device(curve, arr(*[c.data_ptr() for c, _ in pairs]), arr(*[b.data_ptr() for _, b in pairs]),
+                                   (C.c_size_t * len(pairs))(*[c.shape[0] for c, _ in pairs]), len(pairs), form,
+                                   OUT_AFFINE if affine else OUT_JACOBIAN, arr(*[out[i].data_ptr() for i in range(len(pairs))]),
+                                   _stream_ptr())
+    check(rc, "h2_msm_batch_device")
+    return out
+
+
 def best_fft(a, omega, log_n: int, field: int, form: int = FORM_MONTGOMERY):
     """In-place radix-2 FFT, natural order in and out (arithmetic.rs:192).  Raises ValueError unless
     len(a) == 1 << log_n (the reference asserts, :205).  `omega`: (4,) limbs in the same form as `a`."""

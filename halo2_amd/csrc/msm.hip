@@ -1088,6 +1088,39 @@ extern "C" int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars
     return rc;
 }
 
+// Independent multiexps over caller-supplied bases in one call (the L_j / R_j pair of an opening-argument round,
+// poly/commitment/prover.rs:107-108): same fork / join as the batched commits, so the latency-bound window combine of
+// one overlaps the bucket accumulation of the other.
+extern "C" int h2_msm_batch_device(int curve, const void *const *d_scalars, const void *const *d_bases_xy, const size_t *n, size_t count,
+                                   int form, int out_kind, void *const *d_outs, void *stream) {
+    if (!d_scalars || !d_bases_xy || !n || !d_outs) return H2_ERR_ARGS;
+    if (count == 0) return H2_OK;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    BatchStreams &bs = batch_streams();
+    std::lock_guard<std::mutex> lk(bs.mu);
+    const size_t want = std::min<size_t>(3, count);
+    while (bs.s.size() < want) {
+        hipStream_t st;
+        hipEvent_t ev;
+        H2_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        H2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        bs.s.push_back(st);
+        bs.done.push_back(ev);
+    }
+    if (!bs.fork) H2_HIP(hipEventCreateWithFlags(&bs.fork, hipEventDisableTiming));
+    hipStream_t user = (hipStream_t)stream;
+    H2_HIP(hipEventRecord(bs.fork, user));
+    for (size_t i = 0; i < want; ++i) H2_HIP(hipStreamWaitEvent(bs.s[i], bs.fork, 0));
+    for (size_t i = 0; i < count && rc == H2_OK; ++i)
+        rc = h2_msm_device(curve, d_scalars[i], d_bases_xy[i], n[i], form, out_kind, d_outs[i], bs.s[i % want]);
+    for (size_t i = 0; i < want; ++i) {
+        H2_HIP(hipEventRecord(bs.done[i], bs.s[i]));
+        H2_HIP(hipStreamWaitEvent(user, bs.done[i], 0));
+    }
+    return rc;
+}
+
 extern "C" int h2_commit(h2_bases_t g, const uint64_t *scalars, size_t n, const uint64_t *w_xy, const uint64_t *blind,
                          int form, int out_kind, uint64_t *out) {
     auto b = find_bases(g);

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import fields
 from ._lib import FORM_MONTGOMERY
-from .arithmetic import (best_multiexp, compute_inner_product, eval_polynomial, fold_scalars, parallel_generator_collapse,
+from .arithmetic import (best_multiexp_batch, compute_inner_product, eval_polynomial, fold_scalars, parallel_generator_collapse,
                          powers, scale_add)
 from .commitment import Blind, Params
 
@@ -65,16 +65,18 @@ def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, d
     for j in range(k):                                                                    # prover.rs:104-142
         half = 1 << (k - j - 1)
         lo_p, hi_p = d_pp[:half], d_pp[half:2 * half]
-        value_l = as_int(_host(compute_inner_product(hi_p.contiguous(), d_b[:half].contiguous(), sf)))
-        value_r = as_int(_host(compute_inner_product(lo_p.contiguous(), d_b[half:2 * half].contiguous(), sf)))
+        values = _host(torch.stack([compute_inner_product(hi_p, d_b[:half], sf),                 # prover.rs:109-110
+                                    compute_inner_product(lo_p, d_b[half:2 * half], sf)]))
+        value_l, value_r = as_int(values[0]), as_int(values[1])
         l_rand, r_rand = rng(2)
         # L_j = <p'_hi, G'_lo> + [value_l z] U + [l_rand] W as ONE multiexp over half + 2 points (the reference's TODO, :108-110)
         tail_l = to_dev(np.stack([as_limbs(value_l * z_i), l_rand]))
         tail_r = to_dev(np.stack([as_limbs(value_r * z_i), r_rand]))
-        l_j = best_multiexp(torch.cat([hi_p, tail_l]), torch.cat([d_g[:half], d_uw]), curve, FORM_MONTGOMERY, affine=True)
-        r_j = best_multiexp(torch.cat([lo_p, tail_r]), torch.cat([d_g[half:2 * half], d_uw]), curve, FORM_MONTGOMERY, affine=True)
-        transcript.write_point(_host(l_j))                                                # prover.rs:121-122
-        transcript.write_point(_host(r_j))
+        lr = _host(best_multiexp_batch([(torch.cat([hi_p, tail_l]), torch.cat([d_g[:half], d_uw])),
+                                        (torch.cat([lo_p, tail_r]), torch.cat([d_g[half:2 * half], d_uw]))],
+                                       curve, FORM_MONTGOMERY, affine=True))
+        transcript.write_point(lr[0])                                                     # prover.rs:121-122
+        transcript.write_point(lr[1])
         u_j = transcript.squeeze_challenge_scalar()                                       # prover.rs:124
         u_i = as_int(u_j)
         u_inv_i = pow(u_i, -1, m)                                                         # prover.rs:125

@@ -129,6 +129,11 @@ int h2_commit_device(h2_bases_t g, const void *d_scalars, size_t n, const void *
 int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars, size_t count, size_t n,
                            const void *d_w_xy, const void *const *d_blinds, int form, int out_kind,
                            void *const *d_outs, void *stream);
+/* `count` independent multiexps over caller-supplied bases (e.g. the L_j / R_j pair of one opening-argument round,
+ * halo2_proofs/src/poly/commitment/prover.rs:107-108), overlapped on internal streams and joined on `stream`.
+ * Arrays of `count` device pointers / lengths; argument meaning per entry as h2_msm_device. */
+int h2_msm_batch_device(int curve, const void *const *d_scalars, const void *const *d_bases_xy, const size_t *n,
+                        size_t count, int form, int out_kind, void *const *d_outs, void *stream);
 int h2_ntt_device(int field, void *d_a, unsigned log_n, const uint64_t *omega, int form, void *stream);
 int h2_ifft_device(int field, void *d_a, unsigned log_n, const uint64_t *omega_inv,
                    const uint64_t *divisor, int form, void *stream);

@@ -487,3 +487,24 @@ def test_registered_heavy_buckets_2_16():
     assert lib.h2_commit(hd, _p(many), n, None, None, h.FORM_MONTGOMERY, 0, _p(out)) == 0
     assert affine_of(curve, out) == co.jac_to_affine_ints(curve, co.best_multiexp(curve, many, g))
     assert lib.h2_bases_free(hd) == 0
+
+
+def test_msm_batch_matches_oracle():
+    """h2_msm_batch_device: ragged independent multiexps in one call (the L_j / R_j pairs of the opening argument)."""
+    import torch
+    from halo2_amd.arithmetic import best_multiexp_batch
+    curve = h.VESTA
+    sf = fields.CURVE_FIELDS[curve][1]
+    dev = torch.device("cuda:0")
+    sizes = [1, 2, 33, 1000, 4097, 1 << 15, 0, 700]
+    pairs, want = [], []
+    for i, n in enumerate(sizes):
+        sc, bs = co.random_field(sf, 300 + i, max(n, 1))[:n], co.generate_bases(curve, 400 + i, max(n, 1))[:n]
+        pairs.append((torch.from_numpy(sc.view(np.int64)).to(dev), torch.from_numpy(bs.view(np.int64)).to(dev)))
+        want.append(affine_of(curve, co.best_multiexp(curve, sc, bs)))
+    got = best_multiexp_batch(pairs, curve).cpu().numpy().view(np.uint64)
+    assert [affine_of(curve, g) for g in got] == want
+    got_aff = best_multiexp_batch(pairs, curve, affine=True).cpu().numpy().view(np.uint64)
+    assert [affine_of(curve, g) for g in got_aff] == want
+    with pytest.raises(ValueError):
+        best_multiexp_batch([(pairs[3][0], pairs[4][1])], curve)
