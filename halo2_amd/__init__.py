@@ -6,5 +6,5 @@ from ._lib import (FORM_CANONICAL, FORM_MONTGOMERY, FP, FQ, LIB_PATH, PALLAS, VE
 from .arithmetic import (batch_invert, best_fft, best_multiexp, compute_inner_product, eval_polynomial,  # noqa: F401
                          fold_scalars, grand_product, kate_division, msm_window_bits, parallel_generator_collapse,
                          points_sum, powers, scale_add, small_multiexp)
-from .commitment import Blind, Params, lagrange_basis  # noqa: F401
+from .commitment import Blind, Params, lagrange_basis, points_from_bytes, points_to_bytes  # noqa: F401
 from .domain import EvaluationDomain  # noqa: F401

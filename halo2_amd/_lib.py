@@ -7,7 +7,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-H2_OK, H2_ERR_ARGS, H2_ERR_HIP, H2_ERR_NODEV, H2_ERR_HANDLE = 0, 1, 2, 3, 4
+H2_OK, H2_ERR_ARGS, H2_ERR_HIP, H2_ERR_NODEV, H2_ERR_HANDLE, H2_ERR_DECODE = 0, 1, 2, 3, 4, 5
 FP, FQ = 0, 1
 PALLAS, VESTA = 0, 1
 FORM_CANONICAL, FORM_MONTGOMERY = 0, 1
@@ -68,6 +68,10 @@ SIGNATURES = {
     "h2_batch_invert_device": ([C.c_int, vp, C.c_size_t, C.c_int, vp], C.c_int),
     "h2_grand_product": ([C.c_int, u64p, C.c_size_t, u64p, C.c_int, u64p], C.c_int),
     "h2_grand_product_device": ([C.c_int, vp, C.c_size_t, u64p, C.c_int, vp, vp], C.c_int),
+    "h2_points_compress": ([C.c_int, u64p, C.c_size_t, C.c_int, C.POINTER(C.c_uint8)], C.c_int),
+    "h2_points_compress_device": ([C.c_int, vp, C.c_size_t, C.c_int, vp, vp], C.c_int),
+    "h2_points_decompress": ([C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.c_int, u64p], C.c_int),
+    "h2_points_decompress_device": ([C.c_int, vp, C.c_size_t, C.c_int, vp, vp], C.c_int),
     "h2_profile_enable": ([C.c_int], C.c_int),
     "h2_profile_read": ([C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),
     "h2_debug_timeline": ([C.POINTER(C.c_ulonglong), C.c_uint], C.c_int),
@@ -119,6 +123,8 @@ def check(rc: int, what: str):
     if rc == H2_ERR_ARGS:
         # the reference panics (assert_eq!) on bad lengths: arithmetic.rs:144, :205
         raise ValueError(f"{what}: bad arguments")
+    if rc == H2_ERR_DECODE:
+        raise ValueError(f"{what}: invalid point encoding")      # the reference returns io::Error (commitment.rs:193-198)
     msg = lib().h2_last_error().decode()
     names = {H2_ERR_HIP: "HIP failure", H2_ERR_NODEV: "no MI355X device", H2_ERR_HANDLE: "bad handle"}
     raise H2Error(f"{what}: {names.get(rc, rc)}: {msg}")

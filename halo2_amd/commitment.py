@@ -32,6 +32,26 @@ def lagrange_basis(g, curve: int, k: int, form: int = FORM_MONTGOMERY) -> np.nda
     return out
 
 
+def points_to_bytes(points, curve: int, form: int = FORM_MONTGOMERY) -> bytes:
+    """pasta_curves `to_bytes` for n affine points (n, 8): 32 bytes each, x little-endian | parity(y) << 255."""
+    pts = _np(np.asarray(points).reshape(-1, 8), 8)
+    out = np.zeros(pts.shape[0] * 32, dtype=np.uint8)
+    check(lib().h2_points_compress(curve, _p(pts), pts.shape[0], form, out.ctypes.data_as(C.POINTER(C.c_uint8))), "h2_points_compress")
+    return out.tobytes()
+
+
+def points_from_bytes(raw: bytes, curve: int, form: int = FORM_MONTGOMERY) -> np.ndarray:
+    """`from_bytes` for len(raw) / 32 points -> (n, 8) affine limbs.  ValueError on an invalid encoding (the reference
+    returns an io::Error from Params::read, commitment.rs:193-198)."""
+    if len(raw) % 32:
+        raise ValueError("points_from_bytes: length is not a multiple of 32")
+    buf = np.frombuffer(raw, dtype=np.uint8).copy()
+    n = buf.shape[0] // 32
+    out = np.zeros((n, 8), dtype=np.uint64)
+    check(lib().h2_points_decompress(curve, buf.ctypes.data_as(C.POINTER(C.c_uint8)), n, form, _p(out)), "h2_points_decompress")
+    return out
+
+
 class Params:
     def __init__(self, curve: int, k: int, g, g_lagrange, w, u):
         self.curve, self.k, self.n = curve, k, 1 << k
@@ -54,6 +74,29 @@ class Params:
         if g_lagrange is None:
             g_lagrange = lagrange_basis(g, curve, k)
         return cls(curve, k, g, g_lagrange, w, u)
+
+    def write(self, writer) -> None:
+        """Params::write (commitment.rs:169-181): k (u32 LE), g, g_lagrange, w, u as compressed points."""
+        writer.write(int(self.k).to_bytes(4, "little"))
+        writer.write(points_to_bytes(self.g, self.curve))
+        writer.write(points_to_bytes(self.g_lagrange, self.curve))
+        writer.write(points_to_bytes(np.stack([self.w, self.u]), self.curve))
+
+    @classmethod
+    def read(cls, reader, curve: int) -> "Params":
+        """Params::read (commitment.rs:184-205); the 2^(k+1) + 2 square roots run on the device."""
+        head = reader.read(4)
+        if len(head) != 4:
+            raise ValueError("Params.read: truncated header")
+        k = int.from_bytes(head, "little")
+        if k >= 32:
+            raise ValueError("Params.read: k out of range")                 # commitment.rs:41
+        n = 1 << k
+        raw = reader.read(32 * (2 * n + 2))
+        if len(raw) != 32 * (2 * n + 2):
+            raise ValueError("Params.read: truncated point data")
+        pts = points_from_bytes(raw, curve)
+        return cls(curve, k, pts[:n], pts[n:2 * n], pts[2 * n], pts[2 * n + 1])
 
     def close(self):
         for h in (self._h_g, self._h_gl):

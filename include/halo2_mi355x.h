@@ -43,6 +43,7 @@ extern "C" {
 #define H2_ERR_HIP 2    /* a HIP runtime call failed; see h2_last_error() */
 #define H2_ERR_NODEV 3  /* no gfx950 device / HIP runtime unavailable */
 #define H2_ERR_HANDLE 4 /* unknown or freed handle */
+#define H2_ERR_DECODE 5 /* a compressed point does not decode (where pasta_curves' from_bytes returns None) */
 
 #define H2_FP 0
 #define H2_FQ 1
@@ -200,6 +201,18 @@ int h2_batch_invert_device(int field, void *d_a, size_t n, int form, void *strea
  * n - 1 factors; z has n elements and must not alias m. */
 int h2_grand_product(int field, const uint64_t *m, size_t n, const uint64_t *init, int form, uint64_t *z);
 int h2_grand_product_device(int field, const void *d_m, size_t n, const uint64_t *init, int form, void *d_z, void *stream);
+
+/* ---- compressed points: the URS file and proof encoding --------------------------------------- */
+/* pasta_curves `to_bytes` as Params::write uses it (halo2_proofs/src/poly/commitment.rs:169-181) and write_point
+ * (transcript.rs:183-187): out[32 i ..] = x little-endian with the parity of y in bit 255; identity = 32 zero bytes.
+ * Input: n affine points in `form`. */
+int h2_points_compress(int curve, const uint64_t *xy, size_t n, int form, uint8_t *out_bytes);
+int h2_points_compress_device(int curve, const void *d_xy, size_t n, int form, void *d_out_bytes, void *stream);
+/* `from_bytes` as Params::read uses it (commitment.rs:184-205): one base-field square root per point.  Returns
+ * H2_ERR_DECODE if any encoding is invalid (x >= p, x^3 + 5 not a square, or (0, odd)); those entries are zeroed.
+ * The device variant synchronises `stream` to learn the verdict. */
+int h2_points_decompress(int curve, const uint8_t *bytes, size_t n, int form, uint64_t *out_xy);
+int h2_points_decompress_device(int curve, const void *d_bytes, size_t n, int form, void *d_out_xy, void *stream);
 
 /* ---- measurement aid (no reference counterpart) ------------------------------------------------ */
 /* When enabled, the library brackets its dominant kernels with HIP events on the launching stream.

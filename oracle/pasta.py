@@ -371,3 +371,50 @@ def synth_point(rng: SplitMix64, m: int):
             if rng.next() & 1:
                 y = m - y
             return (x, y)
+
+
+# --- compressed encoding (pasta_curves to_bytes / from_bytes; used by Params::write/read, poly/commitment.rs:169-205,
+# --- and transcript write_point, transcript.rs:183-187) -------------------------------------------------------------
+def point_to_bytes(pt, m: int) -> bytes:
+    """pt: canonical affine (x, y) or None (identity -> 32 zero bytes)."""
+    if pt is None:
+        return bytes(32)
+    b = bytearray(int(pt[0]).to_bytes(32, "little"))
+    b[31] |= (pt[1] & 1) << 7
+    return bytes(b)
+
+
+def point_from_bytes(raw: bytes, m: int):
+    """Returns (x, y), None for the identity; raises ValueError where from_bytes yields CtOption::none."""
+    raw = bytearray(raw)
+    sign = raw[31] >> 7
+    raw[31] &= 0x7F
+    x = int.from_bytes(raw, "little")
+    if x >= m:
+        raise ValueError("x not canonical")
+    if x == 0:
+        if sign:
+            raise ValueError("(0, odd) is not a point")
+        return None
+    y = sqrt_mod((x * x * x + CURVE_B) % m, m)
+    if y is None:
+        raise ValueError("x^3 + 5 is not a square")
+    if y & 1 != sign:
+        y = m - y
+    return (x, y)
+
+
+def params_write(k: int, g, g_lagrange, w, u, m: int) -> bytes:
+    """Params::write (poly/commitment.rs:169-181): k as u32 LE, then g, g_lagrange, w, u compressed."""
+    out = bytearray(int(k).to_bytes(4, "little"))
+    for pt in list(g) + list(g_lagrange) + [w, u]:
+        out += point_to_bytes(pt, m)
+    return bytes(out)
+
+
+def params_read(raw: bytes, m: int):
+    """Params::read (poly/commitment.rs:184-205)."""
+    k = int.from_bytes(raw[:4], "little")
+    n = 1 << k
+    pts = [point_from_bytes(raw[4 + 32 * i: 36 + 32 * i], m) for i in range(2 * n + 2)]
+    return k, pts[:n], pts[n:2 * n], pts[2 * n], pts[2 * n + 1]

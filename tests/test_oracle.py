@@ -322,3 +322,25 @@ def test_poly_helpers_c_vs_python_definition(name, fid, m):
         want.append(cur)
         cur = cur * b[i] % m
     assert z == want
+
+
+def test_point_encoding_roundtrip_and_rejections(vks):
+    """oracle to_bytes / from_bytes (Params::write/read, poly/commitment.rs:169-205) on the reference's pinned Vesta
+    points: decode(encode(P)) == P, sign bit = parity of y, identity = zeros, invalid encodings rejected."""
+    m = o.Q
+    pts = [(int(pt["x"], 16), int(pt["y"], 16)) for pt in vks[0]["points"]][:12]      # tests/plonk_api.rs:959-980
+    assert len(pts) == 12 and all(o.on_curve(pt, m) for pt in pts)
+    for pt in pts:
+        enc = o.point_to_bytes(pt, m)
+        assert enc[31] >> 7 == pt[1] & 1
+        assert o.point_from_bytes(enc, m) == pt
+        neg = (pt[0], m - pt[1])
+        assert o.point_from_bytes(o.point_to_bytes(neg, m), m) == neg
+    assert o.point_to_bytes(None, m) == bytes(32) and o.point_from_bytes(bytes(32), m) is None
+    with pytest.raises(ValueError):
+        o.point_from_bytes(bytes(31) + b"\x80", m)                     # (0, odd)
+    with pytest.raises(ValueError):
+        o.point_from_bytes(b"\xff" * 31 + b"\x7f", m)                  # x >= modulus
+    raw = o.params_write(2, pts[:4], pts[4:8], pts[8], pts[9], m)
+    assert len(raw) == 4 + 32 * 10
+    assert o.params_read(raw, m) == (2, pts[:4], pts[4:8], pts[8], pts[9])
