@@ -5,13 +5,17 @@
 //     arithmetic::best_multiexp / best_fft            halo2_proofs/src/arithmetic.rs:143, :192
 //     EvaluationDomain::{new, lagrange_to_coeff, coeff_to_extended, extended_to_coeff}
 //                                                     halo2_proofs/src/poly/domain.rs:40, :227, :241, :303
-//     Params::{commit, commit_lagrange}, Blind        halo2_proofs/src/poly/commitment.rs:119, :135, :208
+//     arithmetic::{eval_polynomial, compute_inner_product, kate_division}   arithmetic.rs:298, :308, :322
+//     EvaluationDomain::divide_by_vanishing_poly      halo2_proofs/src/poly/domain.rs:329
+//     Params::{commit, commit_lagrange, write, read}, Blind   halo2_proofs/src/poly/commitment.rs:119, :135, :169, :184, :208
 // Where the reference panics (assert_eq! on lengths) these throw std::invalid_argument; HIP / device
 // failures throw std::runtime_error with h2_last_error().  All compute happens in libhalo2_mi355x.so.
 #pragma once
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <istream>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -112,6 +116,26 @@ template <int FIELD> inline void best_fft(std::vector<Fe> &a, const Fe &omega, u
     check(h2_ntt(FIELD, a[0].data(), log_n, omega.data(), H2_FORM_MONTGOMERY), "h2_ntt");
 }
 
+template <int FIELD> inline Fe eval_polynomial(const std::vector<Fe> &poly, const Fe &point) {                  // arithmetic.rs:298
+    Fe out{};
+    check(h2_eval_polynomial(FIELD, poly.empty() ? nullptr : poly[0].data(), poly.size(), point.data(), H2_FORM_MONTGOMERY, out.data()),
+          "h2_eval_polynomial");
+    return out;
+}
+template <int FIELD> inline Fe compute_inner_product(const std::vector<Fe> &a, const std::vector<Fe> &b) {       // arithmetic.rs:308
+    if (a.size() != b.size()) throw std::invalid_argument("compute_inner_product: a.len() != b.len()");          // :311
+    Fe out{};
+    check(h2_inner_product(FIELD, a.empty() ? nullptr : a[0].data(), b.empty() ? nullptr : b[0].data(), a.size(), H2_FORM_MONTGOMERY,
+                           out.data()), "h2_inner_product");
+    return out;
+}
+template <int FIELD> inline std::vector<Fe> kate_division(const std::vector<Fe> &a, const Fe &b) {              // arithmetic.rs:322
+    if (a.empty()) throw std::invalid_argument("kate_division: empty polynomial");
+    std::vector<Fe> q(a.size() - 1);
+    check(h2_kate_division(FIELD, a[0].data(), a.size(), b.data(), H2_FORM_MONTGOMERY, q.empty() ? nullptr : q[0].data()), "h2_kate_division");
+    return q;
+}
+
 // ---- poly/domain.rs ------------------------------------------------------------------------------------------
 template <int FIELD> class EvaluationDomain {
   public:
@@ -162,6 +186,12 @@ template <int FIELD> class EvaluationDomain {
         a.resize(n * quotient_poly_degree);
         return a;
     }
+    std::vector<Fe> divide_by_vanishing_poly(std::vector<Fe> a) const {                                         // domain.rs:329
+        if (a.size() != extended_len()) throw std::invalid_argument("divide_by_vanishing_poly: wrong length");  // :333
+        check(h2_divide_by_vanishing_poly(FIELD, a[0].data(), extended_k, t_evaluations[0].data(), t_evaluations.size(), H2_FORM_MONTGOMERY),
+              "h2_divide_by_vanishing_poly");
+        return a;
+    }
 };
 
 // ---- poly/commitment.rs ------------------------------------------------------------------------------------------
@@ -187,6 +217,35 @@ template <int CURVE> class Params {
     Jacobian commit(const std::vector<Fe> &poly, const Blind<CURVE> &r) const { return run(h_g, poly, r); }            // :119
     Jacobian commit_lagrange(const std::vector<Fe> &poly, const Blind<CURVE> &r) const { return run(h_gl, poly, r); }  // :135
     std::vector<Affine> get_g() const { return g; }
+
+    void write(std::ostream &writer) const {                                                                            // :169-181
+        const uint32_t k_le = k;                      // little-endian hosts only, like the GPU
+        writer.write(reinterpret_cast<const char *>(&k_le), 4);
+        std::vector<uint8_t> buf(n * 32);
+        for (const std::vector<Affine> *v : {&g, &g_lagrange}) {
+            check(h2_points_compress(CURVE, (*v)[0].data(), n, H2_FORM_MONTGOMERY, buf.data()), "h2_points_compress");
+            writer.write(reinterpret_cast<const char *>(buf.data()), (std::streamsize)buf.size());
+        }
+        const Affine wu[2] = {w, u};
+        check(h2_points_compress(CURVE, wu[0].data(), 2, H2_FORM_MONTGOMERY, buf.data()), "h2_points_compress");
+        writer.write(reinterpret_cast<const char *>(buf.data()), 64);
+    }
+    static Params read(std::istream &reader) {                                                                          // :184-205
+        uint32_t k_le = 0;
+        if (!reader.read(reinterpret_cast<char *>(&k_le), 4) || k_le >= 32) throw std::runtime_error("Params::read: bad header");
+        const size_t n_ = (size_t)1 << k_le;
+        std::vector<uint8_t> buf(32 * (2 * n_ + 2));
+        if (!reader.read(reinterpret_cast<char *>(buf.data()), (std::streamsize)buf.size())) throw std::runtime_error("Params::read: truncated");
+        std::vector<Affine> pts(2 * n_ + 2);
+        int rc = h2_points_decompress(CURVE, buf.data(), pts.size(), H2_FORM_MONTGOMERY, pts[0].data());
+        if (rc == H2_ERR_DECODE) throw std::runtime_error("Params::read: invalid point encoding");                      // io::Error in the reference
+        check(rc, "h2_points_decompress");
+        return Params(k_le, std::vector<Affine>(pts.begin(), pts.begin() + n_), std::vector<Affine>(pts.begin() + n_, pts.begin() + 2 * n_),
+                      pts[2 * n_], pts[2 * n_ + 1]);
+    }
+    Params(Params &&o) noexcept : k(o.k), n(o.n), g(std::move(o.g)), g_lagrange(std::move(o.g_lagrange)), w(o.w), u(o.u), h_g(o.h_g), h_gl(o.h_gl) {
+        o.h_g = o.h_gl = 0;
+    }
 
   private:
     h2_bases_t h_g = 0, h_gl = 0;

@@ -4,6 +4,7 @@
 // Build: g++ -O2 -std=c++17 tests/native/host_mirror_check.cpp -Lhalo2_amd -lhalo2_mi355x -Loracle -lh2oracle (see __graft_entry__.build)
 #include <cstdio>
 #include <cstring>
+#include <sstream>
 #include <vector>
 
 #include "../../halo2_amd/host/halo2_host.hpp"
@@ -18,6 +19,10 @@ int orc_best_fft(int field, uint64_t *a, const uint64_t *omega, unsigned log_n);
 int orc_ifft(int field, uint64_t *a, const uint64_t *omega_inv, unsigned log_n, const uint64_t *divisor);
 int orc_coeff_to_extended(int field, uint64_t *a_ext, unsigned k, unsigned ext_k, const uint64_t *g_coset, const uint64_t *g_coset_inv, const uint64_t *extended_omega);
 void orc_to_mont(int field, uint64_t *a, size_t n);
+void orc_eval_polynomial(int field, const uint64_t *poly, size_t n, const uint64_t *point, uint64_t *out);
+void orc_inner_product(int field, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out);
+void orc_kate_division(int field, const uint64_t *a, size_t n, const uint64_t *point, uint64_t *q);
+void orc_divide_by_vanishing_poly(int field, uint64_t *a_ext, unsigned ext_k, const uint64_t *t_evals, size_t nt);
 }
 using namespace halo2;
 
@@ -94,6 +99,36 @@ int main() {
     std::vector<Fe> fref = a;
     orc_best_fft(FIELD, fref[0].data(), dom.omega.data(), k);
     EXPECT(f == fref, "best_fft == oracle");
+    // arithmetic.rs:298-341 helpers and divide_by_vanishing_poly (domain.rs:329)
+    Fe pt = field::from_u64(FIELD, 0x1234567), ev_ref, ip_ref;
+    orc_eval_polynomial(FIELD, a[0].data(), n, pt.data(), ev_ref.data());
+    EXPECT(eval_polynomial<FIELD>(a, pt) == ev_ref, "eval_polynomial == oracle");
+    orc_inner_product(FIELD, a[0].data(), coeffs[0].data(), n, ip_ref.data());
+    EXPECT(compute_inner_product<FIELD>(a, coeffs) == ip_ref, "compute_inner_product == oracle");
+    threw = false;
+    try { std::vector<Fe> c2(n - 1); compute_inner_product<FIELD>(a, c2); } catch (const std::invalid_argument &) { threw = true; }
+    EXPECT(threw, "compute_inner_product rejects mismatched lengths (arithmetic.rs:311)");
+    std::vector<Fe> q_ref(n - 1);
+    orc_kate_division(FIELD, a[0].data(), n, pt.data(), q_ref[0].data());
+    EXPECT(kate_division<FIELD>(a, pt) == q_ref, "kate_division == oracle");
+    std::vector<Fe> dv_ref = ext;
+    orc_divide_by_vanishing_poly(FIELD, dv_ref[0].data(), dom.extended_k, dom.t_evaluations[0].data(), dom.t_evaluations.size());
+    EXPECT(dom.divide_by_vanishing_poly(ext) == dv_ref, "divide_by_vanishing_poly == oracle");
+
+    // Params::write -> Params::read (commitment.rs:323-326 in test_opening_proof)
+    std::stringstream file;
+    params.write(file);
+    EXPECT(file.str().size() == 4 + 32 * (2 * n + 2), "Params::write: 4 + 32 (2n + 2) bytes");
+    Params<CURVE> again = Params<CURVE>::read(file);
+    EXPECT(again.k == k && again.g == g && again.g_lagrange == gl && again.w == w && again.u == u, "Params::read(Params::write(p)) == p");
+    orc_commit(CURVE, g[0].data(), w.data(), coeffs[0].data(), r.value.data(), n, want);
+    EXPECT(same_point(CURVE, again.commit(coeffs, r), want), "re-read Params commit == oracle");
+    std::string bad = file.str();
+    bad[4 + 31] = (char)0x7f; for (int i = 0; i < 31; i++) bad[4 + i] = (char)0xff;     // x >= p
+    std::stringstream bad_file(bad);
+    threw = false;
+    try { Params<CURVE>::read(bad_file); } catch (const std::runtime_error &) { threw = true; }
+    EXPECT(threw, "Params::read rejects a non-canonical x");
     printf(fails ? "HOST MIRROR CHECK FAILED (%d)\n" : "HOST MIRROR CHECK OK\n", fails);
     return fails ? 1 : 0;
 }

@@ -508,3 +508,31 @@ def test_msm_batch_matches_oracle():
     assert [affine_of(curve, g) for g in got_aff] == want
     with pytest.raises(ValueError):
         best_multiexp_batch([(pairs[3][0], pairs[4][1])], curve)
+
+
+def test_concurrent_host_threads():
+    """SURVEY.md section 8b 'Threading': entry points are re-entrant -- rayon workers of the reference call best_multiexp /
+    best_fft concurrently.  Four host threads hammer the host-pointer entry points; every result must equal the
+    single-threaded one."""
+    from concurrent.futures import ThreadPoolExecutor
+    curve, field = h.VESTA, h.FP
+    sf = fields.CURVE_FIELDS[curve][1]
+    jobs = []
+    for i in range(12):
+        n = [257, 1 << 12, 3000, 1 << 14][i % 4]
+        sc, bs = co.random_field(sf, 500 + i, n), co.generate_bases(curve, 600 + i, n)
+        log_n = 9 + i % 4
+        a = co.random_field(field, 700 + i, 1 << log_n)
+        omega = mont(field, o.omega_for(fields.MODULUS[field], log_n))
+        jobs.append((sc, bs, a, omega, log_n))
+
+    def run(job):
+        sc, bs, a, omega, log_n = job
+        return (affine_of(curve, h.best_multiexp(sc, bs, curve)), h.best_fft(a.copy(), omega, log_n, field),
+                h.eval_polynomial(a, omega, field), h.kate_division(a, omega, field))
+    want = [run(j) for j in jobs]
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for rep in range(3):
+            got = list(ex.map(run, jobs))
+            for g, w in zip(got, want):
+                assert g[0] == w[0] and all(np.array_equal(x, y) for x, y in zip(g[1:], w[1:]))
