@@ -251,6 +251,348 @@ __global__ void __launch_bounds__(1024) msm_scatter(const uint16_t *__restrict__
     }
 }
 
+// ---- two-pass sort for the registered (one bucket slice) path ------------------------------------------------------
+// A counting sort straight into 2^15 buckets writes 16.8 M 4-byte entries to 16.8 M unrelated places: every workgroup
+// keeps 32768 cache lines open, nothing combines in L2, and the pass runs at random-scatter speed (0.2 ms,
+// bench/ubench_scatter.hip) on top of 32 MiB of per-chunk histograms.  Split the bucket id instead:
+//   pass 1  partition by the top HIB bits (~512 bins): a workgroup keeps one open line per bin, so its 4-byte writes
+//           combine in its XCD's L2; the low LOWB bits of the bucket ride in the unused bits of the entry;
+//           the digits are recomputed from the scalars (same 32 B per scalar as a digit buffer would cost to read);
+//   pass 2  chunks of 16 K entries of the pass-1 output span one or two bins = 64..128 buckets: counting sort inside
+//           that window, a few hundred bytes per bucket per chunk.
+// Per-chunk histograms shrink from 32 MiB to ~2.4 MiB.  Entry order inside a bucket is irrelevant to the sum.
+struct Sort2 {
+    u32 m;            // scalars incl. the optional blind
+    int c, W, mont;
+    u32 stride, extra_col;
+    int lowb, lb;     // low bucket bits carried in the entry at bit `lb`
+    u32 nh;           // pass-1 bins = NB >> lowb
+    u32 B1;           // pass-1 workgroups (kS1Scalars scalars each)
+    u32 K2, B2;       // pass-2 chunk size and worst-case chunk count
+};
+static constexpr u32 kS1Scalars = 2048;   // x W <= 32768 staged entries = 128 KiB of LDS
+static constexpr u32 kS2Chunk = 16384;
+
+// signed window digits of one scalar (same recoding as msm_recode), handed to f(w, code)
+template <typename Fn> __device__ __forceinline__ void for_each_digit(const fe &s, int c, int W, Fn f) {
+    u32 carry = 0;
+    if (c == 16) {   // the k = 20 table: windows are the 16-bit halves of the limbs, no dynamic limb selection
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const u32 raw = ((s.v[w >> 1] >> ((w & 1) * 16)) & 0xFFFFu) + carry;
+            u32 code;
+            if (raw > 0x8000u) {
+                carry = 1;
+                code = ((0x10000u - raw - 1) | 0x8000u) & 0xFFFFu;   // raw = 2^16 (digit 0, carry out) wraps to kZeroCode
+            } else {
+                carry = 0;
+                code = raw ? raw - 1 : kZeroCode;
+            }
+            f(w, code);
+        }
+        return;
+    }
+    const u32 mask = (1u << c) - 1, half = 1u << (c - 1);
+    for (int w = 0; w < W; ++w) {
+        int bit = w * c, word = bit >> 5, sh = bit & 31;
+        u64 two = (u64)limb_at(s, word) | ((u64)limb_at(s, word + 1) << 32);
+        u32 raw = ((u32)(two >> sh) & mask) + carry;
+        u32 code;
+        if (raw > half) {
+            carry = 1;
+            code = (((1u << c) - raw - 1) | 0x8000u) & 0xFFFFu;   // raw = 2^c (digit 0 with a carry out) wraps to kZeroCode
+        } else {
+            carry = 0;
+            code = raw ? raw - 1 : kZeroCode;
+        }
+        f(w, code);
+    }
+}
+
+// pass 1, COUNT: hist1[blk][h] = this workgroup's entries per bin
+template <int FS>
+__global__ void __launch_bounds__(1024) msm_s1_count(const u32 *__restrict__ scalars, const u32 *__restrict__ extra_scalar, Sort2 P,
+                                                     u32 *__restrict__ hist1) {
+    H2_LATENCY_STAGE();
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [nh] counters
+    const u32 nh = P.nh, blk = blockIdx.x;
+    for (u32 h = threadIdx.x; h < nh; h += blockDim.x) sh[h] = 0;
+    __syncthreads();
+    for (u32 k = 0; k < kS1Scalars / 1024; ++k) {
+        const u32 i = blk * kS1Scalars + k * 1024 + threadIdx.x;
+        if (i >= P.m) break;
+        fe s = (extra_scalar && i == P.m - 1) ? fe_load(extra_scalar) : fe_load(scalars + 8 * (size_t)i);
+        if (P.mont) s = fe_from_mont<FS>(s);
+        for_each_digit(s, P.c, P.W, [&](int, u32 code) {
+            if (code != kZeroCode) atomicAdd(&sh[(code & 0x7FFFu) >> P.lowb], 1u);
+        });
+    }
+    __syncthreads();
+    for (u32 h = threadIdx.x; h < nh; h += blockDim.x) hist1[(size_t)blk * nh + h] = sh[h];
+}
+
+// exclusive scan of v[0 .. n) in LDS by the first wave (n <= 4096); returns the total to every lane of that wave
+__device__ __forceinline__ u32 wave0_excl_scan(u32 *v, u32 n) {
+    const u32 per = (n + 63) / 64, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    u32 sum = 0;
+    for (u32 h = lo; h < hi; ++h) sum += v[h];
+    u32 incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        u32 t = __shfl_up(incl, off, 64);
+        if ((int)threadIdx.x >= off) incl += t;
+    }
+    u32 run = incl - sum;
+    for (u32 h = lo; h < hi; ++h) {
+        u32 t = v[h];
+        v[h] = run;
+        run += t;
+    }
+    return __shfl(incl, 63, 64);
+}
+
+// pass 1, SCATTER: the workgroup's entries are first grouped by bin in LDS (its per-bin counts are known from the
+// count pass), then every bin's run goes out as one contiguous copy -- scattered 4-byte stores issue one lane per
+// clock and were the cost of this pass.  hist1 holds the exclusive prefix over workgroups by now.
+template <int FS>
+__global__ void __launch_bounds__(1024) msm_s1_scatter(const u32 *__restrict__ scalars, const u32 *__restrict__ extra_scalar, Sort2 P,
+                                                       const u32 *__restrict__ hist1, const u32 *__restrict__ bin_count,
+                                                       u32 *__restrict__ bin_start, u32 *__restrict__ tagged) {
+    H2_LATENCY_STAGE();
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    const u32 nh = P.nh, blk = blockIdx.x, B1 = gridDim.x;
+    u32 *gstart = sh;                 // [nh] bin_start, then bin_start + this workgroup's offset inside the bin
+    u32 *lstart = sh + nh;            // [nh + 1] where the bin's run begins in the stage
+    u32 *cursor = lstart + nh + 1;    // [nh]
+    u32 *stage = cursor + nh;         // [kS1Scalars * W] entries
+    for (u32 h = threadIdx.x; h < nh; h += blockDim.x) {
+        const u32 mine = hist1[(size_t)blk * nh + h];
+        const u32 next = blk + 1 < B1 ? hist1[(size_t)(blk + 1) * nh + h] : bin_count[h];
+        gstart[h] = bin_count[h];
+        lstart[h] = next - mine;      // this workgroup's entries in bin h
+        cursor[h] = mine;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const u32 M = wave0_excl_scan(gstart, nh);
+        const u32 L = wave0_excl_scan(lstart, nh);
+        if (threadIdx.x == 0) {
+            lstart[nh] = L;
+            if (blk == 0) bin_start[nh] = M;
+        }
+    }
+    __syncthreads();
+    for (u32 h = threadIdx.x; h < nh; h += blockDim.x) {
+        if (blk == 0) bin_start[h] = gstart[h];
+        gstart[h] += cursor[h];
+        cursor[h] = lstart[h];
+    }
+    __syncthreads();
+    const u32 lowmask = (1u << P.lowb) - 1;
+    for (u32 k = 0; k < kS1Scalars / 1024; ++k) {
+        const u32 i = blk * kS1Scalars + k * 1024 + threadIdx.x;
+        if (i >= P.m) break;
+        fe s = (extra_scalar && i == P.m - 1) ? fe_load(extra_scalar) : fe_load(scalars + 8 * (size_t)i);
+        if (P.mont) s = fe_from_mont<FS>(s);
+        u32 col = i;
+        if (i == P.m - 1 && P.extra_col != 0xFFFFFFFFu) col = P.extra_col;
+        for_each_digit(s, P.c, P.W, [&](int w, u32 code) {
+            if (code == kZeroCode) return;
+            const u32 j = code & 0x7FFFu;
+            const u32 pos = atomicAdd(&cursor[j >> P.lowb], 1u);
+            stage[pos] = ((u32)w * P.stride + col) | ((j & lowmask) << P.lb) | ((code & 0x8000u) << 16);
+        });
+    }
+    __syncthreads();
+    // one wave per bin at a time: contiguous LDS run -> contiguous global run
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    for (u32 h = wave; h < nh; h += nwaves) {
+        const u32 l0 = lstart[h], l1 = lstart[h + 1];
+        u32 *dst = tagged + gstart[h];
+        for (u32 q = l0 + lane; q < l1; q += 64) dst[q - l0] = stage[q];
+    }
+}
+
+// column-wise exclusive scan of hist1[B1][nh]; bin_count[h] = column total.  16 columns per workgroup, 64 row groups.
+__global__ void __launch_bounds__(1024) msm_s1_prefix(u32 *__restrict__ hist1, u32 *__restrict__ bin_count, u32 B1, u32 nh) {
+    H2_LATENCY_STAGE();
+    __shared__ u32 part[64][17];
+    const u32 r = threadIdx.x >> 4, cl = threadIdx.x & 15, col = blockIdx.x * 16 + cl;
+    const u32 rg = (B1 + 63) / 64, r0 = min(B1, r * rg), r1 = min(B1, r0 + rg);
+    u32 sum = 0;
+    if (col < nh)
+        for (u32 row = r0; row < r1; ++row) sum += hist1[(size_t)row * nh + col];
+    part[r][cl] = sum;
+    __syncthreads();
+    u32 run = 0;
+    for (u32 q = 0; q < r; ++q) run += part[q][cl];
+    if (col < nh) {
+        for (u32 row = r0; row < r1; ++row) {
+            const size_t k = (size_t)row * nh + col;
+            const u32 t = hist1[k];
+            hist1[k] = run;
+            run += t;
+        }
+        if (r == 63) bin_count[col] = run;
+    }
+}
+
+// largest h in [0, nh) with bin_start[h] <= p   (bin_start non-decreasing, bin_start[0] = 0 <= p < bin_start[nh])
+__device__ __forceinline__ u32 bin_of(const u32 *__restrict__ bin_start, u32 nh, u32 p) {
+    u32 lo = 0, hi = nh;
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (bin_start[mid] <= p) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// pass-2 plan: first bin and histogram offset of every chunk (window = the bins the chunk touches); one workgroup
+__global__ void __launch_bounds__(kScanBlock) msm_s2_plan(const u32 *__restrict__ bin_start, Sort2 P, u32 *__restrict__ hlo,
+                                                          u32 *__restrict__ woff) {
+    H2_LATENCY_STAGE();
+    __shared__ u32 sh[kScanBlock];
+    const u32 M = bin_start[P.nh];
+    u32 carry = 0;
+    for (u32 base = 0; base < P.B2; base += kScanBlock) {
+        const u32 cidx = base + threadIdx.x;
+        u32 size = 0, h0 = 0;
+        if (cidx < P.B2 && (size_t)cidx * P.K2 < M) {
+            const u32 p0 = cidx * P.K2, p1 = min(M, p0 + P.K2) - 1;
+            h0 = bin_of(bin_start, P.nh, p0);
+            size = (bin_of(bin_start, P.nh, p1) - h0 + 1) << P.lowb;
+        }
+        u32 tot;
+        const u32 ex = block_excl_scan(size, sh, tot);
+        if (cidx < P.B2) {
+            hlo[cidx] = h0;
+            woff[cidx] = carry + ex;
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) woff[P.B2] = carry;
+}
+
+// bin (relative to the chunk's first bin) of list position p; bounds[q] = bin_start[h0 + q + 1]
+__device__ __forceinline__ u32 rel_bin(const u32 *bounds, u32 nbins, u32 p) {
+    if (p < bounds[0]) return 0;
+    u32 lo = 0, hi = nbins - 1;                                 // invariant: bounds[lo] <= p < bounds[hi]
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (bounds[mid] <= p) lo = mid;
+        else hi = mid;
+    }
+    return hi;
+}
+
+// pass 2, COUNT over one chunk of the tagged list: hist2[woff[c] + (bucket - window base)]
+__global__ void __launch_bounds__(1024) msm_s2_count(const u32 *__restrict__ tagged, const u32 *__restrict__ bin_start, const u32 *__restrict__ hlo,
+                                                     const u32 *__restrict__ woff, Sort2 P, u32 *__restrict__ hist2) {
+    H2_LATENCY_STAGE();
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [window] counters, then the window's bin boundaries
+    const u32 cidx = blockIdx.x, M = bin_start[P.nh];
+    const size_t p0 = (size_t)cidx * P.K2;
+    if (p0 >= M) return;
+    const u32 p1 = (u32)min((size_t)M, p0 + P.K2);
+    const u32 h0 = hlo[cidx], wo = woff[cidx], wsize = woff[cidx + 1] - wo, nbins = wsize >> P.lowb;
+    u32 *bounds = sh + wsize;
+    for (u32 k = threadIdx.x; k < wsize; k += blockDim.x) sh[k] = 0u;
+    for (u32 q = threadIdx.x; q < nbins; q += blockDim.x) bounds[q] = bin_start[h0 + q + 1];
+    __syncthreads();
+    const u32 lowmask = (1u << P.lowb) - 1;
+    for (u32 p = (u32)p0 + threadIdx.x; p < p1; p += blockDim.x) {
+        const u32 e = tagged[p];
+        atomicAdd(&sh[(rel_bin(bounds, nbins, p) << P.lowb) | ((e >> P.lb) & lowmask)], 1u);
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < wsize; k += blockDim.x) hist2[wo + k] = sh[k];
+}
+
+// pass 2, SCATTER: final entries (low bits stripped) at starts[bucket] + the chunk's share (hist2 holds the exclusive
+// prefix over chunks by now).  Windows of up to kS2StageWindow buckets -- every chunk of a dense or moderately sparse
+// column -- group the chunk by bucket in LDS first and copy each bucket's run out contiguously; wider windows write
+// straight from the counters.
+static constexpr u32 kS2StageWindow = 4096;
+__global__ void __launch_bounds__(1024) msm_s2_scatter(const u32 *__restrict__ tagged, const u32 *__restrict__ bin_start,
+                                                       const u32 *__restrict__ hlo, const u32 *__restrict__ woff, Sort2 P,
+                                                       const u32 *__restrict__ hist2, const u32 *__restrict__ starts, u32 *__restrict__ entries) {
+    H2_LATENCY_STAGE();
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    const u32 cidx = blockIdx.x, M = bin_start[P.nh];
+    const size_t p0 = (size_t)cidx * P.K2;
+    if (p0 >= M) return;
+    const u32 p1 = (u32)min((size_t)M, p0 + P.K2);
+    const u32 h0 = hlo[cidx], wo = woff[cidx], wsize = woff[cidx + 1] - wo, nbins = wsize >> P.lowb;
+    const u32 lowmask = (1u << P.lowb) - 1, strip = ~(lowmask << P.lb);
+    if (wsize > kS2StageWindow) {
+        u32 *bounds = sh + wsize;
+        for (u32 k = threadIdx.x; k < wsize; k += blockDim.x) sh[k] = starts[(h0 << P.lowb) + k] + hist2[wo + k];
+        for (u32 q = threadIdx.x; q < nbins; q += blockDim.x) bounds[q] = bin_start[h0 + q + 1];
+        __syncthreads();
+        for (u32 p = (u32)p0 + threadIdx.x; p < p1; p += blockDim.x) {
+            const u32 e = tagged[p];
+            const u32 pos = atomicAdd(&sh[(rel_bin(bounds, nbins, p) << P.lowb) | ((e >> P.lb) & lowmask)], 1u);
+            entries[pos] = e & strip;
+        }
+        return;
+    }
+    u32 *gstart = sh;                      // [wsize] where the chunk's run of bucket k starts in `entries`
+    u32 *lstart = gstart + wsize;          // [wsize + 1] ... and in the stage
+    u32 *cursor = lstart + wsize + 1;      // [wsize]
+    u32 *bounds = cursor + wsize;          // [nbins]
+    u32 *stage = bounds + nbins;           // [K2]
+    for (u32 k = threadIdx.x; k < wsize; k += blockDim.x) {
+        gstart[k] = starts[(h0 << P.lowb) + k] + hist2[wo + k];
+        lstart[k] = 0;
+    }
+    for (u32 q = threadIdx.x; q < nbins; q += blockDim.x) bounds[q] = bin_start[h0 + q + 1];
+    __syncthreads();
+    for (u32 p = (u32)p0 + threadIdx.x; p < p1; p += blockDim.x) {
+        const u32 e = tagged[p];
+        atomicAdd(&lstart[(rel_bin(bounds, nbins, p) << P.lowb) | ((e >> P.lb) & lowmask)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const u32 L = wave0_excl_scan(lstart, wsize);
+        if (threadIdx.x == 0) lstart[wsize] = L;
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < wsize; k += blockDim.x) cursor[k] = lstart[k];
+    __syncthreads();
+    for (u32 p = (u32)p0 + threadIdx.x; p < p1; p += blockDim.x) {
+        const u32 e = tagged[p];                                 // second read of the chunk comes from L2
+        const u32 pos = atomicAdd(&cursor[(rel_bin(bounds, nbins, p) << P.lowb) | ((e >> P.lb) & lowmask)], 1u);
+        stage[pos] = e & strip;
+    }
+    __syncthreads();
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    for (u32 k = wave; k < wsize; k += nwaves) {
+        const u32 l0 = lstart[k], l1 = lstart[k + 1];
+        u32 *dst = entries + gstart[k];
+        for (u32 q = l0 + lane; q < l1; q += 64) dst[q - l0] = stage[q];
+    }
+}
+
+// per-bucket totals; each chunk's count becomes the bucket-relative offset of that chunk
+__global__ void __launch_bounds__(256) msm_s2_prefix(u32 *__restrict__ hist2, const u32 *__restrict__ bin_start, const u32 *__restrict__ hlo,
+                                                     const u32 *__restrict__ woff, Sort2 P, u32 *__restrict__ counts, u32 NB) {
+    H2_LATENCY_STAGE();
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= NB) return;
+    const u32 h = j >> P.lowb, b0 = bin_start[h], b1 = bin_start[h + 1];
+    u32 run = 0;
+    if (b1 > b0) {
+        const u32 c0 = b0 / P.K2, c1 = (b1 - 1) / P.K2;
+        for (u32 cidx = c0; cidx <= c1; ++cidx) {
+            const size_t k = (size_t)woff[cidx] + (j - (hlo[cidx] << P.lowb));
+            const u32 t = hist2[k];
+            hist2[k] = run;
+            run += t;
+        }
+    }
+    counts[j] = run;
+}
+
 // lanes actually used for M sorted entries: the launch is sized for the worst case (no zero digits); sparse or tiny
 // columns use fewer lanes so that a lane's range keeps >= 16 entries
 __device__ __forceinline__ u32 eff_lanes(u32 M, u32 T) { return min(T, max(256u, (M + 15) / 16)); }
@@ -626,8 +968,8 @@ static bool timeline_on() {
 struct MsmContext {
     std::mutex mu;
     DevBuf digits, hist, counts, starts, bsums, entries, heads, heavy, hscratch, buckets, partial, ssums, stage_s, stage_b,
-        out, small;
-    bool attr_set = false;
+        out, small, tagged, plan;
+    bool attr_set = false, attr2_set = false;
     u32 lanes[2] = {0, 0};  // resident lanes of msm_accumulate<FP>, <FQ> on this device
 };
 
@@ -694,8 +1036,44 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     const u32 usable = std::max(256u, (u32)(lanes * fraction) / 256u * 256u);
     u32 T = (u32)std::min<size_t>(usable, std::max<size_t>(256, (all_items / 16 + 255) / 256 * 256));
     const u32 max_heavy = kMaxHeavy;
-    if ((rc = cx.digits.reserve(all_items * 2)) != H2_OK) return rc;
-    if ((rc = cx.hist.reserve((size_t)sh.slices * sh.B * sh.NB * 4)) != H2_OK) return rc;
+    // two-pass sort (registered path, large bucket counts, low bucket bits fit beside the table index)
+    Sort2 S2;
+    memset(&S2, 0, sizeof S2);
+    bool use_sort2 = false;
+    if (a.table && sh.NB >= 4096 && m >= 8192) {
+        static const int force_old = [] { const char *e = getenv("H2_MSM_SORT"); return e && atoi(e) == 1 ? 1 : 0; }();
+        const u64 top = (u64)sh.W * a.stride - 1;
+        int lb = 0;
+        while ((top >> lb) != 0) ++lb;
+        const int bucket_bits = sh.c - 1;
+        int lowb = std::min(31 - lb, bucket_bits - 9);
+        const bool stage_fits = ((size_t)(sh.NB >> std::max(lowb, 1)) * 3 + 1 + (size_t)kS1Scalars * sh.W) * 4 <= 160 * 1024 - 512;
+        if (!force_old && lowb >= 1 && bucket_bits - lowb <= 12 && stage_fits) {
+            use_sort2 = true;
+            S2.m = (u32)m; S2.c = sh.c; S2.W = sh.W; S2.mont = a.form == H2_FORM_MONTGOMERY;
+            S2.stride = a.stride; S2.extra_col = a.d_extra_scalar ? a.extra_col : 0xFFFFFFFFu;
+            S2.lowb = lowb; S2.lb = lb; S2.nh = sh.NB >> lowb;
+            S2.B1 = (u32)((m + kS1Scalars - 1) / kS1Scalars);
+            S2.K2 = kS2Chunk;
+            S2.B2 = (u32)((all_items + kS2Chunk - 1) / kS2Chunk);
+        }
+    }
+    if (use_sort2) {
+        if (!cx.attr2_set) {
+            H2_HIP(hipFuncSetAttribute((const void *)msm_s2_count, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+            H2_HIP(hipFuncSetAttribute((const void *)msm_s2_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+            H2_HIP(hipFuncSetAttribute((const void *)msm_s1_scatter<FP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+            H2_HIP(hipFuncSetAttribute((const void *)msm_s1_scatter<FQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+            cx.attr2_set = true;
+        }
+        if ((rc = cx.hist.reserve((size_t)S2.B1 * S2.nh * 4)) != H2_OK) return rc;
+        if ((rc = cx.tagged.reserve(all_items * 4)) != H2_OK) return rc;
+        const size_t plan_words = (size_t)S2.nh * 2 + 1 + (size_t)S2.B2 * 2 + 1 + (((size_t)S2.nh + S2.B2 + 1) << S2.lowb);
+        if ((rc = cx.plan.reserve(plan_words * 4)) != H2_OK) return rc;
+    } else {
+        if ((rc = cx.digits.reserve(all_items * 2)) != H2_OK) return rc;
+        if ((rc = cx.hist.reserve((size_t)sh.slices * sh.B * sh.NB * 4)) != H2_OK) return rc;
+    }
     if ((rc = cx.counts.reserve((size_t)tb * 4)) != H2_OK) return rc;
     if ((rc = cx.starts.reserve((size_t)(tb + 1) * 4)) != H2_OK) return rc;
     if ((rc = cx.bsums.reserve((size_t)(nblocks + 4) * 4)) != H2_OK) return rc;
@@ -711,21 +1089,79 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     const u32 tl_id = (u32)(((uintptr_t)st >> 4) & 0xFFFF) << 8;
     TL_STAMP(tl_id | 1);
     prof_begin(PROF_MSM_SORT, st);
-    hipLaunchKernelGGL((msm_recode<FS>), dim3((m32 + 255) / 256), dim3(256), 0, st, (const u32 *)a.d_scalars,
-                       (const u32 *)a.d_extra_scalar, cx.digits.as<uint16_t>(), m32, sh.c, sh.W,
-                       a.form == H2_FORM_MONTGOMERY);
-    hipLaunchKernelGGL(msm_count, dim3(sh.B, sh.slices), dim3(1024), sh.NB * 4, st, cx.digits.as<uint16_t>(),
-                       cx.hist.as<u32>(), sh.items, sh.chunk, sh.NB);
-    hipLaunchKernelGGL(msm_chunk_prefix, dim3((tb + 255) / 256), dim3(256), 0, st, cx.hist.as<u32>(), cx.counts.as<u32>(),
-                       sh.NB, sh.B, tb);
-    hipLaunchKernelGGL(msm_scan_blocksums, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), tb);
-    hipLaunchKernelGGL(msm_scan_top, dim3(1), dim3(kScanBlock), 0, st, cx.bsums.as<u32>(), nblocks, grand);
-    hipLaunchKernelGGL(msm_scan_apply, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), grand,
-                       cx.starts.as<u32>(), tb);
     const u32 extra_col = a.d_extra_scalar ? (a.table ? a.extra_col : (u32)a.n_used) : 0xFFFFFFFFu;
-    hipLaunchKernelGGL(msm_scatter, dim3(sh.B, sh.slices), dim3(1024), sh.NB * 4, st, cx.digits.as<uint16_t>(),
-                       cx.hist.as<u32>(), cx.starts.as<u32>(), cx.entries.as<u32>(), sh.items, sh.chunk, sh.NB, m32,
-                       a.table ? a.stride : 0u, extra_col, a.table ? 1 : 0);
+    if (use_sort2) {
+        u32 *hist1 = cx.hist.as<u32>(), *bin_count = cx.plan.as<u32>(), *bin_start = bin_count + S2.nh, *hlo = bin_start + S2.nh + 1,
+            *woff = hlo + S2.B2, *hist2 = woff + S2.B2 + 1;
+        hipLaunchKernelGGL((msm_s1_count<FS>), dim3(S2.B1), dim3(1024), S2.nh * 4, st, (const u32 *)a.d_scalars,
+                           (const u32 *)a.d_extra_scalar, S2, hist1);
+        hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh);
+        const size_t lds1 = ((size_t)S2.nh * 3 + 1 + (size_t)kS1Scalars * sh.W) * 4;
+        hipLaunchKernelGGL((msm_s1_scatter<FS>), dim3(S2.B1), dim3(1024), lds1, st, (const u32 *)a.d_scalars,
+                           (const u32 *)a.d_extra_scalar, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>());
+        hipLaunchKernelGGL(msm_s2_plan, dim3(1), dim3(kScanBlock), 0, st, bin_start, S2, hlo, woff);
+        const size_t lds2 = ((size_t)sh.NB + S2.nh + 1) * 4;
+        hipLaunchKernelGGL(msm_s2_count, dim3(S2.B2), dim3(1024), lds2, st, cx.tagged.as<u32>(), bin_start, hlo, woff, S2, hist2);
+        hipLaunchKernelGGL(msm_s2_prefix, dim3((sh.NB + 255) / 256), dim3(256), 0, st, hist2, bin_start, hlo, woff, S2, cx.counts.as<u32>(),
+                           sh.NB);
+        hipLaunchKernelGGL(msm_scan_blocksums, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), tb);
+        hipLaunchKernelGGL(msm_scan_top, dim3(1), dim3(kScanBlock), 0, st, cx.bsums.as<u32>(), nblocks, grand);
+        hipLaunchKernelGGL(msm_scan_apply, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), grand,
+                           cx.starts.as<u32>(), tb);
+        const size_t lds2s = std::max<size_t>(lds2, ((size_t)kS2StageWindow * 3 + 1 + S2.nh + kS2Chunk) * 4);
+        hipLaunchKernelGGL(msm_s2_scatter, dim3(S2.B2), dim3(1024), lds2s, st, cx.tagged.as<u32>(), bin_start, hlo, woff, S2, hist2,
+                           cx.starts.as<u32>(), cx.entries.as<u32>());
+    } else {
+        hipLaunchKernelGGL((msm_recode<FS>), dim3((m32 + 255) / 256), dim3(256), 0, st, (const u32 *)a.d_scalars,
+                           (const u32 *)a.d_extra_scalar, cx.digits.as<uint16_t>(), m32, sh.c, sh.W,
+                           a.form == H2_FORM_MONTGOMERY);
+        hipLaunchKernelGGL(msm_count, dim3(sh.B, sh.slices), dim3(1024), sh.NB * 4, st, cx.digits.as<uint16_t>(),
+                           cx.hist.as<u32>(), sh.items, sh.chunk, sh.NB);
+        hipLaunchKernelGGL(msm_chunk_prefix, dim3((tb + 255) / 256), dim3(256), 0, st, cx.hist.as<u32>(), cx.counts.as<u32>(),
+                           sh.NB, sh.B, tb);
+        hipLaunchKernelGGL(msm_scan_blocksums, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), tb);
+        hipLaunchKernelGGL(msm_scan_top, dim3(1), dim3(kScanBlock), 0, st, cx.bsums.as<u32>(), nblocks, grand);
+        hipLaunchKernelGGL(msm_scan_apply, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), grand,
+                           cx.starts.as<u32>(), tb);
+        hipLaunchKernelGGL(msm_scatter, dim3(sh.B, sh.slices), dim3(1024), sh.NB * 4, st, cx.digits.as<uint16_t>(),
+                           cx.hist.as<u32>(), cx.starts.as<u32>(), cx.entries.as<u32>(), sh.items, sh.chunk, sh.NB, m32,
+                           a.table ? a.stride : 0u, extra_col, a.table ? 1 : 0);
+    }
+#ifdef H2_SORT_DEBUG
+    if (use_sort2) {
+        std::vector<u32> sa(tb + 1), ea(all_items), sb(tb + 1), eb(all_items);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(sa.data(), cx.starts.ptr, (tb + 1) * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(ea.data(), cx.entries.ptr, (size_t)sa[tb] * 4, hipMemcpyDeviceToHost);
+        (void)cx.digits.reserve(all_items * 2);
+        DevBuf h2b;
+        (void)h2b.reserve((size_t)sh.slices * sh.B * sh.NB * 4);
+        hipLaunchKernelGGL((msm_recode<FS>), dim3((m32 + 255) / 256), dim3(256), 0, st, (const u32 *)a.d_scalars,
+                           (const u32 *)a.d_extra_scalar, cx.digits.as<uint16_t>(), m32, sh.c, sh.W, a.form == H2_FORM_MONTGOMERY);
+        hipLaunchKernelGGL(msm_count, dim3(sh.B, sh.slices), dim3(1024), sh.NB * 4, st, cx.digits.as<uint16_t>(), h2b.as<u32>(), sh.items, sh.chunk, sh.NB);
+        hipLaunchKernelGGL(msm_chunk_prefix, dim3((tb + 255) / 256), dim3(256), 0, st, h2b.as<u32>(), cx.counts.as<u32>(), sh.NB, sh.B, tb);
+        hipLaunchKernelGGL(msm_scan_blocksums, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), tb);
+        hipLaunchKernelGGL(msm_scan_top, dim3(1), dim3(kScanBlock), 0, st, cx.bsums.as<u32>(), nblocks, grand);
+        hipLaunchKernelGGL(msm_scan_apply, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), grand, cx.starts.as<u32>(), tb);
+        hipLaunchKernelGGL(msm_scatter, dim3(sh.B, sh.slices), dim3(1024), sh.NB * 4, st, cx.digits.as<uint16_t>(), h2b.as<u32>(), cx.starts.as<u32>(),
+                           cx.entries.as<u32>(), sh.items, sh.chunk, sh.NB, m32, a.table ? a.stride : 0u, extra_col, a.table ? 1 : 0);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(sb.data(), cx.starts.ptr, (tb + 1) * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(eb.data(), cx.entries.ptr, (size_t)sb[tb] * 4, hipMemcpyDeviceToHost);
+        h2b.release();
+        size_t bad_s = 0, bad_e = 0, first_s = (size_t)-1, first_e = (size_t)-1;
+        for (u32 j = 0; j <= tb; ++j) if (sa[j] != sb[j]) { if (!bad_s) first_s = j; ++bad_s; }
+        if (!bad_s)
+            for (u32 j = 0; j < tb; ++j) {
+                std::sort(ea.begin() + sa[j], ea.begin() + sa[j + 1]);
+                std::sort(eb.begin() + sb[j], eb.begin() + sb[j + 1]);
+                if (!std::equal(ea.begin() + sa[j], ea.begin() + sa[j + 1], eb.begin() + sb[j])) { if (!bad_e) first_e = j; ++bad_e; }
+            }
+        fprintf(stderr, "[sort-debug] m=%zu NB=%u nh=%u lowb=%d lb=%d M=%u/%u starts mismatches %zu (first %zu: %u vs %u) bucket-content mismatches %zu (first %zu)\n",
+                m, sh.NB, S2.nh, S2.lowb, S2.lb, sa[tb], sb[tb], bad_s, first_s, first_s != (size_t)-1 ? sa[first_s] : 0,
+                first_s != (size_t)-1 ? sb[first_s] : 0, bad_e, first_e);
+    }
+#endif
     H2_HIP(hipMemsetAsync(cx.buckets.ptr, 0, (size_t)tb * 128, st));
     H2_HIP(hipMemsetAsync(cx.heavy.ptr, 0, 8, st));
     prof_end(PROF_MSM_SORT, st);
