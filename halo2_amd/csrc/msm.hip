@@ -47,8 +47,30 @@
 namespace h2 {
 
 static std::atomic<double> g_lane_fraction{1.0};
-static constexpr int kMaxC = 16;
+static constexpr int kMaxC = 16;          // generic path (and the 16-bit digit codes of the one-pass sort)
+static constexpr int kMaxCShared = 20;    // registered path: one bucket slice, two-pass sort, 32-bit digit codes
 static constexpr u32 kZeroCode = 0xFFFFu;
+static constexpr u32 kZero32 = 0xFFFFFFFFu;
+static constexpr u32 kS1Scalars = 2048;   // scalars per workgroup of the two-pass sort's first pass
+static constexpr u32 kS2Chunk = 16384;    // entries per workgroup of its second pass
+static constexpr size_t kLdsCap = 160 * 1024 - 512;
+
+// Two-pass sort geometry for a table of `stride` columns and window width c: the low `lowb` bucket bits ride in the
+// entry above the table index (`lb` bits); the remaining bucket_bits - lowb bits select the pass-1 bin.
+static bool sort2_geometry(u32 stride, int c, int *lowb_out, int *lb_out) {
+    const int W = 255 / c + 1, bucket_bits = c - 1;
+    const uint64_t top = (uint64_t)W * stride - 1;
+    if (top >= ((uint64_t)1 << 31)) return false;
+    int lb = 0;
+    while ((top >> lb) != 0) ++lb;
+    const int lowb = std::min(31 - lb, bucket_bits - 9);
+    if (lowb < 1 || bucket_bits - lowb > 12) return false;
+    const size_t nh = (size_t)1 << (bucket_bits - lowb);
+    if ((nh * 3 + 1 + (size_t)kS1Scalars * W) * 4 > kLdsCap) return false;   // pass-1 stage in LDS
+    *lowb_out = lowb;
+    *lb_out = lb;
+    return true;
+}
 static constexpr int kSeg = 8;     // buckets per reduce segment
 static constexpr u32 kScanBlock = 1024;
 
@@ -64,10 +86,18 @@ struct MsmShape {
 
 // window width: minimise mixed adds + reduce work.  `shared_buckets`: registered bases (one slice).
 static int choose_c(size_t n, bool shared_buckets) {
-    if (const char *e = getenv("H2_MSM_C")) {   // tuning sweeps only
+    auto feasible = [&](int c) {
+        if (c <= kMaxC) return true;
+        int lowb, lb;
+        return shared_buckets && n + 1 < ((size_t)1 << 31) && sort2_geometry((u32)n + 1, c, &lowb, &lb);
+    };
+    if (const char *e = getenv("H2_MSM_C")) {   // tuning sweeps only; the only way to windows beyond 16 bits (see below)
         int v = atoi(e);
-        if (v >= 4 && v <= kMaxC) return v;
+        if (v >= 4 && v <= kMaxCShared && feasible(v)) return v;
     }
+    // Windows of 17..20 bits (registered path) are implemented and parity-tested but not chosen: at n = 2^20, c = 20 cuts
+    // the accumulate from 1.29 to 1.07 ms (13 windows instead of 16) and loses more than that in the sort (4096 pass-1
+    // bins: 6-entry runs) and in the fold over 2^19 buckets (0.49 vs 0.27 ms).  DESIGN.md section 8.
     double best = 1e300;
     int bc = 4;
     for (int c = 4; c <= kMaxC; ++c) {
@@ -269,42 +299,39 @@ struct Sort2 {
     u32 nh;           // pass-1 bins = NB >> lowb
     u32 B1;           // pass-1 workgroups (kS1Scalars scalars each)
     u32 K2, B2;       // pass-2 chunk size and worst-case chunk count
+    u32 lds_window;   // widest pass-2 window (buckets) whose counters fit LDS; wider ones count in HBM
 };
-static constexpr u32 kS1Scalars = 2048;   // x W <= 32768 staged entries = 128 KiB of LDS
-static constexpr u32 kS2Chunk = 16384;
 
-// signed window digits of one scalar (same recoding as msm_recode), handed to f(w, code)
-template <typename Fn> __device__ __forceinline__ void for_each_digit(const fe &s, int c, int W, Fn f) {
+// signed window digits of one scalar (same recoding as msm_recode, 32-bit codes so that windows may exceed 16 bits),
+// handed to f(w, code): code = kZero32 for digit 0, else (|d| - 1) | (d < 0) << 31
+template <int C, typename Fn> __device__ __forceinline__ void for_each_digit_static(const fe &s, Fn f) {
+    constexpr int W = 255 / C + 1;
+    constexpr u32 mask = (1u << C) - 1, half = 1u << (C - 1), full = 1u << C;
     u32 carry = 0;
-    if (c == 16) {   // the k = 20 table: windows are the 16-bit halves of the limbs, no dynamic limb selection
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const u32 raw = ((s.v[w >> 1] >> ((w & 1) * 16)) & 0xFFFFu) + carry;
-            u32 code;
-            if (raw > 0x8000u) {
-                carry = 1;
-                code = ((0x10000u - raw - 1) | 0x8000u) & 0xFFFFu;   // raw = 2^16 (digit 0, carry out) wraps to kZeroCode
-            } else {
-                carry = 0;
-                code = raw ? raw - 1 : kZeroCode;
-            }
-            f(w, code);
-        }
-        return;
+    for (int w = 0; w < W; ++w) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int bit = w * C, word = bit >> 5, sh = bit & 31;     // compile-time after unrolling: plain register picks
+        u32 v = s.v[word] >> sh;
+        if (sh + C > 32 && word + 1 < 8) v |= s.v[word + 1] << (32 - sh);
+        const u32 raw = (v & mask) + carry;
+        carry = raw > half;
+        const u32 code = carry ? (raw == full ? kZero32 : ((full - raw - 1) | 0x80000000u)) : (raw ? raw - 1 : kZero32);   // raw = 2^C: digit 0, carry out
+        f(w, code);
     }
-    const u32 mask = (1u << c) - 1, half = 1u << (c - 1);
+}
+template <typename Fn> __device__ __forceinline__ void for_each_digit(const fe &s, int c, int W, Fn f) {
+    if (c == 16) { for_each_digit_static<16>(s, f); return; }
+    if (c == 20) { for_each_digit_static<20>(s, f); return; }
+    u32 carry = 0;
+    const u32 mask = (1u << c) - 1, half = 1u << (c - 1), full = 1u << c;
     for (int w = 0; w < W; ++w) {
         int bit = w * c, word = bit >> 5, sh = bit & 31;
         u64 two = (u64)limb_at(s, word) | ((u64)limb_at(s, word + 1) << 32);
-        u32 raw = ((u32)(two >> sh) & mask) + carry;
-        u32 code;
-        if (raw > half) {
-            carry = 1;
-            code = (((1u << c) - raw - 1) | 0x8000u) & 0xFFFFu;   // raw = 2^c (digit 0 with a carry out) wraps to kZeroCode
-        } else {
-            carry = 0;
-            code = raw ? raw - 1 : kZeroCode;
-        }
+        const u32 raw = ((u32)(two >> sh) & mask) + carry;
+        carry = raw > half;
+        const u32 code = carry ? (raw == full ? kZero32 : ((full - raw - 1) | 0x80000000u)) : (raw ? raw - 1 : kZero32);
         f(w, code);
     }
 }
@@ -324,7 +351,7 @@ __global__ void __launch_bounds__(1024) msm_s1_count(const u32 *__restrict__ sca
         fe s = (extra_scalar && i == P.m - 1) ? fe_load(extra_scalar) : fe_load(scalars + 8 * (size_t)i);
         if (P.mont) s = fe_from_mont<FS>(s);
         for_each_digit(s, P.c, P.W, [&](int, u32 code) {
-            if (code != kZeroCode) atomicAdd(&sh[(code & 0x7FFFu) >> P.lowb], 1u);
+            if (code != kZero32) atomicAdd(&sh[(code & 0x7FFFFFFFu) >> P.lowb], 1u);
         });
     }
     __syncthreads();
@@ -396,10 +423,10 @@ __global__ void __launch_bounds__(1024) msm_s1_scatter(const u32 *__restrict__ s
         u32 col = i;
         if (i == P.m - 1 && P.extra_col != 0xFFFFFFFFu) col = P.extra_col;
         for_each_digit(s, P.c, P.W, [&](int w, u32 code) {
-            if (code == kZeroCode) return;
-            const u32 j = code & 0x7FFFu;
+            if (code == kZero32) return;
+            const u32 j = code & 0x7FFFFFFFu;
             const u32 pos = atomicAdd(&cursor[j >> P.lowb], 1u);
-            stage[pos] = ((u32)w * P.stride + col) | ((j & lowmask) << P.lb) | ((code & 0x8000u) << 16);
+            stage[pos] = ((u32)w * P.stride + col) | ((j & lowmask) << P.lb) | (code & 0x80000000u);
         });
     }
     __syncthreads();
@@ -495,11 +522,21 @@ __global__ void __launch_bounds__(1024) msm_s2_count(const u32 *__restrict__ tag
     if (p0 >= M) return;
     const u32 p1 = (u32)min((size_t)M, p0 + P.K2);
     const u32 h0 = hlo[cidx], wo = woff[cidx], wsize = woff[cidx + 1] - wo, nbins = wsize >> P.lowb;
+    const u32 lowmask = (1u << P.lowb) - 1;
+    if (wsize > P.lds_window) {
+        // a very sparse column: the chunk's window does not fit LDS.  Few entries by construction -- count in HBM
+        // (hist2 is zeroed before this kernel).
+        const u32 *gb = bin_start + h0 + 1;
+        for (u32 p = (u32)p0 + threadIdx.x; p < p1; p += blockDim.x) {
+            const u32 e = tagged[p];
+            atomicAdd(&hist2[wo + ((rel_bin(gb, nbins, p) << P.lowb) | ((e >> P.lb) & lowmask))], 1u);
+        }
+        return;
+    }
     u32 *bounds = sh + wsize;
     for (u32 k = threadIdx.x; k < wsize; k += blockDim.x) sh[k] = 0u;
     for (u32 q = threadIdx.x; q < nbins; q += blockDim.x) bounds[q] = bin_start[h0 + q + 1];
     __syncthreads();
-    const u32 lowmask = (1u << P.lowb) - 1;
     for (u32 p = (u32)p0 + threadIdx.x; p < p1; p += blockDim.x) {
         const u32 e = tagged[p];
         atomicAdd(&sh[(rel_bin(bounds, nbins, p) << P.lowb) | ((e >> P.lb) & lowmask)], 1u);
@@ -515,7 +552,7 @@ __global__ void __launch_bounds__(1024) msm_s2_count(const u32 *__restrict__ tag
 static constexpr u32 kS2StageWindow = 4096;
 __global__ void __launch_bounds__(1024) msm_s2_scatter(const u32 *__restrict__ tagged, const u32 *__restrict__ bin_start,
                                                        const u32 *__restrict__ hlo, const u32 *__restrict__ woff, Sort2 P,
-                                                       const u32 *__restrict__ hist2, const u32 *__restrict__ starts, u32 *__restrict__ entries) {
+                                                       u32 *__restrict__ hist2, const u32 *__restrict__ starts, u32 *__restrict__ entries) {
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
     const u32 cidx = blockIdx.x, M = bin_start[P.nh];
@@ -524,6 +561,15 @@ __global__ void __launch_bounds__(1024) msm_s2_scatter(const u32 *__restrict__ t
     const u32 p1 = (u32)min((size_t)M, p0 + P.K2);
     const u32 h0 = hlo[cidx], wo = woff[cidx], wsize = woff[cidx + 1] - wo, nbins = wsize >> P.lowb;
     const u32 lowmask = (1u << P.lowb) - 1, strip = ~(lowmask << P.lb);
+    if (wsize > P.lds_window) {             // very sparse column: hist2 (exclusive offsets by now) doubles as the cursor
+        const u32 *gb = bin_start + h0 + 1;
+        for (u32 p = (u32)p0 + threadIdx.x; p < p1; p += blockDim.x) {
+            const u32 e = tagged[p];
+            const u32 k = (rel_bin(gb, nbins, p) << P.lowb) | ((e >> P.lb) & lowmask);
+            entries[starts[(h0 << P.lowb) + k] + atomicAdd(&hist2[wo + k], 1u)] = e & strip;
+        }
+        return;
+    }
     if (wsize > kS2StageWindow) {
         u32 *bounds = sh + wsize;
         for (u32 k = threadIdx.x; k < wsize; k += blockDim.x) sh[k] = starts[(h0 << P.lowb) + k] + hist2[wo + k];
@@ -811,6 +857,43 @@ __global__ void __launch_bounds__(256) msm_sum_slice(const u32 *__restrict__ par
     }
 }
 
+// ---- wide bucket slices (NB > 2^15, registered path with c > 16): sum_j (j + 1) B_j with j = hi * S + lo splits into
+//      S * sum_hi hi * R_hi + sum_lo (lo + 1) * C_lo   (R = row sums, C = column sums of the NR x S bucket matrix),
+// i.e. ~one add per bucket, all of them independent (a tree per row / column) instead of a running sum plus a
+// small-scalar multiple per 8-bucket segment.  Output laid out as two slices of NR points for the ordinary reduce:
+// slice 0 = C_0 .. C_{S-1} (then identities), slice 1 = R_1 .. R_{NR-1} (then one identity); msm_combine's Horner
+// step with "window width" log2 S then forms S * (slice 1) + (slice 0).
+template <int FB>
+__global__ void __launch_bounds__(256) msm_rowcol_sums(const u32 *__restrict__ buckets, u32 *__restrict__ wide, u32 S, u32 NR) {
+    H2_LATENCY_STAGE();
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    const u32 t = threadIdx.x / kGroup, nl = blockDim.x / kGroup;
+    const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
+    const bool is_col = blockIdx.x < S;
+    const u32 id = is_col ? blockIdx.x : blockIdx.x - S + 1;          // column lo, or row hi (row 0 carries weight 0)
+    const u32 cnt = is_col ? NR : S;
+    const size_t base = is_col ? id : (size_t)id * S, step = is_col ? S : 1;
+    xyzz<FB> acc = xyzz_identity<FB>();
+    for (u32 i = t; i < cnt; i += nl) {
+        xyzz<FB> p = xyzz_load<FB>(buckets + 32 * (base + (size_t)i * step));
+        xyzz_add_wide<FB>(acc, p);
+    }
+    if (lead) xyzz_store<FB>(sh + 32 * t, acc);
+    __syncthreads();
+    for (u32 off = nl / 2; off > 0; off >>= 1) {
+        if (t < off) {
+            xyzz<FB> a = xyzz_load<FB>(sh + 32 * t), b = xyzz_load<FB>(sh + 32 * (t + off));
+            xyzz_add_wide<FB>(a, b);
+            if (lead) xyzz_store<FB>(sh + 32 * t, a);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        xyzz<FB> r = xyzz_load<FB>(sh);
+        xyzz_store<FB>(wide + 32 * (is_col ? (size_t)id : (size_t)NR + id - 1), r);
+    }
+}
+
 // ---- combine: Horner over slices (windows), emit Jacobian / affine; one quad of lanes ---------------
 template <int FB>
 __global__ void __launch_bounds__(64) msm_combine(const u32 *__restrict__ slice_sums, int slices, int c, u32 *__restrict__ out,
@@ -1036,19 +1119,14 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     const u32 usable = std::max(256u, (u32)(lanes * fraction) / 256u * 256u);
     u32 T = (u32)std::min<size_t>(usable, std::max<size_t>(256, (all_items / 16 + 255) / 256 * 256));
     const u32 max_heavy = kMaxHeavy;
-    // two-pass sort (registered path, large bucket counts, low bucket bits fit beside the table index)
+    // two-pass sort (registered path): always for windows beyond 16 bits, else for large bucket counts
     Sort2 S2;
     memset(&S2, 0, sizeof S2);
     bool use_sort2 = false;
-    if (a.table && sh.NB >= 4096 && m >= 8192) {
+    if (a.table && (sh.c > kMaxC || (sh.NB >= 4096 && m >= 8192))) {
         static const int force_old = [] { const char *e = getenv("H2_MSM_SORT"); return e && atoi(e) == 1 ? 1 : 0; }();
-        const u64 top = (u64)sh.W * a.stride - 1;
-        int lb = 0;
-        while ((top >> lb) != 0) ++lb;
-        const int bucket_bits = sh.c - 1;
-        int lowb = std::min(31 - lb, bucket_bits - 9);
-        const bool stage_fits = ((size_t)(sh.NB >> std::max(lowb, 1)) * 3 + 1 + (size_t)kS1Scalars * sh.W) * 4 <= 160 * 1024 - 512;
-        if (!force_old && lowb >= 1 && bucket_bits - lowb <= 12 && stage_fits) {
+        int lowb = 0, lb = 0;
+        if (sort2_geometry(a.stride, sh.c, &lowb, &lb) && (sh.c > kMaxC || !force_old)) {
             use_sort2 = true;
             S2.m = (u32)m; S2.c = sh.c; S2.W = sh.W; S2.mont = a.form == H2_FORM_MONTGOMERY;
             S2.stride = a.stride; S2.extra_col = a.d_extra_scalar ? a.extra_col : 0xFFFFFFFFu;
@@ -1056,7 +1134,16 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
             S2.B1 = (u32)((m + kS1Scalars - 1) / kS1Scalars);
             S2.K2 = kS2Chunk;
             S2.B2 = (u32)((all_items + kS2Chunk - 1) / kS2Chunk);
+            S2.lds_window = std::min<u32>(sh.NB, 32768u);
         }
+    }
+    if (sh.c > kMaxC && !use_sort2) return H2_ERR_ARGS;   // choose_c only picks wide windows the two-pass sort can take
+    const bool wide_reduce = sh.NB > 32768u;              // implies the registered path (one slice)
+    u32 wideS = 0, wideNR = 0;
+    if (wide_reduce) {
+        const int bb = sh.c - 1;
+        wideS = 1u << (bb / 2);
+        wideNR = sh.NB / wideS;
     }
     if (use_sort2) {
         if (!cx.attr2_set) {
@@ -1082,8 +1169,8 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     if ((rc = cx.heavy.reserve((size_t)(max_heavy + 2) * 4)) != H2_OK) return rc;
     if ((rc = cx.hscratch.reserve((size_t)max_heavy * kHeavyBlocks * 128)) != H2_OK) return rc;
     if ((rc = cx.buckets.reserve((size_t)tb * 128)) != H2_OK) return rc;
-    if ((rc = cx.partial.reserve((size_t)segs * 128)) != H2_OK) return rc;
-    if ((rc = cx.ssums.reserve((size_t)sh.slices * 128)) != H2_OK) return rc;
+    if ((rc = cx.partial.reserve(wide_reduce ? ((size_t)2 * wideNR / kSeg + 2 * wideNR) * 128 : (size_t)segs * 128)) != H2_OK) return rc;
+    if ((rc = cx.ssums.reserve((size_t)std::max<u32>(sh.slices, 2) * 128)) != H2_OK) return rc;
     const u32 m32 = (u32)m;
     u32 *grand = cx.bsums.as<u32>() + nblocks;
     const u32 tl_id = (u32)(((uintptr_t)st >> 4) & 0xFFFF) << 8;
@@ -1100,7 +1187,9 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         hipLaunchKernelGGL((msm_s1_scatter<FS>), dim3(S2.B1), dim3(1024), lds1, st, (const u32 *)a.d_scalars,
                            (const u32 *)a.d_extra_scalar, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>());
         hipLaunchKernelGGL(msm_s2_plan, dim3(1), dim3(kScanBlock), 0, st, bin_start, S2, hlo, woff);
-        const size_t lds2 = ((size_t)sh.NB + S2.nh + 1) * 4;
+        const size_t hist2_words = ((size_t)S2.nh + S2.B2 + 1) << S2.lowb;
+        if (sh.NB > S2.lds_window) H2_HIP(hipMemsetAsync(hist2, 0, hist2_words * 4, st));   // the HBM-counted windows start from zero
+        const size_t lds2 = ((size_t)S2.lds_window + S2.nh + 1) * 4;
         hipLaunchKernelGGL(msm_s2_count, dim3(S2.B2), dim3(1024), lds2, st, cx.tagged.as<u32>(), bin_start, hlo, woff, S2, hist2);
         hipLaunchKernelGGL(msm_s2_prefix, dim3((sh.NB + 255) / 256), dim3(256), 0, st, hist2, bin_start, hlo, woff, S2, cx.counts.as<u32>(),
                            sh.NB);
@@ -1128,7 +1217,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                            a.table ? a.stride : 0u, extra_col, a.table ? 1 : 0);
     }
 #ifdef H2_SORT_DEBUG
-    if (use_sort2) {
+    if (use_sort2 && sh.c <= kMaxC) {
         std::vector<u32> sa(tb + 1), ea(all_items), sb(tb + 1), eb(all_items);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(sa.data(), cx.starts.ptr, (tb + 1) * 4, hipMemcpyDeviceToHost);
@@ -1179,24 +1268,40 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                        cx.heads.as<u32>(), cx.starts.as<u32>(), cx.hscratch.as<u32>(), cx.heavy.as<u32>(), tb, T);
     hipLaunchKernelGGL((msm_finish_heavy2<FB>), dim3(max_heavy), dim3(64), 0, st, cx.hscratch.as<u32>(), cx.buckets.as<u32>(),
                        cx.heavy.as<u32>());
-    hipLaunchKernelGGL((msm_reduce_segments<FB>), dim3((segs * kGroup + 255) / 256), dim3(256), 0, st, cx.buckets.as<u32>(),
-                       cx.partial.as<u32>(), sh.NB, segs);
-    {   // 64 logical lanes per workgroup; first level leaves <= 32 block sums per slice
-        const u32 per_slice = sh.NB / kSeg, nl = 256 / kGroup;
+    {
+        // what the fold runs over: the bucket slices themselves, or (wide slices) the row / column sums as two slices
+        const u32 *fold_src = cx.buckets.as<u32>();
+        u32 fold_nb = sh.NB, fold_slices = sh.slices;
+        int fold_c = sh.c;
+        if (wide_reduce) {
+            u32 *wide = cx.partial.as<u32>() + 32 * (size_t)(2 * wideNR / kSeg);     // after the fold's own partials
+            H2_HIP(hipMemsetAsync(wide, 0, (size_t)2 * wideNR * 128, st));
+            hipLaunchKernelGGL((msm_rowcol_sums<FB>), dim3(wideS + wideNR - 1), dim3(256), (256 / kGroup) * 128, st, cx.buckets.as<u32>(),
+                               wide, wideS, wideNR);
+            fold_src = wide;
+            fold_nb = wideNR;
+            fold_slices = 2;
+            fold_c = (sh.c - 1) / 2;      // log2 S
+        }
+        const u32 fold_segs = fold_slices * fold_nb / kSeg;
+        hipLaunchKernelGGL((msm_reduce_segments<FB>), dim3((fold_segs * kGroup + 255) / 256), dim3(256), 0, st, fold_src,
+                           cx.partial.as<u32>(), fold_nb, fold_segs);
+        // 64 logical lanes per workgroup; first level leaves <= 32 block sums per slice
+        const u32 per_slice = fold_nb / kSeg, nl = 256 / kGroup;
         const u32 bps = std::max(1u, std::min(32u, per_slice / (2 * nl)));
         const u32 share = (per_slice + bps - 1) / bps;
         if (bps > 1) {
-            hipLaunchKernelGGL((msm_sum_slice<FB>), dim3(bps, sh.slices), dim3(256), nl * 128, st, cx.partial.as<u32>(),
+            hipLaunchKernelGGL((msm_sum_slice<FB>), dim3(bps, fold_slices), dim3(256), nl * 128, st, cx.partial.as<u32>(),
                                cx.heads.as<u32>(), per_slice, share);     // heads[] is free again: reuse as level-1 output
-            hipLaunchKernelGGL((msm_sum_slice<FB>), dim3(1, sh.slices), dim3(256), nl * 128, st, cx.heads.as<u32>(),
+            hipLaunchKernelGGL((msm_sum_slice<FB>), dim3(1, fold_slices), dim3(256), nl * 128, st, cx.heads.as<u32>(),
                                cx.ssums.as<u32>(), bps, bps);
         } else {
-            hipLaunchKernelGGL((msm_sum_slice<FB>), dim3(1, sh.slices), dim3(256), nl * 128, st, cx.partial.as<u32>(),
+            hipLaunchKernelGGL((msm_sum_slice<FB>), dim3(1, fold_slices), dim3(256), nl * 128, st, cx.partial.as<u32>(),
                                cx.ssums.as<u32>(), per_slice, per_slice);
         }
+        hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, cx.ssums.as<u32>(), (int)fold_slices, fold_c, (u32 *)a.d_out,
+                           a.out_kind, a.form == H2_FORM_MONTGOMERY);
     }
-    hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, cx.ssums.as<u32>(), (int)sh.slices, sh.c, (u32 *)a.d_out,
-                       a.out_kind, a.form == H2_FORM_MONTGOMERY);
     prof_end(PROF_MSM_REDUCE, st);
     TL_STAMP(tl_id | 4);
     H2_HIP(hipGetLastError());

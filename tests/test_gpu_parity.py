@@ -536,3 +536,27 @@ def test_concurrent_host_threads():
             got = list(ex.map(run, jobs))
             for g, w in zip(got, want):
                 assert g[0] == w[0] and all(np.array_equal(x, y) for x, y in zip(g[1:], w[1:]))
+
+
+def test_registered_wide_windows_c20(monkeypatch):
+    """Windows beyond 16 bits on the registered path (H2_MSM_C sweep knob: 13 windows of 20 bits, 2^19 buckets): 32-bit digit
+    codes, the two-pass sort with 4096 bins, HBM-counted giant windows for sparse columns, row / column-sum fold."""
+    import ctypes as C
+    from halo2_amd.arithmetic import _p
+    monkeypatch.setenv("H2_MSM_C", "20")
+    curve, n = h.VESTA, 1 << 15
+    sf = fields.CURVE_FIELDS[curve][1]
+    g = co.generate_bases(curve, 910, n)
+    w, blind = co.generate_bases(curve, 911, 1)[0], co.random_field(sf, 912, 1)[0]
+    lib = h.lib()
+    hd = C.c_uint64(0)
+    assert lib.h2_bases_register(curve, _p(g), n, h.FORM_MONTGOMERY, C.byref(hd)) == 0
+    monkeypatch.delenv("H2_MSM_C")
+    dense = co.random_field(sf, 913, n)
+    sparse = dense.copy()
+    sparse[np.arange(n) % 50 != 0] = 0
+    out = np.zeros(12, dtype=np.uint64)
+    for col, nn in ((dense, n), (sparse, n), (dense, 1000), (dense, 1)):
+        assert lib.h2_commit(hd, _p(col), nn, _p(w), _p(blind), h.FORM_MONTGOMERY, 0, _p(out)) == 0
+        assert affine_of(curve, out) == co.jac_to_affine_ints(curve, co.commit(curve, g[:nn], w, col[:nn], blind))
+    assert lib.h2_bases_free(hd) == 0
