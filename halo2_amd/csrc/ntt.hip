@@ -140,29 +140,49 @@ __global__ void __launch_bounds__(1024) ntt_pass(const u32 *__restrict__ in, u32
             hi16[e] = src[1];
         }
     }
-    __syncthreads();
+    
 
     // ---- R butterfly stages as radix-4 rounds (two stages per LDS round trip and per barrier; LDS writes
     //      are the slow direction on gfx950), plus one radix-2 round when R is odd.  One lane owns one radix-4
     //      group: elements mid00, mid00 | 2^u, mid00 | 2^(u+1), mid00 | 2^u | 2^(u+1).
     const size_t lo_x = FIRST ? 0 : (lo0 + (tid & (T - 1)));
     const u32 ngrp = tile >> 2;
+    // twiddles of round u: stage t = s0 + u shares one (wA) between its two butterflies, stage t + 1 needs two (wB0 and,
+    // n/4 further on, wB1).  They are fetched one round AHEAD: the L2 round trip of round u + 2's twiddles overlaps round
+    // u's multiplications instead of following its barrier (every workgroup on the chip reaches that barrier at about
+    // the same time, so nobody else has work to cover the latency).
+    auto tw_addr = [&](int u, size_t &eA, size_t &eB0, size_t &eB1) {
+        const int t = s0 + u;
+        const u32 q = tid >> logT, low = q & ((1u << u) - 1);
+        const size_t xm = ((size_t)low << s0) + lo_x;
+        eA = xm << (L - t - 1);
+        eB0 = xm << (L - t - 2);
+        eB1 = eB0 + ((size_t)1 << (L - 2));
+    };
+    fe wA, wB0, wB1;
+    if (R >= 2 && tid < ngrp) {
+        size_t eA, eB0, eB1;
+        tw_addr(0, eA, eB0, eB1);
+        if (!FIRST) wA = fe_load(tw + 8 * eA);
+        wB0 = fe_load(tw + 8 * eB0);
+        wB1 = fe_load(tw + 8 * eB1);
+    }
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u + 1 < R; u += 2) {
+        fe nA, nB0, nB1;
         if (tid < ngrp) {
-            const int t = s0 + u;
+            if (u + 3 < R) {            // next radix-4 round exists: start its twiddle loads now
+                size_t eA, eB0, eB1;
+                tw_addr(u + 2, eA, eB0, eB1);
+                nA = fe_load(tw + 8 * eA);
+                nB0 = fe_load(tw + 8 * eB0);
+                nB1 = fe_load(tw + 8 * eB1);
+            }
             const u32 col = tid & (T - 1), q = tid >> logT;
             const u32 low = q & ((1u << u) - 1);
             const u32 mid00 = ((q >> u) << (u + 2)) | low;
             const u32 s00 = (mid00 << logT) + col, s01 = s00 + (T << u), s10 = s00 + (T << (u + 1)), s11 = s10 + (T << u);
-            // twiddle exponents (x mod 2^t) * 2^(L-t-1): stage t shares one twiddle between its two butterflies,
-            // stage t+1 needs two (the second is n/4 further on)
-            const size_t xm = ((size_t)low << s0) + lo_x;
-            const size_t eA = xm << (L - t - 1), eB0 = xm << (L - t - 2), eB1 = eB0 + ((size_t)1 << (L - 2));
-            fe wA, wB0, wB1;
-            if (!(FIRST && u == 0)) wA = fe_load(tw + 8 * eA);
-            wB0 = fe_load(tw + 8 * eB0);
-            wB1 = fe_load(tw + 8 * eB1);
             uint4 l0 = lo16[s00], h0 = hi16[s00], l1 = lo16[s01], h1 = hi16[s01];
             uint4 l2 = lo16[s10], h2 = hi16[s10], l3 = lo16[s11], h3 = hi16[s11];
             fe e0{{l0.x, l0.y, l0.z, l0.w, h0.x, h0.y, h0.z, h0.w}}, e1{{l1.x, l1.y, l1.z, l1.w, h1.x, h1.y, h1.z, h1.w}};
@@ -186,6 +206,9 @@ __global__ void __launch_bounds__(1024) ntt_pass(const u32 *__restrict__ in, u32
             hi16[s10] = make_uint4(e2.v[4], e2.v[5], e2.v[6], e2.v[7]);
             lo16[s11] = make_uint4(e3.v[0], e3.v[1], e3.v[2], e3.v[3]);
             hi16[s11] = make_uint4(e3.v[4], e3.v[5], e3.v[6], e3.v[7]);
+            wA = nA;
+            wB0 = nB0;
+            wB1 = nB1;
         }
         __syncthreads();
     }
