@@ -119,3 +119,67 @@ class EvaluationDomain:
         check(lib().h2_divide_by_vanishing_poly(self.field, _p(a), self.extended_k, _p(t), t.shape[0], FORM_MONTGOMERY),
               "h2_divide_by_vanishing_poly")
         return a
+
+    # -- the small accessors and rotations (host logic; integers are canonical field values) ----------------------
+    def get_omega(self) -> int:                                    # domain.rs:391
+        return self.omega
+
+    def get_omega_inv(self) -> int:                                # domain.rs:397
+        return self.omega_inv
+
+    def get_extended_omega(self) -> int:                           # domain.rs:402
+        return self.extended_omega
+
+    def get_quotient_poly_degree(self) -> int:                     # domain.rs:475
+        return self.quotient_poly_degree
+
+    def empty_coeff(self) -> np.ndarray:                           # domain.rs:173
+        return np.zeros((self.n, 4), dtype=np.uint64)
+
+    def empty_lagrange(self) -> np.ndarray:                        # domain.rs:181
+        return np.zeros((self.n, 4), dtype=np.uint64)
+
+    def empty_extended(self) -> np.ndarray:                        # domain.rs:207
+        return np.zeros((self.extended_len(), 4), dtype=np.uint64)
+
+    def constant_lagrange(self, scalar: int) -> np.ndarray:        # domain.rs:198
+        return np.tile(self._c(scalar), (self.n, 1))
+
+    def constant_extended(self, scalar: int) -> np.ndarray:        # domain.rs:216
+        return np.tile(self._c(scalar), (self.extended_len(), 1))
+
+    def coeff_from_vec(self, values) -> np.ndarray:                # domain.rs:163
+        if values.shape[0] != self.n:
+            raise ValueError("coeff_from_vec: wrong length")
+        return values
+
+    def lagrange_from_vec(self, values) -> np.ndarray:             # domain.rs:151
+        if values.shape[0] != self.n:
+            raise ValueError("lagrange_from_vec: wrong length")
+        return values
+
+    def rotate_omega(self, value: int, rotation: int) -> int:
+        """value * omega^rotation (domain.rs:408-419)."""
+        w = self.omega if rotation >= 0 else self.omega_inv
+        return value * pow(w, abs(rotation), self.m) % self.m
+
+    def rotate_extended(self, poly, rotation: int):
+        """Rotate an extended-domain polynomial by `rotation` rows of the original domain (domain.rs:258-274):
+        rotate_left for rotation >= 0, rotate_right otherwise.  numpy or torch CUDA tensor; returns a new array."""
+        if poly.shape[0] != self.extended_len():
+            raise ValueError("rotate_extended: wrong length")
+        shift = (1 << (self.extended_k - self.k)) * abs(rotation)
+        shift = -shift if rotation >= 0 else shift                 # roll(-s) == rotate_left(s)
+        if _is_torch(poly):
+            import torch
+            return torch.roll(poly, shift, 0)                      # a device-to-device copy in two pieces
+        return np.roll(poly, shift, axis=0)
+
+    def l_i_range(self, x: int, xn: int, rotations) -> list[int]:
+        """Evaluations at x of the Lagrange basis polynomials l_i for the given rotations i (domain.rs:447-472)."""
+        rotations = list(rotations)
+        m = self.m
+        results = [(x - self.rotate_omega(1, r)) % m for r in rotations]
+        results = [pow(v, -1, m) if v else 0 for v in results]     # batch_invert leaves zeros alone
+        common = (xn - 1) * self.barycentric_weight % m
+        return [self.rotate_omega(v * common % m, r) for v, r in zip(results, rotations)]

@@ -164,3 +164,35 @@ def test_transcript_mirror_matches_oracle_restatement():
     vt = ipa.Transcript(curve, bytes(t.out))
     vt.read_point(), vt.squeeze_challenge(), vt.read_scalar()
     assert not ipa.verify_proof(curve, k, g, w, u, vt, p, x, (v + 1))
+
+
+def test_domain_rotations_and_lagrange_basis_evaluations():
+    """EvaluationDomain host logic (domain.rs:258-274, 408-472), shaped after the reference's test_rotate and test_l_i
+    (domain.rs:500-569): rotate_extended is a row rotation; l_i_range matches the direct product formula."""
+    import numpy as np
+    k = 4
+    d = h.EvaluationDomain(3, k, h.FP)
+    m, n = d.m, d.n
+    assert d.get_omega() == d.omega and pow(d.omega, n, m) == 1 and d.get_quotient_poly_degree() == 2
+    assert d.rotate_omega(7, 3) == 7 * pow(d.omega, 3, m) % m and d.rotate_omega(7, -2) == 7 * pow(d.omega_inv, 2, m) % m
+    ext = np.arange(d.extended_len() * 4, dtype=np.uint64).reshape(-1, 4)
+    step = 1 << (d.extended_k - d.k)
+    assert np.array_equal(d.rotate_extended(ext, 1), np.concatenate([ext[step:], ext[:step]]))         # rotate_left
+    assert np.array_equal(d.rotate_extended(ext, -2), np.concatenate([ext[-2 * step:], ext[:-2 * step]]))
+    assert d.constant_lagrange(5).shape == (n, 4) and d.empty_extended().shape == (d.extended_len(), 4)
+    with pytest.raises(ValueError):
+        d.rotate_extended(ext[:-1], 1)
+    # l_i(x) = prod_{j != i} (x - w^j) / (w^i - w^j)   (domain.rs:541-569)
+    x = 0x1234567890ABCDEF % m
+    xn = pow(x, n, m)
+    pts = [pow(d.omega, i, m) for i in range(n)]
+
+    def l_direct(i):
+        num = den = 1
+        for j in range(n):
+            if j != i:
+                num = num * (x - pts[j]) % m
+                den = den * (pts[i] - pts[j]) % m
+        return num * pow(den, -1, m) % m
+    rots = [0, 1, 5, -1, -3]
+    assert d.l_i_range(x, xn, rots) == [l_direct(r % n) for r in rots]
