@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Turns the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- collected in separate runs, no trace domains) into
+profiles/r01_pmc_traffic.json, the per-launch HBM byte counts bench.py quotes as `roofline.traffic`.
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_f -o f --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1
+    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_w -o w --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1
+    python bench/pmc_summary.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv > profiles/r01_pmc_traffic.json
+
+Counter values are KiB per dispatch.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide coalesced streaming
+reads by exactly 2x (calibrated for 16 B/lane streams); the x2 is applied to the streaming kernels named in STREAMING and
+not to msm_accumulate's 64-byte random gathers (uncalibrated pattern: lower bound)."""
+from __future__ import annotations
+
+import collections
+import csv
+import json
+import sys
+
+STREAMING = ("ntt_pass", "msm_s1_count", "msm_s1_scatter", "msm_s2_count", "msm_s2_scatter")
+
+
+def collect(path, counter):
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        per[f"{name} grid={r['Grid_Size']}"].append(float(r["Counter_Value"]))
+    return per
+
+
+def main():
+    fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fetch) | set(write)):
+        if not k.startswith("h2::"):
+            continue
+        f, w = fetch.get(k, []), write.get(k, [])
+        kernels[k] = {"FETCH_SIZE_KiB_avg": round(sum(f) / len(f), 1) if f else None, "FETCH_SIZE_KiB_max": round(max(f), 1) if f else None,
+                      "launches_FETCH_SIZE": len(f), "WRITE_SIZE_KiB_avg": round(sum(w) / len(w), 1) if w else None,
+                      "WRITE_SIZE_KiB_max": round(max(w), 1) if w else None, "launches_WRITE_SIZE": len(w)}
+
+    def pick(prefix):
+        return {k: v for k, v in kernels.items() if k.startswith(prefix) and v["FETCH_SIZE_KiB_max"] is not None}
+
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1 "
+                     "--no-cpu-baseline --streams 1, one MI355X; summarised by bench/pmc_summary.py",
+           "units": __doc__.split("Counter values")[1].strip().replace("\n", " "),
+           "kernels": kernels}
+    acc = pick("h2::msm_accumulate<0>")
+    if acc:
+        k = max(acc, key=lambda k_: acc[k_]["FETCH_SIZE_KiB_max"])
+        out["msm_accumulate_2^20"] = {
+            "algorithmic_bytes": 96 << 20, "fetch_bytes_reported_max": int(acc[k]["FETCH_SIZE_KiB_max"] * 1024),
+            "write_bytes_max": int((acc[k]["WRITE_SIZE_KiB_max"] or 0) * 1024),
+            "note": "the registered-bases path gathers one 64-B point per (scalar, window) from the 1 GiB table of precomputed "
+                    "2^(16w) multiples: 16 x 2^20 x 64 B = 1 GiB of gathers + 64 MiB of sorted entries by design; bench/ubench_madd "
+                    "shows the kernel runs at the same speed when the table is L2-resident, i.e. this traffic is not what bounds it"}
+    sort = {}
+    for k, v in kernels.items():
+        base = k.split("<")[0].split(" ")[0].replace("h2::", "")
+        if base.startswith(("msm_s1_", "msm_s2_", "msm_scan_")) and v["FETCH_SIZE_KiB_max"] is not None:
+            mult = 2 if base in STREAMING else 1
+            sort[k] = {"read_bytes_corrected": int(v["FETCH_SIZE_KiB_max"] * 1024 * mult), "write_bytes": int((v["WRITE_SIZE_KiB_max"] or 0) * 1024)}
+    if sort:
+        out["msm_bucket_sort_2^20"] = {"kernels": sort, "total_hbm_bytes_corrected": sum(v["read_bytes_corrected"] + v["write_bytes"] for v in sort.values()),
+                                       "algorithmic_bytes_model": 320 << 20,
+                                       "model": "per scalar: 32 B read twice (count, scatter passes recompute the digits) + 16 entries x 4 B "
+                                                "written by pass 1, read twice and written once by pass 2 = 320 B"}
+    ntt = {}
+    for k, v in kernels.items():
+        if "ntt_pass" in k and k.endswith("grid=262144") and v["FETCH_SIZE_KiB_max"] is not None:
+            ntt[k] = {"read_bytes_corrected": int(v["FETCH_SIZE_KiB_max"] * 1024 * 2), "write_bytes": int((v["WRITE_SIZE_KiB_max"] or 0) * 1024)}
+    if ntt:
+        out["ntt_2^20"] = {"algorithmic_bytes": 64 << 20, "passes": ntt,
+                           "total_hbm_bytes_corrected": sum(v["read_bytes_corrected"] + v["write_bytes"] for v in ntt.values())}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
