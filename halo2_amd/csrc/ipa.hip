@@ -3,38 +3,75 @@
 //
 //   h2_generator_collapse   parallel_generator_collapse (:154-166):  g'[i] = g_lo[i] + [u_j] * g_hi[i], normalised to
 //                           affine -- n / 2^(j+1) FULL 255-bit scalar multiplications per round, an order of
-//                           magnitude more group operations per proof than one commit.  One lane per point; the
-//                           challenge is the same for every lane, so its NAF recoding (done once on the host, ~85
-//                           non-zero digits) drives a divergence-free double-and-add; one Fermat inversion per lane
-//                           normalises (10 % of the lane's work).
+//                           magnitude more group operations per proof than one commit.  The challenge is the same
+//                           for every lane, so the host splits it once with the curve endomorphism
+//                           phi(x, y) = (zeta x, y) = [lambda](x, y):  u = k1 + k2 lambda, |k1|, |k2| < 2^129, and
+//                           the NAFs of k1 and k2 drive a divergence-free JOINT double-and-add over P and phi(P):
+//                           ~130 doublings + ~87 mixed adds instead of 255 + 85.  One lane per point for large
+//                           rounds; the last rounds (<= 2^13 points, pure latency) run one point per quad of lanes
+//                           (curve_wide.cuh).  One Fermat inversion per point normalises.
 //   h2_fold_scalars         the `p'` / `b` collapse (:128-131):  a[i] += a[i + half] * factor.
 //
 // Both keep their vectors on the device across rounds (d_* variants), removing 2k host round trips per proof.
 #include <vector>
 
 #include "common.h"
-#include "curve.cuh"
+#include "curve_wide.cuh"
 #include "host_field.h"
 
 namespace h2 {
 
-// naf: 256 signed digits in {-1, 0, 1}, little-endian, uniform across lanes
+template <int F> __device__ __forceinline__ fe glv_zeta() {   // cube root of unity of the BASE field matching lambda below, Montgomery
+    if (F == FP) return fe{{0x619a153du, 0x02021cf6u, 0x4980b78eu, 0x9e8c2697u, 0xc87a4666u, 0x2a676d5cu, 0xa7a17876u, 0x15d8049du}};
+    return fe{{0x7feeeee3u, 0x410e7d20u, 0xd8fa2279u, 0x6afdf14fu, 0xeca4d4d7u, 0xfd3d8a04u, 0x77dba4efu, 0x2de2d607u}};
+}
+
+// naf1 / naf2: signed digits in {-1, 0, 1} of k1 and k2 (signs folded in), little-endian, uniform across lanes;
+// g[i] <- g[i] + [k1] g[half + i] + [k2] phi(g[half + i])
 template <int FB>
-__global__ void __launch_bounds__(256) ipa_collapse(u32 *__restrict__ g, u32 half, const int8_t *__restrict__ naf, int top) {
+__global__ void __launch_bounds__(256) ipa_collapse(u32 *__restrict__ g, u32 half, const int8_t *__restrict__ naf1,
+                                                    const int8_t *__restrict__ naf2, int top) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     const affine<FB> hi = aff_load<FB>(g + 16 * (size_t)(half + i));
-    affine<FB> hi_neg = hi;
-    hi_neg.y = fe_neg<FB>(hi.y);
+    const fe neg_y = fe_neg<FB>(hi.y);
+    const fe phi_x = fe_mulx<FB>(hi.x, glv_zeta<FB>());
     xyzz<FB> acc = xyzz_identity<FB>();
     for (int b = top; b >= 0; --b) {           // uniform control flow: every lane walks the same digits
         acc = xyzz_dbl<FB>(acc);
-        const int d = naf[b];
-        if (d > 0) xyzz_madd<FB>(acc, hi);
-        else if (d < 0) xyzz_madd<FB>(acc, hi_neg);
+        const int d1 = naf1[b], d2 = naf2[b];
+        if (d1) xyzz_madd<FB>(acc, affine<FB>{hi.x, d1 > 0 ? hi.y : neg_y});
+        if (d2) xyzz_madd<FB>(acc, affine<FB>{phi_x, d2 > 0 ? hi.y : neg_y});
     }
     const affine<FB> lo = aff_load<FB>(g + 16 * (size_t)i);
     xyzz_madd<FB>(acc, lo);
+    const affine<FB> r = xyzz_to_affine<FB>(acc);
+    fe_store(g + 16 * (size_t)i, r.x);
+    fe_store(g + 16 * (size_t)i + 8, r.y);
+}
+
+// the same walk with one point per quad of lanes: the last rounds of an argument have a handful of points and are
+// bound by the ~220 sequential point operations, which the quad runs at 3-4 multiplication levels each
+template <int FB>
+__global__ void __launch_bounds__(256) ipa_collapse_wide(u32 *__restrict__ g, u32 half, const int8_t *__restrict__ naf1,
+                                                         const int8_t *__restrict__ naf2, int top) {
+    const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+    if (i >= half) return;
+    const affine<FB> hi = aff_load<FB>(g + 16 * (size_t)(half + i));
+    const fe one = fe_one<FB>();
+    const fe neg_y = fe_neg<FB>(hi.y);
+    const fe phi_x = fe_mulx<FB>(hi.x, glv_zeta<FB>());
+    xyzz<FB> acc = xyzz_identity<FB>();
+    const bool hi_id = fe_is_zero(hi.x) && fe_is_zero(hi.y);      // the identity as an affine operand: nothing to add
+    for (int b = top; b >= 0 && !hi_id; --b) {
+        acc = xyzz_dbl_wide<FB>(acc);
+        const int d1 = naf1[b], d2 = naf2[b];
+        if (d1) xyzz_add_wide<FB>(acc, xyzz<FB>{hi.x, d1 > 0 ? hi.y : neg_y, one, one});
+        if (d2) xyzz_add_wide<FB>(acc, xyzz<FB>{phi_x, d2 > 0 ? hi.y : neg_y, one, one});
+    }
+    const affine<FB> lo = aff_load<FB>(g + 16 * (size_t)i);
+    if (!(fe_is_zero(lo.x) && fe_is_zero(lo.y))) xyzz_add_wide<FB>(acc, xyzz<FB>{lo.x, lo.y, one, one});
+    if ((threadIdx.x & (kGroup - 1)) != 0) return;
     const affine<FB> r = xyzz_to_affine<FB>(acc);
     fe_store(g + 16 * (size_t)i, r.x);
     fe_store(g + 16 * (size_t)i + 8, r.y);
@@ -64,7 +101,7 @@ static IpaContext &ipa_ctx() {
     return c;
 }
 
-// non-adjacent form of a canonical 256-bit scalar; returns the index of the top non-zero digit (-1 for zero)
+// non-adjacent form of a canonical scalar below 2^256; returns the index of the top non-zero digit (-1 for zero)
 static int naf_recode(const u64 k_in[4], int8_t out[257]) {
     u64 k[5] = {k_in[0], k_in[1], k_in[2], k_in[3], 0};
     memset(out, 0, 257);
@@ -87,6 +124,93 @@ static int naf_recode(const u64 k_in[4], int8_t out[257]) {
     return top;
 }
 
+// ---- GLV split of the challenge: u = k1 + k2 * lambda (mod the scalar-field modulus), |k1|, |k2| < 2^129 -----------
+// Lattice basis (a1, b1), (a2, b2) with a + b * lambda = 0, and g_i = floor(2^256 * (b2, -b1) / q): all derived with
+// oracle/pasta.py big integers (extended Euclid on (q, lambda)); lambda is the root of X^2 + X + 1 with
+// [lambda](x, y) = (zeta x, y) for the zeta in glv_zeta().  c_i = (u * g_i) >> 256 only has to be CLOSE to the exact
+// quotient: any integers c1, c2 give k1 + k2 lambda = u; closeness keeps k1, k2 short.
+struct GlvConst {
+    u64 a1[2], b1_abs[2], a2[2], b2[2], g1[3], g2[3];   // b1 is negative for both curves, everything else positive
+};
+static const GlvConst kGlv[2] = {
+    // scalar field Fq (Pallas)
+    {{0x7fcae1c700000001ULL, 0x49e69d1640f04915ULL}, {0x8cb1279300000000ULL, 0x49e69d1640a89953ULL},
+     {0x8cb1279300000000ULL, 0x49e69d1640a89953ULL}, {0x0c7c095a00000001ULL, 0x93cd3a2c8198e269ULL},
+     {0x31f0256800000002ULL, 0x4f34e8b2066389a4ULL, 2}, {0x32c49e4bffffffffULL, 0x279a745902a2654eULL, 1}},
+    // scalar field Fp (Vesta)
+    {{0x8cb1279300000001ULL, 0x49e69d1640a89953ULL}, {0x7fcae1c700000000ULL, 0x49e69d1640f04915ULL},
+     {0x0c7c095a00000001ULL, 0x93cd3a2c8198e269ULL}, {0x8cb1279300000001ULL, 0x49e69d1640a89953ULL},
+     {0x32c49e4c00000003ULL, 0x279a745902a2654eULL, 1}, {0xff2b871bffffffffULL, 0x279a745903c12455ULL, 1}},
+};
+// out[na + nb] = a * b
+static void limbs_mul(u64 *out, const u64 *a, int na, const u64 *b, int nb) {
+    memset(out, 0, (size_t)(na + nb) * 8);
+    for (int i = 0; i < na; ++i) {
+        u128 carry = 0;
+        for (int j = 0; j < nb; ++j) {
+            carry += (u128)a[i] * b[j] + out[i + j];
+            out[i + j] = (u64)carry;
+            carry >>= 64;
+        }
+        out[i + nb] = (u64)carry;
+    }
+}
+// 6-limb two's complement: r = a +/- b (b zero-extended from nb limbs)
+static void acc6(u64 r[6], const u64 *b, int nb, bool subtract) {
+    u64 t[6] = {0, 0, 0, 0, 0, 0};
+    memcpy(t, b, (size_t)nb * 8);
+    unsigned carry = subtract ? 1 : 0;
+    for (int i = 0; i < 6; ++i) {
+        const u64 x = subtract ? ~t[i] : t[i];
+        const u128 v = (u128)r[i] + x + carry;
+        r[i] = (u64)v;
+        carry = (unsigned)(v >> 64);
+    }
+}
+// |v| of a 6-limb two's complement value into 4 limbs; returns true when v < 0
+static bool abs6(const u64 v[6], u64 out[4]) {
+    const bool neg = (v[5] >> 63) != 0;
+    u64 t[6];
+    memcpy(t, v, 48);
+    if (neg) {
+        unsigned carry = 1;
+        for (int i = 0; i < 6; ++i) {
+            const u128 w = (u128)(~t[i]) + carry;
+            t[i] = (u64)w;
+            carry = (unsigned)(w >> 64);
+        }
+    }
+    memcpy(out, t, 32);   // |k_i| < 2^129
+    return neg;
+}
+// digits of k1 and k2 with their signs folded in; returns the highest index used by either
+static int glv_recode(int scalar_field, const u64 u_canonical[4], int8_t naf1[257], int8_t naf2[257]) {
+    const GlvConst &G = kGlv[scalar_field == H2_FQ ? 0 : 1];
+    u64 prod[7], c1[3], c2[3];
+    limbs_mul(prod, u_canonical, 4, G.g1, 3);
+    memcpy(c1, prod + 4, 24);
+    limbs_mul(prod, u_canonical, 4, G.g2, 3);
+    memcpy(c2, prod + 4, 24);
+    // k1 = u - c1 a1 - c2 a2;   k2 = -c1 b1 - c2 b2 = c1 |b1| - c2 b2
+    u64 k1[6] = {u_canonical[0], u_canonical[1], u_canonical[2], u_canonical[3], 0, 0}, k2[6] = {0, 0, 0, 0, 0, 0}, t[5];
+    limbs_mul(t, c1, 3, G.a1, 2);
+    acc6(k1, t, 5, true);
+    limbs_mul(t, c2, 3, G.a2, 2);
+    acc6(k1, t, 5, true);
+    limbs_mul(t, c1, 3, G.b1_abs, 2);
+    acc6(k2, t, 5, false);
+    limbs_mul(t, c2, 3, G.b2, 2);
+    acc6(k2, t, 5, true);
+    u64 m1[4], m2[4];
+    const bool n1 = abs6(k1, m1), n2 = abs6(k2, m2);
+    int top1 = naf_recode(m1, naf1), top2 = naf_recode(m2, naf2);
+    if (n1)
+        for (int i = 0; i <= top1; ++i) naf1[i] = (int8_t)-naf1[i];
+    if (n2)
+        for (int i = 0; i <= top2; ++i) naf2[i] = (int8_t)-naf2[i];
+    return top1 > top2 ? top1 : top2;
+}
+
 static int collapse_launch(int curve, void *d_g, size_t half, const u64 *u, int form, hipStream_t st) {
     IpaContext &cx = ipa_ctx();
     std::lock_guard<std::mutex> lk(cx.mu);
@@ -94,21 +218,29 @@ static int collapse_launch(int curve, void *d_g, size_t half, const u64 *u, int 
     u64 canon[4];
     if (form == H2_FORM_MONTGOMERY) host_from_mont(sf, canon, u);
     else memcpy(canon, u, 32);
-    int8_t naf[257];
-    int top = naf_recode(canon, naf);
-    int rc = cx.naf.reserve(512);
+    int8_t naf[2 * 264];
+    memset(naf, 0, sizeof naf);
+    int top = glv_recode(sf, canon, naf, naf + 264);
+    int rc = cx.naf.reserve(sizeof naf);
     if (rc != H2_OK) return rc;
     // the digit buffer is reused across calls: order the copy after earlier kernels that read it
     H2_HIP(hipStreamSynchronize(st));
-    H2_HIP(hipMemcpyAsync(cx.naf.ptr, naf, 257, hipMemcpyHostToDevice, st));
-    dim3 grid((unsigned)((half + 255) / 256)), block(256);
+    H2_HIP(hipMemcpyAsync(cx.naf.ptr, naf, sizeof naf, hipMemcpyHostToDevice, st));
+    const int8_t *d1 = cx.naf.as<int8_t>(), *d2 = d1 + 264;
+    const bool wide = half <= 8192;       // few points: latency-bound, one point per quad of lanes
+    dim3 grid((unsigned)(((wide ? half * kGroup : half) + 255) / 256)), block(256);
     if (form == H2_FORM_CANONICAL) {
         dim3 g2((unsigned)((half * 4 + 255) / 256));
         if (curve == H2_PALLAS) hipLaunchKernelGGL((ipa_to_mont<FP>), g2, block, 0, st, (u32 *)d_g, half * 4, 1);
         else hipLaunchKernelGGL((ipa_to_mont<FQ>), g2, block, 0, st, (u32 *)d_g, half * 4, 1);
     }
-    if (curve == H2_PALLAS) hipLaunchKernelGGL((ipa_collapse<FP>), grid, block, 0, st, (u32 *)d_g, (u32)half, cx.naf.as<int8_t>(), top);
-    else hipLaunchKernelGGL((ipa_collapse<FQ>), grid, block, 0, st, (u32 *)d_g, (u32)half, cx.naf.as<int8_t>(), top);
+    if (wide) {
+        if (curve == H2_PALLAS) hipLaunchKernelGGL((ipa_collapse_wide<FP>), grid, block, 0, st, (u32 *)d_g, (u32)half, d1, d2, top);
+        else hipLaunchKernelGGL((ipa_collapse_wide<FQ>), grid, block, 0, st, (u32 *)d_g, (u32)half, d1, d2, top);
+    } else {
+        if (curve == H2_PALLAS) hipLaunchKernelGGL((ipa_collapse<FP>), grid, block, 0, st, (u32 *)d_g, (u32)half, d1, d2, top);
+        else hipLaunchKernelGGL((ipa_collapse<FQ>), grid, block, 0, st, (u32 *)d_g, (u32)half, d1, d2, top);
+    }
     if (form == H2_FORM_CANONICAL) {
         dim3 g2((unsigned)((half * 2 + 255) / 256));
         if (curve == H2_PALLAS) hipLaunchKernelGGL((ipa_to_mont<FP>), g2, block, 0, st, (u32 *)d_g, half * 2, 0);
