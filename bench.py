@@ -40,8 +40,8 @@ HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec (MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--log-n", type=int, default=K_LOG, help="override the MSM size (parity/debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--columns", type=int, default=4, help="distinct scalar columns resident in HBM")
