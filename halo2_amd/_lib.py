@@ -45,6 +45,8 @@ SIGNATURES = {
                              C.POINTER(vp), vp], C.c_int),
     "h2_ntt_device": ([C.c_int, vp, C.c_uint, u64p, C.c_int, vp], C.c_int),
     "h2_ifft_device": ([C.c_int, vp, C.c_uint, u64p, u64p, C.c_int, vp], C.c_int),
+    "h2_ntt_batch_device": ([C.c_int, C.POINTER(vp), C.c_size_t, C.c_uint, u64p, C.c_int, vp], C.c_int),
+    "h2_ifft_batch_device": ([C.c_int, C.POINTER(vp), C.c_size_t, C.c_uint, u64p, u64p, C.c_int, vp], C.c_int),
     "h2_coeff_to_extended_device": ([C.c_int, vp, vp, C.c_uint, C.c_uint, u64p, u64p, u64p, C.c_int, vp], C.c_int),
     "h2_extended_to_coeff_device": ([C.c_int, vp, C.c_uint, u64p, u64p, u64p, u64p, C.c_int, vp], C.c_int),
     "h2_points_sum": ([C.c_int, u64p, C.c_size_t, u64p], C.c_int),

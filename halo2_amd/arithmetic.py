@@ -97,6 +97,20 @@ def best_fft(a, omega, log_n: int, field: int, form: int = FORM_MONTGOMERY):
     return a
 
 
+def best_fft_batch(columns, omega, log_n: int, field: int, form: int = FORM_MONTGOMERY):
+    """`best_fft` over several independent device vectors of one size in one call (the column FFTs of a prover phase,
+    plonk/prover.rs:111-117, 322-327); in place, overlapped on internal streams."""
+    omega = np.ascontiguousarray(omega, dtype=np.uint64).reshape(4)
+    for a in columns:
+        if a.shape[0] != (1 << log_n):
+            raise ValueError("best_fft: len(a) != 1 << log_n")
+        assert a.is_cuda and a.is_contiguous()
+    if columns:
+        arr = (C.c_void_p * len(columns))(*[a.data_ptr() for a in columns])
+        check(lib().h2_ntt_batch_device(field, arr, len(columns), log_n, _p(omega), form, _stream_ptr()), "h2_ntt_batch_device")
+    return columns
+
+
 def points_sum(points_xyz, curve: int) -> np.ndarray:
     """Sum of Jacobian points (count, 12): the local step after all-gathering per-GPU partial MSM results."""
     pts = _np(np.asarray(points_xyz).reshape(-1, 12), 12)

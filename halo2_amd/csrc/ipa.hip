@@ -126,7 +126,7 @@ static int naf_recode(const u64 k_in[4], int8_t out[257]) {
 
 // ---- GLV split of the challenge: u = k1 + k2 * lambda (mod the scalar-field modulus), |k1|, |k2| < 2^129 -----------
 // Lattice basis (a1, b1), (a2, b2) with a + b * lambda = 0, and g_i = floor(2^256 * (b2, -b1) / q): all derived with
-// oracle/pasta.py big integers (extended Euclid on (q, lambda)); lambda is the root of X^2 + X + 1 with
+// big-integer arithmetic offline (extended Euclid on (q, lambda)); lambda is the root of X^2 + X + 1 with
 // [lambda](x, y) = (zeta x, y) for the zeta in glv_zeta().  c_i = (u * g_i) >> 256 only has to be CLOSE to the exact
 // quotient: any integers c1, c2 give k1 + k2 lambda = u; closeness keeps k1, k2 short.
 struct GlvConst {

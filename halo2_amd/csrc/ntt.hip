@@ -359,7 +359,7 @@ static int launch_pass_t(const PassArgs &A, unsigned tiles, u32 threads, size_t 
                          const u32 *tw) {
     static bool attr = false;  // raise the dynamic-LDS cap once per instantiation
     if (!attr) {
-        H2_HIP(hipFuncSetAttribute((const void *)ntt_pass<F, R, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        H2_HIP(hipFuncSetAttribute((const void *)ntt_pass<F, R, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         attr = true;
     }
     hipLaunchKernelGGL((ntt_pass<F, R, FIRST>), dim3(tiles), dim3(threads), lds, st, src, dst, tw, A);
@@ -411,6 +411,7 @@ struct NttJob {
     u64 omega[4];       // Montgomery
     u64 lk0[4], lk1[4];           // load multipliers (Montgomery)
     u64 sk0[4], sk1[4], sk2[4];   // store multipliers (Montgomery)
+    int plan = 0;                 // 0: fewest passes (one transform owns the chip); 1: small tiles, for concurrent transforms
 };
 
 static int ntt_run(const NttJob &J, hipStream_t st) {
@@ -432,9 +433,19 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
     int rc = get_twiddles(cx, J.field, L, J.omega, st, tw);
     if (rc != H2_OK) return rc;
 
-    // pass plan: ceil(L / maxr) passes, stages spread evenly (H2_NTT_MAXR / H2_NTT_LOGT: tuning sweeps only)
-    static const int maxr = [] { const char *e = getenv("H2_NTT_MAXR"); int v = e ? atoi(e) : 8; return v >= 1 && v <= 10 ? v : 8; }();
+    // pass plan: ceil(L / maxr) passes, stages spread evenly (H2_NTT_MAXR / H2_NTT_LOGT / H2_NTT_LDS: tuning sweeps only).
+    // Up to 10 stages per pass with 128 KiB tiles: 2^20 runs as TWO passes of 10 stages (one workgroup per CU, the whole
+    // vector resident in LDS across the chip) instead of three of 7, 7, 6 -- 0.137 -> 0.128 ms; 2^22 still needs three.
+    // Plan 0 (a transform alone): up to 10 stages per pass with 128 KiB tiles -- 2^20 runs as TWO passes of 10 stages (one
+    // workgroup per CU, the whole vector resident in LDS across the chip) instead of three of 7, 7, 6: 0.137 -> 0.128 ms.
+    // Plan 1 (the batch entry points: independent column transforms on internal streams): at most 8 stages and 64 KiB, so
+    // workgroups of several transforms share a CU and one column's load / store phases hide under another's butterflies
+    // (0.105 ms per 2^20 transform over 3 streams, against 0.131 with plan 0).  H2_NTT_MAXR / _LOGT / _LDS: sweeps only.
+    static const int env_maxr = [] { const char *e = getenv("H2_NTT_MAXR"); int v = e ? atoi(e) : 10; return v >= 1 && v <= 10 ? v : 10; }();
     static const int want_logT = [] { const char *e = getenv("H2_NTT_LOGT"); int v = e ? atoi(e) : 3; return v >= 0 && v <= 5 ? v : 3; }();
+    static const u32 env_lds = [] { const char *e = getenv("H2_NTT_LDS"); int v = e ? atoi(e) : 131072; return (u32)(v >= 32768 && v <= 131072 ? v : 131072); }();
+    const int maxr = J.plan == 1 ? std::min(env_maxr, 8) : env_maxr;
+    const u32 lds_cap = J.plan == 1 ? std::min<u32>(env_lds, 65536u) : env_lds;
     const int P = (L + maxr - 1) / maxr;
     int stages[40];
     for (int i = 0; i < P; ++i) stages[i] = L / P + (i < L % P ? 1 : 0);
@@ -459,9 +470,9 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
         const bool last = i == P - 1;
         int colbits = A.first ? (L - A.r) : s0;
         A.logT = std::min(want_logT, colbits);
-        while (A.logT > 0 && ((32u << A.r) << A.logT) > 65536) A.logT--;
+        while (A.logT > 0 && ((32u << A.r) << A.logT) > lds_cap) A.logT--;
         // keep >= 256 lanes per workgroup when the pass is narrow
-        while (A.logT < colbits && ((1 << A.r) << A.logT) < 1024 && ((32u << A.r) << (A.logT + 1)) <= 65536) A.logT++;
+        while (A.logT < colbits && ((1 << A.r) << A.logT) < 1024 && ((32u << A.r) << (A.logT + 1)) <= lds_cap) A.logT++;
         if (A.first) {
             A.load_mode = J.load_mode;
             A.lk0 = to_param(J.lk0);
@@ -539,6 +550,74 @@ extern "C" int h2_ifft_device(int field, void *d_a, unsigned log_n, const uint64
     J.store_mode = 1;
     host_to_mont(field, J.sk0, divisor, form);
     return ntt_run(J, (hipStream_t)stream);
+}
+
+// ---- independent column transforms in one call (plonk/prover.rs:111-117, 322-327): forked over internal streams with the
+// small-tile plan so that they share the chip, joined on the caller's stream
+namespace {
+struct NttBatchStreams {
+    std::mutex mu;
+    std::vector<hipStream_t> s;
+    std::vector<hipEvent_t> done;
+    hipEvent_t fork = nullptr;
+};
+NttBatchStreams &ntt_batch_streams() {
+    static NttBatchStreams b[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return b[dev & 15];
+}
+int ntt_batch(int field, void *const *d_a, size_t count, unsigned log_n, const uint64_t *omega, const uint64_t *divisor, int form,
+              hipStream_t user) {
+    NttBatchStreams &bs = ntt_batch_streams();
+    std::lock_guard<std::mutex> lk(bs.mu);
+    const size_t want = std::min<size_t>(3, count);
+    while (bs.s.size() < want) {
+        hipStream_t st;
+        hipEvent_t ev;
+        H2_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        H2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        bs.s.push_back(st);
+        bs.done.push_back(ev);
+    }
+    if (!bs.fork) H2_HIP(hipEventCreateWithFlags(&bs.fork, hipEventDisableTiming));
+    H2_HIP(hipEventRecord(bs.fork, user));
+    for (size_t i = 0; i < want; ++i) H2_HIP(hipStreamWaitEvent(bs.s[i], bs.fork, 0));
+    int rc = H2_OK;
+    for (size_t i = 0; i < count && rc == H2_OK; ++i) {
+        if (!d_a[i]) return H2_ERR_ARGS;
+        NttJob J;
+        job_ntt(J, field, d_a[i], log_n, omega, form);
+        if (divisor) {
+            J.store_mode = 1;
+            host_to_mont(field, J.sk0, divisor, form);
+        }
+        J.plan = want > 1 ? 1 : 0;
+        rc = ntt_run(J, bs.s[i % want]);
+    }
+    for (size_t i = 0; i < want; ++i) {
+        H2_HIP(hipEventRecord(bs.done[i], bs.s[i]));
+        H2_HIP(hipStreamWaitEvent(user, bs.done[i], 0));
+    }
+    return rc;
+}
+}  // namespace
+
+extern "C" int h2_ntt_batch_device(int field, void *const *d_a, size_t count, unsigned log_n, const uint64_t *omega, int form, void *stream) {
+    if (bad_field(field, form) || !d_a || !omega || log_n > 32) return H2_ERR_ARGS;
+    if (!count) return H2_OK;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    return ntt_batch(field, d_a, count, log_n, omega, nullptr, form, (hipStream_t)stream);
+}
+
+extern "C" int h2_ifft_batch_device(int field, void *const *d_a, size_t count, unsigned log_n, const uint64_t *omega_inv,
+                                    const uint64_t *divisor, int form, void *stream) {
+    if (bad_field(field, form) || !d_a || !omega_inv || !divisor || log_n > 32) return H2_ERR_ARGS;
+    if (!count) return H2_OK;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    return ntt_batch(field, d_a, count, log_n, omega_inv, divisor, form, (hipStream_t)stream);
 }
 
 extern "C" int h2_coeff_to_extended_device(int field, const void *d_a, void *d_out, unsigned k, unsigned ext_k,

@@ -62,6 +62,19 @@ class EvaluationDomain:
             raise ValueError("lagrange_to_coeff: wrong length")
         return self._ifft(a, self.omega_inv, self.k, self.ifft_divisor)
 
+    def lagrange_to_coeff_batch(self, columns):
+        """lagrange_to_coeff over the independent columns of a phase (device tensors, in place) in one call."""
+        for a in columns:
+            if a.shape[0] != self.n:
+                raise ValueError("lagrange_to_coeff: wrong length")
+            assert a.is_cuda and a.is_contiguous()
+        if columns:
+            import ctypes as C
+            arr = (C.c_void_p * len(columns))(*[a.data_ptr() for a in columns])
+            check(lib().h2_ifft_batch_device(self.field, arr, len(columns), self.k, _p(self._c(self.omega_inv)),
+                                             _p(self._c(self.ifft_divisor)), FORM_MONTGOMERY, _stream_ptr()), "h2_ifft_batch_device")
+        return columns
+
     def _ifft(self, a, omega_inv, log_n, divisor):
         """EvaluationDomain::ifft, domain.rs:375-383 (scale fused into the last NTT pass)."""
         if _is_torch(a):

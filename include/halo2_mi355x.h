@@ -138,6 +138,13 @@ int h2_msm_batch_device(int curve, const void *const *d_scalars, const void *con
 int h2_ntt_device(int field, void *d_a, unsigned log_n, const uint64_t *omega, int form, void *stream);
 int h2_ifft_device(int field, void *d_a, unsigned log_n, const uint64_t *omega_inv,
                    const uint64_t *divisor, int form, void *stream);
+/* `count` independent transforms of one size (the column FFTs of a prover phase, halo2_proofs/src/plonk/prover.rs:111-117,
+ * 322-327) in one call: overlapped on internal streams, joined on `stream`.  d_a: array of `count` device pointers; each
+ * vector is transformed in place as by h2_ntt_device / h2_ifft_device. */
+int h2_ntt_batch_device(int field, void *const *d_a, size_t count, unsigned log_n, const uint64_t *omega, int form,
+                        void *stream);
+int h2_ifft_batch_device(int field, void *const *d_a, size_t count, unsigned log_n, const uint64_t *omega_inv,
+                         const uint64_t *divisor, int form, void *stream);
 int h2_coeff_to_extended_device(int field, const void *d_a, void *d_out, unsigned k, unsigned ext_k,
                                 const uint64_t *g_coset, const uint64_t *g_coset_inv,
                                 const uint64_t *extended_omega, int form, void *stream);

@@ -560,3 +560,26 @@ def test_registered_wide_windows_c20(monkeypatch):
         assert lib.h2_commit(hd, _p(col), nn, _p(w), _p(blind), h.FORM_MONTGOMERY, 0, _p(out)) == 0
         assert affine_of(curve, out) == co.jac_to_affine_ints(curve, co.commit(curve, g[:nn], w, col[:nn], blind))
     assert lib.h2_bases_free(hd) == 0
+
+
+def test_fft_batch_matches_single():
+    """h2_ntt_batch_device / h2_ifft_batch_device: independent columns on internal streams (small-tile plan) give the same
+    vectors as one-at-a-time transforms (fewest-passes plan) and as the oracle."""
+    import torch
+    field, k = h.FP, 13
+    m = fields.MODULUS[field]
+    dev = torch.device("cuda:0")
+    dom = h.EvaluationDomain(3, k, field)
+    cols = [co.random_field(field, 1200 + i, 1 << k) for i in range(5)]
+    omega = mont(field, o.omega_for(m, k))
+    d = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]
+    h.best_fft_batch(d, omega, k, field)
+    for c, t in zip(cols, d):
+        assert np.array_equal(t.cpu().numpy().view(np.uint64), co.best_fft(field, c, omega, k))
+    d = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]
+    dom.lagrange_to_coeff_batch(d)
+    for c, t in zip(cols, d):
+        assert np.array_equal(t.cpu().numpy().view(np.uint64), dom.lagrange_to_coeff(c.copy()))
+    assert h.best_fft_batch([], omega, k, field) == []
+    with pytest.raises(ValueError):
+        h.best_fft_batch([d[0][:-1]], omega, k, field)
