@@ -17,14 +17,10 @@
 
 #include "common.h"
 #include "curve_wide.cuh"
+#include "glv.cuh"
 #include "host_field.h"
 
 namespace h2 {
-
-template <int F> __device__ __forceinline__ fe glv_zeta() {   // cube root of unity of the BASE field matching lambda below, Montgomery
-    if (F == FP) return fe{{0x619a153du, 0x02021cf6u, 0x4980b78eu, 0x9e8c2697u, 0xc87a4666u, 0x2a676d5cu, 0xa7a17876u, 0x15d8049du}};
-    return fe{{0x7feeeee3u, 0x410e7d20u, 0xd8fa2279u, 0x6afdf14fu, 0xeca4d4d7u, 0xfd3d8a04u, 0x77dba4efu, 0x2de2d607u}};
-}
 
 // naf1 / naf2: signed digits in {-1, 0, 1} of k1 and k2 (signs folded in), little-endian, uniform across lanes;
 // g[i] <- g[i] + [k1] g[half + i] + [k2] phi(g[half + i])

@@ -43,6 +43,7 @@
 
 #include "common.h"
 #include "curve_wide.cuh"
+#include "glv.cuh"
 
 namespace h2 {
 
@@ -85,6 +86,11 @@ struct MsmShape {
 };
 
 // window width: minimise mixed adds + reduce work.  `shared_buckets`: registered bases (one slice).
+// The generic path always splits scalars with the endomorphism (glv.cuh): the window Horner it halves (0.35 ms) and the
+// smaller fold (9 slices instead of 16) outweigh the extra bucket additions (2n x 9 windows against n x 16, and the
+// on-the-fly phi) at every size measured, 2.76 against 3.09 ms even at 2^20.  The size cap only keeps 2n below 2^31.
+static bool glv_applies(size_t n) { return n <= ((size_t)1 << 28); }
+
 static int choose_c(size_t n, bool shared_buckets) {
     auto feasible = [&](int c) {
         if (c <= kMaxC) return true;
@@ -98,21 +104,31 @@ static int choose_c(size_t n, bool shared_buckets) {
     // Windows of 17..20 bits (registered path) are implemented and parity-tested but not chosen: at n = 2^20, c = 20 cuts
     // the accumulate from 1.29 to 1.07 ms (13 windows instead of 16) and loses more than that in the sort (4096 pass-1
     // bins: 6-entry runs) and in the fold over 2^19 buckets (0.49 vs 0.27 ms).  DESIGN.md section 8.
+    const bool glv = !shared_buckets && glv_applies(n);
+    // With the split, magnitudes have 128 bits, so the TOP window of width c holds 128 - c floor(127 / c) significant
+    // bits: 2 for c = 14, 8 for c = 12 or 15 -- every entry of that window then lands in a few hundred buckets, which are
+    // summed by the (slow) heavy-bucket path.  c = 10, 13 and 16 fill their top window (8 of 10, 11 of 13, 16 of 16 bits).
+    // Small multiexps are pure latency (a chain of ~128 doublings plus the per-slice folds); measured over c = 4..14
+    // (build/c_sweep_small.py): 0.67-0.72 ms at c = 10 up to 2^12 points, c = 13 up to 2^17, c = 16 beyond.
+    if (glv) return n <= 4096 ? 10 : n <= 131072 ? 13 : 16;
     double best = 1e300;
     int bc = 4;
     for (int c = 4; c <= kMaxC; ++c) {
-        int W = 255 / c + 1;
+        // with the endomorphism split: 2n half-length scalars, 130 / c + 1 windows
+        int W = glv ? 130 / c + 1 : 255 / c + 1;
+        double pairs = glv ? 2.0 * (double)n : (double)n;
         double buckets = (double)(1u << (c - 1)) * (shared_buckets ? 1 : W);
-        double cost = (double)W * (double)n * 10.5 + buckets * 60.0;
+        double cost = (double)W * pairs * 10.5 + buckets * 60.0;
         if (cost < best) { best = cost; bc = c; }
     }
     return bc;
 }
 
-static MsmShape make_shape(size_t m, int c, bool shared_buckets) {
+// m: digit columns (generic path with the endomorphism split: 2 x scalars, `glv` picks the shorter window count)
+static MsmShape make_shape(size_t m, int c, bool shared_buckets, bool glv = false) {
     MsmShape s;
     s.c = c;
-    s.W = 255 / c + 1;
+    s.W = glv ? 130 / c + 1 : 255 / c + 1;
     s.NB = 1u << (c - 1);
     s.slices = shared_buckets ? 1 : (u32)s.W;
     s.m = m;
@@ -162,6 +178,46 @@ __global__ void __launch_bounds__(256) msm_recode(const u32 *__restrict__ scalar
             code = raw ? raw - 1 : kZeroCode;
         }
         digits[(size_t)w * m + i] = (uint16_t)code;
+    }
+}
+
+// ---- recode with the endomorphism split (generic path): scalar i yields two columns of signed digits, column i for k1
+// (base P_i) and column m + i for k2 (base phi(P_i)); half as many windows, so the final Horner over windows needs 128
+// doublings instead of 255.  digits[w * 2m + col]
+template <int FS>
+__global__ void __launch_bounds__(256) msm_recode_glv(const u32 *__restrict__ scalars, uint16_t *__restrict__ digits, u32 m, int c, int W,
+                                                      int mont) {
+    H2_LATENCY_STAGE();
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    fe s = fe_load(scalars + 8 * (size_t)i);
+    if (mont) s = fe_from_mont<FS>(s);
+    u32 mag[2][5], neg[2];
+    glv_split<FS>(s, mag[0], neg[0], mag[1], neg[1]);
+    const u32 mask = (1u << c) - 1, half = 1u << (c - 1);
+    const size_t M = 2 * (size_t)m;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        u32 carry = 0;
+        for (int w = 0; w < W; ++w) {
+            const int bit = w * c, word = bit >> 5, sh = bit & 31;
+            u32 lo = 0, hi = 0;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                lo = (word == q) ? mag[part][q] : lo;
+                hi = (word + 1 == q) ? mag[part][q] : hi;
+            }
+            const u64 two = (u64)lo | ((u64)hi << 32);
+            const u32 raw = ((u32)(two >> sh) & mask) + carry;
+            // digits of |k_part| in [-half + 1, half] (or [-half, half - 1] when the part is negative, so that after the
+            // sign flip every digit is again in the encodable set: the code has no room for -half)
+            const bool up = neg[part] ? raw >= half : raw > half;
+            carry = up;
+            const u32 digit_mag = up ? (1u << c) - raw : raw;     // 0 when raw = 0 or raw = 2^c
+            const u32 negative = (up ? 1u : 0u) ^ neg[part];
+            const u32 code = digit_mag ? ((digit_mag - 1) | (negative ? 0x8000u : 0u)) : kZeroCode;
+            digits[(size_t)w * M + (size_t)part * m + i] = (uint16_t)code;
+        }
     }
 }
 
@@ -661,7 +717,8 @@ __device__ __forceinline__ u32 upper_bucket(const u32 *__restrict__ arr, u32 n, 
 // heads[t]; every later segment starts a new bucket and is that bucket's only non-head segment, stored
 // straight into buckets[b] (zeroed beforehand).  bucket b = buckets[b] + sum of heads[t] for
 // ceil(start_b / chunk) <= t < ceil(start_{b+1} / chunk), which msm_finish_buckets adds up.
-template <int FB>
+// GLV: entries index 2m columns; column m + i is phi(P_i) = (zeta x_i, y_i), formed on the fly (extra_index = m then)
+template <int FB, bool GLV>
 __global__ void __launch_bounds__(256, 4) msm_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
                                                       u32 extra_index, const u32 *__restrict__ entries,
                                                       const u32 *__restrict__ starts, u32 *__restrict__ heads,
@@ -679,8 +736,10 @@ __global__ void __launch_bounds__(256, 4) msm_accumulate(const u32 *__restrict__
         bool first = true;
         u32 e0 = entries[lo], e1 = lo + 1 < hi ? entries[lo + 1] : 0;
         u32 idx = e0 & 0x7FFFFFFFu;
+        bool phi = GLV && idx >= extra_index, phi_nxt = false;
         // the blind's base `w` (Params::commit, poly/commitment.rs:127) may live in its own buffer
-        affine<FB> nxt = aff_load<FB>(idx == extra_index ? extra_base : bases + 16 * (size_t)idx);
+        affine<FB> nxt = GLV ? aff_load<FB>(bases + 16 * (size_t)(phi ? idx - extra_index : idx))
+                             : aff_load<FB>(idx == extra_index ? extra_base : bases + 16 * (size_t)idx);
         for (u32 i = lo; i < hi; ++i) {
             affine<FB> p = nxt;
             const u32 neg = e0 >> 31;
@@ -688,10 +747,14 @@ __global__ void __launch_bounds__(256, 4) msm_accumulate(const u32 *__restrict__
             const u32 e2 = i + 2 < hi ? entries[i + 2] : 0;
             if (i + 1 < hi) {
                 idx = e1 & 0x7FFFFFFFu;
-                nxt = aff_load<FB>(idx == extra_index ? extra_base : bases + 16 * (size_t)idx);
+                phi_nxt = GLV && idx >= extra_index;
+                nxt = GLV ? aff_load<FB>(bases + 16 * (size_t)(phi_nxt ? idx - extra_index : idx))
+                          : aff_load<FB>(idx == extra_index ? extra_base : bases + 16 * (size_t)idx);
             }
             e0 = e1;
             e1 = e2;
+            if (GLV && phi) p.x = fe_mulx<FB>(p.x, glv_zeta<FB>());
+            phi = phi_nxt;
             if (neg) p.y = fe_neg<FB>(p.y);
             xyzz_madd<FB>(acc, p);
             if (i + 1 == bend && i + 1 < hi) {  // bucket b ends inside the range: flush, open the next non-empty bucket
@@ -1053,7 +1116,7 @@ struct MsmContext {
     DevBuf digits, hist, counts, starts, bsums, entries, heads, heavy, hscratch, buckets, partial, ssums, stage_s, stage_b,
         out, small, tagged, plan;
     bool attr_set = false, attr2_set = false;
-    u32 lanes[2] = {0, 0};  // resident lanes of msm_accumulate<FP>, <FQ> on this device
+    u32 lanes[2][2] = {{0, 0}, {0, 0}};  // resident lanes of msm_accumulate<FP / FQ, plain / GLV> on this device
 };
 
 // One workspace per (device, stream): calls enqueued on different streams never share scratch.
@@ -1084,7 +1147,7 @@ struct MsmArgs {
 };
 
 template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a, hipStream_t st) {
-    const size_t m = a.n_used + (a.d_extra_scalar ? 1 : 0);
+    size_t m = a.n_used + (a.d_extra_scalar ? 1 : 0);
     int rc;
     if (m == 0) {
         if ((rc = cx.ssums.reserve(128)) != H2_OK) return rc;
@@ -1094,7 +1157,12 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         H2_HIP(hipGetLastError());
         return H2_OK;
     }
-    const MsmShape sh = make_shape(m, a.c, a.table);
+    // generic path: every scalar is split k = k1 + k2 lambda (glv.cuh) into two half-length digit columns, i for P_i and
+    // n + i for phi(P_i): as many bucket additions (2n x 9 windows against n x 16), half the doublings in the final Horner
+    const bool glv = !a.table && !a.d_extra_scalar && glv_applies(a.n_used);
+    const size_t scalars_n = m;
+    if (glv) m *= 2;
+    const MsmShape sh = make_shape(m, a.c, a.table, glv);
     const u32 tb = sh.total_buckets, segs = tb / kSeg;
     const size_t all_items = (size_t)sh.W * m;
     if (all_items >= ((size_t)1 << 31)) return H2_ERR_ARGS;  // entry = table index | sign << 31
@@ -1104,12 +1172,13 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         H2_HIP(hipFuncSetAttribute((const void *)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         cx.attr_set = true;
     }
-    u32 &lanes = cx.lanes[FB];
+    u32 &lanes = cx.lanes[FB][glv ? 1 : 0];
     if (!lanes) {  // how many lanes of the accumulate kernel the chip holds at once
         int dev = 0, cus = 0, per_cu = 0;
         H2_HIP(hipGetDevice(&dev));
         H2_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB>, 256, 0));
+        if (glv) H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB, true>, 256, 0));
+        else H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB, false>, 256, 0));
         lanes = (u32)cus * (u32)std::max(per_cu, 1) * 256u;
     }
     // one round of resident lanes; small problems use fewer lanes so a range keeps >= 16 entries
@@ -1201,9 +1270,13 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         hipLaunchKernelGGL(msm_s2_scatter, dim3(S2.B2), dim3(1024), lds2s, st, cx.tagged.as<u32>(), bin_start, hlo, woff, S2, hist2,
                            cx.starts.as<u32>(), cx.entries.as<u32>());
     } else {
-        hipLaunchKernelGGL((msm_recode<FS>), dim3((m32 + 255) / 256), dim3(256), 0, st, (const u32 *)a.d_scalars,
-                           (const u32 *)a.d_extra_scalar, cx.digits.as<uint16_t>(), m32, sh.c, sh.W,
-                           a.form == H2_FORM_MONTGOMERY);
+        if (glv)
+            hipLaunchKernelGGL((msm_recode_glv<FS>), dim3(((u32)scalars_n + 255) / 256), dim3(256), 0, st, (const u32 *)a.d_scalars,
+                               cx.digits.as<uint16_t>(), (u32)scalars_n, sh.c, sh.W, a.form == H2_FORM_MONTGOMERY);
+        else
+            hipLaunchKernelGGL((msm_recode<FS>), dim3((m32 + 255) / 256), dim3(256), 0, st, (const u32 *)a.d_scalars,
+                               (const u32 *)a.d_extra_scalar, cx.digits.as<uint16_t>(), m32, sh.c, sh.W,
+                               a.form == H2_FORM_MONTGOMERY);
         hipLaunchKernelGGL(msm_count, dim3(sh.B, sh.slices), dim3(1024), sh.NB * 4, st, cx.digits.as<uint16_t>(),
                            cx.hist.as<u32>(), sh.items, sh.chunk, sh.NB);
         hipLaunchKernelGGL(msm_chunk_prefix, dim3((tb + 255) / 256), dim3(256), 0, st, cx.hist.as<u32>(), cx.counts.as<u32>(),
@@ -1256,9 +1329,13 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     prof_end(PROF_MSM_SORT, st);
     TL_STAMP(tl_id | 2);
     prof_begin(PROF_MSM_ACCUMULATE, st);
-    hipLaunchKernelGGL((msm_accumulate<FB>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases,
-                       (const u32 *)a.d_extra_base, (!a.table && a.d_extra_base) ? (u32)a.n_used : 0xFFFFFFFFu,
-                       cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T);
+    if (glv)
+        hipLaunchKernelGGL((msm_accumulate<FB, true>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases, (const u32 *)nullptr,
+                           (u32)scalars_n, cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T);
+    else
+        hipLaunchKernelGGL((msm_accumulate<FB, false>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases,
+                           (const u32 *)a.d_extra_base, (!a.table && a.d_extra_base) ? (u32)a.n_used : 0xFFFFFFFFu,
+                           cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T);
     prof_end(PROF_MSM_ACCUMULATE, st);
     TL_STAMP(tl_id | 3);
     prof_begin(PROF_MSM_REDUCE, st);
