@@ -167,7 +167,7 @@ def run_resident(config: str, k: int, curve: int = 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         params.commit_batch(d_cols, blinds[:ncol], lagrange=True)                        # prover.rs:95,308; permutation z
-        coeffs = [dom.lagrange_to_coeff(c.clone()) for c in d_cols]
+        coeffs = dom.lagrange_to_coeff_batch([c.clone() for c in d_cols])
         exts = [dom.coeff_to_extended(c) for c in coeffs]
         torch.cuda.synchronize()
         t["columns: commit_lagrange + iFFT + coset FFT"] = time.perf_counter() - t0

@@ -8,7 +8,7 @@
 //                           phi(x, y) = (zeta x, y) = [lambda](x, y):  u = k1 + k2 lambda, |k1|, |k2| < 2^129, and
 //                           the NAFs of k1 and k2 drive a divergence-free JOINT double-and-add over P and phi(P):
 //                           ~130 doublings + ~87 mixed adds instead of 255 + 85.  One lane per point for large
-//                           rounds; the last rounds (<= 2^13 points, pure latency) run one point per quad of lanes
+//                           rounds; the last rounds (<= 2^15 points, pure latency) run one point per quad of lanes
 //                           (curve_wide.cuh).  One Fermat inversion per point normalises.
 //   h2_fold_scalars         the `p'` / `b` collapse (:128-131):  a[i] += a[i + half] * factor.
 //
@@ -223,7 +223,7 @@ static int collapse_launch(int curve, void *d_g, size_t half, const u64 *u, int 
     H2_HIP(hipStreamSynchronize(st));
     H2_HIP(hipMemcpyAsync(cx.naf.ptr, naf, sizeof naf, hipMemcpyHostToDevice, st));
     const int8_t *d1 = cx.naf.as<int8_t>(), *d2 = d1 + 264;
-    const bool wide = half <= 8192;       // few points: latency-bound, one point per quad of lanes
+    const bool wide = half <= 32768;      // few points: latency-bound, one point per quad of lanes
     dim3 grid((unsigned)(((wide ? half * kGroup : half) + 255) / 256)), block(256);
     if (form == H2_FORM_CANONICAL) {
         dim3 g2((unsigned)((half * 4 + 255) / 256));
