@@ -25,6 +25,7 @@ SIGNATURES = {
     "h2_device_count": ([], C.c_int),
     "h2_init": ([C.c_int], C.c_int),
     "h2_last_error": ([], C.c_char_p),
+    "h2_trim": ([], C.c_int),
     "h2_msm_window_bits": ([C.c_size_t], C.c_int),
     "h2_set_option": ([C.c_char_p, C.c_double], C.c_int),
     "h2_msm": ([C.c_int, u64p, u64p, C.c_size_t, C.c_int, C.c_int, u64p], C.c_int),

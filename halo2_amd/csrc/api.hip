@@ -125,3 +125,14 @@ extern "C" int h2_init(int device) {
 }
 
 extern "C" const char *h2_last_error(void) { return h2::g_err; }
+
+extern "C" int h2_trim(void) {
+    int rc = h2::ensure_device();
+    if (rc != H2_OK) return rc;
+    H2_HIP(hipDeviceSynchronize());
+    h2::msm_release_workspaces();
+    h2::ntt_release_workspaces();
+    h2::poly_release_workspaces();
+    h2::ipa_release_workspaces();
+    return H2_OK;
+}

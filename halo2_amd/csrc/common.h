@@ -59,6 +59,12 @@ void prof_end(int slot, hipStream_t st);
 // (ntt.hip); built on `st` when missing.  Shared with the curve-point FFT (ecfft.hip).
 int ntt_twiddle_table(int field, int L, const uint64_t omega_mont[4], hipStream_t st, const uint32_t **d_tw);
 
+// h2_trim: each translation unit hands its cached device scratch of the current device back to the allocator
+void msm_release_workspaces();
+void ntt_release_workspaces();
+void poly_release_workspaces();
+void ipa_release_workspaces();
+
 // Confirms a usable gfx950 device exists; every entry point calls this first so a missing GPU or
 // runtime fails loudly (H2_ERR_NODEV) instead of silently doing nothing.
 int ensure_device();

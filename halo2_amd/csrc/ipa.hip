@@ -96,6 +96,12 @@ static IpaContext &ipa_ctx() {
     static IpaContext c;
     return c;
 }
+void ipa_release_workspaces() {   // h2_trim
+    IpaContext &cx = ipa_ctx();
+    std::lock_guard<std::mutex> lk(cx.mu);
+    cx.naf.release();
+    cx.stage.release();
+}
 
 // non-adjacent form of a canonical scalar below 2^256; returns the index of the top non-zero digit (-1 for zero)
 static int naf_recode(const u64 k_in[4], int8_t out[257]) {

@@ -1115,20 +1115,36 @@ struct MsmContext {
     std::mutex mu;
     DevBuf digits, hist, counts, starts, bsums, entries, heads, heavy, hscratch, buckets, partial, ssums, stage_s, stage_b,
         out, small, tagged, plan;
+    void release_all() {
+        for (DevBuf *b : {&digits, &hist, &counts, &starts, &bsums, &entries, &heads, &heavy, &hscratch, &buckets, &partial, &ssums,
+                          &stage_s, &stage_b, &out, &small, &tagged, &plan})
+            b->release();
+    }
     bool attr_set = false, attr2_set = false;
     u32 lanes[2][2] = {{0, 0}, {0, 0}};  // resident lanes of msm_accumulate<FP / FQ, plain / GLV> on this device
 };
 
 // One workspace per (device, stream): calls enqueued on different streams never share scratch.
+static std::mutex g_ctx_mu;
+static std::map<std::pair<int, hipStream_t>, std::unique_ptr<MsmContext>> g_ctxs;
 static MsmContext &msm_ctx(hipStream_t st = nullptr) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, std::unique_ptr<MsmContext>> ctxs;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(mu);
-    auto &slot = ctxs[std::make_pair(dev, st)];
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto &slot = g_ctxs[std::make_pair(dev, st)];
     if (!slot) slot.reset(new MsmContext());
     return *slot;
+}
+// h2_trim: the per-(device, stream) scratch of this device goes back to the allocator (the device is idle by then)
+void msm_release_workspaces() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    for (auto &kv : g_ctxs) {
+        if (kv.first.first != dev) continue;
+        std::lock_guard<std::mutex> cl(kv.second->mu);
+        kv.second->release_all();
+    }
 }
 
 struct MsmArgs {

@@ -303,6 +303,15 @@ static NttContext &ntt_ctx() {
     return c;
 }
 static const size_t kTwCacheBytes = (size_t)6 << 30;  // HBM is 288 GB: keep tables around
+void ntt_release_workspaces() {   // h2_trim: scratch vectors and cached twiddle tables (rebuilt on the next transform)
+    NttContext &cx = ntt_ctx();
+    std::lock_guard<std::mutex> lk(cx.mu);
+    for (auto &kv : cx.tmp) kv.second.release();
+    for (auto &kv : cx.stage) kv.second.release();
+    cx.cache.clear();
+    cx.lru.clear();
+    cx.cache_bytes = 0;
+}
 
 // returns the device table omega^0..omega^(n/2-1); builds it on `st` when missing
 static int get_twiddles(NttContext &cx, int field, int L, const u64 omega_m[4], hipStream_t st, std::shared_ptr<TwEntry> &out) {

@@ -330,6 +330,15 @@ PolyContext &poly_ctx() {
     return c[dev & 15];
 }
 
+}  // namespace
+void poly_release_workspaces() {   // h2_trim
+    PolyContext &cx = poly_ctx();
+    std::lock_guard<std::mutex> lk(cx.mu);
+    cx.scratch.release();
+    cx.consts.release();
+}
+namespace {
+
 inline fe to_fe(const u64 m[4]) {
     fe f;
     memcpy(f.v, m, 32);

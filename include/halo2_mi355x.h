@@ -62,6 +62,10 @@ int h2_device_count(void);
 int h2_init(int device);
 /* Human-readable description of the last failure on this thread (static storage). */
 const char *h2_last_error(void);
+/* Returns the library's cached device scratch (per-stream multiexp / NTT workspaces, twiddle tables) of the current
+ * device to the allocator after a device-wide synchronise.  Registered bases stay.  A long-lived prover that used many
+ * streams calls this between phases; everything is re-created on demand. */
+int h2_trim(void);
 /* Window width the MSM would use for n points (informational; the result does not depend on it). */
 int h2_msm_window_bits(size_t n);
 /* Tuning knobs (never change results).  "msm_lane_fraction" in (0.05, 1]: share of the resident wave slots

@@ -583,3 +583,20 @@ def test_fft_batch_matches_single():
     assert h.best_fft_batch([], omega, k, field) == []
     with pytest.raises(ValueError):
         h.best_fft_batch([d[0][:-1]], omega, k, field)
+
+
+def test_trim_releases_and_recreates_workspaces():
+    """h2_trim hands cached scratch back to the allocator; the next calls rebuild it and give the same results."""
+    import torch
+    curve, field = h.PALLAS, h.FP
+    sf = fields.CURVE_FIELDS[curve][1]
+    n = 1 << 12
+    sc, bs = co.random_field(sf, 31, n), co.generate_bases(curve, 32, n)
+    a = co.random_field(field, 33, n)
+    omega = mont(field, o.omega_for(fields.MODULUS[field], 12))
+    before = (affine_of(curve, h.best_multiexp(sc, bs, curve)), h.best_fft(a.copy(), omega, 12, field))
+    free0 = torch.cuda.mem_get_info()[0]
+    assert h.lib().h2_trim() == 0
+    assert torch.cuda.mem_get_info()[0] >= free0
+    after = (affine_of(curve, h.best_multiexp(sc, bs, curve)), h.best_fft(a.copy(), omega, 12, field))
+    assert before[0] == after[0] and np.array_equal(before[1], after[1])
