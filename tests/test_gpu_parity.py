@@ -600,3 +600,22 @@ def test_trim_releases_and_recreates_workspaces():
     assert torch.cuda.mem_get_info()[0] >= free0
     after = (affine_of(curve, h.best_multiexp(sc, bs, curve)), h.best_fft(a.copy(), omega, 12, field))
     assert before[0] == after[0] and np.array_equal(before[1], after[1])
+
+
+def test_sizes_beyond_the_bench_config_2_21():
+    """Maximum-size edge of the parity suite: a 2^21-point registered commit (two-pass sort geometry changes: 27-bit table
+    index, 5 low bucket bits, 1024 bins) and the generic multiexp (2^22 split columns), against the C restatement."""
+    import ctypes as C
+    from halo2_amd.arithmetic import _p
+    curve, n = h.VESTA, 1 << 21
+    sf = fields.CURVE_FIELDS[curve][1]
+    g, col = co.generate_bases(curve, 977, n), co.random_field(sf, 978, n)
+    want = co.jac_to_affine_ints(curve, co.best_multiexp(curve, col, g))
+    lib = h.lib()
+    hd = C.c_uint64(0)
+    assert lib.h2_bases_register(curve, _p(g), n, h.FORM_MONTGOMERY, C.byref(hd)) == 0
+    out = np.zeros(12, dtype=np.uint64)
+    assert lib.h2_commit(hd, _p(col), n, None, None, h.FORM_MONTGOMERY, 0, _p(out)) == 0
+    assert affine_of(curve, out) == want
+    assert lib.h2_bases_free(hd) == 0
+    assert affine_of(curve, h.best_multiexp(col, g, curve)) == want
