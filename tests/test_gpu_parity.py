@@ -619,3 +619,50 @@ def test_sizes_beyond_the_bench_config_2_21():
     assert affine_of(curve, out) == want
     assert lib.h2_bases_free(hd) == 0
     assert affine_of(curve, h.best_multiexp(col, g, curve)) == want
+
+
+@pytest.mark.parametrize("curve", [h.PALLAS, h.VESTA])
+def test_generic_multiexp_endomorphism_edge_scalars(curve):
+    """Scalars that stress the device-side endomorphism split of the generic path (glv.cuh): 0, +-1, lambda and its
+    neighbours (k2 = +-1, k1 = 0), powers of two around the 128-bit half length, the largest scalars, and every digit
+    position set to +-2^(c-1) (the extreme signed digits)."""
+    sm = o.CURVES[curve][1]
+    sf = fields.CURVE_FIELDS[curve][1]
+    lam = {0: 0x6819a58283e528e511db4d81cf70f5a0fed467d47c033af2aa9d2e050aa0e4f,
+           1: 0x2d33357cb532458ed3552a23a8554e5005270d29d19fc7d27b7fd22f0201b547}[curve]
+    assert (lam * lam + lam + 1) % sm == 0
+    vals = [0, 1, 2, sm - 1, sm - 2, lam, lam + 1, lam - 1, sm - lam, (sm - lam) - 1, lam * lam % sm, 1 << 127, 1 << 128,
+            (1 << 128) - 1, (1 << 128) + 1, 1 << 129, 1 << 254, (sm - 1) // 2, (sm + 1) // 2, 0x8000, 0x8001, 0x7FFF,
+            sum(0x8000 << (16 * i) for i in range(15)), sum(0x8000 << (13 * i) for i in range(19)) % sm,
+            sum(0x200 << (10 * i) for i in range(25)) % sm, (lam << 1) % sm, (lam * 0x8000) % sm]
+    vals = [v % sm for v in vals]
+    for n in (len(vals), 5000):                       # c = 10 and c = 13 shapes
+        reps = -(-n // len(vals))
+        sc = fields.to_limbs((vals * reps)[:n], sf, True)
+        bs = co.generate_bases(curve, 990 + n, n)
+        assert affine_of(curve, h.best_multiexp(sc, bs, curve)) == co.jac_to_affine_ints(curve, co.best_multiexp(curve, sc, bs))
+        # one scalar at a time: isolates a wrong split from cancellation between terms
+        if n == len(vals):
+            for i in range(n):
+                got = affine_of(curve, h.best_multiexp(sc[i:i + 1], bs[i:i + 1], curve))
+                assert got == co.jac_to_affine_ints(curve, co.best_multiexp(curve, sc[i:i + 1], bs[i:i + 1])), hex(vals[i])
+
+
+def test_generator_collapse_edge_challenges():
+    """Challenges that stress the host-side endomorphism split of h2_generator_collapse: 0, 1, -1, lambda, -lambda,
+    lambda +- 1, 2^127, 2^128 +- 1, the largest scalar; narrow (2^16 points) and quad-wide (64 points) kernels."""
+    curve = h.VESTA
+    sm = o.CURVES[curve][1]
+    sf = fields.CURVE_FIELDS[curve][1]
+    lam = 0x2d33357cb532458ed3552a23a8554e5005270d29d19fc7d27b7fd22f0201b547
+    vals = [0, 1, sm - 1, lam, sm - lam, lam + 1, lam - 1, 1 << 127, (1 << 128) - 1, (1 << 128) + 1, sm - 2, (sm - 1) // 2]
+    g_small = co.generate_bases(curve, 61, 128)
+    g_small[7] = 0                                                   # identity in the low half
+    g_small[64 + 9] = 0                                              # identity in the high half
+    for v in vals:
+        u = fields.scalar_limbs(v, sf, True)
+        assert np.array_equal(h.parallel_generator_collapse(g_small, u, curve), co.generator_collapse(curve, g_small, u)), hex(v)
+    g_big = co.generate_bases(curve, 62, 1 << 17)
+    for v in (lam, sm - 1, (1 << 128) + 1):
+        u = fields.scalar_limbs(v, sf, True)
+        assert np.array_equal(h.parallel_generator_collapse(g_big, u, curve), co.generator_collapse(curve, g_big, u)), hex(v)
