@@ -356,6 +356,8 @@ struct Sort2 {
     u32 B1;           // pass-1 workgroups (kS1Scalars scalars each)
     u32 K2, B2;       // pass-2 chunk size and worst-case chunk count
     u32 lds_window;   // widest pass-2 window (buckets) whose counters fit LDS; wider ones count in HBM
+    u32 s1_scalars;   // scalars per pass-1 workgroup (a multiple of 1024)
+    u32 nb;           // buckets per slice; generic path: sort key = window * nb + bucket, entry = digit column
 };
 
 // signed window digits of one scalar (same recoding as msm_recode, 32-bit codes so that windows may exceed 16 bits),
@@ -392,8 +394,45 @@ template <typename Fn> __device__ __forceinline__ void for_each_digit(const fe &
     }
 }
 
+// every non-zero window digit of scalar i as f(sort key, entry base index, sign << 31).
+// Registered path: key = bucket (one slice), base = w * stride + column.  Generic path (GLV): the scalar is split
+// (glv.cuh), key = w * nb + bucket (slice-major), base = digit column (i for k1 / P_i, m + i for k2 / phi(P_i)).
+template <int FS, bool GLV, typename Fn>
+__device__ __forceinline__ void emit_entries(const fe &s, u32 i, const Sort2 &P, Fn f) {
+    if (!GLV) {
+        u32 col = i;
+        if (i == P.m - 1 && P.extra_col != 0xFFFFFFFFu) col = P.extra_col;
+        for_each_digit(s, P.c, P.W, [&](int w, u32 code) {
+            if (code != kZero32) f(code & 0x7FFFFFFFu, (u32)w * P.stride + col, code & 0x80000000u);
+        });
+        return;
+    }
+    u32 mag[2][5], neg[2];
+    glv_split<FS>(s, mag[0], neg[0], mag[1], neg[1]);
+    const int c = P.c;
+    const u32 mask = (1u << c) - 1, half = 1u << (c - 1);
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        u32 carry = 0;
+        for (int w = 0; w < P.W; ++w) {
+            const int bit = w * c, word = bit >> 5, sh = bit & 31;
+            u32 lo = 0, hi = 0;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                lo = (word == q) ? mag[part][q] : lo;
+                hi = (word + 1 == q) ? mag[part][q] : hi;
+            }
+            const u32 raw = ((u32)(((u64)lo | ((u64)hi << 32)) >> sh) & mask) + carry;
+            const bool up = neg[part] ? raw >= half : raw > half;      // same digit set as msm_recode_glv
+            carry = up;
+            const u32 digit_mag = up ? (1u << c) - raw : raw;
+            if (digit_mag) f((u32)w * P.nb + digit_mag - 1, (u32)part * P.m + i, (((up ? 1u : 0u) ^ neg[part]) << 31));
+        }
+    }
+}
+
 // pass 1, COUNT: hist1[blk][h] = this workgroup's entries per bin
-template <int FS>
+template <int FS, bool GLV>
 __global__ void __launch_bounds__(1024) msm_s1_count(const u32 *__restrict__ scalars, const u32 *__restrict__ extra_scalar, Sort2 P,
                                                      u32 *__restrict__ hist1) {
     H2_LATENCY_STAGE();
@@ -401,14 +440,12 @@ __global__ void __launch_bounds__(1024) msm_s1_count(const u32 *__restrict__ sca
     const u32 nh = P.nh, blk = blockIdx.x;
     for (u32 h = threadIdx.x; h < nh; h += blockDim.x) sh[h] = 0;
     __syncthreads();
-    for (u32 k = 0; k < kS1Scalars / 1024; ++k) {
-        const u32 i = blk * kS1Scalars + k * 1024 + threadIdx.x;
+    for (u32 k = 0; k < P.s1_scalars / 1024; ++k) {
+        const u32 i = blk * P.s1_scalars + k * 1024 + threadIdx.x;
         if (i >= P.m) break;
         fe s = (extra_scalar && i == P.m - 1) ? fe_load(extra_scalar) : fe_load(scalars + 8 * (size_t)i);
         if (P.mont) s = fe_from_mont<FS>(s);
-        for_each_digit(s, P.c, P.W, [&](int, u32 code) {
-            if (code != kZero32) atomicAdd(&sh[(code & 0x7FFFFFFFu) >> P.lowb], 1u);
-        });
+        emit_entries<FS, GLV>(s, i, P, [&](u32 key, u32, u32) { atomicAdd(&sh[key >> P.lowb], 1u); });
     }
     __syncthreads();
     for (u32 h = threadIdx.x; h < nh; h += blockDim.x) hist1[(size_t)blk * nh + h] = sh[h];
@@ -436,7 +473,7 @@ __device__ __forceinline__ u32 wave0_excl_scan(u32 *v, u32 n) {
 // pass 1, SCATTER: the workgroup's entries are first grouped by bin in LDS (its per-bin counts are known from the
 // count pass), then every bin's run goes out as one contiguous copy -- scattered 4-byte stores issue one lane per
 // clock and were the cost of this pass.  hist1 holds the exclusive prefix over workgroups by now.
-template <int FS>
+template <int FS, bool GLV>
 __global__ void __launch_bounds__(1024) msm_s1_scatter(const u32 *__restrict__ scalars, const u32 *__restrict__ extra_scalar, Sort2 P,
                                                        const u32 *__restrict__ hist1, const u32 *__restrict__ bin_count,
                                                        u32 *__restrict__ bin_start, u32 *__restrict__ tagged) {
@@ -446,7 +483,7 @@ __global__ void __launch_bounds__(1024) msm_s1_scatter(const u32 *__restrict__ s
     u32 *gstart = sh;                 // [nh] bin_start, then bin_start + this workgroup's offset inside the bin
     u32 *lstart = sh + nh;            // [nh + 1] where the bin's run begins in the stage
     u32 *cursor = lstart + nh + 1;    // [nh]
-    u32 *stage = cursor + nh;         // [kS1Scalars * W] entries
+    u32 *stage = cursor + nh;         // [s1_scalars * digits per scalar] entries
     for (u32 h = threadIdx.x; h < nh; h += blockDim.x) {
         const u32 mine = hist1[(size_t)blk * nh + h];
         const u32 next = blk + 1 < B1 ? hist1[(size_t)(blk + 1) * nh + h] : bin_count[h];
@@ -471,18 +508,14 @@ __global__ void __launch_bounds__(1024) msm_s1_scatter(const u32 *__restrict__ s
     }
     __syncthreads();
     const u32 lowmask = (1u << P.lowb) - 1;
-    for (u32 k = 0; k < kS1Scalars / 1024; ++k) {
-        const u32 i = blk * kS1Scalars + k * 1024 + threadIdx.x;
+    for (u32 k = 0; k < P.s1_scalars / 1024; ++k) {
+        const u32 i = blk * P.s1_scalars + k * 1024 + threadIdx.x;
         if (i >= P.m) break;
         fe s = (extra_scalar && i == P.m - 1) ? fe_load(extra_scalar) : fe_load(scalars + 8 * (size_t)i);
         if (P.mont) s = fe_from_mont<FS>(s);
-        u32 col = i;
-        if (i == P.m - 1 && P.extra_col != 0xFFFFFFFFu) col = P.extra_col;
-        for_each_digit(s, P.c, P.W, [&](int w, u32 code) {
-            if (code == kZero32) return;
-            const u32 j = code & 0x7FFFFFFFu;
-            const u32 pos = atomicAdd(&cursor[j >> P.lowb], 1u);
-            stage[pos] = ((u32)w * P.stride + col) | ((j & lowmask) << P.lb) | (code & 0x80000000u);
+        emit_entries<FS, GLV>(s, i, P, [&](u32 key, u32 base, u32 sign) {
+            const u32 pos = atomicAdd(&cursor[key >> P.lowb], 1u);
+            stage[pos] = base | ((key & lowmask) << P.lb) | sign;
         });
     }
     __syncthreads();
@@ -605,7 +638,7 @@ __global__ void __launch_bounds__(1024) msm_s2_count(const u32 *__restrict__ tag
 // prefix over chunks by now).  Windows of up to kS2StageWindow buckets -- every chunk of a dense or moderately sparse
 // column -- group the chunk by bucket in LDS first and copy each bucket's run out contiguously; wider windows write
 // straight from the counters.
-static constexpr u32 kS2StageWindow = 4096;
+static constexpr u32 kS2StageWindow = 3072;
 __global__ void __launch_bounds__(1024) msm_s2_scatter(const u32 *__restrict__ tagged, const u32 *__restrict__ bin_start,
                                                        const u32 *__restrict__ hlo, const u32 *__restrict__ woff, Sort2 P,
                                                        u32 *__restrict__ hist2, const u32 *__restrict__ starts, u32 *__restrict__ entries) {
@@ -642,7 +675,8 @@ __global__ void __launch_bounds__(1024) msm_s2_scatter(const u32 *__restrict__ t
     u32 *lstart = gstart + wsize;          // [wsize + 1] ... and in the stage
     u32 *cursor = lstart + wsize + 1;      // [wsize]
     u32 *bounds = cursor + wsize;          // [nbins]
-    u32 *stage = bounds + nbins;           // [K2]
+    u32 *stage = bounds + nbins;           // [K2] entries grouped by bucket
+    uint16_t *kid = reinterpret_cast<uint16_t *>(stage + P.K2);   // [K2] window-relative bucket of each staged entry
     for (u32 k = threadIdx.x; k < wsize; k += blockDim.x) {
         gstart[k] = starts[(h0 << P.lowb) + k] + hist2[wo + k];
         lstart[k] = 0;
@@ -663,15 +697,16 @@ __global__ void __launch_bounds__(1024) msm_s2_scatter(const u32 *__restrict__ t
     __syncthreads();
     for (u32 p = (u32)p0 + threadIdx.x; p < p1; p += blockDim.x) {
         const u32 e = tagged[p];                                 // second read of the chunk comes from L2
-        const u32 pos = atomicAdd(&cursor[(rel_bin(bounds, nbins, p) << P.lowb) | ((e >> P.lb) & lowmask)], 1u);
+        const u32 k = (rel_bin(bounds, nbins, p) << P.lowb) | ((e >> P.lb) & lowmask);
+        const u32 pos = atomicAdd(&cursor[k], 1u);
         stage[pos] = e & strip;
+        kid[pos] = (uint16_t)k;
     }
     __syncthreads();
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-    for (u32 k = wave; k < wsize; k += nwaves) {
-        const u32 l0 = lstart[k], l1 = lstart[k + 1];
-        u32 *dst = entries + gstart[k];
-        for (u32 q = l0 + lane; q < l1; q += 64) dst[q - l0] = stage[q];
+    // consecutive lanes copy consecutive staged entries: runs of one bucket leave as contiguous stores
+    for (u32 q = threadIdx.x; q < p1 - (u32)p0; q += blockDim.x) {
+        const u32 k = kid[q];
+        entries[gstart[k] + (q - lstart[k])] = stage[q];
     }
 }
 
@@ -1216,10 +1251,34 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
             S2.m = (u32)m; S2.c = sh.c; S2.W = sh.W; S2.mont = a.form == H2_FORM_MONTGOMERY;
             S2.stride = a.stride; S2.extra_col = a.d_extra_scalar ? a.extra_col : 0xFFFFFFFFu;
             S2.lowb = lowb; S2.lb = lb; S2.nh = sh.NB >> lowb;
+            S2.s1_scalars = kS1Scalars;
+            S2.nb = sh.NB;
             S2.B1 = (u32)((m + kS1Scalars - 1) / kS1Scalars);
             S2.K2 = kS2Chunk;
             S2.B2 = (u32)((all_items + kS2Chunk - 1) / kS2Chunk);
             S2.lds_window = std::min<u32>(sh.NB, 32768u);
+        }
+    } else if (glv && scalars_n >= 65536) {
+        // generic path, large: sort key = window * NB + bucket over all slices, entry = digit column (< 2 * scalars)
+        static const int force_old = [] { const char *e = getenv("H2_MSM_SORT"); return e && atoi(e) == 1 ? 1 : 0; }();
+        int lb = 0, kb = 0;
+        while (((u64)(m - 1) >> lb) != 0) ++lb;
+        while (((u64)(tb - 1) >> kb) != 0) ++kb;
+        const int lowb = std::min(31 - lb, std::max(1, kb - 9));
+        const u32 nh = (tb + (1u << lowb) - 1) >> lowb;
+        const u32 s1 = 1024;
+        const bool fits = ((size_t)nh * 3 + 1 + (size_t)s1 * 2 * sh.W) * 4 <= kLdsCap;
+        if (!force_old && lowb >= 1 && nh <= 4096 && fits) {
+            use_sort2 = true;
+            S2.m = (u32)scalars_n; S2.c = sh.c; S2.W = sh.W; S2.mont = a.form == H2_FORM_MONTGOMERY;
+            S2.stride = 0; S2.extra_col = 0xFFFFFFFFu;
+            S2.lowb = lowb; S2.lb = lb; S2.nh = nh;
+            S2.s1_scalars = s1;
+            S2.nb = sh.NB;
+            S2.B1 = (u32)((scalars_n + s1 - 1) / s1);
+            S2.K2 = kS2Chunk;
+            S2.B2 = (u32)((all_items + kS2Chunk - 1) / kS2Chunk);
+            S2.lds_window = std::min<u32>(tb, 32768u);
         }
     }
     if (sh.c > kMaxC && !use_sort2) return H2_ERR_ARGS;   // choose_c only picks wide windows the two-pass sort can take
@@ -1234,8 +1293,10 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         if (!cx.attr2_set) {
             H2_HIP(hipFuncSetAttribute((const void *)msm_s2_count, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
             H2_HIP(hipFuncSetAttribute((const void *)msm_s2_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-            H2_HIP(hipFuncSetAttribute((const void *)msm_s1_scatter<FP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-            H2_HIP(hipFuncSetAttribute((const void *)msm_s1_scatter<FQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+            H2_HIP(hipFuncSetAttribute((const void *)msm_s1_scatter<FP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+            H2_HIP(hipFuncSetAttribute((const void *)msm_s1_scatter<FQ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+            H2_HIP(hipFuncSetAttribute((const void *)msm_s1_scatter<FP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+            H2_HIP(hipFuncSetAttribute((const void *)msm_s1_scatter<FQ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
             cx.attr2_set = true;
         }
         if ((rc = cx.hist.reserve((size_t)S2.B1 * S2.nh * 4)) != H2_OK) return rc;
@@ -1265,24 +1326,32 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     if (use_sort2) {
         u32 *hist1 = cx.hist.as<u32>(), *bin_count = cx.plan.as<u32>(), *bin_start = bin_count + S2.nh, *hlo = bin_start + S2.nh + 1,
             *woff = hlo + S2.B2, *hist2 = woff + S2.B2 + 1;
-        hipLaunchKernelGGL((msm_s1_count<FS>), dim3(S2.B1), dim3(1024), S2.nh * 4, st, (const u32 *)a.d_scalars,
-                           (const u32 *)a.d_extra_scalar, S2, hist1);
-        hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh);
-        const size_t lds1 = ((size_t)S2.nh * 3 + 1 + (size_t)kS1Scalars * sh.W) * 4;
-        hipLaunchKernelGGL((msm_s1_scatter<FS>), dim3(S2.B1), dim3(1024), lds1, st, (const u32 *)a.d_scalars,
-                           (const u32 *)a.d_extra_scalar, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>());
+        const size_t lds1 = ((size_t)S2.nh * 3 + 1 + (size_t)S2.s1_scalars * (glv ? 2 : 1) * sh.W) * 4;
+        if (glv) {
+            hipLaunchKernelGGL((msm_s1_count<FS, true>), dim3(S2.B1), dim3(1024), S2.nh * 4, st, (const u32 *)a.d_scalars,
+                               (const u32 *)nullptr, S2, hist1);
+            hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh);
+            hipLaunchKernelGGL((msm_s1_scatter<FS, true>), dim3(S2.B1), dim3(1024), lds1, st, (const u32 *)a.d_scalars,
+                               (const u32 *)nullptr, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>());
+        } else {
+            hipLaunchKernelGGL((msm_s1_count<FS, false>), dim3(S2.B1), dim3(1024), S2.nh * 4, st, (const u32 *)a.d_scalars,
+                               (const u32 *)a.d_extra_scalar, S2, hist1);
+            hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh);
+            hipLaunchKernelGGL((msm_s1_scatter<FS, false>), dim3(S2.B1), dim3(1024), lds1, st, (const u32 *)a.d_scalars,
+                               (const u32 *)a.d_extra_scalar, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>());
+        }
         hipLaunchKernelGGL(msm_s2_plan, dim3(1), dim3(kScanBlock), 0, st, bin_start, S2, hlo, woff);
         const size_t hist2_words = ((size_t)S2.nh + S2.B2 + 1) << S2.lowb;
-        if (sh.NB > S2.lds_window) H2_HIP(hipMemsetAsync(hist2, 0, hist2_words * 4, st));   // the HBM-counted windows start from zero
+        if (tb > S2.lds_window) H2_HIP(hipMemsetAsync(hist2, 0, hist2_words * 4, st));   // the HBM-counted windows start from zero
         const size_t lds2 = ((size_t)S2.lds_window + S2.nh + 1) * 4;
         hipLaunchKernelGGL(msm_s2_count, dim3(S2.B2), dim3(1024), lds2, st, cx.tagged.as<u32>(), bin_start, hlo, woff, S2, hist2);
-        hipLaunchKernelGGL(msm_s2_prefix, dim3((sh.NB + 255) / 256), dim3(256), 0, st, hist2, bin_start, hlo, woff, S2, cx.counts.as<u32>(),
-                           sh.NB);
+        hipLaunchKernelGGL(msm_s2_prefix, dim3((tb + 255) / 256), dim3(256), 0, st, hist2, bin_start, hlo, woff, S2, cx.counts.as<u32>(),
+                           tb);
         hipLaunchKernelGGL(msm_scan_blocksums, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), tb);
         hipLaunchKernelGGL(msm_scan_top, dim3(1), dim3(kScanBlock), 0, st, cx.bsums.as<u32>(), nblocks, grand);
         hipLaunchKernelGGL(msm_scan_apply, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), grand,
                            cx.starts.as<u32>(), tb);
-        const size_t lds2s = std::max<size_t>(lds2, ((size_t)kS2StageWindow * 3 + 1 + S2.nh + kS2Chunk) * 4);
+        const size_t lds2s = std::max<size_t>(lds2, ((size_t)kS2StageWindow * 3 + 1 + S2.nh + kS2Chunk) * 4 + (size_t)kS2Chunk * 2);
         hipLaunchKernelGGL(msm_s2_scatter, dim3(S2.B2), dim3(1024), lds2s, st, cx.tagged.as<u32>(), bin_start, hlo, woff, S2, hist2,
                            cx.starts.as<u32>(), cx.entries.as<u32>());
     } else {
@@ -1306,7 +1375,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                            a.table ? a.stride : 0u, extra_col, a.table ? 1 : 0);
     }
 #ifdef H2_SORT_DEBUG
-    if (use_sort2 && sh.c <= kMaxC) {
+    if (use_sort2 && sh.c <= kMaxC && a.table) {
         std::vector<u32> sa(tb + 1), ea(all_items), sb(tb + 1), eb(all_items);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(sa.data(), cx.starts.ptr, (tb + 1) * 4, hipMemcpyDeviceToHost);
