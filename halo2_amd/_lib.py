@@ -71,6 +71,8 @@ SIGNATURES = {
     "h2_batch_invert_device": ([C.c_int, vp, C.c_size_t, C.c_int, vp], C.c_int),
     "h2_grand_product": ([C.c_int, u64p, C.c_size_t, u64p, C.c_int, u64p], C.c_int),
     "h2_grand_product_device": ([C.c_int, vp, C.c_size_t, u64p, C.c_int, vp, vp], C.c_int),
+    "h2_evaluate_device": ([C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_size_t, u64p, C.c_size_t, C.POINTER(vp), C.c_size_t, C.c_uint,
+                            u64p, vp, vp], C.c_int),
     "h2_points_compress": ([C.c_int, u64p, C.c_size_t, C.c_int, C.POINTER(C.c_uint8)], C.c_int),
     "h2_points_compress_device": ([C.c_int, vp, C.c_size_t, C.c_int, vp, vp], C.c_int),
     "h2_points_decompress": ([C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.c_int, u64p], C.c_int),

@@ -213,6 +213,30 @@ int h2_batch_invert_device(int field, void *d_a, size_t n, int form, void *strea
 int h2_grand_product(int field, const uint64_t *m, size_t n, const uint64_t *init, int form, uint64_t *z);
 int h2_grand_product_device(int field, const void *d_m, size_t n, const uint64_t *init, int form, void *d_z, void *stream);
 
+/* ---- expression evaluation between the coset FFTs and the quotient iFFT ----------------------- */
+/* poly::Evaluator::evaluate (halo2_proofs/src/poly/evaluator.rs:129-228): one expression tree over registered
+ * polynomials, evaluated element by element in a single kernel.  The tree arrives flattened in post-order as 32-bit
+ * words `op | operand << 8`:
+ *   H2_EV_POLY   operand = polynomial index; the NEXT word is the signed element shift (rotation * 1 for the Lagrange
+ *                basis, * 2^(extended_k - k) for the extended basis; must be 0 in the coefficient basis, evaluator.rs:519)
+ *   H2_EV_CONST  operand = constant index (Ast::ConstantTerm)      H2_EV_LINEAR  operand = constant index (Ast::LinearTerm:
+ *                value consts[c] * omega^i; the caller folds ZETA into the constant for the extended basis, :590-600)
+ *   H2_EV_ADD, H2_EV_MUL (extended basis only, as in the reference), H2_EV_SCALE operand = constant index,
+ *   H2_EV_MULADD operand = constant index of the base: one fold step acc * base + term of Ast::DistributePowers (:186-196)
+ * basis: 0 coefficient, 1 Lagrange, 2 extended Lagrange.  consts: n_consts field elements, d_polys: n_polys device
+ * vectors of 2^log_len elements, all in MONTGOMERY form (products of canonical-form data would not be canonical).
+ * omega: the domain's (extended) root of unity, needed only when the program has a LINEAR node.  Stack depth <= 9. */
+#define H2_EV_POLY 1
+#define H2_EV_CONST 2
+#define H2_EV_LINEAR 3
+#define H2_EV_ADD 4
+#define H2_EV_MUL 5
+#define H2_EV_SCALE 6
+#define H2_EV_MULADD 7
+int h2_evaluate_device(int field, int basis, const uint32_t *program, size_t n_words, const uint64_t *consts, size_t n_consts,
+                       const void *const *d_polys, size_t n_polys, unsigned log_len, const uint64_t *omega, void *d_out,
+                       void *stream);
+
 /* ---- compressed points: the URS file and proof encoding --------------------------------------- */
 /* pasta_curves `to_bytes` as Params::write uses it (halo2_proofs/src/poly/commitment.rs:169-181) and write_point
  * (transcript.rs:183-187): out[32 i ..] = x little-endian with the parity of y in bit 255; identity = 32 zero bytes.
