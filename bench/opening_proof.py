@@ -79,6 +79,16 @@ def main():
     timed("scale_add", lambda: h.scale_add(d_a, x, d_b, sf))
     timed("batch_invert", lambda: h.batch_invert(d_a, sf))
     timed("grand_product", lambda: h.grand_product(d_a, n, x, sf))
+    # expression evaluation over the extended domain (poly/evaluator.rs): a gate-shaped tree with 4 leaves at 2^(k+1)
+    from halo2_amd.evaluator import EXTENDED, Ast, new_evaluator
+    dom = h.EvaluationDomain(3, k, sf)
+    ext = [torch.from_numpy(co.random_field(sf, 20 + j, dom.extended_len()).view(np.int64)).to(dev) for j in range(4)]
+    ev = new_evaluator(EXTENDED)
+    la, lb, lc, lq = (ev.register_poly(t) for t in ext)
+    tree = Ast.distribute_powers([(Ast.of(la) * Ast.of(lb.with_rotation(1)) - Ast.of(lc.with_rotation(-1))) * Ast.of(lq),
+                                  Ast.of(la) + Ast.linear(3), Ast.one()], 0x1234567)
+    timed("evaluate_gate_tree_2^%d" % dom.extended_k, lambda: ev.evaluate(tree, dom))
+    del ext
     g_dev = torch.from_numpy(g.view(np.int64)).to(dev)
     timed("generator_collapse_2^19", lambda: h.parallel_generator_collapse(g_dev.clone(), x, curve), reps=5)
     print(json.dumps(res))
