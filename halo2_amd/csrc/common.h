@@ -5,7 +5,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <map>
+#include <memory>
 #include <mutex>
+#include <utility>
 
 #include "../../include/halo2_mi355x.h"
 
@@ -46,6 +49,31 @@ struct DevBuf {
         cap = 0;
     }
     template <typename T> T *as() const { return reinterpret_cast<T *>(ptr); }
+};
+
+// One workspace per (device, stream): calls enqueued on different streams never share scratch (a mutex inside T only
+// serialises host-side enqueueing).  T needs `std::mutex mu` and `void release_all()`.
+template <typename T> struct StreamContexts {
+    std::mutex mu;
+    std::map<std::pair<int, hipStream_t>, std::unique_ptr<T>> ctxs;
+    T &get(hipStream_t st) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu);
+        auto &slot = ctxs[std::make_pair(dev, st)];
+        if (!slot) slot.reset(new T());
+        return *slot;
+    }
+    void release_current_device() {   // h2_trim
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &kv : ctxs) {
+            if (kv.first.first != dev) continue;
+            std::lock_guard<std::mutex> cl(kv.second->mu);
+            kv.second->release_all();
+        }
+    }
 };
 
 // Optional kernel timing with HIP events on the launching stream (h2_profile_enable): bench.py uses it to

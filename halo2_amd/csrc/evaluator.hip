@@ -86,21 +86,15 @@ namespace {
 struct EvalContext {
     std::mutex mu;
     DevBuf prog, consts, ptrs;
+    void release_all() {
+        prog.release();
+        consts.release();
+        ptrs.release();
+    }
 };
-EvalContext &eval_ctx() {
-    static EvalContext c[16];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    return c[dev & 15];
-}
+StreamContexts<EvalContext> g_eval_ctxs;
 }  // namespace
-void eval_release_workspaces() {
-    EvalContext &cx = eval_ctx();
-    std::lock_guard<std::mutex> lk(cx.mu);
-    cx.prog.release();
-    cx.consts.release();
-    cx.ptrs.release();
-}
+void eval_release_workspaces() { g_eval_ctxs.release_current_device(); }
 
 }  // namespace h2
 
@@ -162,7 +156,7 @@ extern "C" int h2_evaluate_device(int field, int basis, const uint32_t *program,
     if (has_linear && basis != 0 && log_len >= 1) {
         if ((rc = ntt_twiddle_table(field, (int)log_len, omega, st, &d_tw)) != H2_OK) return rc;
     }
-    EvalContext &cx = eval_ctx();
+    EvalContext &cx = g_eval_ctxs.get(st);
     std::lock_guard<std::mutex> lk(cx.mu);
     if ((rc = cx.prog.reserve(n_words * 4)) != H2_OK || (rc = cx.consts.reserve(n_consts * 32 + 32)) != H2_OK ||
         (rc = cx.ptrs.reserve(n_polys * 8 + 8)) != H2_OK)

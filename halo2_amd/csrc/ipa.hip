@@ -91,17 +91,13 @@ template <int F> __global__ void __launch_bounds__(256) ipa_to_mont(u32 *a, size
 struct IpaContext {
     std::mutex mu;
     DevBuf naf, stage;
+    void release_all() {
+        naf.release();
+        stage.release();
+    }
 };
-static IpaContext &ipa_ctx() {
-    static IpaContext c;
-    return c;
-}
-void ipa_release_workspaces() {   // h2_trim
-    IpaContext &cx = ipa_ctx();
-    std::lock_guard<std::mutex> lk(cx.mu);
-    cx.naf.release();
-    cx.stage.release();
-}
+static StreamContexts<IpaContext> g_ipa_ctxs;
+void ipa_release_workspaces() { g_ipa_ctxs.release_current_device(); }   // h2_trim
 
 // non-adjacent form of a canonical scalar below 2^256; returns the index of the top non-zero digit (-1 for zero)
 static int naf_recode(const u64 k_in[4], int8_t out[257]) {
@@ -214,7 +210,7 @@ static int glv_recode(int scalar_field, const u64 u_canonical[4], int8_t naf1[25
 }
 
 static int collapse_launch(int curve, void *d_g, size_t half, const u64 *u, int form, hipStream_t st) {
-    IpaContext &cx = ipa_ctx();
+    IpaContext &cx = g_ipa_ctxs.get(st);
     std::lock_guard<std::mutex> lk(cx.mu);
     const int sf = curve == H2_PALLAS ? H2_FQ : H2_FP;      // the challenge lives in the scalar field
     u64 canon[4];

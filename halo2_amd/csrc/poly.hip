@@ -322,21 +322,16 @@ namespace {
 struct PolyContext {
     std::mutex mu;
     DevBuf scratch, consts;
+    void release_all() {
+        scratch.release();
+        consts.release();
+    }
 };
-PolyContext &poly_ctx() {
-    static PolyContext c[16];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    return c[dev & 15];
-}
+StreamContexts<PolyContext> g_poly_ctxs;
+PolyContext &poly_ctx(hipStream_t st) { return g_poly_ctxs.get(st); }
 
 }  // namespace
-void poly_release_workspaces() {   // h2_trim
-    PolyContext &cx = poly_ctx();
-    std::lock_guard<std::mutex> lk(cx.mu);
-    cx.scratch.release();
-    cx.consts.release();
-}
+void poly_release_workspaces() { g_poly_ctxs.release_current_device(); }   // h2_trim
 namespace {
 
 inline fe to_fe(const u64 m[4]) {
@@ -396,7 +391,7 @@ unsigned reduce_blocks(size_t n) { return (unsigned)std::min<size_t>(1024, (n + 
     } while (0)
 
 int eval_launch(int field, const void *d_a, size_t n, const u64 *point, int form, void *d_out, hipStream_t st) {
-    PolyContext &cx = poly_ctx();
+    PolyContext &cx = poly_ctx(st);
     std::lock_guard<std::mutex> lk(cx.mu);
     if (n == 0) { H2_HIP(hipMemsetAsync(d_out, 0, 32, st)); return H2_OK; }
     const unsigned blocks = reduce_blocks(n);
@@ -413,7 +408,7 @@ int eval_launch(int field, const void *d_a, size_t n, const u64 *point, int form
 }
 
 int inner_launch(int field, const void *d_a, const void *d_b, size_t n, int form, void *d_out, hipStream_t st) {
-    PolyContext &cx = poly_ctx();
+    PolyContext &cx = poly_ctx(st);
     std::lock_guard<std::mutex> lk(cx.mu);
     if (n == 0) { H2_HIP(hipMemsetAsync(d_out, 0, 32, st)); return H2_OK; }
     const unsigned blocks = reduce_blocks(n);
@@ -430,7 +425,7 @@ int kate_launch(int field, const void *d_a, size_t n, const u64 *point, int form
     if (n <= 1) return H2_OK;
     int rc = poly_kernel_attrs();
     if (rc != H2_OK) return rc;
-    PolyContext &cx = poly_ctx();
+    PolyContext &cx = poly_ctx(st);
     std::lock_guard<std::mutex> lk(cx.mu);
     const unsigned nblk = (unsigned)((n + kTile - 1) / kTile);
     if ((rc = cx.scratch.reserve((size_t)nblk * 64)) != H2_OK) return rc;
@@ -462,7 +457,7 @@ int product_launch(int field, const void *d_m, size_t n, const u64 *init, int fo
     if (n == 0) return H2_OK;
     int rc = poly_kernel_attrs();
     if (rc != H2_OK) return rc;
-    PolyContext &cx = poly_ctx();
+    PolyContext &cx = poly_ctx(st);
     std::lock_guard<std::mutex> lk(cx.mu);
     const unsigned nblk = (unsigned)((n + kTile - 1) / kTile);
     if ((rc = cx.scratch.reserve((size_t)nblk * 64)) != H2_OK) return rc;
