@@ -118,3 +118,38 @@ def test_bad_arguments():
         h.grand_product(a[:3], 8, a[0], field)
     with pytest.raises(ValueError):
         h.eval_polynomial(a, a[0], 7)          # unknown field id -> H2_ERR_ARGS
+
+
+def test_helpers_on_concurrent_streams():
+    """Calls on different streams own separate scratch: interleaved reductions / scans / evaluations on three streams give
+    the single-stream results."""
+    import torch
+    from halo2_amd.evaluator import LAGRANGE, Ast, new_evaluator
+    field, n = h.FP, 1 << 16
+    dev = torch.device("cuda:0")
+    dom = h.EvaluationDomain(3, 16, field)
+    cols = [_vec(field, 200 + i, n) for i in range(3)]
+    xs = [_vec(field, 210 + i, 1)[0] for i in range(3)]
+    d = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]
+    want = [(co.eval_polynomial(field, c, x), co.inner_product(field, c, cols[0]), co.kate_division(field, c, x)) for c, x in zip(cols, xs)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    torch.cuda.synchronize()
+    got = [None] * 3
+    evs = []
+    for rep in range(4):
+        for i, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                ev = new_evaluator(LAGRANGE)
+                leaf = ev.register_poly(d[i])
+                e = ev.evaluate(Ast.of(leaf) * 3 + Ast.linear(5), dom)
+                got[i] = (h.eval_polynomial(d[i], xs[i], field), h.compute_inner_product(d[i], d[0], field), h.kate_division(d[i], xs[i], field), e)
+    torch.cuda.synchronize()
+    m = dom.m
+    for i in range(3):
+        a, b, c, e = got[i]
+        assert np.array_equal(a.cpu().numpy().view(np.uint64), want[i][0])
+        assert np.array_equal(b.cpu().numpy().view(np.uint64), want[i][1])
+        assert np.array_equal(c.cpu().numpy().view(np.uint64), want[i][2])
+        vals = co.limbs_to_ints(co.from_mont(field, cols[i][:4]))
+        lin = [5 * pow(dom.omega, j, m) % m for j in range(4)]
+        assert fields.from_limbs(e[:4].cpu().numpy().view(np.uint64), field, True) == [(3 * v + l) % m for v, l in zip(vals, lin)]
