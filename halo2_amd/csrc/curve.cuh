@@ -94,6 +94,44 @@ template <int F> __device__ __forceinline__ void xyzz_madd(xyzz<F> &acc, const a
     acc.zzz = fe_mulx<F>(acc.zzz, ppp);
 }
 
+// acc += affine q with LAZY accumulator coordinates (field.cuh: products are not conditionally subtracted, values live in
+// [0, 2p + d)); q is canonical.  The bucket accumulation runs tens of these back to back per lane; xyzz_reduce_lazy makes
+// the accumulator canonical again before it leaves the lane.
+template <int F> __device__ __forceinline__ void xyzz_madd_lazy(xyzz<F> &acc, const affine<F> &q) {
+    if (aff_is_identity(q)) return;
+    if (xyzz_is_identity(acc)) {       // the identity is stored as exact zeros
+        acc.x = q.x;
+        acc.y = q.y;
+        acc.zz = fe_one<F>();
+        acc.zzz = fe_one<F>();
+        return;
+    }
+    fe u2 = fe_mul_lazy<F>(q.x, acc.zz);
+    fe s2 = fe_mul_lazy<F>(q.y, acc.zzz);
+    fe p = fe_sub_lazy<F>(u2, acc.x);
+    fe r = fe_sub_lazy<F>(s2, acc.y);
+    if (fe_is_zero_lazy<F>(p)) {  // same x: doubling or inverse pair (rare; duplicate bases)
+        if (fe_is_zero_lazy<F>(r)) acc = xyzz_dbl_affine<F>(q);
+        else acc = xyzz_identity<F>();
+        return;
+    }
+    fe pp = fe_mul_lazy<F>(p, p);
+    fe ppp = fe_mul_lazy<F>(p, pp);
+    fe qq = fe_mul_lazy<F>(acc.x, pp);
+    fe x3 = fe_sub_lazy<F>(fe_sub_lazy<F>(fe_sub_lazy<F>(fe_mul_lazy<F>(r, r), ppp), qq), qq);
+    fe y3 = fe_sub_lazy<F>(fe_mul_lazy<F>(r, fe_sub_lazy<F>(qq, x3)), fe_mul_lazy<F>(acc.y, ppp));
+    acc.x = x3;
+    acc.y = y3;
+    acc.zz = fe_mul_lazy<F>(acc.zz, pp);
+    acc.zzz = fe_mul_lazy<F>(acc.zzz, ppp);
+}
+template <int F> __device__ __forceinline__ void xyzz_reduce_lazy(xyzz<F> &acc) {
+    acc.x = fe_reduce_lazy<F>(acc.x);
+    acc.y = fe_reduce_lazy<F>(acc.y);
+    acc.zz = fe_reduce_lazy<F>(acc.zz);
+    acc.zzz = fe_reduce_lazy<F>(acc.zzz);
+}
+
 // acc += XYZZ q   (add-2008-s); complete
 template <int F> __device__ __forceinline__ void xyzz_add(xyzz<F> &acc, const xyzz<F> &q) {
     if (xyzz_is_identity(q)) return;

@@ -201,6 +201,66 @@ template <int F> __device__ __forceinline__ fe fe_mul_sched(const fe &a, const f
     return fe_reduce_once<F>(r);
 }
 
+// ---- lazy reduction for long chains (the MSM bucket accumulation) ---------------------------------------------------
+// The conditional subtraction after every multiplication is 8 borrow-chained subtracts + 8 selects + the wait states the
+// carries need: 28 issue slots of 276.  Dropping it leaves products in [0, 2p + d): with a, b < 2p + d the Montgomery
+// quotient gives (ab + mp) / R < p + ab / R, and ab / R <= p (1 + e) + (d_a + d_b) / 2 with e = (4p - R) / R ~ 2^-128
+// (both Pasta primes sit just ABOVE 2^254, so R = 2^256 misses the classical "R > 4p, no final subtraction" condition by
+// a hair): the excess over 2p grows by at most p e ~ 2^126 per level of dependent multiplications, i.e. stays far below
+// the 2^254 of headroom to 2^256 for any chain a lane can execute.  Differences use 2p as the bias.
+template <int F> __device__ __forceinline__ u32 mod2_limb(int i) {   // 2p
+    if (F == FP) { const u32 v[8] = {0x00000002u, 0x325a61dau, 0x1299f237u, 0x448d31f8u, 0, 0, 0, 0x80000000u}; return v[i]; }
+    const u32 v[8] = {0x00000002u, 0x188dd642u, 0x132951bbu, 0x448d31f8u, 0, 0, 0, 0x80000000u};
+    return v[i];
+}
+template <int F> __device__ __forceinline__ fe fe_mul_lazy(const fe &a, const fe &b) {
+#include "field_mul_sched.inc"
+    return r;
+}
+// a - b for lazy operands: adds 2p when the difference is negative (twice in the ~2^-120 case that once is not enough)
+template <int F> __device__ __forceinline__ fe fe_sub_lazy(const fe &a, const fe &b) {
+    fe d;
+    u32 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u32 bo;
+        d.v[i] = __builtin_subc(a.v[i], b.v[i], br, &bo);
+        br = bo;
+    }
+    const u32 mask = 0u - br;
+    fe r;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u32 co;
+        r.v[i] = __builtin_addc(d.v[i], mod2_limb<F>(i) & mask, c, &co);
+        c = co;
+    }
+    if (br && !c) {          // still negative: b exceeded a by more than 2p (b in the excess range above 2p, a tiny)
+        c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            u32 co;
+            r.v[i] = __builtin_addc(r.v[i], mod2_limb<F>(i), c, &co);
+            c = co;
+        }
+    }
+    return r;
+}
+// canonical representative of a lazy value (< 3p)
+template <int F> __device__ __forceinline__ fe fe_reduce_lazy(const fe &a) { return fe_reduce_once<F>(fe_reduce_once<F>(a)); }
+// lazy value = 0 mod p ?
+template <int F> __device__ __forceinline__ bool fe_is_zero_lazy(const fe &a) {
+    u32 z = 0, e1 = 0, e2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        z |= a.v[i];
+        e1 |= a.v[i] ^ mod_limb<F>(i);
+        e2 |= a.v[i] ^ mod2_limb<F>(i);
+    }
+    return z == 0 || e1 == 0 || e2 == 0;
+}
+
 // Variant: plain C operand-scanning (CIOS); the compiler picks the instructions.  Kept as the
 // readable specification of the multiplier and as an A/B baseline for the asm variants.
 template <int F> __device__ __forceinline__ fe fe_mul_c(const fe &a, const fe &b) {

@@ -791,14 +791,16 @@ __global__ void __launch_bounds__(256, 4) msm_accumulate(const u32 *__restrict__
             if (GLV && phi) p.x = fe_mulx<FB>(p.x, glv_zeta<FB>());
             phi = phi_nxt;
             if (neg) p.y = fe_neg<FB>(p.y);
-            xyzz_madd<FB>(acc, p);
+            xyzz_madd_lazy<FB>(acc, p);
             if (i + 1 == bend && i + 1 < hi) {  // bucket b ends inside the range: flush, open the next non-empty bucket
+                xyzz_reduce_lazy<FB>(acc);
                 xyzz_store<FB>(first ? heads + 32 * (size_t)t : buckets + 32 * (size_t)b, acc);
                 first = false;
                 acc = xyzz_identity<FB>();
                 do { ++b; bend = starts[b + 1]; } while (bend <= i + 1);
             }
         }
+        xyzz_reduce_lazy<FB>(acc);
         xyzz_store<FB>(first ? heads + 32 * (size_t)t : buckets + 32 * (size_t)b, acc);
         if (first) return;
         acc = xyzz_identity<FB>();
