@@ -217,8 +217,13 @@ template <int F> __device__ __forceinline__ fe fe_mul_lazy(const fe &a, const fe
 #include "field_mul_sched.inc"
     return r;
 }
-// a - b for lazy operands: adds 2p when the difference is negative (twice in the ~2^-120 case that once is not enough)
-template <int F> __device__ __forceinline__ fe fe_sub_lazy(const fe &a, const fe &b) {
+// a - b for lazy operands: a - b + 2p when the difference is negative.  That is non-negative whenever b <= 2p; a lazy
+// value only reaches [2^255, 2p + d) when its canonical residue lies within ~2^128 of p (probability ~2^-126), and such a
+// subtrahend is made canonical first -- a uniform, practically never taken loop, kept as a loop so that the compiler does
+// not if-convert it into a third carry chain.
+template <int F> __device__ __forceinline__ fe fe_sub_lazy(const fe &a, const fe &b_in) {
+    fe b = b_in;
+    while (b.v[7] >> 31) b = fe_reduce_once<F>(b);
     fe d;
     u32 br = 0;
 #pragma unroll
@@ -235,15 +240,6 @@ template <int F> __device__ __forceinline__ fe fe_sub_lazy(const fe &a, const fe
         u32 co;
         r.v[i] = __builtin_addc(d.v[i], mod2_limb<F>(i) & mask, c, &co);
         c = co;
-    }
-    if (br && !c) {          // still negative: b exceeded a by more than 2p (b in the excess range above 2p, a tiny)
-        c = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            u32 co;
-            r.v[i] = __builtin_addc(r.v[i], mod2_limb<F>(i), c, &co);
-            c = co;
-        }
     }
     return r;
 }
