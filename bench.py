@@ -332,7 +332,7 @@ def main():
                          "traffic": traffic, "avg_kernel_ms": round(avg_ms, 4), "launches": int(acc_cnt),
                          "valu": {"madd_per_launch": 16 * n, "achieved_Gmadd_per_s": round(16 * n / (avg_ms * 1e-3) / 1e9, 2) if acc_cnt else None,
                                   "isolated_Gmadd_per_s": round(16 * n / (iso["msm_accumulate"] * 1e-3) / 1e9, 2) if iso.get("msm_accumulate") else None,
-                                  "peak_Gmadd_per_s": 12.7, "peak_source": "bench/ubench_madd.hip on the same chip (XYZZ mixed adds, any memory feed)"},
+                                  "peak_Gmadd_per_s": 14.4, "peak_source": "bench/ubench_madd.hip on the same chip (XYZZ mixed adds with lazy reduction as the kernel runs them, any memory feed; 13.1 with a conditional subtraction after every product)"},
                          "note": "VALU integer-multiply bound, not HBM bound (DESIGN.md section 3): the HBM fraction is reported as the contract "
                                  "asks, the VALU fraction is what tracks kernel quality; avg_kernel_ms is measured inside the timed region, where "
                                  "launches of several streams share the chip (kernel_ms_isolated = the same kernel alone); traffic = PMC bytes of "
