@@ -37,6 +37,40 @@ template <int F> __global__ void k_ops(const u32 *a, const u32 *b, u32 *out, int
     fe_store(out + 8 * i, r);
 }
 
+// ---- lazy arithmetic (field.cuh "lazy reduction"): every result, made canonical, must equal the canonical computation.
+// a, b arrive canonical; `ka`, `kb` in {0, 1, 2} pick the representative a + ka p / b + kb p (skipped when it would not be
+// a legal lazy value, i.e. >= 2p + 2^200).  mode 0: mul, 1: sub, 2: is-zero of (a - b), 3: 300 dependent squarings + subs.
+template <int F> __device__ fe add_kp(fe v, int k) {
+    for (int r = 0; r < k; ++r) {
+        u32 c = 0;
+        for (int i = 0; i < 8; i++) { u32 co; v.v[i] = __builtin_addc(v.v[i], mod_limb<F>(i), c, &co); c = co; }
+    }
+    return v;
+}
+template <int F> __global__ void k_lazy(const u32 *a, const u32 *b, u32 *out, int n, int mode, int ka, int kb) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe x = fe_load(a + 8 * i), y = fe_load(b + 8 * i);
+    // a value may only sit in [2p, 2p + d) if its residue is tiny: keep the representative legal
+    const bool x_small = (x.v[7] | x.v[6] | x.v[5] | x.v[4]) == 0, y_small = (y.v[7] | y.v[6] | y.v[5] | y.v[4]) == 0;
+    fe xl = add_kp<F>(x, (ka == 2 && !x_small) ? 1 : ka), yl = add_kp<F>(y, (kb == 2 && !y_small) ? 1 : kb);
+    fe r;
+    if (mode == 0) r = fe_reduce_lazy<F>(fe_mul_lazy<F>(xl, yl));
+    else if (mode == 1) r = fe_reduce_lazy<F>(fe_sub_lazy<F>(xl, yl));
+    else if (mode == 2) { r = fe_zero(); r.v[0] = fe_is_zero_lazy<F>(fe_sub_lazy<F>(xl, yl)) ? 1u : 0u; }
+    else {
+        fe u = xl, v = x;
+        for (int it = 0; it < 300; ++it) {
+            u = fe_sub_lazy<F>(fe_mul_lazy<F>(u, u), yl);      // u <- u^2 - y, lazily
+            v = fe_sub<F>(fe_mulx<F>(v, v), y);                // canonically
+        }
+        r = fe_reduce_lazy<F>(u);
+        if (!fe_eq(r, v)) r.v[0] ^= 0xdeadbeefu;               // flagged below as a mismatch against v
+        else r = fe_zero();
+    }
+    fe_store(out + 8 * i, r);
+}
+
 template <int F, int IMPL> __global__ void __launch_bounds__(256) k_chain(const u32 *a, u32 *out, int iters) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     fe x = fe_load(a + 8 * (i & 1023)), y = fe_load(a + 8 * ((i + 7) & 1023));
@@ -88,6 +122,25 @@ template <int F> int run_field() {
         printf("field %d %-8s: %d/%d mismatches\n", F, names[op], bad, cnt);
         fails += bad;
     }
+    // lazy arithmetic against the canonical oracle results, every pair of representatives
+    for (int mode = 0; mode < 4; ++mode)
+        for (int ka = 0; ka < 3; ++ka)
+            for (int kb = 0; kb < 3; ++kb) {
+                hipLaunchKernelGGL((k_lazy<F>), dim3((n + 255) / 256), dim3(256), 0, 0, da, db, dout, n, mode, ka, kb);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(got.data(), dout, 32 * n, hipMemcpyDeviceToHost));
+                int bad = 0;
+                for (int i = 0; i < n; ++i) {
+                    uint64_t w[4] = {0, 0, 0, 0};
+                    if (mode == 0) orc_f_mul(F, w, &a[4 * i], &b[4 * i]);
+                    else if (mode == 1) orc_f_sub(F, w, &a[4 * i], &b[4 * i]);
+                    else if (mode == 2) w[0] = memcmp(&a[4 * i], &b[4 * i], 32) == 0;
+                    if (memcmp(w, &got[4 * i], 32)) { if (!bad) printf("  first lazy mismatch mode %d reps (%d, %d) idx %d\n", mode, ka, kb, i); bad++; }
+                }
+                if (bad) printf("field %d lazy mode %d reps (%d, %d): %d/%d mismatches\n", F, mode, ka, kb, bad, n);
+                fails += bad;
+            }
+    printf("field %d lazy mul / sub / zero-test / 300-step chain over 9 representative pairs: done\n", F);
     CK(hipFree(da)); CK(hipFree(db)); CK(hipFree(dout));
     return fails;
 }
