@@ -243,6 +243,30 @@ template <int F> __device__ __forceinline__ fe fe_sub_lazy(const fe &a, const fe
     }
     return r;
 }
+// a + b for lazy operands: the sum may pass 2^256 (4p > 2^256), so the carry out of the top limb counts as ">= 2p"
+template <int F> __device__ __forceinline__ fe fe_add_lazy(const fe &a, const fe &b) {
+    fe s;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u32 co;
+        s.v[i] = __builtin_addc(a.v[i], b.v[i], c, &co);
+        c = co;
+    }
+    fe d;
+    u32 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u32 bo;
+        d.v[i] = __builtin_subc(s.v[i], mod2_limb<F>(i), br, &bo);
+        br = bo;
+    }
+    const bool take = c != 0 || br == 0;      // true sum >= 2p
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = take ? d.v[i] : s.v[i];
+    return r;
+}
 // canonical representative of a lazy value (< 3p)
 template <int F> __device__ __forceinline__ fe fe_reduce_lazy(const fe &a) { return fe_reduce_once<F>(fe_reduce_once<F>(a)); }
 // lazy value = 0 mod p ?

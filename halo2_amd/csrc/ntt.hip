@@ -75,6 +75,7 @@ struct PassArgs {
     int r;        // stages in this pass
     int logT;     // log2 of tile columns
     int first;    // 1: gather input through the bit-reversal permutation, transposing store
+    int last;     // 1: results leave the transform: store canonical values (between passes they stay lazy, field.cuh)
     int load_mode;   // 0 none; 1: x {1, k0, k1}[j % 3] for j < n_in, zero for j >= n_in (coeff_to_extended)
     int store_mode;  // 0 none; 1: x k0 (ifft divisor); 2: x {k0, k1, k2}[x % 3] (extended_to_coeff)
     size_t n_in;     // valid input elements (first pass); elements beyond are read as zero
@@ -187,17 +188,19 @@ __global__ void __launch_bounds__(1024) ntt_pass(const u32 *__restrict__ in, u32
             uint4 l2 = lo16[s10], h2 = hi16[s10], l3 = lo16[s11], h3 = hi16[s11];
             fe e0{{l0.x, l0.y, l0.z, l0.w, h0.x, h0.y, h0.z, h0.w}}, e1{{l1.x, l1.y, l1.z, l1.w, h1.x, h1.y, h1.z, h1.w}};
             fe e2{{l2.x, l2.y, l2.z, l2.w, h2.x, h2.y, h2.z, h2.w}}, e3{{l3.x, l3.y, l3.z, l3.w, h3.x, h3.y, h3.z, h3.w}};
+            // lazy arithmetic (field.cuh): values stay in [0, 2p + d) inside and between the passes; the last pass's store
+            // makes them canonical
             if (!(FIRST && u == 0)) {
-                e1 = fe_mulx<F>(e1, wA);
-                e3 = fe_mulx<F>(e3, wA);
+                e1 = fe_mul_lazy<F>(e1, wA);
+                e3 = fe_mul_lazy<F>(e3, wA);
             }
-            fe a0 = fe_add<F>(e0, e1), a1 = fe_sub<F>(e0, e1), a2 = fe_add<F>(e2, e3), a3 = fe_sub<F>(e2, e3);
-            a2 = fe_mulx<F>(a2, wB0);
-            a3 = fe_mulx<F>(a3, wB1);
-            e0 = fe_add<F>(a0, a2);
-            e2 = fe_sub<F>(a0, a2);
-            e1 = fe_add<F>(a1, a3);
-            e3 = fe_sub<F>(a1, a3);
+            fe a0 = fe_add_lazy<F>(e0, e1), a1 = fe_sub_lazy<F>(e0, e1), a2 = fe_add_lazy<F>(e2, e3), a3 = fe_sub_lazy<F>(e2, e3);
+            a2 = fe_mul_lazy<F>(a2, wB0);
+            a3 = fe_mul_lazy<F>(a3, wB1);
+            e0 = fe_add_lazy<F>(a0, a2);
+            e2 = fe_sub_lazy<F>(a0, a2);
+            e1 = fe_add_lazy<F>(a1, a3);
+            e3 = fe_sub_lazy<F>(a1, a3);
             lo16[s00] = make_uint4(e0.v[0], e0.v[1], e0.v[2], e0.v[3]);
             hi16[s00] = make_uint4(e0.v[4], e0.v[5], e0.v[6], e0.v[7]);
             lo16[s01] = make_uint4(e1.v[0], e1.v[1], e1.v[2], e1.v[3]);
@@ -225,8 +228,8 @@ __global__ void __launch_bounds__(1024) ntt_pass(const u32 *__restrict__ in, u32
             uint4 al = lo16[s_a], ah = hi16[s_a], bl = lo16[s_b], bh = hi16[s_b];
             fe a{{al.x, al.y, al.z, al.w, ah.x, ah.y, ah.z, ah.w}};
             fe b{{bl.x, bl.y, bl.z, bl.w, bh.x, bh.y, bh.z, bh.w}};
-            if (!(FIRST && u == 0)) b = fe_mulx<F>(b, fe_load(tw + 8 * (xm << (L - t - 1))));
-            fe sm = fe_add<F>(a, b), d = fe_sub<F>(a, b);
+            if (!(FIRST && u == 0)) b = fe_mul_lazy<F>(b, fe_load(tw + 8 * (xm << (L - t - 1))));
+            fe sm = fe_add_lazy<F>(a, b), d = fe_sub_lazy<F>(a, b);
             lo16[s_a] = make_uint4(sm.v[0], sm.v[1], sm.v[2], sm.v[3]);
             hi16[s_a] = make_uint4(sm.v[4], sm.v[5], sm.v[6], sm.v[7]);
             lo16[s_b] = make_uint4(d.v[0], d.v[1], d.v[2], d.v[3]);
@@ -253,7 +256,12 @@ __global__ void __launch_bounds__(1024) ntt_pass(const u32 *__restrict__ in, u32
         if (A.store_mode) {
             fe v{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
             u32 m3 = A.store_mode == 2 ? (u32)(x % 3) : 0;
-            v = fe_mulx<F>(v, from_param(m3 == 0 ? A.k0 : m3 == 1 ? A.k1 : A.k2));
+            v = fe_mulx<F>(v, from_param(m3 == 0 ? A.k0 : m3 == 1 ? A.k1 : A.k2));     // canonical product of a lazy value
+            a = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+            b = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+        } else if (A.last) {
+            fe v{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+            v = fe_reduce_lazy<F>(v);
             a = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
             b = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
         }
@@ -477,6 +485,7 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
         A.first = i == 0;
         A.n_in = J.n_in;
         const bool last = i == P - 1;
+        A.last = last;
         int colbits = A.first ? (L - A.r) : s0;
         A.logT = std::min(want_logT, colbits);
         while (A.logT > 0 && ((32u << A.r) << A.logT) > lds_cap) A.logT--;
