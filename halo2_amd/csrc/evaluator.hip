@@ -161,8 +161,7 @@ extern "C" int h2_evaluate_device(int field, int basis, const uint32_t *program,
     if ((rc = cx.prog.reserve(n_words * 4)) != H2_OK || (rc = cx.consts.reserve(n_consts * 32 + 32)) != H2_OK ||
         (rc = cx.ptrs.reserve(n_polys * 8 + 8)) != H2_OK)
         return rc;
-    // the staging buffers are reused across calls: order the copies after kernels that still read them
-    H2_HIP(hipStreamSynchronize(st));
+    // the staging buffers belong to this (device, stream): the copies are stream-ordered after the kernel that last read them
     H2_HIP(hipMemcpyAsync(cx.prog.ptr, program, n_words * 4, hipMemcpyHostToDevice, st));
     if (n_consts) H2_HIP(hipMemcpyAsync(cx.consts.ptr, consts, n_consts * 32, hipMemcpyHostToDevice, st));
     if (n_polys) H2_HIP(hipMemcpyAsync(cx.ptrs.ptr, d_polys, n_polys * 8, hipMemcpyHostToDevice, st));

@@ -221,8 +221,8 @@ static int collapse_launch(int curve, void *d_g, size_t half, const u64 *u, int 
     int top = glv_recode(sf, canon, naf, naf + 264);
     int rc = cx.naf.reserve(sizeof naf);
     if (rc != H2_OK) return rc;
-    // the digit buffer is reused across calls: order the copy after earlier kernels that read it
-    H2_HIP(hipStreamSynchronize(st));
+    // the digit buffer belongs to this (device, stream): the copy is stream-ordered after the previous collapse that read
+    // it, and hipMemcpyAsync from pageable memory has consumed `naf` when it returns
     H2_HIP(hipMemcpyAsync(cx.naf.ptr, naf, sizeof naf, hipMemcpyHostToDevice, st));
     const int8_t *d1 = cx.naf.as<int8_t>(), *d2 = d1 + 264;
     const bool wide = half <= 32768;      // few points: latency-bound, one point per quad of lanes

@@ -435,8 +435,7 @@ int kate_launch(int field, const void *d_a, size_t n, const u64 *point, int form
     host_pow(field, pw[0], b, kPC);
     for (int k = 1; k < 8; ++k) host_mul(field, pw[k], pw[k - 1], pw[k - 1]);
     host_mul(field, m, pw[7], pw[7]);      // b^(kPC * 256) = b^kTile
-    // the constant table is reused across calls: order the copy after kernels that still read it
-    H2_HIP(hipStreamSynchronize(st));
+    // the constant table belongs to this (device, stream): the copy is stream-ordered after the kernels that last read it
     H2_HIP(hipMemcpyAsync(cx.consts.ptr, pw, sizeof(pw), hipMemcpyHostToDevice, st));
     u32 *agg = cx.scratch.as<u32>(), *carry = agg + 8 * (size_t)nblk;
     // linear in the coefficients, so canonical and Montgomery inputs take the same path
