@@ -138,9 +138,13 @@ template <int F> __global__ void __launch_bounds__(kPT) poly_powers(u32 *__restr
     tile_store(sh, out, base, 0, n, 0);
 }
 
-// a[i] <- 1 / a[i], zeros stay zero; one Fermat inversion per lane (8 elements)
+// a[i] <- 1 / a[i], zeros stay zero.  Montgomery's trick at two levels: a lane folds its 8 elements into one product,
+// groups of kInvGroup lanes fold those through LDS, and ONE Fermat inversion (255 squarings) serves 8 * kInvGroup = 64
+// elements -- the inversion was 90 % of the kernel when every lane did its own.
+constexpr int kInvGroup = 8;
 template <int F> __global__ void __launch_bounds__(kPT) poly_batch_invert(u32 *__restrict__ a, size_t n, int canonical) {
-    extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    u32 *sh = lds, *sc = lds + kPT * kPitch;          // sc: one lane product per lane
     const size_t base = (size_t)blockIdx.x * kTile;
     tile_load(sh, a, base, n, 0);
     __syncthreads();
@@ -154,7 +158,29 @@ template <int F> __global__ void __launch_bounds__(kPT) poly_batch_invert(u32 *_
         pre[e] = run;
         if (!fe_is_zero(v)) run = fe_mulx<F>(run, v);
     }
-    fe inv = fe_inv<F>(run);
+    // group level: lane g of a group needs 1 / run_g = (product of the other lanes' runs) / (product of all).  The 32 group
+    // inversions of a workgroup are done by the first 32 lanes, so ONE wave walks the 255-squaring loop instead of four
+    // (a lane that sits idle inside a divergent loop saves nothing).
+    lds_put(sc + threadIdx.x * kSPitch, run);
+    __syncthreads();
+    const u32 g0 = threadIdx.x & ~(u32)(kInvGroup - 1), gl = threadIdx.x & (kInvGroup - 1);
+    fe before = fe_one<F>(), after = fe_one<F>();             // products of the group's runs before / after this lane
+#pragma unroll
+    for (int q = 0; q < kInvGroup; ++q) {
+        const fe rq = lds_get(sc + (g0 + q) * kSPitch);
+        if (q < (int)gl) before = fe_mulx<F>(before, rq);
+        if (q > (int)gl) after = fe_mulx<F>(after, rq);
+    }
+    const fe others = fe_mulx<F>(before, after);
+    fe total = fe_one<F>();
+    if (threadIdx.x < kPT / kInvGroup) {
+#pragma unroll
+        for (int q = 0; q < kInvGroup; ++q) total = fe_mulx<F>(total, lds_get(sc + (threadIdx.x * kInvGroup + q) * kSPitch));
+    }
+    __syncthreads();
+    if (threadIdx.x < kPT / kInvGroup) lds_put(sc + threadIdx.x * kSPitch, fe_inv<F>(total));
+    __syncthreads();
+    fe inv = fe_mulx<F>(lds_get(sc + (threadIdx.x / kInvGroup) * kSPitch), others);       // = 1 / run
 #pragma unroll
     for (int e = kPC - 1; e >= 0; --e) {
         fe v = lds_get(row + 8 * e);
@@ -374,8 +400,8 @@ int poly_kernel_attrs() {
     H2_LDS_ATTR((poly_product_tile<FP, true>), kScanLds);
     H2_LDS_ATTR((poly_product_tile<FQ, false>), kScanLds);
     H2_LDS_ATTR((poly_product_tile<FQ, true>), kScanLds);
-    H2_LDS_ATTR((poly_batch_invert<FP>), kTileLds);
-    H2_LDS_ATTR((poly_batch_invert<FQ>), kTileLds);
+    H2_LDS_ATTR((poly_batch_invert<FP>), kScanLds);
+    H2_LDS_ATTR((poly_batch_invert<FQ>), kScanLds);
     H2_LDS_ATTR((poly_powers<FP>), kTileLds);
     H2_LDS_ATTR((poly_powers<FQ>), kTileLds);
 #undef H2_LDS_ATTR
@@ -618,7 +644,7 @@ extern "C" int h2_batch_invert_device(int field, void *d_a, size_t n, int form, 
     if (rc != H2_OK) return rc;
     if (!n) return H2_OK;
     if ((rc = poly_kernel_attrs()) != H2_OK) return rc;
-    H2_FIELD_LAUNCH(field, poly_batch_invert, dim3((unsigned)((n + kTile - 1) / kTile)), dim3(kPT), kTileLds, (hipStream_t)stream, (u32 *)d_a, n,
+    H2_FIELD_LAUNCH(field, poly_batch_invert, dim3((unsigned)((n + kTile - 1) / kTile)), dim3(kPT), kScanLds, (hipStream_t)stream, (u32 *)d_a, n,
                     form == H2_FORM_CANONICAL ? 1 : 0);
     H2_HIP(hipGetLastError());
     return H2_OK;
