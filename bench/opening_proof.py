@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--curve", type=int, default=1)
+    ap.add_argument("--schedule", default=None, help="original | collapse (default: opening.py's choice)")
     a = ap.parse_args()
     import torch
     import halo2_amd as h
@@ -45,7 +46,7 @@ def main():
         pos[0] = (pos[0] + count) % 32
         return pool[n + pos[0]: n + pos[0] + count]
 
-    res = {"k": k, "curve": curve}
+    res = {"k": k, "curve": curve, "schedule": a.schedule or "default"}
     for rep in range(3):
         tr = Blake2bWrite(curve)
         tr.write_point(params.commit(d_px, blind, affine=True).cpu().numpy().view(np.uint64))
@@ -53,7 +54,7 @@ def main():
         tr.write_scalar(h.eval_polynomial(d_px, x, sf).cpu().numpy().view(np.uint64))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        create_proof(params, rng, tr, d_px, blind, x)
+        create_proof(params, rng, tr, d_px, blind, x, schedule=a.schedule)
         torch.cuda.synchronize()
         res[f"create_proof_s_run{rep}"] = round(time.perf_counter() - t0, 4)
     res["proof_bytes"] = len(tr.finalize())

@@ -194,7 +194,7 @@ def run_resident(config: str, k: int, curve: int = 1):
     return dict(config=config, k=k, mode="resident", seconds={k_: round(v, 4) for k_, v in best.items()},
                 msm_full=ncol + cfg["h_pieces"] + 3, ifft_n=ncol, coset_fft=ncol, ifft_ext=1, extended_k=dom.extended_k,
                 note="columns resident in HBM; includes the real opening argument (k rounds: two multiexps, two inner products, "
-                     "folds, generator collapse, Blake2b transcript on the host)")
+                     "folds, Blake2b transcript on the host; L_j / R_j over the original registered generators)")
 
 
 if __name__ == "__main__":

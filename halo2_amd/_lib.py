@@ -55,6 +55,7 @@ SIGNATURES = {
     "h2_generator_collapse_device": ([C.c_int, vp, C.c_size_t, u64p, C.c_int, vp], C.c_int),
     "h2_fold_scalars": ([C.c_int, u64p, C.c_size_t, u64p, C.c_int], C.c_int),
     "h2_fold_scalars_device": ([C.c_int, vp, C.c_size_t, u64p, C.c_int, vp], C.c_int),
+    "h2_ipa_round_scalars_device": ([C.c_int, vp, C.c_uint, C.c_uint, u64p, C.c_int, vp, vp, vp], C.c_int),
     "h2_lagrange_basis": ([C.c_int, u64p, u64p, C.c_uint, C.c_int], C.c_int),
     "h2_lagrange_basis_device": ([C.c_int, vp, vp, C.c_uint, C.c_int, vp], C.c_int),
     "h2_eval_polynomial": ([C.c_int, u64p, C.c_size_t, u64p, C.c_int, u64p], C.c_int),

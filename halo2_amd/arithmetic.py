@@ -156,6 +156,18 @@ def fold_scalars(a, factor, field: int, form: int = FORM_MONTGOMERY):
     return a[:half]
 
 
+def ipa_round_scalars(p_prime, k: int, j: int, challenges, field: int, out_l, out_r, form: int = FORM_MONTGOMERY) -> None:
+    """Scalars of round j's L_j / R_j (poly/commitment/prover.rs:107-108) over the ORIGINAL generators (see
+    h2_ipa_round_scalars_device): p_prime is the current p' (2^(k-j), 4) CUDA tensor, challenges the j challenges drawn so
+    far, out_l / out_r CUDA tensors whose first 2^k rows are written."""
+    assert p_prime.is_cuda and p_prime.is_contiguous() and out_l.is_cuda and out_r.is_cuda
+    if p_prime.shape[0] != 1 << (k - j) or out_l.shape[0] < 1 << k or out_r.shape[0] < 1 << k or len(challenges) != j:
+        raise ValueError("ipa_round_scalars: shapes do not match (k, j)")
+    ch = np.ascontiguousarray(np.stack(challenges), dtype=np.uint64).reshape(j, 4) if j else None
+    check(lib().h2_ipa_round_scalars_device(field, p_prime.data_ptr(), k, j, _p(ch) if j else None, form, out_l.data_ptr(),
+                                            out_r.data_ptr(), _stream_ptr()), "h2_ipa_round_scalars_device")
+
+
 # ---- polynomial helpers of arithmetic.rs / the opening argument (numpy in -> numpy out; torch CUDA in -> torch out) ----
 def _fe(v) -> np.ndarray:
     return np.ascontiguousarray(v, dtype=np.uint64).reshape(4)

@@ -67,6 +67,7 @@ class Params:
         check(lib().h2_bases_register(curve, _p(self.g_lagrange), self.n, FORM_MONTGOMERY, C.byref(self._h_gl)),
               "h2_bases_register")
         self._w_dev = None
+        self._h_gu = C.c_uint64(0)        # g || u, registered on the first opening argument (opening.py)
 
     @classmethod
     def from_generators(cls, curve: int, k: int, g, g_lagrange, w, u) -> "Params":
@@ -99,7 +100,7 @@ class Params:
         return cls(curve, k, pts[:n], pts[n:2 * n], pts[2 * n], pts[2 * n + 1])
 
     def close(self):
-        for h in (self._h_g, self._h_gl):
+        for h in (self._h_g, self._h_gl, self._h_gu):
             if h.value:
                 lib().h2_bases_free(h)
                 h.value = 0
@@ -158,6 +159,29 @@ class Params:
         check(lib().h2_commit_batch_device(self._h_gl if lagrange else self._h_g, sc, n_, self.n, self._w_dev.data_ptr(), bl,
                                            FORM_MONTGOMERY, OUT_AFFINE if affine else OUT_JACOBIAN, outs, _stream_ptr()),
               "h2_commit_batch_device")
+        return out
+
+    def opening_columns_commit(self, cols, blinds, affine: bool = True):
+        """sum_m col[m] * (g || u)[m] + blind * w for each (n + 1)-row CUDA column: the shape of L_j / R_j
+        (poly/commitment/prover.rs:107-114) once they are written over the original generators (opening.py)."""
+        import torch
+        if not self._h_gu.value:
+            gu = np.ascontiguousarray(np.concatenate([self.g, self.u.reshape(1, 8)]))
+            check(lib().h2_bases_register(self.curve, _p(gu), self.n + 1, FORM_MONTGOMERY, C.byref(self._h_gu)), "h2_bases_register")
+        dev = cols[0].device
+        n_ = len(cols)
+        out = torch.empty((n_, 8 if affine else 12), dtype=torch.int64, device=dev)
+        if self._w_dev is None or self._w_dev.device != dev:
+            self._w_dev = torch.from_numpy(self.w.view(np.int64)).to(dev)
+        d_bl = torch.from_numpy(np.stack([np.ascontiguousarray(b, dtype=np.uint64).reshape(4) for b in blinds]).view(np.int64)).to(dev)
+        arr = C.c_void_p * n_
+        for c_ in cols:
+            if c_.shape[0] != self.n + 1 or not c_.is_contiguous():
+                raise ValueError("opening_columns_commit: columns must hold n + 1 scalars")
+        check(lib().h2_commit_batch_device(self._h_gu, arr(*[c_.data_ptr() for c_ in cols]), n_, self.n + 1, self._w_dev.data_ptr(),
+                                           arr(*[d_bl[i].data_ptr() for i in range(n_)]), FORM_MONTGOMERY,
+                                           OUT_AFFINE if affine else OUT_JACOBIAN, arr(*[out[i].data_ptr() for i in range(n_)]),
+                                           _stream_ptr()), "h2_commit_batch_device")
         return out
 
     def commit(self, poly, r: Blind, affine: bool = False):

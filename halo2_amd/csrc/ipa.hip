@@ -88,12 +88,41 @@ template <int F> __global__ void __launch_bounds__(256) ipa_to_mont(u32 *a, size
     fe_store(a + 8 * i, to ? fe_to_mont<F>(v) : fe_from_mont<F>(v));
 }
 
+// ---- L_j / R_j over the ORIGINAL generators (h2_ipa_round_scalars_device) ----
+// s_j(h) = prod_{r < j} u_r^{bit_{j-1-r}(h)}: round r's collapse pairs index bit k-1-r, which is bit j-1-r of h = m >> (k-j).
+// (verifier.rs:156-172 compute_s builds the same products for the verifier.)  One lane per h, <= j multiplications.
+template <int F>
+__global__ void __launch_bounds__(256) ipa_s_table(u32 *__restrict__ s, const u32 *__restrict__ u_mont, u32 j) {
+    const u32 h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >> j) return;
+    fe acc = fe_one<F>();
+    for (u32 r = 0; r < j; ++r)
+        if ((h >> (j - 1 - r)) & 1) acc = fe_mulx<F>(acc, fe_load(u_mont + 8 * r));
+    fe_store(s + 8 * (size_t)h, acc);
+}
+
+// cl[m] = p'[half + i] s_j(h) for i < half (else 0); cr[m] = p'[i - half] s_j(h) for i >= half (else 0); m = h 2^(k-j) + i.
+// s is Montgomery, so the products keep whatever form p' is in.
+template <int F>
+__global__ void __launch_bounds__(256) ipa_round_scalars(const u32 *__restrict__ p, const u32 *__restrict__ s, u32 k, u32 j,
+                                                         u32 *__restrict__ cl, u32 *__restrict__ cr) {
+    const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >> k) return;
+    const u32 blk = k - j, half = 1u << (blk - 1);
+    const u32 h = m >> blk, i = m & ((1u << blk) - 1);
+    const fe v = fe_mulx<F>(fe_load(p + 8 * (size_t)(i ^ half)), fe_load(s + 8 * (size_t)h));
+    const bool lo = i < half;
+    fe_store(cl + 8 * (size_t)m, lo ? v : fe_zero());
+    fe_store(cr + 8 * (size_t)m, lo ? fe_zero() : v);
+}
+
 struct IpaContext {
     std::mutex mu;
-    DevBuf naf, stage;
+    DevBuf naf, stage, stab;
     void release_all() {
         naf.release();
         stage.release();
+        stab.release();
     }
 };
 static StreamContexts<IpaContext> g_ipa_ctxs;
@@ -248,6 +277,29 @@ static int collapse_launch(int curve, void *d_g, size_t half, const u64 *u, int 
     return H2_OK;
 }
 
+static int round_scalars_launch(int field, const void *d_p, unsigned k, unsigned j, const u64 *challenges, int form, void *d_cl,
+                                void *d_cr, hipStream_t st) {
+    IpaContext &cx = g_ipa_ctxs.get(st);
+    std::lock_guard<std::mutex> lk(cx.mu);
+    u64 um[32 * 4];
+    for (unsigned r = 0; r < j; ++r) host_to_mont(field, um + 4 * r, challenges + 4 * r, form);
+    int rc = cx.stage.reserve(32 * 32);
+    if (rc == H2_OK) rc = cx.stab.reserve(((size_t)32 << j));
+    if (rc != H2_OK) return rc;
+    // stream-ordered after the previous round's kernels that read the staging buffer; pageable source consumed on return
+    if (j) H2_HIP(hipMemcpyAsync(cx.stage.ptr, um, 32 * j, hipMemcpyHostToDevice, st));
+    dim3 block(256), gs((unsigned)((((size_t)1 << j) + 255) / 256)), gc((unsigned)((((size_t)1 << k) + 255) / 256));
+    if (field == H2_FP) {
+        hipLaunchKernelGGL((ipa_s_table<FP>), gs, block, 0, st, cx.stab.as<u32>(), cx.stage.as<u32>(), j);
+        hipLaunchKernelGGL((ipa_round_scalars<FP>), gc, block, 0, st, (const u32 *)d_p, cx.stab.as<u32>(), k, j, (u32 *)d_cl, (u32 *)d_cr);
+    } else {
+        hipLaunchKernelGGL((ipa_s_table<FQ>), gs, block, 0, st, cx.stab.as<u32>(), cx.stage.as<u32>(), j);
+        hipLaunchKernelGGL((ipa_round_scalars<FQ>), gc, block, 0, st, (const u32 *)d_p, cx.stab.as<u32>(), k, j, (u32 *)d_cl, (u32 *)d_cr);
+    }
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
 }  // namespace h2
 
 using namespace h2;
@@ -320,4 +372,14 @@ extern "C" int h2_fold_scalars(int field, uint64_t *a, size_t half, const uint64
     (void)hipFree(d);
     if (e != hipSuccess) { set_last_hip_error(e, __FILE__, __LINE__); return H2_ERR_HIP; }
     return rc;
+}
+
+extern "C" int h2_ipa_round_scalars_device(int field, const void *d_p, unsigned k, unsigned j, const uint64_t *challenges, int form,
+                                           void *d_cl, void *d_cr, void *stream) {
+    if ((field != H2_FP && field != H2_FQ) || (form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY) || k < 1 || k > 30 || j >= k ||
+        (j && !challenges) || !d_p || !d_cl || !d_cr)
+        return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    return round_scalars_launch(field, d_p, k, j, challenges, form, d_cl, d_cr, (hipStream_t)stream);
 }

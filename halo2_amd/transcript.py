@@ -43,7 +43,19 @@ class _Blake2bTranscript:
         return fields.scalar_limbs(self.squeeze_challenge(), self.scalar, True)
 
     def _coords(self, point) -> tuple[int, int]:
-        x, y = fields.from_limbs(np.ascontiguousarray(point, dtype=np.uint64).reshape(2, 4), self.base, True)
+        """Affine (8 limbs) or Jacobian (12 limbs, what `C::Curve` is) -> canonical affine integers.  The Jacobian case is
+        the prover's `.to_affine()` before `write_point` (poly/commitment/prover.rs:116-117): one modular inversion on the
+        host costs microseconds, on the device a 255-step dependent chain on a single lane."""
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1)
+        if point.shape[0] == 12:
+            xj, yj, zj = fields.from_limbs(point.reshape(3, 4), self.base, True)
+            m = fields.MODULUS[self.base]
+            if zj == 0:
+                raise ValueError("cannot write points at infinity to the transcript")    # transcript.rs:209-214
+            zi = pow(zj, -1, m)
+            zi2 = zi * zi % m
+            return xj * zi2 % m, yj * zi2 * zi % m
+        x, y = fields.from_limbs(point.reshape(2, 4), self.base, True)
         if x == 0 and y == 0:
             raise ValueError("cannot write points at infinity to the transcript")        # transcript.rs:209-214
         return x, y

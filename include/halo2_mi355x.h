@@ -173,6 +173,18 @@ int h2_generator_collapse_device(int curve, void *d_g_xy, size_t half, const uin
 /* replaces the p' / b collapse loop (prover.rs:128-131): a[i] += a[half + i] * factor for i < half. */
 int h2_fold_scalars(int field, uint64_t *a, size_t half, const uint64_t *factor, int form);
 int h2_fold_scalars_device(int field, void *d_a, size_t half, const uint64_t *factor, int form, void *stream);
+/* The scalars of round j's L_j / R_j multiexps (prover.rs:107-108) over the ORIGINAL generators instead of the collapsed
+ * G': after j collapses G'[i] = sum_h s_j(h) * G[i + h * 2^(k-j)], where s_j(h) is the product of the challenges u_r, r < j,
+ * selected by the bits of h (bit j-1-r <-> u_r; the products compute_s builds for the verifier, verifier.rs:156-172).  So with
+ * m = h * 2^(k-j) + i and half = 2^(k-j-1):
+ *     L_j = <p'_hi, G'_lo> = sum_m cl[m] * G[m],   cl[m] = p'[half + i] * s_j(h) for i <  half, else 0
+ *     R_j = <p'_lo, G'_hi> = sum_m cr[m] * G[m],   cr[m] = p'[i - half] * s_j(h) for i >= half, else 0
+ * Both become commits over a registered G (h2_commit_batch_device): every round costs two half-empty registered multiexps,
+ * and the generator collapse (prover.rs:136-137, 2^(k-j-1) scalar multiplications per round) is never needed.
+ * d_p: the current p' (2^(k-j) elements); challenges: u_0 .. u_{j-1} (host, `form`; may be NULL when j = 0);
+ * d_cl, d_cr: 2^k elements each, in the form of d_p.  1 <= k <= 30, j < k. */
+int h2_ipa_round_scalars_device(int field, const void *d_p, unsigned k, unsigned j, const uint64_t *challenges, int form,
+                                void *d_cl, void *d_cr, void *stream);
 
 /* ---- Params set-up: Lagrange basis by an FFT over curve points -------------------------------- */
 /* replaces the point FFT + 2^-k scaling + batch_normalize of Params::new

@@ -24,8 +24,11 @@ def _rng(sf, seed):
     return rng
 
 
-@pytest.mark.parametrize("curve,k", [(h.PALLAS, 1), (h.PALLAS, 4), (h.PALLAS, 6), (h.VESTA, 6), (h.VESTA, 11)])
-def test_opening_proof_bytes_and_verification(curve, k):
+@pytest.mark.parametrize("schedule", ["collapse", "original", None])
+@pytest.mark.parametrize("curve,k", [(h.PALLAS, 1), (h.PALLAS, 4), (h.PALLAS, 6), (h.VESTA, 6), (h.VESTA, 11), (h.VESTA, 13)])
+def test_opening_proof_bytes_and_verification(curve, k, schedule):
+    if schedule is None and k != 6:
+        pytest.skip("the default schedule is 'original'; its plumbing is covered once")
     n = 1 << k
     sf = fields.CURVE_FIELDS[curve][1]
     g = co.generate_bases(curve, 50 + k, n)
@@ -41,7 +44,7 @@ def test_opening_proof_bytes_and_verification(curve, k):
     x = tr.squeeze_challenge_scalar()
     v = h.eval_polynomial(px, x, sf)
     tr.write_scalar(v)
-    create_proof(params, _rng(sf, 1000), tr, px, blind, x)
+    create_proof(params, _rng(sf, 1000), tr, px, blind, x, schedule=schedule)
     ch_prover = tr.squeeze_challenge()
     proof = tr.finalize()
     assert len(proof) == 32 + 32 + 32 + 64 * k + 64
@@ -72,3 +75,36 @@ def test_opening_proof_bytes_and_verification(curve, k):
     vt.read_point(), vt.squeeze_challenge(), vt.read_scalar()
     assert not ipa.verify_proof(curve, k, g, w, u, vt, p_int, ox, ov)
     params.close()
+
+
+@pytest.mark.parametrize("field", [h.FP, h.FQ])
+@pytest.mark.parametrize("k,j", [(1, 0), (5, 0), (5, 2), (5, 4), (9, 5), (12, 11)])
+def test_ipa_round_scalars_against_definition(field, k, j):
+    """cl / cr of h2_ipa_round_scalars_device against the definition: p'[i ^ half] * prod of the challenges picked by the
+    bits of h = m >> (k - j), placed by the half i falls in."""
+    import torch
+    from halo2_amd.arithmetic import ipa_round_scalars
+    m_ = fields.MODULUS[field]
+    n, blk = 1 << k, k - j
+    half = 1 << (blk - 1)
+    p_l = co.random_field(field, 300 + k + j, 1 << blk)
+    u_l = co.random_field(field, 400 + k + j, max(j, 1))[:j]
+    p_i = fields.from_limbs(p_l, field, True)
+    u_i = fields.from_limbs(u_l, field, True) if j else []
+    dev = torch.device("cuda:0")
+    d_p = torch.from_numpy(p_l.view(np.int64)).to(dev)
+    d_l = torch.full((n + 1, 4), -1, dtype=torch.int64, device=dev)
+    d_r = torch.full((n + 1, 4), -1, dtype=torch.int64, device=dev)
+    ipa_round_scalars(d_p, k, j, [u_l[r] for r in range(j)], field, d_l, d_r)
+    got_l = fields.from_limbs(d_l[:n].cpu().numpy().view(np.uint64), field, True)
+    got_r = fields.from_limbs(d_r[:n].cpu().numpy().view(np.uint64), field, True)
+    for m in range(n):
+        hh, i = m >> blk, m & ((1 << blk) - 1)
+        s = 1
+        for r in range(j):
+            if (hh >> (j - 1 - r)) & 1:
+                s = s * u_i[r] % m_
+        v = p_i[i ^ half] * s % m_
+        assert got_l[m] == (v if i < half else 0), (m, "l")
+        assert got_r[m] == (0 if i < half else v), (m, "r")
+    assert (d_l[n] == -1).all() and (d_r[n] == -1).all()          # the tail slot belongs to the caller
