@@ -108,3 +108,35 @@ def test_ipa_round_scalars_against_definition(field, k, j):
         assert got_l[m] == (v if i < half else 0), (m, "l")
         assert got_r[m] == (0 if i < half else v), (m, "r")
     assert (d_l[n] == -1).all() and (d_r[n] == -1).all()          # the tail slot belongs to the caller
+
+
+def test_opening_proof_full_size_schedules_agree_and_verify():
+    """k = 20 (BASELINE's size): the two schedules -- independent device algorithms for L_j, R_j -- write identical proof
+    bytes, and the oracle's restatement of the reference verifier (one 2^20 multiexp on the host) accepts them."""
+    curve, k = h.VESTA, 20
+    n = 1 << k
+    sf = fields.CURVE_FIELDS[curve][1]
+    g = co.generate_bases(curve, 77, n)
+    w, u = co.generate_bases(curve, 60, 1)[0], co.generate_bases(curve, 61, 1)[0]
+    params = h.Params(curve, k, g, g, w, u)                        # g_lagrange is not used by the opening argument
+    px = co.random_field(sf, 78, n)
+    blind = h.Blind(co.random_field(sf, 70, 1)[0])
+    p = params.commit(px, blind, affine=True)
+    proofs = []
+    for schedule in ("original", "collapse"):
+        tr = Blake2bWrite(curve)
+        tr.write_point(p)
+        x = tr.squeeze_challenge_scalar()
+        v = h.eval_polynomial(px, x, sf)
+        tr.write_scalar(v)
+        create_proof(params, _rng(sf, 2000), tr, px, blind, x, schedule=schedule)
+        proofs.append(tr.finalize())
+    assert proofs[0] == proofs[1] and len(proofs[0]) == 32 + 32 + 32 + 64 * k + 64
+    p_int = co.affine_to_ints(curve, p)
+    vt = ipa.Transcript(curve, proofs[0])
+    assert vt.read_point() == p_int
+    ox = vt.squeeze_challenge()
+    ov = vt.read_scalar()
+    assert ox == fields.from_limbs(x, sf, True)[0] and ov == fields.from_limbs(v, sf, True)[0]
+    assert ipa.verify_proof(curve, k, g, w, u, vt, p_int, ox, ov)
+    params.close()
