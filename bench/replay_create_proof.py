@@ -129,11 +129,12 @@ def run_trace(config: str, k: int, check: bool, curve: int = 1):
 
 def run_resident(config: str, k: int, curve: int = 1):
     """The same trace with every column resident in HBM (what a device-aware prover would do): phase commits through
-    `Params.commit_batch`, transforms on device tensors, the opening argument through `halo2_amd.opening.create_proof`."""
+    `Params.commit_batch`, transforms on device tensors, then the real multi-point opening (`halo2_amd.multiopen.create_proof`:
+    q' construction, its commit, the q evaluations) ending in the real opening argument (`halo2_amd.opening.create_proof`)."""
     import torch
     import halo2_amd as h
     from halo2_amd import fields
-    from halo2_amd.opening import create_proof
+    from halo2_amd.multiopen import ProverQuery, create_proof
     from halo2_amd.transcript import Blake2bWrite
     from oracle import c_oracle as co          # input generation only
 
@@ -152,7 +153,6 @@ def run_resident(config: str, k: int, curve: int = 1):
     blinds = [h.Blind(co.random_field(sf, 2000 + i, 1)[0]) for i in range(ncol + cfg["h_pieces"] + 3)]
     d_random = up(co.random_field(sf, 3000, n))
     d_h_ext = up(co.random_field(sf, 3001, dom.extended_len()))
-    d_q = up(co.random_field(sf, 3002, n))
     pool = co.random_field(sf, 3003, n + 64)
     pos = [0]
 
@@ -176,15 +176,20 @@ def run_resident(config: str, k: int, curve: int = 1):
         hq = dom.extended_to_coeff(dom.divide_by_vanishing_poly(d_h_ext.clone()))        # vanishing/prover.rs:85-88
         pieces = [hq[i * n:(i + 1) * n].contiguous() if (i + 1) * n <= hq.shape[0] else d_random for i in range(cfg["h_pieces"])]
         params.commit_batch(pieces, blinds[ncol + 1: ncol + 1 + cfg["h_pieces"]])         # vanishing/prover.rs:105
-        params.commit(d_q, blinds[-2])                                                   # multiopen/prover.rs:97
         torch.cuda.synchronize()
-        t["vanishing + multiopen commits, quotient iFFT"] = time.perf_counter() - t1
+        t["vanishing: random_poly + h-piece commits, quotient iFFT"] = time.perf_counter() - t1
         t2 = time.perf_counter()
         tr = Blake2bWrite(curve)
-        x3 = tr.squeeze_challenge_scalar()
-        create_proof(params, rng, tr, d_q, blinds[-2], x3)                               # commitment/prover.rs:26-151
+        x, xw, xwi = (tr.squeeze_challenge_scalar() for _ in range(3))                   # stand-ins for x, omega x, omega^-1 x
+        # the query shape of plonk/prover.rs:664-722: every column at x, two also at omega x, one of them at omega^-1 x as well;
+        # the h pieces and random_poly at x
+        queries = [ProverQuery(x, c, blinds[i]) for i, c in enumerate(coeffs)]
+        queries += [ProverQuery(xw, coeffs[0], blinds[0]), ProverQuery(xw, coeffs[1], blinds[1]), ProverQuery(xwi, coeffs[1], blinds[1])]
+        queries += [ProverQuery(x, pc, blinds[ncol + 1 + i]) for i, pc in enumerate(pieces) if pc is not d_random]
+        queries += [ProverQuery(x, d_random, blinds[ncol])]
+        create_proof(params, rng, tr, queries)                                           # multiopen/prover.rs:21-125
         torch.cuda.synchronize()
-        t["opening argument (create_proof)"] = time.perf_counter() - t2
+        t["multiopen (q', its commit, evaluations) + opening argument"] = time.perf_counter() - t2
         t["total"] = time.perf_counter() - t0
         del exts
         return t
@@ -193,8 +198,8 @@ def run_resident(config: str, k: int, curve: int = 1):
     params.close()
     return dict(config=config, k=k, mode="resident", seconds={k_: round(v, 4) for k_, v in best.items()},
                 msm_full=ncol + cfg["h_pieces"] + 3, ifft_n=ncol, coset_fft=ncol, ifft_ext=1, extended_k=dom.extended_k,
-                note="columns resident in HBM; includes the real opening argument (k rounds: two multiexps, two inner products, "
-                     "folds, Blake2b transcript on the host; L_j / R_j over the original registered generators)")
+                note="columns resident in HBM; ends with the real multi-point opening and opening argument (k rounds: two multiexps, "
+                     "two inner products, folds, Blake2b transcript on the host; L_j / R_j over the original registered generators)")
 
 
 if __name__ == "__main__":

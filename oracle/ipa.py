@@ -128,14 +128,15 @@ def create_proof(curve, k, g, w, u, rng, transcript: Transcript, p_poly, p_blind
     transcript.write_scalar(f)
 
 
-def verify_proof(curve, k, g, w, u, transcript: Transcript, commitment, x: int, v: int) -> bool:
+def verify_proof(curve, k, g, w, u, transcript: Transcript, commitment, x: int, v: int, terms=None) -> bool:
     """verifier.rs:65-141 followed by Guard::use_challenges (:35-41) and MSM::eval: True iff the opening is accepted.
-    `commitment`: canonical affine (x, y) of P; x, v canonical integers."""
+    `commitment`: canonical affine (x, y) of P; x, v canonical integers.  `terms`: the caller's `msm` as a list of
+    (scalar, point) pairs when it is more than [1] P (multiopen/verifier.rs:127-139); then `commitment` is ignored."""
     sf = co.field_of_curve(curve, "scalar")
     m = o.CURVES[curve][1]
     n = 1 << k
     L = lambda vals: co.to_mont(sf, co.ints_to_limbs([t % m for t in vals]))
-    terms = [(1, commitment)]                                   # the caller's msm: [1] P
+    terms = [(1, commitment)] if terms is None else list(terms)   # the caller's msm: [1] P
     g_scalars = [0] * n
     g_scalars[0] = -v                                           # add_constant_term(-v): [-v] G_0
     s_commitment = transcript.read_point()
