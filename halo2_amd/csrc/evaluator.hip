@@ -11,7 +11,7 @@
 //   POLY p, r       polys[p][(i + r) mod len]      r = rotation * step, step = 1 (Lagrange) or 2^(ext_k - k) (extended)
 //   CONST c         Lagrange / extended: c at every i;  coefficient basis: c at i = 0, else 0
 //   LINEAR c        Lagrange / extended: c * omega^i (the caller folds ZETA into c for the extended basis);  coefficient basis: c at i = 1
-//   ADD, MUL        element-wise (MUL: extended basis only, as in the reference)
+//   ADD, MUL        element-wise (MUL: not in the coefficient basis)
 //   SCALE c         x * c
 //   MULADD b        DistributePowers fold: acc * b + term
 #include <vector>
@@ -132,7 +132,9 @@ extern "C" int h2_evaluate_device(int field, int basis, const uint32_t *program,
                 if (arg >= n_consts || depth < 1) return H2_ERR_ARGS;
                 break;
             case EV_MUL:
-                if (basis != 2) return H2_ERR_ARGS;                    // AstMul exists for the extended basis only (:228-233)
+                // the reference's Ast has Mul for the extended basis only (:228-233); row-wise products of Lagrange columns are
+                // what the permutation / lookup grand products are made of (plonk/permutation/prover.rs:101-141), so they run here too
+                if (basis == 0) return H2_ERR_ARGS;
                 [[fallthrough]];
             case EV_ADD:
                 if (depth < 2) return H2_ERR_ARGS;

@@ -77,10 +77,14 @@ def _as_ast(x) -> Ast:
 
 
 class Evaluator:
-    def __init__(self, basis: int):
+    def __init__(self, basis: int, row_products: bool = False):
+        """row_products: also allow `*` over Lagrange-basis columns -- not a polynomial product (the reference's Ast has none
+        outside the extended basis) but the row-wise products the permutation / lookup arguments form with plain loops
+        (plonk/permutation/prover.rs:101-141)."""
         if basis not in (COEFF, LAGRANGE, EXTENDED):
             raise ValueError("unknown basis")
         self.basis, self.polys = basis, []
+        self.row_products = bool(row_products) and basis == LAGRANGE
 
     def register_poly(self, poly) -> AstLeaf:             # evaluator.rs:118-127
         if self.polys and poly.shape != self.polys[0].shape:
@@ -124,7 +128,7 @@ class Evaluator:
             zeta = domain.g_coset if self.basis == EXTENDED else 1                          # F::ZETA, evaluator.rs:595
             words.append(_LINEAR | const_index(ast.args[0] * zeta) << 8)
         elif k in ("add", "mul"):
-            if k == "mul" and self.basis != EXTENDED:
+            if k == "mul" and self.basis != EXTENDED and not self.row_products:
                 raise ValueError("Ast multiplication exists for the extended Lagrange basis only")
             first, second = ast.args
             if self._need(second) > self._need(first):       # + and * commute: deeper side first keeps the stack shallow

@@ -28,6 +28,12 @@ def zeta(field: int) -> int:
     return z * z % m if field == FP else z
 
 
+def delta(field: int) -> int:
+    """ff::PrimeField::DELTA = MULTIPLICATIVE_GENERATOR^(2^S): generator of the odd-order subgroup; separates the columns of the
+    permutation argument (plonk/permutation/prover.rs:141, keygen.rs)."""
+    return pow(MULTIPLICATIVE_GENERATOR, 1 << S, MODULUS[field])
+
+
 def to_limbs(vals, field: int | None = None, montgomery: bool = True) -> np.ndarray:
     """ints -> (n, 4) uint64 limbs; Montgomery form (x * 2^256 mod p) when `montgomery`."""
     vals = list(vals)
