@@ -132,8 +132,7 @@ extern "C" int h2_evaluate_device(int field, int basis, const uint32_t *program,
                 if (arg >= n_consts || depth < 1) return H2_ERR_ARGS;
                 break;
             case EV_MUL:
-                // the reference's Ast has Mul for the extended basis only (:228-233); row-wise products of Lagrange columns are
-                // what the permutation / lookup grand products are made of (plonk/permutation/prover.rs:101-141), so they run here too
+                // Mul exists for Ast<_, _, LagrangeCoeff> and Ast<_, _, ExtendedLagrangeCoeff> (evaluator.rs:370-418)
                 if (basis == 0) return H2_ERR_ARGS;
                 [[fallthrough]];
             case EV_ADD:

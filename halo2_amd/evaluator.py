@@ -66,7 +66,7 @@ class Ast:
     def __neg__(self):                                    # :300-316: Scale(-1)
         return Ast("scale", self, -1)
 
-    def __mul__(self, other):                             # Mul<Ast> (extended basis only, :362-390) or Mul<F> = Scale (:392-410)
+    def __mul__(self, other):                             # Mul<Ast> (Lagrange and extended bases, :370-418) or Mul<F> = Scale (:420-434)
         if isinstance(other, Ast) or isinstance(other, AstLeaf):
             return Ast("mul", self, _as_ast(other))
         return Ast("scale", self, int(other))
@@ -77,14 +77,10 @@ def _as_ast(x) -> Ast:
 
 
 class Evaluator:
-    def __init__(self, basis: int, row_products: bool = False):
-        """row_products: also allow `*` over Lagrange-basis columns -- not a polynomial product (the reference's Ast has none
-        outside the extended basis) but the row-wise products the permutation / lookup arguments form with plain loops
-        (plonk/permutation/prover.rs:101-141)."""
+    def __init__(self, basis: int):
         if basis not in (COEFF, LAGRANGE, EXTENDED):
             raise ValueError("unknown basis")
         self.basis, self.polys = basis, []
-        self.row_products = bool(row_products) and basis == LAGRANGE
 
     def register_poly(self, poly) -> AstLeaf:             # evaluator.rs:118-127
         if self.polys and poly.shape != self.polys[0].shape:
@@ -128,8 +124,9 @@ class Evaluator:
             zeta = domain.g_coset if self.basis == EXTENDED else 1                          # F::ZETA, evaluator.rs:595
             words.append(_LINEAR | const_index(ast.args[0] * zeta) << 8)
         elif k in ("add", "mul"):
-            if k == "mul" and self.basis != EXTENDED and not self.row_products:
-                raise ValueError("Ast multiplication exists for the extended Lagrange basis only")
+            if k == "mul" and self.basis == COEFF:
+                # `Mul` is implemented for Ast<_, _, LagrangeCoeff> and Ast<_, _, ExtendedLagrangeCoeff> (evaluator.rs:370-418)
+                raise ValueError("Ast multiplication exists for the Lagrange bases only")
             first, second = ast.args
             if self._need(second) > self._need(first):       # + and * commute: deeper side first keeps the stack shallow
                 first, second = second, first

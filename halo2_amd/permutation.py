@@ -3,7 +3,7 @@ the grand products z_i over column chunks, their commitments, the constraint exp
 the evaluations and the opening queries.  Everything O(n) runs on the device:
 
 * the row fractions prod_j (v_j + delta^j omega^i beta + gamma) / (v_j + beta s_j + gamma) (prover.rs:101-141) are two
-  `h2_evaluate_device` programs over the Lagrange columns (row-wise products, `Evaluator(LAGRANGE, row_products=True)`; the
+  `h2_evaluate_device` programs over the Lagrange columns (products in the Lagrange basis are row-wise, evaluator.rs:370-392; the
   delta^j omega^i beta term is an `Ast.linear`) around one `h2_batch_invert_device`;
 * the running product z (:153-160) is `h2_grand_product_device`;
 * commit_lagrange, lagrange_to_coeff, coeff_to_extended (:172-178) are the registered commit and the NTT entry points.
@@ -64,7 +64,7 @@ class Argument:
         for c0 in range(0, self.num_columns, chunk_len):
             cols = columns[c0:c0 + chunk_len]
             perms = pkey.permutations[c0:c0 + chunk_len]
-            rows = Evaluator(LAGRANGE, row_products=True)
+            rows = Evaluator(LAGRANGE)
             v_leaves = [rows.register_poly(v) for v in cols]
             s_leaves = [rows.register_poly(s) for s in perms]
             den = None

@@ -233,8 +233,7 @@ int h2_grand_product_device(int field, const void *d_m, size_t n, const uint64_t
  *                basis, * 2^(extended_k - k) for the extended basis; must be 0 in the coefficient basis, evaluator.rs:519)
  *   H2_EV_CONST  operand = constant index (Ast::ConstantTerm)      H2_EV_LINEAR  operand = constant index (Ast::LinearTerm:
  *                value consts[c] * omega^i; the caller folds ZETA into the constant for the extended basis, :590-600)
- *   H2_EV_ADD, H2_EV_MUL (row-wise; not in the coefficient basis.  The reference's Ast multiplies in the extended basis only;
- *                the Lagrange-basis case is the row products of plonk/permutation/prover.rs:101-141), H2_EV_SCALE operand = constant index,
+ *   H2_EV_ADD, H2_EV_MUL (element-wise; Lagrange and extended bases, as in the reference: evaluator.rs:370-418), H2_EV_SCALE operand = constant index,
  *   H2_EV_MULADD operand = constant index of the base: one fold step acc * base + term of Ast::DistributePowers (:186-196)
  * basis: 0 coefficient, 1 Lagrange, 2 extended Lagrange.  consts: n_consts field elements, d_polys: n_polys device
  * vectors of 2^log_len elements, all in MONTGOMERY form (products of canonical-form data would not be canonical).

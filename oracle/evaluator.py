@@ -21,7 +21,7 @@ def evaluate(tree, polys, basis: int, m: int, k: int, extended_k: int, omega: in
         if kind == "add":
             return [(a + b) % m for a, b in zip(rec(t[1]), rec(t[2]))]
         if kind == "mul":
-            assert basis == EXTENDED
+            assert basis != COEFF                              # Mul: Lagrange and extended bases (:370-418)
             return [a * b % m for a, b in zip(rec(t[1]), rec(t[2]))]
         if kind == "scale":
             return [a * t[2] % m for a in rec(t[1])]

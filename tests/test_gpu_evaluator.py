@@ -38,7 +38,7 @@ def _random_tree(rng, leaves, basis, m, depth):
     if r < 45:
         b, tb = _random_tree(rng, leaves, basis, m, depth - 1)
         return a + b, ("add", ta, tb)
-    if r < 60 and basis == EXTENDED:
+    if r < 60 and basis != COEFF:
         b, tb = _random_tree(rng, leaves, basis, m, depth - 1)
         return a * b, ("mul", ta, tb)
     if r < 75:
@@ -92,7 +92,7 @@ def test_rejected_trees():
     with pytest.raises(ValueError):
         ev_c.evaluate(Ast.of(a.with_rotation(1)), dom)               # "Can't rotate polynomials in the standard basis"
     with pytest.raises(ValueError):
-        ev_l.evaluate(Ast.of(b) * Ast.of(b), dom)                    # Mul exists for the extended basis only
+        ev_c.evaluate(Ast.of(a) * Ast.of(a), dom)                    # Mul exists for the two Lagrange bases only (evaluator.rs:370-418)
     with pytest.raises(ValueError):
         ev_l.evaluate(Ast.of(c), dom)                                # leaf of another evaluator
     with pytest.raises(ValueError):
