@@ -7,7 +7,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-H2_OK, H2_ERR_ARGS, H2_ERR_HIP, H2_ERR_NODEV, H2_ERR_HANDLE, H2_ERR_DECODE = 0, 1, 2, 3, 4, 5
+H2_OK, H2_ERR_ARGS, H2_ERR_HIP, H2_ERR_NODEV, H2_ERR_HANDLE, H2_ERR_DECODE, H2_ERR_LOOKUP = 0, 1, 2, 3, 4, 5, 6
 FP, FQ = 0, 1
 PALLAS, VESTA = 0, 1
 FORM_CANONICAL, FORM_MONTGOMERY = 0, 1
@@ -74,6 +74,8 @@ SIGNATURES = {
     "h2_grand_product_device": ([C.c_int, vp, C.c_size_t, u64p, C.c_int, vp, vp], C.c_int),
     "h2_evaluate_device": ([C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_size_t, u64p, C.c_size_t, C.POINTER(vp), C.c_size_t, C.c_uint,
                             u64p, vp, vp], C.c_int),
+    "h2_sort_device": ([C.c_int, vp, C.c_size_t, C.c_int, vp], C.c_int),
+    "h2_permute_expression_pair_device": ([C.c_int, vp, vp, C.c_size_t, C.c_int, vp, vp, vp], C.c_int),
     "h2_points_compress": ([C.c_int, u64p, C.c_size_t, C.c_int, C.POINTER(C.c_uint8)], C.c_int),
     "h2_points_compress_device": ([C.c_int, vp, C.c_size_t, C.c_int, vp, vp], C.c_int),
     "h2_points_decompress": ([C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.c_int, u64p], C.c_int),
@@ -123,12 +125,18 @@ class H2Error(RuntimeError):
     pass
 
 
+class ConstraintSystemFailure(ValueError):
+    """plonk::Error::ConstraintSystemFailure (plonk/error.rs): the witness does not satisfy the circuit."""
+
+
 def check(rc: int, what: str):
     if rc == H2_OK:
         return
     if rc == H2_ERR_ARGS:
         # the reference panics (assert_eq!) on bad lengths: arithmetic.rs:144, :205
         raise ValueError(f"{what}: bad arguments")
+    if rc == H2_ERR_LOOKUP:
+        raise ConstraintSystemFailure(f"{what}: an input value does not occur in the table")    # lookup/prover.rs:609-611
     if rc == H2_ERR_DECODE:
         raise ValueError(f"{what}: invalid point encoding")      # the reference returns io::Error (commitment.rs:193-198)
     msg = lib().h2_last_error().decode()

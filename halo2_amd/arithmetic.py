@@ -168,6 +168,30 @@ def ipa_round_scalars(p_prime, k: int, j: int, challenges, field: int, out_l, ou
                                             out_r.data_ptr(), _stream_ptr()), "h2_ipa_round_scalars_device")
 
 
+def sort_field(a, field: int, form: int = FORM_MONTGOMERY):
+    """`Vec<F>::sort()` as the lookup prover uses it (plonk/lookup/prover.rs:574): ascending by canonical value.  CUDA tensor,
+    in place."""
+    assert a.is_cuda and a.is_contiguous()
+    check(lib().h2_sort_device(field, a.data_ptr(), a.shape[0], form, _stream_ptr()), "h2_sort_device")
+    return a
+
+
+def permute_expression_pair(input_expression, table_expression, usable_rows: int, field: int, form: int = FORM_MONTGOMERY):
+    """`permute_expression_pair` over the usable rows (plonk/lookup/prover.rs:557-623): (A', S') as new CUDA tensors of
+    `usable_rows` elements; the caller appends the blinding rows (:624-627).  Raises ConstraintSystemFailure when an input value
+    does not occur in the table (:609-611)."""
+    import torch
+    assert input_expression.is_cuda and table_expression.is_cuda
+    if input_expression.shape[0] < usable_rows or table_expression.shape[0] < usable_rows:
+        raise ValueError("permute_expression_pair: columns shorter than usable_rows")
+    a = torch.empty((usable_rows, 4), dtype=input_expression.dtype, device=input_expression.device)
+    s = torch.empty_like(a)
+    check(lib().h2_permute_expression_pair_device(field, _dev_vec(input_expression).data_ptr(), _dev_vec(table_expression).data_ptr(),
+                                                  usable_rows, form, a.data_ptr(), s.data_ptr(), _stream_ptr()),
+          "h2_permute_expression_pair_device")
+    return a, s
+
+
 # ---- polynomial helpers of arithmetic.rs / the opening argument (numpy in -> numpy out; torch CUDA in -> torch out) ----
 def _fe(v) -> np.ndarray:
     return np.ascontiguousarray(v, dtype=np.uint64).reshape(4)

@@ -135,5 +135,6 @@ extern "C" int h2_trim(void) {
     h2::poly_release_workspaces();
     h2::ipa_release_workspaces();
     h2::eval_release_workspaces();
+    h2::lookup_release_workspaces();
     return H2_OK;
 }

@@ -93,6 +93,7 @@ void ntt_release_workspaces();
 void poly_release_workspaces();
 void ipa_release_workspaces();
 void eval_release_workspaces();
+void lookup_release_workspaces();
 
 // Confirms a usable gfx950 device exists; every entry point calls this first so a missing GPU or
 // runtime fails loudly (H2_ERR_NODEV) instead of silently doing nothing.

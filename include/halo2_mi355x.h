@@ -43,7 +43,8 @@ extern "C" {
 #define H2_ERR_HIP 2    /* a HIP runtime call failed; see h2_last_error() */
 #define H2_ERR_NODEV 3  /* no gfx950 device / HIP runtime unavailable */
 #define H2_ERR_HANDLE 4 /* unknown or freed handle */
-#define H2_ERR_DECODE 5 /* a compressed point does not decode (where pasta_curves' from_bytes returns None) */
+#define H2_ERR_DECODE 5
+#define H2_ERR_LOOKUP 6 /* permute_expression_pair: an input value does not occur in the table (Error::ConstraintSystemFailure) */ /* a compressed point does not decode (where pasta_curves' from_bytes returns None) */
 
 #define H2_FP 0
 #define H2_FQ 1
@@ -248,6 +249,18 @@ int h2_grand_product_device(int field, const void *d_m, size_t n, const uint64_t
 int h2_evaluate_device(int field, int basis, const uint32_t *program, size_t n_words, const uint64_t *consts, size_t n_consts,
                        const void *const *d_polys, size_t n_polys, unsigned log_len, const uint64_t *omega, void *d_out,
                        void *stream);
+
+/* ---- lookup argument: the data-dependent step (plonk/lookup/prover.rs:557-647) ----------------------------------- */
+/* `Vec<F>::sort()` as the prover uses it (:574): ascending by canonical value, in place.  n need not be a power of two. */
+int h2_sort_device(int field, void *d_a, size_t n, int form, void *stream);
+/* replaces permute_expression_pair over the `n` usable rows (the caller appends the blinding rows, :624-627):
+ * permuted_input = the input values sorted ascending; permuted_table[i] = permuted_input[i] on the first row of every run
+ * of equal input values, and the table values not consumed that way -- ascending -- on the repeated rows taken from the
+ * last one up (the reference pops them off the end of its list, :617-622).  Returns H2_ERR_LOOKUP when an input value does
+ * not occur in the table (Error::ConstraintSystemFailure, :609-611).  Synchronises `stream` (the status has to reach the
+ * host).  Inputs are not modified; outputs hold n elements each and may not alias the inputs. */
+int h2_permute_expression_pair_device(int field, const void *d_input, const void *d_table, size_t n, int form,
+                                      void *d_permuted_input, void *d_permuted_table, void *stream);
 
 /* ---- compressed points: the URS file and proof encoding --------------------------------------- */
 /* pasta_curves `to_bytes` as Params::write uses it (halo2_proofs/src/poly/commitment.rs:169-181) and write_point
