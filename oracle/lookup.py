@@ -75,3 +75,42 @@ def verifier_expressions(product_eval, product_next_eval, permuted_input_eval, p
         l_0 * (permuted_input_eval - permuted_table_eval) % m,
         (permuted_input_eval - permuted_table_eval) * (permuted_input_eval - permuted_input_inv_eval) % m * active % m,
     ]
+
+
+def commit_permuted(curve, g_lagrange, w, blinding_factors: int, compressed_input, compressed_table, rng, transcript):
+    """prover.rs:192-222 on integers: permute, append the blinding rows, commit A' then S'.  Returns
+    (A', S', A' blind, S' blind) or raises on ConstraintSystemFailure."""
+    import numpy as np
+    from . import c_oracle as co
+    sf = co.field_of_curve(curve, "scalar")
+    I = lambda limbs: co.limbs_to_ints(co.from_mont(sf, np.ascontiguousarray(limbs).reshape(-1, 4)))
+    L = lambda vals: co.to_mont(sf, co.ints_to_limbs(list(vals)))
+    n = len(compressed_input)
+    usable = n - (blinding_factors + 1)
+    pair = permute_expression_pair(compressed_input, compressed_table, usable)
+    if pair is None:
+        raise ValueError("ConstraintSystemFailure")
+    a = pair[0] + I(rng(blinding_factors + 1))
+    s = pair[1] + I(rng(blinding_factors + 1))
+    a_blind_l = rng(1)[0].copy()
+    a_comm = co.jac_to_affine_ints(curve, co.commit(curve, g_lagrange, w, L(a), a_blind_l))
+    s_blind_l = rng(1)[0].copy()
+    s_comm = co.jac_to_affine_ints(curve, co.commit(curve, g_lagrange, w, L(s), s_blind_l))
+    transcript.write_point(a_comm)
+    transcript.write_point(s_comm)
+    return a, s, I(a_blind_l)[0], I(s_blind_l)[0]
+
+
+def commit_product(curve, g_lagrange, w, blinding_factors: int, compressed_input, compressed_table, permuted_input, permuted_table,
+                   beta: int, gamma: int, m: int, rng, transcript):
+    """prover.rs:263-370 on integers -> (z Lagrange, blind)."""
+    import numpy as np
+    from . import c_oracle as co
+    sf = co.field_of_curve(curve, "scalar")
+    I = lambda limbs: co.limbs_to_ints(co.from_mont(sf, np.ascontiguousarray(limbs).reshape(-1, 4)))
+    L = lambda vals: co.to_mont(sf, co.ints_to_limbs(list(vals)))
+    z = product(compressed_input, compressed_table, permuted_input, permuted_table, beta, gamma,
+                I(rng(blinding_factors)) if blinding_factors else [], m)
+    blind_l = rng(1)[0].copy()
+    transcript.write_point(co.jac_to_affine_ints(curve, co.commit(curve, g_lagrange, w, L(z), blind_l)))
+    return z, I(blind_l)[0]
