@@ -71,9 +71,21 @@ class Ast:
             return Ast("mul", self, _as_ast(other))
         return Ast("scale", self, int(other))
 
+    # integers on the left (`1 - a`, `3 * a`): lowered gate expressions are written once and applied to Asts or to evaluations
+    def __radd__(self, other):
+        return _as_ast(other) + self
+
+    def __rsub__(self, other):
+        return _as_ast(other) - self
+
+    def __rmul__(self, other):
+        return self * other
+
 
 def _as_ast(x) -> Ast:
-    return Ast.of(x) if isinstance(x, AstLeaf) else x
+    if isinstance(x, AstLeaf):
+        return Ast.of(x)
+    return x if isinstance(x, Ast) else Ast.constant(int(x))         # a bare integer is Ast::ConstantTerm
 
 
 class Evaluator:

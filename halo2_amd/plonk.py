@@ -1,0 +1,233 @@
+"""`plonk::create_proof` after synthesis (halo2_proofs/src/plonk/prover.rs:35-724) and the part of `keygen_pk` that
+turns fixed columns and the copy-constraint mapping into the three bases (plonk/keygen.rs:296-380, permutation/keygen.rs:163-190),
+for ONE circuit instance whose columns are already assigned.  This module is orchestration: it sequences the device
+arguments (`halo2_amd.{permutation, lookup, vanishing, multiopen, opening}`), the column commits / iFFTs / coset FFTs and the
+transcript exactly in the reference's order.  What it does not do is run a `Circuit` (floor planning, region assignment,
+selector compression, `Expression<F>` construction): the caller hands over the constraint system in lowered form --
+
+* a gate polynomial or a lookup expression is a callable `cells -> value` using `cells.fixed(col, rot)`, `cells.advice(col, rot)`,
+  `cells.instance(col, rot)` and `+ - *` (integers are constants).  The prover applies it to `Ast` leaves, a verifier to
+  evaluations -- the same role `Expression::evaluate` plays with its closures (prover.rs:553-580, verifier.rs:251-265);
+* queries are (column, rotation) lists in the order the reference's `ConstraintSystem` would have recorded them.
+
+`vk_repr` stands in for `VerifyingKey::transcript_repr` (plonk.rs:94-101; a hash of the Rust Debug print of the pinned
+key, not reproducible without the reference's types).  torch is plumbing; all arithmetic goes through the C ABI."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import fields
+from . import lookup as lookup_arg
+from . import multiopen, permutation
+from . import vanishing as vanishing_arg
+from .arithmetic import eval_polynomial
+from .commitment import Blind, Params
+from .evaluator import EXTENDED, LAGRANGE, Ast, Evaluator
+from .multiopen import ProverQuery
+
+
+@dataclass
+class ConstraintSystem:
+    """The lowered plonk::ConstraintSystem (plonk/circuit.rs:955-1010)."""
+    num_fixed_columns: int
+    num_advice_columns: int
+    num_instance_columns: int
+    gates: list                       # callables cells -> value, one per gate polynomial (Gate::polynomials, flattened)
+    advice_queries: list              # (column, rotation)
+    instance_queries: list
+    fixed_queries: list
+    permutation_columns: list = field(default_factory=list)      # ("advice" | "fixed" | "instance", index), permutation::Argument
+    lookups: list = field(default_factory=list)                  # (input expressions, table expressions): lists of callables
+    degree: int = 3                   # ConstraintSystem::degree() (circuit.rs:1483-1531)
+    blinding_factors: int = 5         # ConstraintSystem::blinding_factors() (circuit.rs:1535-1569)
+
+
+class _Cells:
+    """What a lowered expression sees: column queries as Ast leaves with rotations."""
+
+    def __init__(self, fixed, advice, instance):
+        self._f, self._a, self._i = fixed, advice, instance
+
+    def fixed(self, col: int, rot: int = 0):
+        return Ast.of(self._f[col].with_rotation(rot))
+
+    def advice(self, col: int, rot: int = 0):
+        return Ast.of(self._a[col].with_rotation(rot))
+
+    def instance(self, col: int, rot: int = 0):
+        return Ast.of(self._i[col].with_rotation(rot))
+
+
+def _host(t) -> np.ndarray:
+    return t.cpu().numpy().view(np.uint64)
+
+
+def _up(col, sf, dev):
+    """A column as an (n, 4) Montgomery CUDA tensor: integer lists are converted, CUDA tensors are copied."""
+    import torch
+    if type(col).__module__.startswith("torch"):
+        return col.to(dev).clone()
+    return torch.from_numpy(fields.to_limbs(col, sf, True).view(np.int64)).to(dev)
+
+
+class ProvingKey:
+    """plonk::ProvingKey (plonk.rs:118-130) with its VerifyingKey parts the prover needs."""
+
+    def __init__(self, cs: ConstraintSystem, domain, vk_repr: int, fixed_values, fixed_polys, fixed_cosets, perm_values, perm_polys,
+                 perm_cosets, l0, l_blind, l_last):
+        self.cs, self.domain, self.vk_repr = cs, domain, vk_repr
+        self.fixed_values, self.fixed_polys, self.fixed_cosets = fixed_values, fixed_polys, fixed_cosets
+        self.perm_values, self.perm_polys, self.perm_cosets = perm_values, perm_polys, perm_cosets
+        self.l0, self.l_blind, self.l_last = l0, l_blind, l_last
+
+
+def keygen_pk(params: Params, cs: ConstraintSystem, fixed_columns, mapping, vk_repr: int, device=None) -> ProvingKey:
+    """keygen.rs:296-380 after `synthesize`.  fixed_columns: integer lists of n rows; mapping[c][r] = (c', r') the cell that
+    follows (c, r) in its copy-constraint cycle (permutation/keygen.rs:24-107), identity where unconstrained."""
+    import torch
+    from .domain import EvaluationDomain
+    dev = torch.device(device or "cuda:0")
+    sf = fields.CURVE_FIELDS[params.curve][1]
+    n, k = params.n, params.k
+    domain = EvaluationDomain(cs.degree, k, sf)
+    m = domain.m
+
+    def three(lagrange):
+        coeff = domain.lagrange_to_coeff(lagrange.clone())
+        return lagrange, coeff, domain.coeff_to_extended(coeff)
+    fixed = [three(_up(col, sf, dev)) for col in fixed_columns]
+    # sigma_c(omega^r) = delta^c' omega^r' (permutation/keygen.rs:163-190): the delta^c omega^r tables are Lagrange-basis linear terms
+    n_perm = len(cs.permutation_columns)
+    perms = []
+    if n_perm:
+        rows = Evaluator(LAGRANGE)
+        rows.register_poly(torch.zeros((n, 4), dtype=torch.int64, device=dev))
+        delta = fields.delta(sf)
+        table = torch.cat([rows.evaluate(Ast.linear(pow(delta, c, m)), domain) for c in range(n_perm)])      # (n_perm * n, 4)
+        for c in range(n_perm):
+            if isinstance(mapping, np.ndarray):
+                idx = torch.from_numpy(np.ascontiguousarray(mapping[c], dtype=np.int64)).to(dev)
+            else:
+                idx = torch.tensor([mapping[c][r][0] * n + mapping[c][r][1] for r in range(n)], dtype=torch.int64, device=dev)
+            perms.append(three(table.index_select(0, idx).contiguous()))
+    usable = n - (cs.blinding_factors + 1)
+    one = _up([1], sf, dev)[0]
+
+    def indicator(rows_):
+        v = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+        for r in rows_:
+            v[r] = one
+        return three(v)[2]
+    l0 = indicator([0])                                                     # keygen.rs:343-349
+    l_blind = indicator(range(usable + 1, n))                               # :353-359
+    l_last = indicator([usable])                                            # :363-368
+    return ProvingKey(cs, domain, vk_repr, [t[0] for t in fixed], [t[1] for t in fixed], [t[2] for t in fixed],
+                      [t[0] for t in perms], [t[1] for t in perms], [t[2] for t in perms], l0, l_blind, l_last)
+
+
+def create_proof(params: Params, pk: ProvingKey, advice_columns, instance_columns, rng, transcript, schedule: str | None = None) -> None:
+    """prover.rs:35-724 for one circuit.  advice_columns: integer lists or (n, 4) CUDA tensors (n rows; the last
+    blinding_factors + 1 are overwritten with randomness, :293-298); instance_columns: integer lists of at most
+    n - (blinding_factors + 1) values (:84-86);
+    rng(count) -> (count, 4) Montgomery limbs, drawn in the reference's order."""
+    import torch
+    cs, domain = pk.cs, pk.domain
+    sf, m, n = domain.field, domain.m, params.n
+    bf = cs.blinding_factors
+    usable = n - (bf + 1)
+    dev = pk.l0.device
+    lim = lambda v: fields.scalar_limbs(v % m, sf, True)
+    if len(instance_columns) != cs.num_instance_columns or len(advice_columns) != cs.num_advice_columns:
+        raise ValueError("InvalidInstances")                                              # :53-57
+
+    transcript.common_scalar(lim(pk.vk_repr))                                             # vk.hash_into, :60
+
+    def three(lagrange):
+        coeff = domain.lagrange_to_coeff(lagrange.clone())
+        return lagrange, coeff, domain.coeff_to_extended(coeff)
+
+    # instance columns: commit (blind 1), absorb, three bases (:77-130)
+    inst = []
+    for values in instance_columns:
+        if len(values) > usable:
+            raise ValueError("InstanceTooLarge")                                          # :84-86
+        lag = torch.zeros((n, 4), dtype=torch.int64, device=dev)                          # poly.resize(n, 0), :80-90
+        if len(values):
+            lag[:len(values)] = _up(values, sf, dev)
+        transcript.common_point(_host(params.commit_lagrange(lag, Blind(field=sf))))      # :94-105
+        inst.append(three(lag))
+
+    # advice columns: blinding rows, blinds, commitments (:293-341)
+    adv_lag = [_up(col, sf, dev) for col in advice_columns]
+    for lag in adv_lag:
+        lag[usable:] = torch.from_numpy(np.ascontiguousarray(rng(bf + 1), dtype=np.uint64).view(np.int64)).to(dev)
+    advice_blinds = [Blind(np.ascontiguousarray(rng(1)[0])) for _ in adv_lag]
+    if adv_lag:
+        for c in _host(params.commit_batch(adv_lag, advice_blinds, lagrange=True)):
+            transcript.write_point(c)
+    adv = [three(lag) for lag in adv_lag]
+
+    # evaluators (:344-417)
+    values, cosets = Evaluator(LAGRANGE), Evaluator(EXTENDED)
+    fixed_v = [values.register_poly(t) for t in pk.fixed_values]
+    advice_v = [values.register_poly(t[0]) for t in adv]
+    instance_v = [values.register_poly(t[0]) for t in inst]
+    fixed_c = [cosets.register_poly(t) for t in pk.fixed_cosets]
+    advice_c = [cosets.register_poly(t[2]) for t in adv]
+    instance_c = [cosets.register_poly(t[2]) for t in inst]
+    perm_c = [cosets.register_poly(t) for t in pk.perm_cosets]
+    l0, l_blind, l_last = (cosets.register_poly(t) for t in (pk.l0, pk.l_blind, pk.l_last))
+    cells_v, cells_c = _Cells(fixed_v, advice_v, instance_v), _Cells(fixed_c, advice_c, instance_c)
+
+    theta = transcript.squeeze_challenge()                                                # :421
+    lookups = [lookup_arg.Argument(ins, tabs).commit_permuted(params, domain, bf, values, cosets, theta, cells_v, cells_c, rng, transcript)
+               for ins, tabs in cs.lookups]                                               # :423-454
+    beta = transcript.squeeze_challenge()                                                 # :457
+    gamma = transcript.squeeze_challenge()                                                # :460
+
+    by_kind = {"advice": (adv, advice_c), "fixed": (None, fixed_c), "instance": (inst, instance_c)}
+    perm_lagrange, perm_leaves = [], []
+    for kind, idx in cs.permutation_columns:
+        perm_lagrange.append(pk.fixed_values[idx] if kind == "fixed" else by_kind[kind][0][idx][0])
+        perm_leaves.append(by_kind[kind][1][idx])
+    pkey = permutation.ProvingKey(pk.perm_values, pk.perm_polys, perm_c)
+    perm_argument = permutation.Argument(len(cs.permutation_columns))
+    perm_committed = perm_argument.commit(params, domain, cs.degree, bf, pkey, perm_lagrange, beta, gamma, cosets, rng, transcript) \
+        if cs.permutation_columns else permutation.Committed([])                           # :463-481
+    lookups = [p.commit_product(params, domain, bf, beta, gamma, cosets, rng, transcript) for p in lookups]     # :483-502
+
+    vanishing = vanishing_arg.Argument.commit(params, domain, rng, transcript, device=dev)                      # :505
+    y = transcript.squeeze_challenge()                                                    # :508
+
+    perm_constructed, perm_exprs = perm_committed.construct(domain, cs.degree, bf, pkey, perm_leaves, l0, l_blind, l_last, beta, gamma)
+    lookup_pairs = [p.construct(beta, gamma, l0, l_blind, l_last) for p in lookups]       # :533-543
+    expressions = [g(cells_c) for g in cs.gates] + perm_exprs + [e for _, es in lookup_pairs for e in es]       # :545-586
+    expressions = [e if isinstance(e, Ast) else Ast.constant(int(e)) for e in expressions]
+    vanishing = vanishing.construct(params, domain, cosets, expressions, y, rng, transcript)                    # :589-597
+
+    x_l = transcript.squeeze_challenge_scalar()                                           # :598
+    x = fields.from_limbs(x_l.reshape(1, 4), sf, True)[0]
+    xn = pow(x, n, m)
+    at = lambda rot: lim(domain.rotate_omega(x, rot))
+    for col, rot in cs.instance_queries:                                                  # :602-619
+        transcript.write_scalar(_host(eval_polynomial(inst[col][1], at(rot), sf)))
+    for col, rot in cs.advice_queries:                                                    # :622-639
+        transcript.write_scalar(_host(eval_polynomial(adv[col][1], at(rot), sf)))
+    for col, rot in cs.fixed_queries:                                                     # :642-653
+        transcript.write_scalar(_host(eval_polynomial(pk.fixed_polys[col], at(rot), sf)))
+    vanishing = vanishing.evaluate(x_l, xn, domain, transcript)                           # :655
+    pkey.evaluate(x_l, sf, transcript)                                                    # :658
+    perm_evaluated = perm_constructed.evaluate(domain, bf, x, transcript)                 # :661-664
+    lookups_evaluated = [c.evaluate(domain, x, transcript) for c, _ in lookup_pairs]      # :667-675
+
+    queries = [ProverQuery(at(rot), inst[col][1], Blind(field=sf)) for col, rot in cs.instance_queries]        # :677-722
+    queries += [ProverQuery(at(rot), adv[col][1], advice_blinds[col]) for col, rot in cs.advice_queries]
+    queries += perm_evaluated.open(domain, bf, x)
+    for ev in lookups_evaluated:
+        queries += ev.open(domain, x)
+    queries += [ProverQuery(at(rot), pk.fixed_polys[col], Blind(field=sf)) for col, rot in cs.fixed_queries]
+    queries += pkey.open(x_l, sf)
+    queries += vanishing.open(x_l)
+    multiopen.create_proof(params, rng, transcript, queries, schedule=schedule)           # :724

@@ -1,0 +1,108 @@
+"""`plonk::create_proof` after synthesis, on the device (halo2_amd/plonk.py), for a circuit shaped like the reference's own
+test circuit (halo2_proofs/tests/plonk_api.rs:25-400): a combined add / multiply gate over three advice and four selector
+columns, a public-input gate, a lookup of `a` into a fixed table column, copy constraints over a, b, c (two permutation
+sets at degree 4).  The proof is read by the oracle's restatement of `plonk::verify_proof` (oracle/plonk.py): accepted for
+the true instance; rejected for a wrong instance, a flipped proof bit, and a witness that breaks a gate.
+Runs only on a real MI355X (`-m gpu`)."""
+import random
+
+import pytest
+
+import halo2_amd as h
+from halo2_amd import fields
+from halo2_amd.plonk import ConstraintSystem, create_proof, keygen_pk
+from halo2_amd.transcript import Blake2bWrite
+from oracle import c_oracle as co
+from oracle import plonk as oplonk
+
+pytestmark = pytest.mark.gpu
+
+SA, SB, SC, SM, SP, SL = range(6)
+A, B, C_ = range(3)
+
+
+def _cs():
+    return ConstraintSystem(
+        num_fixed_columns=6, num_advice_columns=3, num_instance_columns=1,
+        gates=[lambda q: q.advice(A) * q.fixed(SA) + q.advice(B) * q.fixed(SB) + q.advice(A) * q.advice(B) * q.fixed(SM)
+               - q.advice(C_) * q.fixed(SC),                                     # plonk_api.rs:281-296 without the d * e term
+               lambda q: q.fixed(SP) * (q.advice(A) - q.instance(0))],           # plonk_api.rs:298-305
+        advice_queries=[(A, 0), (B, 0), (C_, 0)], instance_queries=[(0, 0)], fixed_queries=[(c, 0) for c in range(6)],
+        permutation_columns=[("advice", A), ("advice", B), ("advice", C_)],
+        lookups=[([lambda q: q.advice(A)], [lambda q: q.fixed(SL)])],            # plonk_api.rs:276-279
+        degree=4, blinding_factors=5)
+
+
+def _witness(rnd, m, n, usable, break_gate=False):
+    table_vals = [rnd.randrange(m) for _ in range(8)]
+    fixed = [[0] * n for _ in range(6)]
+    a, b, c = [0] * n, [0] * n, [0] * n
+    groups = {}                                    # value classes that get copy constraints
+    for r in range(usable):
+        fixed[SL][r] = table_vals[r % 8]
+        a[r] = rnd.choice(table_vals)
+        b[r] = c[r - 1] if r and r % 3 == 0 else rnd.randrange(m)          # every third row reuses the previous output
+        if r % 2:
+            fixed[SM][r], fixed[SC][r] = 1, 1
+            c[r] = a[r] * b[r] % m
+        else:
+            fixed[SA][r], fixed[SB][r], fixed[SC][r] = 1, 1, 1
+            c[r] = (a[r] + b[r]) % m
+        if r and r % 3 == 0:
+            groups.setdefault(("chain", r), []).extend([(C_, r - 1), (B, r)])
+        groups.setdefault(("a", a[r]), []).append((A, r))                    # equal `a` cells are tied together
+    fixed[SP][0] = 1
+    if break_gate:
+        c[5] = (c[5] + 1) % m
+    mapping = [[(col, r) for r in range(n)] for col in range(3)]
+    for cells in groups.values():
+        if len(cells) > 1:
+            for i, (col, r) in enumerate(cells):
+                mapping[col][r] = cells[(i + 1) % len(cells)]
+    return fixed, [a, b, c], mapping, [[a[0]]]
+
+
+def _rng(sf, seed):
+    ctr = [seed]
+
+    def rng(count):
+        ctr[0] += 1
+        return co.random_field(sf, ctr[0], count)
+    return rng
+
+
+@pytest.mark.parametrize("k", [5, 7])
+def test_create_proof_is_accepted_by_the_restated_verifier(k):
+    curve = h.VESTA
+    sf = fields.CURVE_FIELDS[curve][1]
+    m = fields.MODULUS[sf]
+    n = 1 << k
+    cs = _cs()
+    usable = n - (cs.blinding_factors + 1)
+    rnd = random.Random(k)
+    fixed, advice, mapping, instances = _witness(rnd, m, n, usable)
+    g = co.generate_bases(curve, 970 + k, n)
+    w, u = co.generate_bases(curve, 60, 1)[0], co.generate_bases(curve, 61, 1)[0]
+    params = h.Params.from_generators(curve, k, g, None, w, u)
+    vk_repr = 0x1234567890ABCDEF ** 3 % m
+    pk = keygen_pk(params, cs, fixed, mapping, vk_repr)
+    tr = Blake2bWrite(curve)
+    create_proof(params, pk, advice, instances, _rng(sf, 7000), tr)
+    proof = tr.finalize()
+    vk = oplonk.keygen_vk(curve, k, g, w, cs, fixed, mapping, vk_repr)
+    assert oplonk.verify_proof(curve, k, g, w, u, vk, instances, proof)
+    assert not oplonk.verify_proof(curve, k, g, w, u, vk, [[(instances[0][0] + 1) % m]], proof)
+    bad = bytearray(proof)
+    bad[-33] ^= 1                                                     # inside the opening argument's scalar c
+    assert not oplonk.verify_proof(curve, k, g, w, u, vk, instances, bytes(bad))
+    # the reference's collapse schedule for the opening argument writes the same proof
+    tr_c = Blake2bWrite(curve)
+    create_proof(params, pk, advice, instances, _rng(sf, 7000), tr_c, schedule="collapse")
+    assert tr_c.finalize() == proof
+
+    # a witness that breaks the arithmetic gate on one row still yields a transcript, which the verifier rejects
+    fixed_b, advice_b, mapping_b, instances_b = _witness(random.Random(k), m, n, usable, break_gate=True)
+    tr_b = Blake2bWrite(curve)
+    create_proof(params, pk, advice_b, instances_b, _rng(sf, 7000), tr_b)
+    assert not oplonk.verify_proof(curve, k, g, w, u, vk, instances_b, tr_b.finalize())
+    params.close()
