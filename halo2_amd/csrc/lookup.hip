@@ -3,7 +3,7 @@
 // ordered by their canonical value), walks it against a BTreeMap of the table column, and hands the leftover table values
 // to the rows whose input value repeats the row above.  Here:
 //   * a bitonic network sorts both columns (canonical 256-bit keys, eight u32 limb planes in LDS: 2048 keys per workgroup;
-//     strides beyond a tile run as global compare-exchange passes);
+//     strides beyond a tile run as global compare-exchange passes, two strides per pass);
 //   * "first occurrence" / "run head" flags, two binary searches per row (is this input value in the table? is this table
 //     run's value in the input?), two exclusive scans and one gather rebuild the reference's sequential walk:
 //       S'[i] = A[i]                      where A[i] differs from A[i-1]                       (:597-607)
@@ -137,6 +137,33 @@ __global__ void __launch_bounds__(256) lk_sort_global(u32 *__restrict__ a, size_
     }
 }
 
+// two global compare-exchange passes in one: strides 2^jl and 2^(jl-1) (both >= kTile) of merge size 2^kl.  A lane owns the four
+// keys that differ in those two index bits, so the second stage needs no further memory round trip.
+__global__ void __launch_bounds__(256) lk_sort_global2(u32 *__restrict__ a, size_t quads, u32 kl, u32 jl) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= quads) return;
+    const size_t j1 = (size_t)1 << jl, j2 = j1 >> 1;
+    const size_t low = t & (j2 - 1), high = t >> (jl - 1);
+    const size_t i = (high << (jl + 1)) | low;
+    const bool asc = ((i >> kl) & 1) == 0;
+    key256 e0 = key_load(a + 8 * i), e1 = key_load(a + 8 * (i | j2)), e2 = key_load(a + 8 * (i | j1)), e3 = key_load(a + 8 * (i | j1 | j2));
+    auto cx = [&](key256 &x, key256 &y) {
+        if (key_less(y, x) == asc) {
+            const key256 tmp = x;
+            x = y;
+            y = tmp;
+        }
+    };
+    cx(e0, e2);
+    cx(e1, e3);
+    cx(e0, e1);
+    cx(e2, e3);
+    key_store(a + 8 * i, e0);
+    key_store(a + 8 * (i | j2), e1);
+    key_store(a + 8 * (i | j1), e2);
+    key_store(a + 8 * (i | j1 | j2), e3);
+}
+
 // lower bound of `key` in the ascending array s[0..n): first index whose element is not less than key
 __device__ __forceinline__ u32 lower_bound(const u32 *__restrict__ s, u32 n, const key256 &key) {
     u32 lo = 0, hi = n;
@@ -266,7 +293,10 @@ int sort_padded(u32 *buf, int log_n, hipStream_t st) {
     const unsigned tiles = (unsigned)((n + kTile - 1) >> kTileLog);
     hipLaunchKernelGGL(lk_sort_tile, dim3(tiles ? tiles : 1), dim3(kSortThreads), 0, st, buf, (u32)log_n, 0u);
     for (int kl = kTileLog + 1; kl <= log_n; ++kl) {
-        for (int jl = kl - 1; jl >= kTileLog; --jl)
+        int jl = kl - 1;
+        for (; jl - 1 >= kTileLog; jl -= 2)          // strides in pairs: half the passes over HBM
+            hipLaunchKernelGGL(lk_sort_global2, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, buf, n / 4, (u32)kl, (u32)jl);
+        if (jl >= kTileLog)
             hipLaunchKernelGGL(lk_sort_global, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, buf, n / 2, (u32)kl, (u32)jl);
         hipLaunchKernelGGL(lk_sort_tile, dim3(tiles), dim3(kSortThreads), 0, st, buf, (u32)log_n, (u32)kl);
     }
