@@ -53,7 +53,23 @@ def main():
         create_proof(params, pk, advice, [[7]], rng, tr)
         torch.cuda.synchronize()
         res[f"create_proof_s_run{rep}"] = round(time.perf_counter() - t0, 4)
-    res["proof_bytes"] = len(tr.finalize())
+    proof = tr.finalize()
+    res["proof_bytes"] = len(proof)
+    from halo2_amd import verifier as hv
+    if os.environ.get("REAL_LAGRANGE", "1") == "1":          # verification needs g_lagrange to be g's Lagrange basis
+        params2 = h.Params.from_generators(curve, k, g, None, g[1], g[2])
+        pk2 = keygen_pk(params2, cs, fixed, mapping, 12345)
+        tr = Blake2bWrite(curve)
+        create_proof(params2, pk2, advice, [[7]], rng, tr)
+        proof = tr.finalize()
+        t0 = time.perf_counter()
+        vk = hv.keygen_vk(params2, pk2)
+        res["keygen_vk_s"] = round(time.perf_counter() - t0, 4)
+        for rep in range(2):
+            t0 = time.perf_counter()
+            ok = hv.verify_proof(params2, vk, [[7]], proof)
+            res[f"verify_proof_s_run{rep}"] = round(time.perf_counter() - t0, 4)
+        res["verify_accepts_random_witness"] = ok          # a random witness does not satisfy the gates: expected False
     print(json.dumps(res))
 
 

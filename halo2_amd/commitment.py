@@ -184,6 +184,16 @@ class Params:
                                            _stream_ptr()), "h2_commit_batch_device")
         return out
 
+    def commit_unblinded(self, scalars):
+        """sum_i scalars[i] * g[i] with no blind term, Jacobian: the g part of `MSM::eval` (poly/commitment/msm.rs:163-166)."""
+        import torch
+        if not _is_torch(scalars) or scalars.shape[0] != self.n:
+            raise ValueError("commit_unblinded: need n scalars on the device")
+        out = torch.empty(12, dtype=torch.int64, device=scalars.device)
+        check(lib().h2_commit_device(self._h_g, scalars.data_ptr(), self.n, None, None, FORM_MONTGOMERY, OUT_JACOBIAN, out.data_ptr(),
+                                     _stream_ptr()), "h2_commit_device")
+        return out
+
     def commit(self, poly, r: Blind, affine: bool = False):
         """commitment.rs:119-130: sum poly[i] * g[i] + r * w."""
         return self._commit(self._h_g, poly, r, affine)

@@ -1,0 +1,477 @@
+"""The verifiers: `plonk::verify_proof` with a single-proof strategy (halo2_proofs/src/plonk/verifier.rs:25-347),
+`multiopen::verify_proof` (poly/multiopen/verifier.rs:15-141), `commitment::verify_proof`, `Guard`, `MSM`
+(poly/commitment/verifier.rs:12-171, poly/commitment/msm.rs:8-175) and the read side of the Blake2b transcript
+(transcript.rs:68-149).  A verifier is host arithmetic on a few hundred scalars plus ONE multiexp of size n + O(k) --
+`MSM::eval` (msm.rs:141-175), a `best_multiexp` call site -- which here is a commit over the registered `g` plus a small
+generic multiexp; the s vector of `Guard::use_challenges` (verifier.rs:35-41, 2^k products) is built on the device too.
+
+Constraint systems come in the lowered form halo2_amd/plonk.py documents.  torch is plumbing; all group / vector arithmetic
+goes through the C ABI."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import fields
+from ._lib import FORM_MONTGOMERY
+from .arithmetic import best_multiexp, points_sum, scale_add
+from .commitment import Blind, Params, points_from_bytes
+from .multiopen import construct_intermediate_sets
+from .transcript import _Blake2bTranscript
+
+
+class VerificationError(Exception):
+    """plonk::Error::{Opening, ConstraintSystemFailure, InvalidInstances, ...} on the verifier side."""
+
+
+# ---- transcript, read side (transcript.rs:68-149) ------------------------------------------------------------------------------
+class Blake2bRead(_Blake2bTranscript):
+    def __init__(self, curve: int, proof: bytes):
+        super().__init__(curve)
+        self.proof, self.pos = bytes(proof), 0
+
+    def read_point(self):
+        """-> (x, y) canonical integers; raises VerificationError on a short read or an invalid encoding (:89-101)."""
+        raw = self.proof[self.pos:self.pos + 32]
+        if len(raw) != 32:
+            raise VerificationError("proof too short")
+        self.pos += 32
+        try:
+            limbs = points_from_bytes(raw, self.curve)[0]
+            self.common_point(limbs)                     # refuses the identity (transcript.rs:209-214)
+        except ValueError as e:
+            raise VerificationError("invalid point encoding in proof") from e
+        return tuple(fields.from_limbs(limbs.reshape(2, 4), self.base, True))
+
+    def read_scalar(self) -> int:
+        """:103-116: canonical 32-byte little-endian field element."""
+        raw = self.proof[self.pos:self.pos + 32]
+        if len(raw) != 32:
+            raise VerificationError("proof too short")
+        self.pos += 32
+        v = int.from_bytes(raw, "little")
+        if v >= fields.MODULUS[self.scalar]:
+            raise VerificationError("invalid field element encoding in proof")
+        self.common_scalar(fields.scalar_limbs(v, self.scalar, True))
+        return v
+
+
+# ---- MSM and Guard (poly/commitment/msm.rs, verifier.rs:12-61) ----------------------------------------------------------------------
+class MSM:
+    """A linear combination of commitments waiting to be checked against the identity.  `other` keys points by x as the
+    reference does (msm.rs:17, :63-84): a point and its negation share an entry."""
+
+    def __init__(self, params: Params):
+        self.params = params
+        self.sf = fields.CURVE_FIELDS[params.curve][1]
+        self.bm = fields.MODULUS[fields.CURVE_FIELDS[params.curve][0]]
+        self.m = fields.MODULUS[self.sf]
+        self.g_scalars = None          # (n, 4) CUDA tensor, Montgomery
+        self.w_scalar = None
+        self.u_scalar = None
+        self.other = {}
+
+    def clone(self) -> "MSM":
+        c = MSM(self.params)
+        c.g_scalars = None if self.g_scalars is None else self.g_scalars.clone()
+        c.w_scalar, c.u_scalar = self.w_scalar, self.u_scalar
+        c.other = {x: list(v) for x, v in self.other.items()}
+        return c
+
+    def append_term(self, scalar: int, point) -> None:                                   # msm.rs:63-84
+        if point is None:
+            return
+        x, y = point
+        if x in self.other:
+            ours = self.other[x]
+            if ours[1] == y:
+                ours[0] = (ours[0] + scalar) % self.m
+            else:
+                assert ours[1] == (self.bm - y) % self.bm
+                ours[0] = (ours[0] - scalar) % self.m
+        else:
+            self.other[x] = [scalar % self.m, y]
+
+    def add_msm(self, other: "MSM") -> None:                                             # msm.rs:35-61
+        for x, (scalar, y) in other.other.items():
+            self.append_term(scalar, (x, y))
+        if other.g_scalars is not None:
+            self.add_to_g_scalars(other.g_scalars)
+        if other.w_scalar is not None:
+            self.add_to_w_scalar(other.w_scalar)
+        if other.u_scalar is not None:
+            self.add_to_u_scalar(other.u_scalar)
+
+    def _dev(self):
+        import torch
+        return torch.device("cuda:0")
+
+    def add_constant_term(self, constant: int) -> None:                                  # msm.rs:86-95
+        import torch
+        if self.g_scalars is None:
+            self.g_scalars = torch.zeros((self.params.n, 4), dtype=torch.int64, device=self._dev())
+        cur = fields.from_limbs(self.g_scalars[0].cpu().numpy().view(np.uint64).reshape(1, 4), self.sf, True)[0]
+        self.g_scalars[0] = torch.from_numpy(fields.scalar_limbs((cur + constant) % self.m, self.sf, True).view(np.int64)).to(self.g_scalars.device)
+
+    def add_to_g_scalars(self, scalars) -> None:                                         # msm.rs:97-107
+        if scalars.shape[0] != self.params.n:
+            raise ValueError("add_to_g_scalars: need n scalars")
+        if self.g_scalars is None:
+            self.g_scalars = scalars.clone()
+        else:
+            scale_add(self.g_scalars, fields.scalar_limbs(1, self.sf, True), scalars, self.sf)      # g * 1 + scalars
+
+    def add_to_w_scalar(self, scalar: int) -> None:
+        self.w_scalar = scalar % self.m if self.w_scalar is None else (self.w_scalar + scalar) % self.m
+
+    def add_to_u_scalar(self, scalar: int) -> None:
+        self.u_scalar = scalar % self.m if self.u_scalar is None else (self.u_scalar + scalar) % self.m
+
+    def scale(self, factor: int) -> None:                                                # msm.rs:117-129
+        import torch
+        if self.g_scalars is not None:
+            scale_add(self.g_scalars, fields.scalar_limbs(factor % self.m, self.sf, True), torch.zeros_like(self.g_scalars), self.sf)
+        for v in self.other.values():
+            v[0] = v[0] * factor % self.m
+        if self.w_scalar is not None:
+            self.w_scalar = self.w_scalar * factor % self.m
+        if self.u_scalar is not None:
+            self.u_scalar = self.u_scalar * factor % self.m
+
+    def eval(self) -> bool:
+        """msm.rs:131-175: is the combination the identity?  The g part is a commit over the registered generators; the
+        handful of other terms, w and u one small generic multiexp; the two partial sums are added on the device."""
+        bf = fields.CURVE_FIELDS[self.params.curve][0]
+        scalars, bases = [], []
+        for x, (scalar, y) in self.other.items():
+            scalars.append(scalar)
+            bases.append(fields.to_limbs([x, y], bf, True).reshape(8))
+        if self.w_scalar is not None:
+            scalars.append(self.w_scalar)
+            bases.append(self.params.w)
+        if self.u_scalar is not None:
+            scalars.append(self.u_scalar)
+            bases.append(self.params.u)
+        parts = []
+        if scalars:
+            parts.append(best_multiexp(fields.to_limbs(scalars, self.sf, True), np.stack(bases), self.params.curve, FORM_MONTGOMERY))
+        if self.g_scalars is not None:
+            parts.append(self.params.commit_unblinded(self.g_scalars).cpu().numpy().view(np.uint64))
+        if not parts:
+            return True
+        total = points_sum(np.stack(parts), self.params.curve)
+        return not total[8:12].any()                                                      # Jacobian Z == 0
+
+
+def compute_s(u, init: int, field: int, device):
+    """verifier.rs:156-171: the 2^k products of challenges, as a CUDA tensor.  Each doubling step is one scale on the device."""
+    import torch
+    m = fields.MODULUS[field]
+    v = torch.from_numpy(fields.scalar_limbs(init % m, field, True).view(np.int64)).reshape(1, 4).to(device)
+    for u_j in reversed(u):
+        right = scale_add(v.clone(), fields.scalar_limbs(u_j % m, field, True), torch.zeros_like(v), field)
+        v = torch.cat([v, right])
+    return v
+
+
+def compute_b(x: int, u, m: int) -> int:
+    """verifier.rs:144-154."""
+    tmp, cur = 1, x
+    for u_j in reversed(u):
+        tmp = tmp * (1 + u_j * cur) % m
+        cur = cur * cur % m
+    return tmp
+
+
+class Guard:
+    def __init__(self, msm: MSM, neg_c: int, u):
+        self.msm, self.neg_c, self.u = msm, neg_c, list(u)
+
+    def use_challenges(self) -> MSM:                                                     # verifier.rs:35-41
+        self.msm.add_to_g_scalars(compute_s(self.u, self.neg_c, self.msm.sf, self.msm._dev()))
+        return self.msm
+
+
+def commitment_verify_proof(params: Params, msm: MSM, transcript: Blake2bRead, x: int, v: int) -> Guard:
+    """poly/commitment/verifier.rs:65-141."""
+    m = msm.m
+    msm.add_constant_term(-v % m)                                                         # [-v] G_0
+    s_poly_commitment = transcript.read_point()
+    xi = transcript.squeeze_challenge()
+    msm.append_term(xi, s_poly_commitment)
+    z = transcript.squeeze_challenge()
+    rounds = []
+    for _ in range(params.k):
+        l = transcript.read_point()
+        r = transcript.read_point()
+        rounds.append((l, r, transcript.squeeze_challenge()))
+    u = []
+    for l, r, u_j in rounds:
+        if u_j == 0:
+            raise VerificationError("zero challenge")
+        msm.append_term(pow(u_j, -1, m), l)
+        msm.append_term(u_j, r)
+        u.append(u_j)
+    c = transcript.read_scalar()
+    neg_c = -c % m
+    f = transcript.read_scalar()
+    msm.add_to_u_scalar(neg_c * compute_b(x, u, m) % m * z % m)
+    msm.add_to_w_scalar(-f % m)
+    return Guard(msm, neg_c, u)
+
+
+# ---- multiopen (poly/multiopen/verifier.rs, poly/multiopen.rs:53-92) -----------------------------------------------------------------
+@dataclass(eq=False)
+class VerifierQuery:
+    """point, eval: canonical integers; commitment: an (x, y) point (`new_commitment`) or an MSM (`new_msm`).  Commitments are
+    told apart by object identity, as the reference's CommitmentReference does (multiopen.rs:96-120)."""
+    point: int
+    commitment: object
+    eval: int
+
+
+def lagrange_interpolate(points, evals, m: int):
+    """arithmetic.rs:379-432."""
+    if len(points) == 1:
+        return [evals[0] % m]
+    out = [0] * len(points)
+    for j, (x_j, ev) in enumerate(zip(points, evals)):
+        basis = [1]
+        for k_, x_k in enumerate(points):
+            if k_ != j:
+                d = pow((x_j - x_k) % m, -1, m)
+                basis = [((basis[i] if i < len(basis) else 0) * (-d * x_k) + (basis[i - 1] if i else 0) * d) % m for i in range(len(basis) + 1)]
+        out = [(o + b * ev) % m for o, b in zip(out, basis)]
+    return out
+
+
+def multiopen_verify_proof(params: Params, transcript: Blake2bRead, queries, msm: MSM) -> Guard:
+    """poly/multiopen/verifier.rs:15-141."""
+    m = msm.m
+    queries = list(queries)
+    x_1 = transcript.squeeze_challenge()
+    x_2 = transcript.squeeze_challenge()
+    by_id = {id(q.commitment): q.commitment for q in queries}
+    sets = construct_intermediate_sets([(q.point, id(q.commitment), q.eval) for q in queries])
+    if sets is None:
+        raise VerificationError("OpeningError: contradictory queries")                   # :39-40
+    commitment_map, point_sets = sets
+    q_commitments = [[MSM(params), 1] for _ in point_sets]                                # (accumulator, next x_1 power), :44-47
+    q_eval_sets = [[0] * len(ps) for ps in point_sets]
+    for data in reversed(commitment_map):                                                 # :75-81
+        acc, power = q_commitments[data["set_index"]]
+        c = by_id[data["commitment"]]
+        if isinstance(c, MSM):
+            scaled = c.clone()
+            scaled.scale(power)
+            acc.add_msm(scaled)
+        else:
+            acc.append_term(power, c)
+        evs = q_eval_sets[data["set_index"]]
+        for i, ev in enumerate(data["evals"]):
+            evs[i] = (evs[i] + ev * power) % m
+        q_commitments[data["set_index"]][1] = power * x_1 % m
+    q_prime_commitment = transcript.read_point()
+    x_3 = transcript.squeeze_challenge()
+    u = [transcript.read_scalar() for _ in q_eval_sets]
+    msm_eval = 0
+    for points, evals, proof_eval in zip(point_sets, q_eval_sets, u):                     # :101-116
+        r_poly = lagrange_interpolate(points, evals, m)
+        r_eval = sum(c * pow(x_3, i, m) for i, c in enumerate(r_poly)) % m
+        ev = (proof_eval - r_eval) % m
+        for pt in points:
+            d = (x_3 - pt) % m
+            if d == 0:
+                raise VerificationError("x_3 collides with a query point")
+            ev = ev * pow(d, -1, m) % m
+        msm_eval = (msm_eval * x_2 + ev) % m
+    x_4 = transcript.squeeze_challenge()
+    msm.append_term(1, q_prime_commitment)                                                # :123-136
+    v = msm_eval
+    for (q_commitment, _), q_eval in zip(q_commitments, u):
+        msm.scale(x_4)
+        msm.add_msm(q_commitment)
+        v = (v * x_4 + q_eval) % m
+    return commitment_verify_proof(params, msm, transcript, x_3, v)
+
+
+# ---- plonk (plonk/verifier.rs, vanishing / permutation / lookup verifiers) --------------------------------------------------------------
+class VerifyingKey:
+    """plonk::VerifyingKey (plonk.rs:44-59): fixed and permutation commitments as (x, y) points."""
+
+    def __init__(self, cs, domain, vk_repr: int, fixed_commitments, permutation_commitments):
+        self.cs, self.domain, self.vk_repr = cs, domain, vk_repr
+        self.fixed_commitments, self.permutation_commitments = fixed_commitments, permutation_commitments
+
+
+def _affine(params: Params, jac) -> tuple:
+    """Jacobian limbs (12) -> (x, y) integers or None."""
+    bf = fields.CURVE_FIELDS[params.curve][0]
+    p_ = fields.MODULUS[bf]
+    x, y, z = fields.from_limbs(np.ascontiguousarray(jac, dtype=np.uint64).reshape(3, 4), bf, True)
+    if z == 0:
+        return None
+    zi = pow(z, -1, p_)
+    return x * zi * zi % p_, y * zi * zi * zi % p_
+
+
+def keygen_vk(params: Params, pk) -> VerifyingKey:
+    """The commitments of keygen_vk (plonk/keygen.rs:240-262, permutation/keygen.rs:140-160: `Blind::default()`), from a
+    halo2_amd.plonk.ProvingKey's Lagrange columns."""
+    sf = fields.CURVE_FIELDS[params.curve][1]
+    one = Blind(field=sf)
+    host = lambda t: t.cpu().numpy().view(np.uint64)
+    fixed = [_affine(params, host(params.commit_lagrange(col, one))) for col in pk.fixed_values]
+    perms = [_affine(params, host(params.commit_lagrange(col, one))) for col in pk.perm_values]
+    return VerifyingKey(pk.cs, pk.domain, pk.vk_repr, fixed, perms)
+
+
+class _EvalCells:
+    """`Expression::evaluate` with the verifier's closures (verifier.rs:251-265): a query is its evaluation."""
+
+    def __init__(self, cs, fixed_evals, advice_evals, instance_evals):
+        self.cs, self.f, self.a, self.i = cs, fixed_evals, advice_evals, instance_evals
+
+    def fixed(self, col: int, rot: int = 0) -> int:
+        return self.f[self.cs.fixed_queries.index((col, rot))]
+
+    def advice(self, col: int, rot: int = 0) -> int:
+        return self.a[self.cs.advice_queries.index((col, rot))]
+
+    def instance(self, col: int, rot: int = 0) -> int:
+        return self.i[self.cs.instance_queries.index((col, rot))]
+
+
+def _fold(base: int, values, m: int) -> int:
+    acc = 0
+    for v in values:
+        acc = (acc * base + v) % m
+    return acc
+
+
+def _permutation_expressions(cs, sf, column_evals, sigma_evals, z_evals, l_0, l_last, l_blind, beta, gamma, x, m):
+    """plonk/permutation/verifier.rs:102-190."""
+    delta = fields.delta(sf)
+    chunk_len = cs.degree - 2
+    out = [l_0 * (1 - z_evals[0][0]) % m, (z_evals[-1][0] ** 2 - z_evals[-1][0]) * l_last % m]
+    for i in range(1, len(z_evals)):
+        out.append((z_evals[i][0] - z_evals[i - 1][2]) * l_0 % m)
+    for ci, (z_x, z_next, _) in enumerate(z_evals):
+        left, right = z_next, z_x
+        cur = beta * x % m * pow(delta, ci * chunk_len, m) % m
+        for j in range(ci * chunk_len, min((ci + 1) * chunk_len, len(column_evals))):
+            left = left * (column_evals[j] + beta * sigma_evals[j] + gamma) % m
+            right = right * (column_evals[j] + cur + gamma) % m
+            cur = cur * delta % m
+        out.append((left - right) * (1 - (l_last + l_blind)) % m)
+    return out
+
+
+def _lookup_expressions(ev, compressed_input, compressed_table, l_0, l_last, l_blind, beta, gamma, m):
+    """plonk/lookup/verifier.rs:96-170.  ev = (product, product_next, permuted_input, permuted_input_inv, permuted_table)."""
+    z, z_next, a, a_inv, s = ev
+    active = (1 - (l_last + l_blind)) % m
+    left = z_next * (a + beta) % m * (s + gamma) % m
+    right = z * (compressed_input + beta) % m * (compressed_table + gamma) % m
+    return [l_0 * (1 - z) % m, l_last * (z * z - z) % m, (left - right) * active % m, l_0 * (a - s) % m,
+            (a - s) * (a - a_inv) % m * active % m]
+
+
+def verify_proof(params: Params, vk: VerifyingKey, instance_columns, proof: bytes) -> bool:
+    """plonk::verify_proof with `SingleVerifier` (plonk/verifier.rs:25-63, 65-347) for one circuit instance: True iff the proof
+    is accepted.  Malformed proofs and failed checks both return False."""
+    try:
+        return _verify(params, vk, instance_columns, proof)
+    except VerificationError:
+        return False
+
+
+def _verify(params: Params, vk: VerifyingKey, instance_columns, proof: bytes) -> bool:
+    import torch
+    cs, domain = vk.cs, vk.domain
+    sf, m, n = domain.field, domain.m, params.n
+    bf = cs.blinding_factors
+    usable = n - (bf + 1)
+    dev = torch.device("cuda:0")
+    host = lambda t: t.cpu().numpy().view(np.uint64)
+    if len(instance_columns) != cs.num_instance_columns:
+        raise VerificationError("InvalidInstances")                                       # :77-81
+    instance_commitments = []
+    for values in instance_columns:                                                       # :83-101
+        if len(values) > usable:
+            raise VerificationError("InstanceTooLarge")
+        lag = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+        if len(values):
+            lag[:len(values)] = torch.from_numpy(fields.to_limbs(values, sf, True).view(np.int64)).to(dev)
+        instance_commitments.append(_affine(params, host(params.commit_lagrange(lag, Blind(field=sf)))))
+    t = Blake2bRead(params.curve, proof)
+    t.common_scalar(fields.scalar_limbs(vk.vk_repr % m, sf, True))                        # :106
+
+    def common_point(pt):
+        if pt is None:
+            raise VerificationError("identity commitment")
+        t.common_point(fields.to_limbs(list(pt), fields.CURVE_FIELDS[params.curve][0], True).reshape(8))
+    for c in instance_commitments:                                                        # :108-112
+        common_point(c)
+    advice_commitments = [t.read_point() for _ in range(cs.num_advice_columns)]           # :114-120
+    theta = t.squeeze_challenge()
+    lookups_permuted = [(t.read_point(), t.read_point()) for _ in cs.lookups]             # :125-135
+    beta = t.squeeze_challenge()
+    gamma = t.squeeze_challenge()
+    n_perm = len(cs.permutation_columns)
+    chunk_len = cs.degree - 2
+    n_sets = -(-n_perm // chunk_len) if n_perm else 0
+    perm_products = [t.read_point() for _ in range(n_sets)]                               # :143-149
+    lookup_products = [t.read_point() for _ in cs.lookups]                                # :151-159
+    random_poly_commitment = t.read_point()                                               # :161
+    y = t.squeeze_challenge()
+    h_commitments = [t.read_point() for _ in range(domain.quotient_poly_degree)]          # :166
+    x = t.squeeze_challenge()
+    instance_evals = [t.read_scalar() for _ in cs.instance_queries]                       # :171-179
+    advice_evals = [t.read_scalar() for _ in cs.advice_queries]
+    fixed_evals = [t.read_scalar() for _ in cs.fixed_queries]
+    random_eval = t.read_scalar()                                                         # :181
+    sigma_evals = [t.read_scalar() for _ in range(n_perm)]                                # :183
+    z_evals = []
+    for i in range(n_sets):                                                               # permutation/verifier.rs:70-96
+        e, e_next = t.read_scalar(), t.read_scalar()
+        z_evals.append((e, e_next, t.read_scalar() if i + 1 < n_sets else None))
+    lookup_evals = [tuple(t.read_scalar() for _ in range(5)) for _ in cs.lookups]         # lookup/verifier.rs:72-93
+
+    xn = pow(x, n, m)
+    if xn == 1:
+        raise VerificationError("x lies in the evaluation domain")
+    l_evals = domain.l_i_range(x, xn, range(-(bf + 1), 1))                                # :205-215
+    l_last, l_blind, l_0 = l_evals[0], sum(l_evals[1:1 + bf]) % m, l_evals[1 + bf]
+    cells = _EvalCells(cs, fixed_evals, advice_evals, instance_evals)
+    exprs = [int(gate(cells)) % m for gate in cs.gates]                                   # :225-243
+    if n_perm:
+        pick = {"advice": cells.advice, "fixed": cells.fixed, "instance": cells.instance}
+        exprs += _permutation_expressions(cs, sf, [pick[kind](idx, 0) for kind, idx in cs.permutation_columns], sigma_evals, z_evals,
+                                          l_0, l_last, l_blind, beta, gamma, x, m)
+    for (ins, tabs), ev in zip(cs.lookups, lookup_evals):
+        compress = lambda es: _fold(theta, [int(e(cells)) % m for e in es], m)
+        exprs += _lookup_expressions(ev, compress(ins), compress(tabs), l_0, l_last, l_blind, beta, gamma, m)
+    expected_h_eval = _fold(y, exprs, m) * pow((xn - 1) % m, -1, m) % m                    # vanishing/verifier.rs:103-105
+    h_commitment = MSM(params)                                                            # :107-116
+    for c in reversed(h_commitments):
+        h_commitment.scale(xn)
+        h_commitment.append_term(1, c)
+
+    rot = lambda r: domain.rotate_omega(x, r)
+    Q = VerifierQuery
+    queries = [Q(rot(r), instance_commitments[c], e) for (c, r), e in zip(cs.instance_queries, instance_evals)]     # :277-345
+    queries += [Q(rot(r), advice_commitments[c], e) for (c, r), e in zip(cs.advice_queries, advice_evals)]
+    x_next, x_last, x_inv = rot(1), rot(-(bf + 1)), rot(-1)
+    for c, (e, e_next, _) in zip(perm_products, z_evals):                                 # permutation/verifier.rs:192-226
+        queries += [Q(x, c, e), Q(x_next, c, e_next)]
+    for c, (_, _, e_last) in reversed(list(zip(perm_products, z_evals))[:-1]):
+        queries.append(Q(x_last, c, e_last))
+    for (pa, ps), pz, ev in zip(lookups_permuted, lookup_products, lookup_evals):         # lookup/verifier.rs:172-208
+        queries += [Q(x, pz, ev[0]), Q(x, pa, ev[2]), Q(x, ps, ev[4]), Q(x_inv, pa, ev[3]), Q(x_next, pz, ev[1])]
+    queries += [Q(rot(r), vk.fixed_commitments[c], e) for (c, r), e in zip(cs.fixed_queries, fixed_evals)]
+    queries += [Q(x, c, e) for c, e in zip(vk.permutation_commitments, sigma_evals)]
+    queries += [Q(x, h_commitment, expected_h_eval), Q(x, random_poly_commitment, random_eval)]   # vanishing/verifier.rs:119-139
+    guard = multiopen_verify_proof(params, t, queries, MSM(params))                       # :347
+    return guard.use_challenges().eval()                                                  # SingleVerifier::process, :48-62

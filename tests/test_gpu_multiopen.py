@@ -10,6 +10,7 @@ import halo2_amd as h
 from halo2_amd import fields
 from halo2_amd.multiopen import ProverQuery, create_proof
 from halo2_amd.transcript import Blake2bWrite
+from halo2_amd import verifier as hv
 from oracle import c_oracle as co
 from oracle import ipa, multiopen as om
 
@@ -52,6 +53,10 @@ def _run(curve, k, polys, blinds, pattern, points, schedule=None):
     i0, j0 = pattern[0]
     vq_bad = [(I(points[j0]), comms[i0], (evals[(i0, j0)] + 1) % fields.MODULUS[sf])] + vq[1:]
     assert not om.verify_proof(curve, k, g, w, u, ipa.Transcript(curve, proof), vq_bad)
+    # the product's verifier (multiopen::verify_proof -> commitment::verify_proof -> Guard::use_challenges -> MSM::eval) agrees
+    for queries, want in ((vq, True), (vq_bad, False)):
+        guard = hv.multiopen_verify_proof(params, hv.Blake2bRead(curve, proof), [hv.VerifierQuery(*q) for q in queries], hv.MSM(params))
+        assert guard.use_challenges().eval() is want
     params.close()
     return proof
 

@@ -12,6 +12,7 @@ import halo2_amd as h
 from halo2_amd import fields
 from halo2_amd.plonk import ConstraintSystem, create_proof, keygen_pk
 from halo2_amd.transcript import Blake2bWrite
+from halo2_amd import verifier as hv
 from oracle import c_oracle as co
 from oracle import plonk as oplonk
 
@@ -71,7 +72,7 @@ def _rng(sf, seed):
     return rng
 
 
-@pytest.mark.parametrize("k", [5, 7])
+@pytest.mark.parametrize("k", [5, 7, 11])
 def test_create_proof_is_accepted_by_the_restated_verifier(k):
     curve = h.VESTA
     sf = fields.CURVE_FIELDS[curve][1]
@@ -95,6 +96,18 @@ def test_create_proof_is_accepted_by_the_restated_verifier(k):
     bad = bytearray(proof)
     bad[-33] ^= 1                                                     # inside the opening argument's scalar c
     assert not oplonk.verify_proof(curve, k, g, w, u, vk, instances, bytes(bad))
+    # the product's own verifier (halo2_amd/verifier.py: MSM::eval on the device) agrees on all of it, and its verifying key
+    # -- commitments computed on the device -- equals the oracle's
+    dvk = hv.keygen_vk(params, pk)
+    assert dvk.fixed_commitments == vk["fixed_commitments"] and dvk.permutation_commitments == vk["permutation_commitments"]
+    assert hv.verify_proof(params, dvk, instances, proof)
+    assert not hv.verify_proof(params, dvk, [[(instances[0][0] + 1) % m]], proof)
+    assert not hv.verify_proof(params, dvk, instances, bytes(bad))
+    assert not hv.verify_proof(params, dvk, instances, proof[:-1])
+    for pos in (5, 40, len(proof) // 2):                              # flips elsewhere: a commitment, an evaluation
+        worse = bytearray(proof)
+        worse[pos] ^= 4
+        assert not hv.verify_proof(params, dvk, instances, bytes(worse))
     # the reference's collapse schedule for the opening argument writes the same proof
     tr_c = Blake2bWrite(curve)
     create_proof(params, pk, advice, instances, _rng(sf, 7000), tr_c, schedule="collapse")
@@ -105,4 +118,5 @@ def test_create_proof_is_accepted_by_the_restated_verifier(k):
     tr_b = Blake2bWrite(curve)
     create_proof(params, pk, advice_b, instances_b, _rng(sf, 7000), tr_b)
     assert not oplonk.verify_proof(curve, k, g, w, u, vk, instances_b, tr_b.finalize())
+    assert not hv.verify_proof(params, dvk, instances_b, tr_b.finalize())
     params.close()
