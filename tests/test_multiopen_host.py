@@ -104,3 +104,25 @@ def test_lagrange_interpolate_restatement():
         assert len(poly) == deg
         for p_, e_ in zip(pts, evs):
             assert sum(c * pow(p_, i, m) for i, c in enumerate(poly)) % m == e_
+
+
+def test_verifier_host_helpers_match_the_restatement():
+    """halo2_amd/verifier.py's pure-host pieces (no GPU needed): lagrange_interpolate against oracle/multiopen.py's and against
+    the defining property; compute_b against its product form (poly/commitment/verifier.rs:144-154)."""
+    from halo2_amd import verifier as hv
+    m = fields.MODULUS[h.FQ]
+    rnd = random.Random(11)
+    for deg in range(1, 7):
+        pts = rnd.sample(range(1, 10 ** 6), deg)
+        evs = [rnd.randrange(m) for _ in pts]
+        got = hv.lagrange_interpolate(pts, evs, m)
+        assert got == om.lagrange_interpolate(pts, evs, m)
+        for p_, e_ in zip(pts, evs):
+            assert sum(c * pow(p_, i, m) for i, c in enumerate(got)) % m == e_
+    u = [rnd.randrange(1, m) for _ in range(6)]
+    x = rnd.randrange(m)
+    # b = <s, (1, x, x^2, ...)> with s = compute_s(u, 1): the definition compute_b shortcuts
+    s = [1]
+    for u_j in reversed(u):
+        s = s + [v * u_j % m for v in s]
+    assert hv.compute_b(x, u, m) == sum(si * pow(x, i, m) for i, si in enumerate(s)) % m
