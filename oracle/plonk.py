@@ -5,7 +5,6 @@ the lowered form halo2_amd/plonk.py documents (gate / lookup expressions are cal
 by the product; tests use it to verify the proofs the device prover writes."""
 from __future__ import annotations
 
-import numpy as np
 
 from . import c_oracle as co
 from . import ipa

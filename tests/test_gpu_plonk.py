@@ -22,7 +22,20 @@ SA, SB, SC, SM, SP, SL = range(6)
 A, B, C_ = range(3)
 
 
-def _cs():
+def _cs(variant="full"):
+    if variant == "gates_only":                 # no lookup, no permutation argument, no instance column
+        return ConstraintSystem(
+            num_fixed_columns=6, num_advice_columns=3, num_instance_columns=0,
+            gates=[lambda q: q.advice(A) * q.fixed(SA) + q.advice(B) * q.fixed(SB) + q.advice(A) * q.advice(B) * q.fixed(SM)
+                   - q.advice(C_) * q.fixed(SC)],
+            advice_queries=[(A, 0), (B, 0), (C_, 0)], instance_queries=[], fixed_queries=[(c, 0) for c in range(4)],
+            degree=3, blinding_factors=5)
+    if variant == "two_lookups":                # a second, degree-2 tuple lookup (a, a^2) in (sl, sl^2): constraint degree 6
+        cs = _cs()
+        cs.lookups = cs.lookups + [([lambda q: q.advice(A), lambda q: q.advice(A) * q.advice(A)],
+                                    [lambda q: q.fixed(SL), lambda q: q.fixed(SL) * q.fixed(SL)])]
+        cs.degree = 6
+        return cs
     return ConstraintSystem(
         num_fixed_columns=6, num_advice_columns=3, num_instance_columns=1,
         gates=[lambda q: q.advice(A) * q.fixed(SA) + q.advice(B) * q.fixed(SB) + q.advice(A) * q.advice(B) * q.fixed(SM)
@@ -119,4 +132,37 @@ def test_create_proof_is_accepted_by_the_restated_verifier(k):
     create_proof(params, pk, advice_b, instances_b, _rng(sf, 7000), tr_b)
     assert not oplonk.verify_proof(curve, k, g, w, u, vk, instances_b, tr_b.finalize())
     assert not hv.verify_proof(params, dvk, instances_b, tr_b.finalize())
+    params.close()
+
+
+@pytest.mark.parametrize("variant,k", [("gates_only", 5), ("two_lookups", 6)])
+def test_constraint_system_shapes(variant, k):
+    """Other shapes of constraint system through the same prover and both verifiers: no lookup / permutation / instance at all;
+    two lookups, one of them over products (degree 6: five h pieces, extended domain 2^(k+3))."""
+    curve = h.VESTA
+    sf = fields.CURVE_FIELDS[curve][1]
+    m = fields.MODULUS[sf]
+    n = 1 << k
+    cs = _cs(variant)
+    usable = n - (cs.blinding_factors + 1)
+    fixed, advice, mapping, instances = _witness(random.Random(17 + k), m, n, usable)
+    if variant == "gates_only":
+        mapping, instances = [], []
+    g = co.generate_bases(curve, 990 + k, n)
+    w, u = co.generate_bases(curve, 60, 1)[0], co.generate_bases(curve, 61, 1)[0]
+    params = h.Params.from_generators(curve, k, g, None, w, u)
+    pk = keygen_pk(params, cs, fixed, mapping, 99)
+    assert pk.domain.extended_k == k + {3: 1, 6: 3}[cs.degree]
+    tr = Blake2bWrite(curve)
+    create_proof(params, pk, advice, instances, _rng(sf, 7100), tr)
+    proof = tr.finalize()
+    vk = oplonk.keygen_vk(curve, k, g, w, cs, fixed, mapping, 99)
+    dvk = hv.keygen_vk(params, pk)
+    assert oplonk.verify_proof(curve, k, g, w, u, vk, instances, proof)
+    assert hv.verify_proof(params, dvk, instances, proof)
+    advice[C_][3] = (advice[C_][3] + 1) % m                   # break one row of the arithmetic gate
+    tr_b = Blake2bWrite(curve)
+    create_proof(params, pk, advice, instances, _rng(sf, 7100), tr_b)
+    assert not hv.verify_proof(params, dvk, instances, tr_b.finalize())
+    assert not oplonk.verify_proof(curve, k, g, w, u, vk, instances, tr_b.finalize())
     params.close()
