@@ -1,6 +1,6 @@
 """`plonk::create_proof` after synthesis (halo2_proofs/src/plonk/prover.rs:35-724) and the part of `keygen_pk` that
 turns fixed columns and the copy-constraint mapping into the three bases (plonk/keygen.rs:296-380, permutation/keygen.rs:163-190),
-for ONE circuit instance whose columns are already assigned.  This module is orchestration: it sequences the device
+for circuit instances whose columns are already assigned (one or several per proof).  This module is orchestration: it sequences the device
 arguments (`halo2_amd.{permutation, lookup, vanishing, multiopen, opening}`), the column commits / iFFTs / coset FFTs and the
 transcript exactly in the reference's order.  What it does not do is run a `Circuit` (floor planning, region assignment,
 selector compression, `Expression<F>` construction): the caller hands over the constraint system in lowered form --
@@ -132,6 +132,13 @@ def create_proof(params: Params, pk: ProvingKey, advice_columns, instance_column
     blinding_factors + 1 are overwritten with randomness, :293-298); instance_columns: integer lists of at most
     n - (blinding_factors + 1) values (:84-86);
     rng(count) -> (count, 4) Montgomery limbs, drawn in the reference's order."""
+    create_proof_many(params, pk, [(advice_columns, instance_columns)], rng, transcript, schedule=schedule)
+
+
+def create_proof_many(params: Params, pk: ProvingKey, circuits, rng, transcript, schedule: str | None = None) -> None:
+    """prover.rs:35-724: one proof for several instances of the same circuit (`circuits: &[ConcreteCircuit]`,
+    `instances: &[&[&[C::Scalar]]]`).  circuits: [(advice_columns, instance_columns), ...] as `create_proof` takes them.  They
+    share the verifying key, the challenges, one vanishing argument and one multi-point opening."""
     import torch
     cs, domain = pk.cs, pk.domain
     sf, m, n = domain.field, domain.m, params.n
@@ -139,8 +146,10 @@ def create_proof(params: Params, pk: ProvingKey, advice_columns, instance_column
     usable = n - (bf + 1)
     dev = pk.l0.device
     lim = lambda v: fields.scalar_limbs(v % m, sf, True)
-    if len(instance_columns) != cs.num_instance_columns or len(advice_columns) != cs.num_advice_columns:
-        raise ValueError("InvalidInstances")                                              # :53-57
+    circuits = list(circuits)
+    for advice_columns, instance_columns in circuits:
+        if len(instance_columns) != cs.num_instance_columns or len(advice_columns) != cs.num_advice_columns:
+            raise ValueError("InvalidInstances")                                          # :49-57
 
     transcript.common_scalar(lim(pk.vk_repr))                                             # vk.hash_into, :60
 
@@ -148,62 +157,79 @@ def create_proof(params: Params, pk: ProvingKey, advice_columns, instance_column
         coeff = domain.lagrange_to_coeff(lagrange.clone())
         return lagrange, coeff, domain.coeff_to_extended(coeff)
 
-    # instance columns: commit (blind 1), absorb, three bases (:77-130)
-    inst = []
-    for values in instance_columns:
-        if len(values) > usable:
-            raise ValueError("InstanceTooLarge")                                          # :84-86
-        lag = torch.zeros((n, 4), dtype=torch.int64, device=dev)                          # poly.resize(n, 0), :80-90
-        if len(values):
-            lag[:len(values)] = _up(values, sf, dev)
-        transcript.common_point(_host(params.commit_lagrange(lag, Blind(field=sf))))      # :94-105
-        inst.append(three(lag))
+    # instance columns of every circuit: commit (blind 1), absorb, three bases (:77-130)
+    inst_all = []
+    for _, instance_columns in circuits:
+        inst = []
+        for values in instance_columns:
+            if len(values) > usable:
+                raise ValueError("InstanceTooLarge")                                      # :84-86
+            lag = torch.zeros((n, 4), dtype=torch.int64, device=dev)                      # poly.resize(n, 0), :80-90
+            if len(values):
+                lag[:len(values)] = _up(values, sf, dev)
+            transcript.common_point(_host(params.commit_lagrange(lag, Blind(field=sf))))  # :94-105
+            inst.append(three(lag))
+        inst_all.append(inst)
 
-    # advice columns: blinding rows, blinds, commitments (:293-341)
-    adv_lag = [_up(col, sf, dev) for col in advice_columns]
-    for lag in adv_lag:
-        lag[usable:] = torch.from_numpy(np.ascontiguousarray(rng(bf + 1), dtype=np.uint64).view(np.int64)).to(dev)
-    advice_blinds = [Blind(np.ascontiguousarray(rng(1)[0])) for _ in adv_lag]
-    if adv_lag:
-        for c in _host(params.commit_batch(adv_lag, advice_blinds, lagrange=True)):
-            transcript.write_point(c)
-    adv = [three(lag) for lag in adv_lag]
+    # advice columns of every circuit: blinding rows, blinds, commitments (:293-341)
+    adv_all, blinds_all = [], []
+    for advice_columns, _ in circuits:
+        adv_lag = [_up(col, sf, dev) for col in advice_columns]
+        for lag in adv_lag:
+            lag[usable:] = torch.from_numpy(np.ascontiguousarray(rng(bf + 1), dtype=np.uint64).view(np.int64)).to(dev)
+        advice_blinds = [Blind(np.ascontiguousarray(rng(1)[0])) for _ in adv_lag]
+        if adv_lag:
+            for c in _host(params.commit_batch(adv_lag, advice_blinds, lagrange=True)):
+                transcript.write_point(c)
+        adv_all.append([three(lag) for lag in adv_lag])
+        blinds_all.append(advice_blinds)
 
     # evaluators (:344-417)
     values, cosets = Evaluator(LAGRANGE), Evaluator(EXTENDED)
     fixed_v = [values.register_poly(t) for t in pk.fixed_values]
-    advice_v = [values.register_poly(t[0]) for t in adv]
-    instance_v = [values.register_poly(t[0]) for t in inst]
     fixed_c = [cosets.register_poly(t) for t in pk.fixed_cosets]
-    advice_c = [cosets.register_poly(t[2]) for t in adv]
-    instance_c = [cosets.register_poly(t[2]) for t in inst]
+    cells_v, cells_c, advice_c_all, instance_c_all = [], [], [], []
+    for adv, inst in zip(adv_all, inst_all):
+        advice_v = [values.register_poly(t[0]) for t in adv]
+        instance_v = [values.register_poly(t[0]) for t in inst]
+        advice_c = [cosets.register_poly(t[2]) for t in adv]
+        instance_c = [cosets.register_poly(t[2]) for t in inst]
+        cells_v.append(_Cells(fixed_v, advice_v, instance_v))
+        cells_c.append(_Cells(fixed_c, advice_c, instance_c))
+        advice_c_all.append(advice_c)
+        instance_c_all.append(instance_c)
     perm_c = [cosets.register_poly(t) for t in pk.perm_cosets]
     l0, l_blind, l_last = (cosets.register_poly(t) for t in (pk.l0, pk.l_blind, pk.l_last))
-    cells_v, cells_c = _Cells(fixed_v, advice_v, instance_v), _Cells(fixed_c, advice_c, instance_c)
 
     theta = transcript.squeeze_challenge()                                                # :421
-    lookups = [lookup_arg.Argument(ins, tabs).commit_permuted(params, domain, bf, values, cosets, theta, cells_v, cells_c, rng, transcript)
-               for ins, tabs in cs.lookups]                                               # :423-454
+    lookups = [[lookup_arg.Argument(ins, tabs).commit_permuted(params, domain, bf, values, cosets, theta, cv, cc, rng, transcript)
+                for ins, tabs in cs.lookups] for cv, cc in zip(cells_v, cells_c)]         # :423-454
     beta = transcript.squeeze_challenge()                                                 # :457
     gamma = transcript.squeeze_challenge()                                                # :460
 
-    by_kind = {"advice": (adv, advice_c), "fixed": (None, fixed_c), "instance": (inst, instance_c)}
-    perm_lagrange, perm_leaves = [], []
-    for kind, idx in cs.permutation_columns:
-        perm_lagrange.append(pk.fixed_values[idx] if kind == "fixed" else by_kind[kind][0][idx][0])
-        perm_leaves.append(by_kind[kind][1][idx])
     pkey = permutation.ProvingKey(pk.perm_values, pk.perm_polys, perm_c)
     perm_argument = permutation.Argument(len(cs.permutation_columns))
-    perm_committed = perm_argument.commit(params, domain, cs.degree, bf, pkey, perm_lagrange, beta, gamma, cosets, rng, transcript) \
-        if cs.permutation_columns else permutation.Committed([])                           # :463-481
-    lookups = [p.commit_product(params, domain, bf, beta, gamma, cosets, rng, transcript) for p in lookups]     # :483-502
+    perm_committed, perm_leaves_all = [], []
+    for adv, inst, advice_c, instance_c in zip(adv_all, inst_all, advice_c_all, instance_c_all):      # :463-481
+        by_kind = {"advice": (adv, advice_c), "fixed": (None, fixed_c), "instance": (inst, instance_c)}
+        perm_lagrange, perm_leaves = [], []
+        for kind, idx in cs.permutation_columns:
+            perm_lagrange.append(pk.fixed_values[idx] if kind == "fixed" else by_kind[kind][0][idx][0])
+            perm_leaves.append(by_kind[kind][1][idx])
+        perm_leaves_all.append(perm_leaves)
+        perm_committed.append(perm_argument.commit(params, domain, cs.degree, bf, pkey, perm_lagrange, beta, gamma, cosets, rng, transcript)
+                              if cs.permutation_columns else permutation.Committed([]))
+    lookups = [[p.commit_product(params, domain, bf, beta, gamma, cosets, rng, transcript) for p in ls] for ls in lookups]      # :483-502
 
     vanishing = vanishing_arg.Argument.commit(params, domain, rng, transcript, device=dev)                      # :505
     y = transcript.squeeze_challenge()                                                    # :508
 
-    perm_constructed, perm_exprs = perm_committed.construct(domain, cs.degree, bf, pkey, perm_leaves, l0, l_blind, l_last, beta, gamma)
-    lookup_pairs = [p.construct(beta, gamma, l0, l_blind, l_last) for p in lookups]       # :533-543
-    expressions = [g(cells_c) for g in cs.gates] + perm_exprs + [e for _, es in lookup_pairs for e in es]       # :545-586
+    perm_pairs = [pc.construct(domain, cs.degree, bf, pkey, leaves, l0, l_blind, l_last, beta, gamma)
+                  for pc, leaves in zip(perm_committed, perm_leaves_all)]                 # :511-531
+    lookup_pairs = [[p.construct(beta, gamma, l0, l_blind, l_last) for p in ls] for ls in lookups]             # :533-543
+    expressions = []
+    for cc, (_, perm_exprs), lps in zip(cells_c, perm_pairs, lookup_pairs):               # :545-586
+        expressions += [g(cc) for g in cs.gates] + perm_exprs + [e for _, es in lps for e in es]
     expressions = [e if isinstance(e, Ast) else Ast.constant(int(e)) for e in expressions]
     vanishing = vanishing.construct(params, domain, cosets, expressions, y, rng, transcript)                    # :589-597
 
@@ -211,22 +237,26 @@ def create_proof(params: Params, pk: ProvingKey, advice_columns, instance_column
     x = fields.from_limbs(x_l.reshape(1, 4), sf, True)[0]
     xn = pow(x, n, m)
     at = lambda rot: lim(domain.rotate_omega(x, rot))
-    for col, rot in cs.instance_queries:                                                  # :602-619
-        transcript.write_scalar(_host(eval_polynomial(inst[col][1], at(rot), sf)))
-    for col, rot in cs.advice_queries:                                                    # :622-639
-        transcript.write_scalar(_host(eval_polynomial(adv[col][1], at(rot), sf)))
+    for inst in inst_all:                                                                 # :602-619
+        for col, rot in cs.instance_queries:
+            transcript.write_scalar(_host(eval_polynomial(inst[col][1], at(rot), sf)))
+    for adv in adv_all:                                                                   # :622-639
+        for col, rot in cs.advice_queries:
+            transcript.write_scalar(_host(eval_polynomial(adv[col][1], at(rot), sf)))
     for col, rot in cs.fixed_queries:                                                     # :642-653
         transcript.write_scalar(_host(eval_polynomial(pk.fixed_polys[col], at(rot), sf)))
     vanishing = vanishing.evaluate(x_l, xn, domain, transcript)                           # :655
     pkey.evaluate(x_l, sf, transcript)                                                    # :658
-    perm_evaluated = perm_constructed.evaluate(domain, bf, x, transcript)                 # :661-664
-    lookups_evaluated = [c.evaluate(domain, x, transcript) for c, _ in lookup_pairs]      # :667-675
+    perm_evaluated = [pc.evaluate(domain, bf, x, transcript) for pc, _ in perm_pairs]     # :661-664
+    lookups_evaluated = [[c.evaluate(domain, x, transcript) for c, _ in lps] for lps in lookup_pairs]          # :667-675
 
-    queries = [ProverQuery(at(rot), inst[col][1], Blind(field=sf)) for col, rot in cs.instance_queries]        # :677-722
-    queries += [ProverQuery(at(rot), adv[col][1], advice_blinds[col]) for col, rot in cs.advice_queries]
-    queries += perm_evaluated.open(domain, bf, x)
-    for ev in lookups_evaluated:
-        queries += ev.open(domain, x)
+    queries = []                                                                          # :677-722
+    for inst, adv, advice_blinds, pe, les in zip(inst_all, adv_all, blinds_all, perm_evaluated, lookups_evaluated):
+        queries += [ProverQuery(at(rot), inst[col][1], Blind(field=sf)) for col, rot in cs.instance_queries]
+        queries += [ProverQuery(at(rot), adv[col][1], advice_blinds[col]) for col, rot in cs.advice_queries]
+        queries += pe.open(domain, bf, x)
+        for ev in les:
+            queries += ev.open(domain, x)
     queries += [ProverQuery(at(rot), pk.fixed_polys[col], Blind(field=sf)) for col, rot in cs.fixed_queries]
     queries += pkey.open(x_l, sf)
     queries += vanishing.open(x_l)

@@ -381,13 +381,19 @@ def _lookup_expressions(ev, compressed_input, compressed_table, l_0, l_last, l_b
 def verify_proof(params: Params, vk: VerifyingKey, instance_columns, proof: bytes) -> bool:
     """plonk::verify_proof with `SingleVerifier` (plonk/verifier.rs:25-63, 65-347) for one circuit instance: True iff the proof
     is accepted.  Malformed proofs and failed checks both return False."""
+    return verify_proof_many(params, vk, [instance_columns], proof)
+
+
+def verify_proof_many(params: Params, vk: VerifyingKey, instances, proof: bytes) -> bool:
+    """The same for a proof over several circuit instances (`instances: &[&[&[C::Scalar]]]`): instances[i] = the instance
+    columns of circuit i."""
     try:
-        return _verify(params, vk, instance_columns, proof)
+        return _verify(params, vk, list(instances), proof)
     except VerificationError:
         return False
 
 
-def _verify(params: Params, vk: VerifyingKey, instance_columns, proof: bytes) -> bool:
+def _verify(params: Params, vk: VerifyingKey, instances, proof: bytes) -> bool:
     import torch
     cs, domain = vk.cs, vk.domain
     sf, m, n = domain.field, domain.m, params.n
@@ -395,16 +401,20 @@ def _verify(params: Params, vk: VerifyingKey, instance_columns, proof: bytes) ->
     usable = n - (bf + 1)
     dev = torch.device("cuda:0")
     host = lambda t: t.cpu().numpy().view(np.uint64)
-    if len(instance_columns) != cs.num_instance_columns:
-        raise VerificationError("InvalidInstances")                                       # :77-81
+    num_proofs = len(instances)
     instance_commitments = []
-    for values in instance_columns:                                                       # :83-101
-        if len(values) > usable:
-            raise VerificationError("InstanceTooLarge")
-        lag = torch.zeros((n, 4), dtype=torch.int64, device=dev)
-        if len(values):
-            lag[:len(values)] = torch.from_numpy(fields.to_limbs(values, sf, True).view(np.int64)).to(dev)
-        instance_commitments.append(_affine(params, host(params.commit_lagrange(lag, Blind(field=sf)))))
+    for instance_columns in instances:                                                    # :77-101
+        if len(instance_columns) != cs.num_instance_columns:
+            raise VerificationError("InvalidInstances")
+        cms = []
+        for values in instance_columns:
+            if len(values) > usable:
+                raise VerificationError("InstanceTooLarge")
+            lag = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+            if len(values):
+                lag[:len(values)] = torch.from_numpy(fields.to_limbs(values, sf, True).view(np.int64)).to(dev)
+            cms.append(_affine(params, host(params.commit_lagrange(lag, Blind(field=sf)))))
+        instance_commitments.append(cms)
     t = Blake2bRead(params.curve, proof)
     t.common_scalar(fields.scalar_limbs(vk.vk_repr % m, sf, True))                        # :106
 
@@ -412,47 +422,54 @@ def _verify(params: Params, vk: VerifyingKey, instance_columns, proof: bytes) ->
         if pt is None:
             raise VerificationError("identity commitment")
         t.common_point(fields.to_limbs(list(pt), fields.CURVE_FIELDS[params.curve][0], True).reshape(8))
-    for c in instance_commitments:                                                        # :108-112
-        common_point(c)
-    advice_commitments = [t.read_point() for _ in range(cs.num_advice_columns)]           # :114-120
+    for cms in instance_commitments:                                                      # :108-112
+        for c in cms:
+            common_point(c)
+    per_proof = range(num_proofs)
+    advice_commitments = [[t.read_point() for _ in range(cs.num_advice_columns)] for _ in per_proof]           # :114-120
     theta = t.squeeze_challenge()
-    lookups_permuted = [(t.read_point(), t.read_point()) for _ in cs.lookups]             # :125-135
+    lookups_permuted = [[(t.read_point(), t.read_point()) for _ in cs.lookups] for _ in per_proof]             # :125-135
     beta = t.squeeze_challenge()
     gamma = t.squeeze_challenge()
     n_perm = len(cs.permutation_columns)
     chunk_len = cs.degree - 2
     n_sets = -(-n_perm // chunk_len) if n_perm else 0
-    perm_products = [t.read_point() for _ in range(n_sets)]                               # :143-149
-    lookup_products = [t.read_point() for _ in cs.lookups]                                # :151-159
+    perm_products = [[t.read_point() for _ in range(n_sets)] for _ in per_proof]          # :143-149
+    lookup_products = [[t.read_point() for _ in cs.lookups] for _ in per_proof]           # :151-159
     random_poly_commitment = t.read_point()                                               # :161
     y = t.squeeze_challenge()
     h_commitments = [t.read_point() for _ in range(domain.quotient_poly_degree)]          # :166
     x = t.squeeze_challenge()
-    instance_evals = [t.read_scalar() for _ in cs.instance_queries]                       # :171-179
-    advice_evals = [t.read_scalar() for _ in cs.advice_queries]
+    instance_evals = [[t.read_scalar() for _ in cs.instance_queries] for _ in per_proof]  # :171-179
+    advice_evals = [[t.read_scalar() for _ in cs.advice_queries] for _ in per_proof]
     fixed_evals = [t.read_scalar() for _ in cs.fixed_queries]
     random_eval = t.read_scalar()                                                         # :181
     sigma_evals = [t.read_scalar() for _ in range(n_perm)]                                # :183
     z_evals = []
-    for i in range(n_sets):                                                               # permutation/verifier.rs:70-96
-        e, e_next = t.read_scalar(), t.read_scalar()
-        z_evals.append((e, e_next, t.read_scalar() if i + 1 < n_sets else None))
-    lookup_evals = [tuple(t.read_scalar() for _ in range(5)) for _ in cs.lookups]         # lookup/verifier.rs:72-93
+    for _ in per_proof:                                                                   # permutation/verifier.rs:70-96
+        zs = []
+        for i in range(n_sets):
+            e, e_next = t.read_scalar(), t.read_scalar()
+            zs.append((e, e_next, t.read_scalar() if i + 1 < n_sets else None))
+        z_evals.append(zs)
+    lookup_evals = [[tuple(t.read_scalar() for _ in range(5)) for _ in cs.lookups] for _ in per_proof]         # lookup/verifier.rs:72-93
 
     xn = pow(x, n, m)
     if xn == 1:
         raise VerificationError("x lies in the evaluation domain")
     l_evals = domain.l_i_range(x, xn, range(-(bf + 1), 1))                                # :205-215
     l_last, l_blind, l_0 = l_evals[0], sum(l_evals[1:1 + bf]) % m, l_evals[1 + bf]
-    cells = _EvalCells(cs, fixed_evals, advice_evals, instance_evals)
-    exprs = [int(gate(cells)) % m for gate in cs.gates]                                   # :225-243
-    if n_perm:
-        pick = {"advice": cells.advice, "fixed": cells.fixed, "instance": cells.instance}
-        exprs += _permutation_expressions(cs, sf, [pick[kind](idx, 0) for kind, idx in cs.permutation_columns], sigma_evals, z_evals,
-                                          l_0, l_last, l_blind, beta, gamma, x, m)
-    for (ins, tabs), ev in zip(cs.lookups, lookup_evals):
-        compress = lambda es: _fold(theta, [int(e(cells)) % m for e in es], m)
-        exprs += _lookup_expressions(ev, compress(ins), compress(tabs), l_0, l_last, l_blind, beta, gamma, m)
+    exprs = []
+    for p_ in per_proof:                                                                  # :217-271
+        cells = _EvalCells(cs, fixed_evals, advice_evals[p_], instance_evals[p_])
+        exprs += [int(gate(cells)) % m for gate in cs.gates]
+        if n_perm:
+            pick = {"advice": cells.advice, "fixed": cells.fixed, "instance": cells.instance}
+            exprs += _permutation_expressions(cs, sf, [pick[kind](idx, 0) for kind, idx in cs.permutation_columns], sigma_evals, z_evals[p_],
+                                              l_0, l_last, l_blind, beta, gamma, x, m)
+        for (ins, tabs), ev in zip(cs.lookups, lookup_evals[p_]):
+            compress = lambda es: _fold(theta, [int(e(cells)) % m for e in es], m)
+            exprs += _lookup_expressions(ev, compress(ins), compress(tabs), l_0, l_last, l_blind, beta, gamma, m)
     expected_h_eval = _fold(y, exprs, m) * pow((xn - 1) % m, -1, m) % m                    # vanishing/verifier.rs:103-105
     h_commitment = MSM(params)                                                            # :107-116
     for c in reversed(h_commitments):
@@ -461,15 +478,17 @@ def _verify(params: Params, vk: VerifyingKey, instance_columns, proof: bytes) ->
 
     rot = lambda r: domain.rotate_omega(x, r)
     Q = VerifierQuery
-    queries = [Q(rot(r), instance_commitments[c], e) for (c, r), e in zip(cs.instance_queries, instance_evals)]     # :277-345
-    queries += [Q(rot(r), advice_commitments[c], e) for (c, r), e in zip(cs.advice_queries, advice_evals)]
     x_next, x_last, x_inv = rot(1), rot(-(bf + 1)), rot(-1)
-    for c, (e, e_next, _) in zip(perm_products, z_evals):                                 # permutation/verifier.rs:192-226
-        queries += [Q(x, c, e), Q(x_next, c, e_next)]
-    for c, (_, _, e_last) in reversed(list(zip(perm_products, z_evals))[:-1]):
-        queries.append(Q(x_last, c, e_last))
-    for (pa, ps), pz, ev in zip(lookups_permuted, lookup_products, lookup_evals):         # lookup/verifier.rs:172-208
-        queries += [Q(x, pz, ev[0]), Q(x, pa, ev[2]), Q(x, ps, ev[4]), Q(x_inv, pa, ev[3]), Q(x_next, pz, ev[1])]
+    queries = []                                                                          # :277-345
+    for p_ in per_proof:
+        queries += [Q(rot(r), instance_commitments[p_][c], e) for (c, r), e in zip(cs.instance_queries, instance_evals[p_])]
+        queries += [Q(rot(r), advice_commitments[p_][c], e) for (c, r), e in zip(cs.advice_queries, advice_evals[p_])]
+        for c, (e, e_next, _) in zip(perm_products[p_], z_evals[p_]):                     # permutation/verifier.rs:192-226
+            queries += [Q(x, c, e), Q(x_next, c, e_next)]
+        for c, (_, _, e_last) in reversed(list(zip(perm_products[p_], z_evals[p_]))[:-1]):
+            queries.append(Q(x_last, c, e_last))
+        for (pa, ps), pz, ev in zip(lookups_permuted[p_], lookup_products[p_], lookup_evals[p_]):              # lookup/verifier.rs:172-208
+            queries += [Q(x, pz, ev[0]), Q(x, pa, ev[2]), Q(x, ps, ev[4]), Q(x_inv, pa, ev[3]), Q(x_next, pz, ev[1])]
     queries += [Q(rot(r), vk.fixed_commitments[c], e) for (c, r), e in zip(cs.fixed_queries, fixed_evals)]
     queries += [Q(x, c, e) for c, e in zip(vk.permutation_commitments, sigma_evals)]
     queries += [Q(x, h_commitment, expected_h_eval), Q(x, random_poly_commitment, random_eval)]   # vanishing/verifier.rs:119-139

@@ -166,3 +166,42 @@ def test_constraint_system_shapes(variant, k):
     assert not hv.verify_proof(params, dvk, instances, tr_b.finalize())
     assert not oplonk.verify_proof(curve, k, g, w, u, vk, instances, tr_b.finalize())
     params.close()
+
+
+def test_two_circuit_instances_in_one_proof():
+    """`create_proof(params, pk, &[circuit_a, circuit_b], &[instances_a, instances_b], ..)` (plonk/prover.rs:35-48): two
+    witnesses of the same circuit share one vanishing argument and one opening; swapping the public inputs is rejected."""
+    from halo2_amd.plonk import create_proof_many
+    curve, k = h.VESTA, 6
+    sf = fields.CURVE_FIELDS[curve][1]
+    m = fields.MODULUS[sf]
+    n = 1 << k
+    cs = _cs()
+    usable = n - (cs.blinding_factors + 1)
+    # same fixed columns / copy constraints need the same selector layout and value classes: reuse the random stream for the
+    # layout and perturb only unconstrained witness values
+    fixed, advice_a, mapping, inst_a = _witness(random.Random(3), m, n, usable)
+    advice_b = [list(col) for col in advice_a]
+    free_rows = [r for r in range(usable) if r % 3 != 0 and (r + 1) % 3 != 0 and r % 2 == 0]     # add rows whose b and c are in no cycle
+    for r in free_rows:
+        advice_b[B][r] = (advice_b[B][r] + 5) % m
+        advice_b[C_][r] = (advice_b[A][r] + advice_b[B][r]) % m
+    g = co.generate_bases(curve, 999, n)
+    w, u = co.generate_bases(curve, 60, 1)[0], co.generate_bases(curve, 61, 1)[0]
+    params = h.Params.from_generators(curve, k, g, None, w, u)
+    pk = keygen_pk(params, cs, fixed, mapping, 5)
+    tr = Blake2bWrite(curve)
+    create_proof_many(params, pk, [(advice_a, inst_a), (advice_b, inst_a)], _rng(sf, 7300), tr)
+    proof = tr.finalize()
+    vk = oplonk.keygen_vk(curve, k, g, w, cs, fixed, mapping, 5)
+    dvk = hv.keygen_vk(params, pk)
+    assert oplonk.verify_proof_many(curve, k, g, w, u, vk, [inst_a, inst_a], proof)
+    assert hv.verify_proof_many(params, dvk, [inst_a, inst_a], proof)
+    wrong = [[(inst_a[0][0] + 1) % m]]
+    assert not hv.verify_proof_many(params, dvk, [inst_a, wrong], proof)
+    assert not oplonk.verify_proof_many(curve, k, g, w, u, vk, [wrong, inst_a], proof)
+    assert not hv.verify_proof(params, dvk, inst_a, proof)                      # a two-instance proof is not a one-instance proof
+    single = Blake2bWrite(curve)
+    create_proof(params, pk, advice_a, inst_a, _rng(sf, 7300), single)
+    assert len(proof) > len(single.finalize())
+    params.close()
