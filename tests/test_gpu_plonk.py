@@ -14,66 +14,12 @@ from halo2_amd.plonk import ConstraintSystem, create_proof, keygen_pk
 from halo2_amd.transcript import Blake2bWrite
 from halo2_amd import verifier as hv
 from oracle import c_oracle as co
+from oracle import ipa
 from oracle import plonk as oplonk
 
 pytestmark = pytest.mark.gpu
 
-SA, SB, SC, SM, SP, SL = range(6)
-A, B, C_ = range(3)
-
-
-def _cs(variant="full"):
-    if variant == "gates_only":                 # no lookup, no permutation argument, no instance column
-        return ConstraintSystem(
-            num_fixed_columns=6, num_advice_columns=3, num_instance_columns=0,
-            gates=[lambda q: q.advice(A) * q.fixed(SA) + q.advice(B) * q.fixed(SB) + q.advice(A) * q.advice(B) * q.fixed(SM)
-                   - q.advice(C_) * q.fixed(SC)],
-            advice_queries=[(A, 0), (B, 0), (C_, 0)], instance_queries=[], fixed_queries=[(c, 0) for c in range(4)],
-            degree=3, blinding_factors=5)
-    if variant == "two_lookups":                # a second, degree-2 tuple lookup (a, a^2) in (sl, sl^2): constraint degree 6
-        cs = _cs()
-        cs.lookups = cs.lookups + [([lambda q: q.advice(A), lambda q: q.advice(A) * q.advice(A)],
-                                    [lambda q: q.fixed(SL), lambda q: q.fixed(SL) * q.fixed(SL)])]
-        cs.degree = 6
-        return cs
-    return ConstraintSystem(
-        num_fixed_columns=6, num_advice_columns=3, num_instance_columns=1,
-        gates=[lambda q: q.advice(A) * q.fixed(SA) + q.advice(B) * q.fixed(SB) + q.advice(A) * q.advice(B) * q.fixed(SM)
-               - q.advice(C_) * q.fixed(SC),                                     # plonk_api.rs:281-296 without the d * e term
-               lambda q: q.fixed(SP) * (q.advice(A) - q.instance(0))],           # plonk_api.rs:298-305
-        advice_queries=[(A, 0), (B, 0), (C_, 0)], instance_queries=[(0, 0)], fixed_queries=[(c, 0) for c in range(6)],
-        permutation_columns=[("advice", A), ("advice", B), ("advice", C_)],
-        lookups=[([lambda q: q.advice(A)], [lambda q: q.fixed(SL)])],            # plonk_api.rs:276-279
-        degree=4, blinding_factors=5)
-
-
-def _witness(rnd, m, n, usable, break_gate=False):
-    table_vals = [rnd.randrange(m) for _ in range(8)]
-    fixed = [[0] * n for _ in range(6)]
-    a, b, c = [0] * n, [0] * n, [0] * n
-    groups = {}                                    # value classes that get copy constraints
-    for r in range(usable):
-        fixed[SL][r] = table_vals[r % 8]
-        a[r] = rnd.choice(table_vals)
-        b[r] = c[r - 1] if r and r % 3 == 0 else rnd.randrange(m)          # every third row reuses the previous output
-        if r % 2:
-            fixed[SM][r], fixed[SC][r] = 1, 1
-            c[r] = a[r] * b[r] % m
-        else:
-            fixed[SA][r], fixed[SB][r], fixed[SC][r] = 1, 1, 1
-            c[r] = (a[r] + b[r]) % m
-        if r and r % 3 == 0:
-            groups.setdefault(("chain", r), []).extend([(C_, r - 1), (B, r)])
-        groups.setdefault(("a", a[r]), []).append((A, r))                    # equal `a` cells are tied together
-    fixed[SP][0] = 1
-    if break_gate:
-        c[5] = (c[5] + 1) % m
-    mapping = [[(col, r) for r in range(n)] for col in range(3)]
-    for cells in groups.values():
-        if len(cells) > 1:
-            for i, (col, r) in enumerate(cells):
-                mapping[col][r] = cells[(i + 1) % len(cells)]
-    return fixed, [a, b, c], mapping, [[a[0]]]
+from plonk_circuits import A, B, C_, SA, SB, SC, SL, SM, SP, make_cs as _cs, make_witness as _witness  # noqa: F401
 
 
 def _rng(sf, seed):
@@ -103,6 +49,11 @@ def test_create_proof_is_accepted_by_the_restated_verifier(k):
     tr = Blake2bWrite(curve)
     create_proof(params, pk, advice, instances, _rng(sf, 7000), tr)
     proof = tr.finalize()
+    if k <= 7:
+        # byte for byte the proof the sequential restatement of plonk::create_proof writes for the same randomness
+        ot = ipa.Transcript(curve)
+        oplonk.create_proof(curve, k, g, w, u, cs, fixed, mapping, vk_repr, advice, instances, _rng(sf, 7000), ot)
+        assert bytes(ot.out) == proof
     vk = oplonk.keygen_vk(curve, k, g, w, cs, fixed, mapping, vk_repr)
     assert oplonk.verify_proof(curve, k, g, w, u, vk, instances, proof)
     assert not oplonk.verify_proof(curve, k, g, w, u, vk, [[(instances[0][0] + 1) % m]], proof)
@@ -158,6 +109,9 @@ def test_constraint_system_shapes(variant, k):
     proof = tr.finalize()
     vk = oplonk.keygen_vk(curve, k, g, w, cs, fixed, mapping, 99)
     dvk = hv.keygen_vk(params, pk)
+    ot = ipa.Transcript(curve)
+    oplonk.create_proof(curve, k, g, w, u, cs, fixed, mapping, 99, advice, instances, _rng(sf, 7100), ot)
+    assert bytes(ot.out) == proof
     assert oplonk.verify_proof(curve, k, g, w, u, vk, instances, proof)
     assert hv.verify_proof(params, dvk, instances, proof)
     advice[C_][3] = (advice[C_][3] + 1) % m                   # break one row of the arithmetic gate
@@ -195,6 +149,9 @@ def test_two_circuit_instances_in_one_proof():
     proof = tr.finalize()
     vk = oplonk.keygen_vk(curve, k, g, w, cs, fixed, mapping, 5)
     dvk = hv.keygen_vk(params, pk)
+    ot = ipa.Transcript(curve)
+    oplonk.create_proof_many(curve, k, g, w, u, cs, fixed, mapping, 5, [(advice_a, inst_a), (advice_b, inst_a)], _rng(sf, 7300), ot)
+    assert bytes(ot.out) == proof
     assert oplonk.verify_proof_many(curve, k, g, w, u, vk, [inst_a, inst_a], proof)
     assert hv.verify_proof_many(params, dvk, [inst_a, inst_a], proof)
     wrong = [[(inst_a[0][0] + 1) % m]]
