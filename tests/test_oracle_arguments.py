@@ -101,3 +101,21 @@ def test_permutation_restatement_ends_at_one_iff_the_copy_constraints_hold(cs_de
     broken[c0][r0] = (broken[c0][r0] + 1) % m
     sets_b = operm.commit(curve, dom, g, w, cs_degree, bf, broken, sigmas, beta, gamma, _rng(sf, 1), ipa.Transcript(curve))
     assert sets_b[-1][0][usable] != 1
+
+
+@pytest.mark.parametrize("field", [h.FP, h.FQ])
+def test_delta_is_the_documented_constant(field):
+    """ff::PrimeField::DELTA = MULTIPLICATIVE_GENERATOR^(2^S) (the `ff` crate's definition; no numeric value is pinned anywhere in
+    the reference tree).  The book asks for a T-th root of unity, p - 1 = 2^S T (book/src/design/proving-system/permutation.md:148):
+    delta^T = 1, delta generates more than any small-index subgroup, and the product's and the oracle's constants agree."""
+    m = fields.MODULUS[field]
+    d = fields.delta(field)
+    assert d == operm.DELTA[m] == pow(5, 1 << 32, m)
+    t = (m - 1) >> 32
+    assert t % 2 == 1 and (m - 1) == t << 32
+    assert pow(d, t, m) == 1 and d != 1
+    for q in (3, 5, 7, 11, 13, 17, 19, 23):
+        if t % q == 0:
+            assert pow(d, t // q, m) != 1
+    # the labels delta^c omega^r of different columns never collide (what the permutation argument needs): delta is outside the 2^S-torsion
+    assert pow(d, 1 << 32, m) != 1
