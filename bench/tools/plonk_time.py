@@ -33,11 +33,13 @@ def main():
         lookups=[([lambda q: q.advice(0)], [lambda q: q.fixed(SL)])], degree=4, blinding_factors=5)
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
     rnd = np.random.default_rng(5)
-    table_rows = co.random_field(sf, 3, 1 << 12)
-    fixed = [up(co.random_field(sf, 10 + i, n)) for i in range(5)] + [up(table_rows[np.arange(n) % (1 << 12)])]
-    advice = [up(table_rows[rnd.integers(0, 1 << 12, n)]), up(co.random_field(sf, 21, n)), up(co.random_field(sf, 22, n))]
+    tsize = min(1 << 12, n // 4)                 # every table value must sit in the usable rows
+    table_rows = co.random_field(sf, 3, tsize)
+    fixed = [up(co.random_field(sf, 10 + i, n)) for i in range(5)] + [up(table_rows[np.arange(n) % tsize])]
+    advice = [up(table_rows[rnd.integers(0, tsize, n)]), up(co.random_field(sf, 21, n)), up(co.random_field(sf, 22, n))]
     mapping = np.stack([np.arange(n, dtype=np.int64) + c * n for c in range(3)])
-    mapping[0, :1000], mapping[1, :1000] = mapping[1, :1000].copy(), mapping[0, :1000].copy()      # some 2-cycles
+    c2 = min(1000, n // 4)
+    mapping[0, :c2], mapping[1, :c2] = mapping[1, :c2].copy(), mapping[0, :c2].copy()      # some 2-cycles
     g = co.generate_bases(curve, 1, n)
     params = h.Params(curve, k, g, g, g[1], g[2])            # timing only: g_lagrange need not be g's Lagrange basis
     t0 = time.perf_counter()
