@@ -1,0 +1,89 @@
+"""CPU-only: host bookkeeping of the product's verifier and transcript that needs no GPU -- `MSM`'s x-keyed term merging
+(poly/commitment/msm.rs:63-84, :117-129) against plain big-integer curve arithmetic, and the transcript's Jacobian -> affine
+path (the prover's `.to_affine()` before `write_point`) against the oracle's transcript."""
+import random
+from types import SimpleNamespace
+
+import numpy as np
+
+import halo2_amd as h
+from halo2_amd import fields
+from halo2_amd.transcript import Blake2bWrite
+from halo2_amd.verifier import MSM
+from oracle import ipa, pasta
+
+
+def _points(curve, count, rnd):
+    bm = pasta.CURVES[curve][0]
+    gen = (bm - 1, 2)
+    return [pasta.ec_mul(rnd.randrange(1, 1 << 64), gen, bm) for _ in range(count)]
+
+
+def _value(msm, curve):
+    """sum of the MSM's `other` terms as a point, by the definition."""
+    bm = pasta.CURVES[curve][0]
+    acc = None
+    for x, (scalar, y) in msm.other.items():
+        acc = pasta.ec_add(acc, pasta.ec_mul(scalar, (x, y), bm) if scalar else None, bm)
+    return acc
+
+
+def test_msm_term_bookkeeping_matches_the_definition():
+    curve = h.VESTA
+    bm, sm = pasta.CURVES[curve]
+    rnd = random.Random(2)
+    pts = _points(curve, 6, rnd)
+    params = SimpleNamespace(curve=curve, n=8)
+    a, b = MSM(params), MSM(params)
+    want_a = want_b = None
+    for _ in range(40):
+        target, acc = (a, "a") if rnd.random() < 0.5 else (b, "b")
+        p_ = rnd.choice(pts)
+        if rnd.random() < 0.4:
+            p_ = (p_[0], (bm - p_[1]) % bm)                 # the negation shares the x key (msm.rs:72-78)
+        s = rnd.randrange(sm)
+        target.append_term(s, p_)
+        term = pasta.ec_mul(s, p_, bm) if s else None
+        if acc == "a":
+            want_a = pasta.ec_add(want_a, term, bm)
+        else:
+            want_b = pasta.ec_add(want_b, term, bm)
+    a.append_term(5, None)                                  # the identity is skipped (msm.rs:64)
+    assert _value(a, curve) == want_a and _value(b, curve) == want_b
+    assert len(a.other) <= len(pts) and len(b.other) <= len(pts)
+    f = rnd.randrange(1, sm)
+    a.scale(f)
+    a.add_to_w_scalar(3)
+    a.add_to_u_scalar(4)
+    a.scale(2)
+    assert (a.w_scalar, a.u_scalar) == (6, 8)
+    want_a = pasta.ec_mul(2 * f % sm, want_a, bm) if want_a is not None else None
+    assert _value(a, curve) == want_a
+    b.add_to_w_scalar(10)
+    a.add_msm(b)
+    assert a.w_scalar == 16 and _value(a, curve) == pasta.ec_add(want_a, want_b, bm)
+    c = a.clone()
+    c.scale(0)
+    assert _value(c, curve) is None and _value(a, curve) is not None
+
+
+def test_transcript_accepts_jacobian_points_like_to_affine():
+    curve = h.PALLAS
+    bf = fields.CURVE_FIELDS[curve][0]
+    bm = fields.MODULUS[bf]
+    rnd = random.Random(4)
+    for pt in _points(curve, 5, rnd):
+        z = rnd.randrange(1, bm)
+        jac = [pt[0] * z * z % bm, pt[1] * z * z * z % bm, z]
+        t_j, t_a, t_o = Blake2bWrite(curve), Blake2bWrite(curve), ipa.Transcript(curve)
+        t_j.write_point(fields.to_limbs(jac, bf, True).reshape(12))
+        t_a.write_point(fields.to_limbs(list(pt), bf, True).reshape(8))
+        t_o.write_point(pt)
+        assert t_j.finalize() == t_a.finalize() == bytes(t_o.out)
+        assert t_j.squeeze_challenge() == t_a.squeeze_challenge() == t_o.squeeze_challenge()
+    inf = np.zeros(12, dtype=np.uint64)
+    try:
+        Blake2bWrite(curve).write_point(inf)
+        assert False, "the identity must be refused (transcript.rs:209-214)"
+    except ValueError:
+        pass
