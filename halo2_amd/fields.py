@@ -34,6 +34,32 @@ def delta(field: int) -> int:
     return pow(MULTIPLICATIVE_GENERATOR, 1 << S, MODULUS[field])
 
 
+def sqrt(a: int, field: int):
+    """A square root of a, or None (ff::Field::sqrt; Tonelli-Shanks over the 2^32-torsion: both primes are 1 mod 2^32).  Host-side,
+    for the handful of points a verifier decodes from a proof; bulk decoding (`Params::read`) is `h2_points_decompress`."""
+    m = MODULUS[field]
+    a %= m
+    if a == 0:
+        return 0
+    t_odd = (m - 1) >> S
+    w = pow(a, (t_odd - 1) // 2, m)              # a^((T-1)/2)
+    r = a * w % m                                # a^((T+1)/2): a root once the 2-power part of a^T is cancelled
+    t = r * w % m                                # a^T, of order dividing 2^S
+    z = root_of_unity(field)                     # generator of the 2^S-torsion
+    order = S
+    while t != 1:
+        i, probe = 0, t
+        while probe != 1:
+            probe = probe * probe % m
+            i += 1
+            if i == order:
+                return None                      # a^T has full order: a is not a square
+        b = pow(z, 1 << (order - i - 1), m)
+        z = b * b % m
+        r, t, order = r * b % m, t * z % m, i
+    return r
+
+
 def to_limbs(vals, field: int | None = None, montgomery: bool = True) -> np.ndarray:
     """ints -> (n, 4) uint64 limbs; Montgomery form (x * 2^256 mod p) when `montgomery`."""
     vals = list(vals)

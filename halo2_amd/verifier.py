@@ -16,7 +16,7 @@ import numpy as np
 from . import fields
 from ._lib import FORM_MONTGOMERY
 from .arithmetic import best_multiexp, points_sum, scale_add
-from .commitment import Blind, Params, points_from_bytes
+from .commitment import Blind, Params
 from .multiopen import construct_intermediate_sets
 from .transcript import _Blake2bTranscript
 
@@ -33,16 +33,25 @@ class Blake2bRead(_Blake2bTranscript):
 
     def read_point(self):
         """-> (x, y) canonical integers; raises VerificationError on a short read or an invalid encoding (:89-101)."""
-        raw = self.proof[self.pos:self.pos + 32]
+        raw = bytearray(self.proof[self.pos:self.pos + 32])
         if len(raw) != 32:
             raise VerificationError("proof too short")
         self.pos += 32
-        try:
-            limbs = points_from_bytes(raw, self.curve)[0]
-            self.common_point(limbs)                     # refuses the identity (transcript.rs:209-214)
-        except ValueError as e:
-            raise VerificationError("invalid point encoding in proof") from e
-        return tuple(fields.from_limbs(limbs.reshape(2, 4), self.base, True))
+        # pasta_curves' from_bytes: x little-endian, the top bit carries the parity of y.  Decoded on the host: one square root
+        # is microseconds of integer arithmetic, a device round trip per point was most of a small proof's verification time.
+        bm = fields.MODULUS[self.base]
+        sign = raw[31] >> 7
+        raw[31] &= 0x7F
+        x = int.from_bytes(raw, "little")
+        if x >= bm or x == 0:                            # non-canonical, or the identity / (0, odd): never valid in a proof (transcript.rs:209-214)
+            raise VerificationError("invalid point encoding in proof")
+        y = fields.sqrt((x * x * x + 5) % bm, self.base)
+        if y is None:
+            raise VerificationError("invalid point encoding in proof")
+        if y & 1 != sign:
+            y = bm - y
+        self.common_point(fields.to_limbs([x, y], self.base, True).reshape(8))
+        return x, y
 
     def read_scalar(self) -> int:
         """:103-116: canonical 32-byte little-endian field element."""

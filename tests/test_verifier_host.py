@@ -87,3 +87,47 @@ def test_transcript_accepts_jacobian_points_like_to_affine():
         assert False, "the identity must be refused (transcript.rs:209-214)"
     except ValueError:
         pass
+
+
+def test_host_point_decoding_matches_the_restatement():
+    """Blake2bRead.read_point decodes on the host (fields.sqrt): same points, same rejections as oracle/pasta.py's restatement of
+    pasta_curves' from_bytes, same transcript state as the writer had."""
+    from halo2_amd.verifier import Blake2bRead, VerificationError
+    rnd = random.Random(8)
+    for curve in (h.PALLAS, h.VESTA):
+        bf = fields.CURVE_FIELDS[curve][0]
+        bm = fields.MODULUS[bf]
+        for v in (0, 1, 4, 5, bm - 1, rnd.randrange(bm), rnd.randrange(bm)):
+            r = fields.sqrt(v, bf)
+            want = pasta.sqrt_mod(v, bm)
+            assert (r is None) == (want is None)
+            if r is not None:
+                assert r * r % bm == v % bm
+        pts = _points(curve, 12, rnd)
+        w = Blake2bWrite(curve)
+        for pt in pts:
+            w.write_point(fields.to_limbs(list(pt), bf, True).reshape(8))
+        proof = w.finalize()
+        rd = Blake2bRead(curve, proof)
+        assert [rd.read_point() for _ in pts] == pts
+        assert rd.squeeze_challenge() == w.squeeze_challenge()
+        # rejections: x not canonical, x^3 + 5 not a square, the identity, a short read
+        bad = []
+        for _ in range(40):
+            x = rnd.randrange(1, bm)
+            if pasta.sqrt_mod((x ** 3 + 5) % bm, bm) is None:
+                bad.append(int(x).to_bytes(32, "little"))
+                break
+        bad += [int(bm).to_bytes(32, "little"), bytes(32), bytes([1]) * 31]
+        for raw in bad:
+            try:
+                pasta.point_from_bytes(raw, bm) if len(raw) == 32 else None
+                restated_ok = len(raw) == 32 and raw != bytes(32)
+            except ValueError:
+                restated_ok = False
+            assert not restated_ok
+            try:
+                Blake2bRead(curve, raw).read_point()
+                assert False, raw.hex()
+            except VerificationError:
+                pass
