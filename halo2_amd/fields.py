@@ -60,30 +60,27 @@ def sqrt(a: int, field: int):
     return r
 
 
+_MASK256 = (1 << 256) - 1
+
+
 def to_limbs(vals, field: int | None = None, montgomery: bool = True) -> np.ndarray:
     """ints -> (n, 4) uint64 limbs; Montgomery form (x * 2^256 mod p) when `montgomery`."""
-    vals = list(vals)
-    out = np.empty((len(vals), 4), dtype=np.uint64)
-    m = MODULUS[field] if field is not None else None
-    for i, v in enumerate(vals):
-        v = int(v)
-        if montgomery:
-            v = v * R % m
-        for j in range(4):
-            out[i, j] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
-    return out
+    if montgomery:
+        m = MODULUS[field]
+        raw = b"".join((int(v) * R % m).to_bytes(32, "little") for v in vals)
+    else:
+        raw = b"".join((int(v) & _MASK256).to_bytes(32, "little") for v in vals)
+    return np.frombuffer(raw, dtype="<u8").reshape(-1, 4).astype(np.uint64)
 
 
 def from_limbs(a: np.ndarray, field: int | None = None, montgomery: bool = True) -> list[int]:
-    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
-    rinv = pow(R, -1, MODULUS[field]) if montgomery else None
-    out = []
-    for r in a:
-        v = int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192
-        if montgomery:
-            v = v * rinv % MODULUS[field]
-        out.append(v)
-    return out
+    raw = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4).astype("<u8").tobytes()
+    vals = [int.from_bytes(raw[i:i + 32], "little") for i in range(0, len(raw), 32)]
+    if montgomery:
+        m = MODULUS[field]
+        rinv = pow(R, -1, m)
+        vals = [v * rinv % m for v in vals]
+    return vals
 
 
 def scalar_limbs(v: int, field: int, montgomery: bool = True) -> np.ndarray:
