@@ -43,8 +43,8 @@ extern "C" {
 #define H2_ERR_HIP 2    /* a HIP runtime call failed; see h2_last_error() */
 #define H2_ERR_NODEV 3  /* no gfx950 device / HIP runtime unavailable */
 #define H2_ERR_HANDLE 4 /* unknown or freed handle */
-#define H2_ERR_DECODE 5
-#define H2_ERR_LOOKUP 6 /* permute_expression_pair: an input value does not occur in the table (Error::ConstraintSystemFailure) */ /* a compressed point does not decode (where pasta_curves' from_bytes returns None) */
+#define H2_ERR_DECODE 5 /* a compressed point does not decode (where pasta_curves' from_bytes returns None) */
+#define H2_ERR_LOOKUP 6 /* permute_expression_pair: an input value does not occur in the table (Error::ConstraintSystemFailure) */
 
 #define H2_FP 0
 #define H2_FQ 1
