@@ -1,0 +1,105 @@
+"""The HIP path against values the REFERENCE TREE pins (not against the builder's restatement): the verifying key of
+halo2_proofs/tests/plonk_api.rs:958-981 recomputed through the C ABI, and group-law anchors on the 288 reference-pinned
+Vesta points.  The oracle supplies only inputs here (hash-to-curve generators, the keygen columns); the expected values
+are the reference's own numbers from tests/golden/pinned_vk.json."""
+import numpy as np
+import pytest
+
+import halo2_amd as h
+from oracle import c_oracle as co
+from oracle import pasta as o
+from oracle import plonk_api as pa
+from test_reference_goldens import PINNED, PINNED_FIXED, _all_pinned_points
+
+pytestmark = pytest.mark.gpu
+VESTA = h.VESTA
+
+
+def affine_of(curve, out):
+    out = np.ascontiguousarray(out, dtype=np.uint64)
+    return co.jac_to_affine_ints(curve, out) if out.shape[0] == 12 else co.affine_to_ints(curve, out)
+
+
+@pytest.fixture(scope="module")
+def keygen():
+    g, _, w, u = pa.params_new("vesta", 5, with_lagrange=False)
+    fixed, mapping = pa.keygen_columns(o.P)
+    om = [pow(o.omega_for(o.P, 5), j, o.P) for j in range(32)]
+    sigmas = [[pow(pa.DELTA[o.P], mapping[i][j][0], o.P) * om[mapping[i][j][1]] % o.P for j in range(32)] for i in range(12)]
+    return g, w, u, fixed + sigmas
+
+
+def test_pinned_vk_through_registered_commit(keygen):
+    """Params (g_lagrange by the device point FFT, h2_lagrange_basis) -> commit_lagrange (h2_commit over the registered
+    table, blind = Blind::default()) for the 7 fixed and 12 permutation columns == plonk_api.rs:958-981."""
+    g, w, u, columns = keygen
+    sf = co.field_of_curve(VESTA, "scalar")
+    params = h.Params.from_generators(VESTA, 5, co.points_to_mont(VESTA, g), None, co.points_to_mont(VESTA, [w])[0],
+                                      co.points_to_mont(VESTA, [u])[0])
+    got = []
+    for col in columns:
+        poly = co.to_mont(sf, co.ints_to_limbs(col))
+        got.append(affine_of(VESTA, params.commit_lagrange(poly, h.Blind(field=sf))))
+    assert got == PINNED
+    # affine output straight from the device (to_affine on the GPU), and device-resident columns in one batch call
+    assert affine_of(VESTA, params.commit_lagrange(co.to_mont(sf, co.ints_to_limbs(columns[6])), h.Blind(field=sf), affine=True)) \
+        == PINNED_FIXED[6]
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    polys = [torch.from_numpy(co.to_mont(sf, co.ints_to_limbs(c)).view(np.int64)).to(dev) for c in columns]
+    out = params.commit_batch(polys, [h.Blind(field=sf)] * len(polys), lagrange=True, affine=True)
+    torch.cuda.synchronize()
+    assert [affine_of(VESTA, out[i].cpu().numpy().view(np.uint64)) for i in range(len(polys))] == PINNED
+    params.close()
+
+
+def test_pinned_vk_through_generic_multiexp(keygen):
+    """The free function best_multiexp (arithmetic.rs:143) over g_lagrange || w, as commit_lagrange calls it
+    (commitment.rs:143-149)."""
+    g, w, _, columns = keygen
+    sf = co.field_of_curve(VESTA, "scalar")
+    gl = h.lagrange_basis(co.points_to_mont(VESTA, g), VESTA, 5)
+    bases = np.concatenate([gl, co.points_to_mont(VESTA, [w])])
+    for col, want in zip(columns, PINNED):
+        sc = co.to_mont(sf, co.ints_to_limbs(col + [1]))
+        assert affine_of(VESTA, h.best_multiexp(sc, bases, VESTA)) == want
+
+
+def test_group_law_on_reference_pinned_points():
+    """[q-1]P = -P and [q-1]P + P = O for every reference-pinned Vesta point, and [2^k]P by doubling == best_multiexp,
+    through h2_msm and through a registered commit."""
+    pts = _all_pinned_points()
+    n = len(pts)
+    sf = co.field_of_curve(VESTA, "scalar")
+    bases = co.points_to_mont(VESTA, pts)
+    neg1 = co.to_mont(sf, co.ints_to_limbs([o.P - 1]))
+    one = co.to_mont(sf, co.ints_to_limbs([1]))
+    for i in range(n):
+        assert affine_of(VESTA, h.best_multiexp(neg1, bases[i:i + 1], VESTA)) == o.ec_neg(pts[i], o.Q)
+        both = h.best_multiexp(np.concatenate([neg1, one]), np.concatenate([bases[i:i + 1], bases[i:i + 1]]), VESTA)
+        assert affine_of(VESTA, both) is None
+    for k in (1, 7, 64, 200, 253):
+        sc = co.to_mont(sf, co.ints_to_limbs([pow(2, k, o.P)] * n))
+        want = None
+        for P_ in pts:
+            d = P_
+            for _ in range(k):
+                d = o.ec_add(d, d, o.Q)
+            want = o.ec_add(want, d, o.Q)
+        assert affine_of(VESTA, h.best_multiexp(sc, bases, VESTA)) == want
+    # all of them at once with scalar q - 1: sum of negations, on the registered (table) path; 288 -> pad to 512
+    pad = np.tile(bases[0], (512, 1))
+    pad[:n] = bases
+    sc = np.zeros((512, 4), dtype=np.uint64)
+    sc[:n] = neg1
+    params = h.Params(VESTA, 9, pad, pad, bases[0], bases[1])
+    got = affine_of(VESTA, params.commit(sc, h.Blind(np.zeros(4, dtype=np.uint64))))
+    want = None
+    for P_ in pts:
+        want = o.ec_add(want, o.ec_neg(P_, o.Q), o.Q)
+    assert got == want
+    params.close()
+    G = (o.P - 1, 2)                                                                  # Pallas (-1, 2), msm.rs:181
+    s0 = co.field_of_curve(h.PALLAS, "scalar")
+    got = h.best_multiexp(co.to_mont(s0, co.ints_to_limbs([o.Q - 1])), co.points_to_mont(h.PALLAS, [G]), h.PALLAS)
+    assert affine_of(h.PALLAS, got) == o.ec_neg(G, o.P)
