@@ -102,6 +102,13 @@ def main():
         if f.startswith("vk_") and f.endswith(".rdata"):
             vks.append(pinned_vk(f"{d}/{f}"))
     json.dump(vks, open(os.path.join(OUT, "pinned_vk.json"), "w"), indent=0)
+    # the whole pretty-printed pinned verifying key (tests/plonk_api.rs:585-984: its compact Debug form is what
+    # VerifyingKey::transcript_repr hashes, plonk.rs:75-89) and the stored proof the reference's test verifies against it
+    text = open(os.path.join(REF, "halo2_proofs/tests/plonk_api.rs")).read()
+    a, b = text.index('r#####"') + 7, text.index('"#####')
+    open(os.path.join(OUT, "plonk_api_pinned_vk.txt"), "w").write(text[a:b])
+    proof = open(os.path.join(REF, "halo2_proofs/tests/plonk_api_proof.bin"), "rb").read()
+    open(os.path.join(OUT, "plonk_api_proof.bin"), "wb").write(proof)
     npts = sum(len(v["points"]) for v in vks)
     print(f"poseidon: {len(pose['fp']['permute'])}+{len(pose['fq']['permute'])} permute vectors; "
           f"{len(vks)} pinned VKs with {npts} Vesta points")

@@ -109,3 +109,72 @@ def pinned_commitments(g_lagrange, w, bm: int, sm: int):
     sigmas = [[pow(DELTA[sm], mapping[i][j][0], sm) * om[mapping[i][j][1]] % sm for j in range(n)]
               for i in range(N_PERM_COLUMNS)]
     return [commit_lagrange(c) for c in fixed], [commit_lagrange(s) for s in sigmas]
+
+
+# --- VerifyingKey::transcript_repr (plonk.rs:75-89) -------------------------------------------------------------------
+def compact_debug(pretty: str) -> str:
+    """Rust's `{:#?}` output -> the `{:?}` output of the same value (what `format!("{:?}", vk.pinned())` yields, plonk.rs:81):
+    struct `Name { a: x, b: y }`, tuple `Name(x, y)`, list `[x, y]`; points and field elements print inline in both modes."""
+    out = ""
+    for line in pretty.split("\n"):
+        l = line.strip()
+        if not l:
+            continue
+        if l[0] in "})]":
+            if out.endswith(", "):
+                out = out[:-2]
+            out += (" " if l[0] == "}" else "") + l[0]
+            assert l[1:] in ("", ",")
+            if l[1:] == ",":
+                out += ", "
+        else:
+            out += l
+            if l.endswith(",") or l.endswith("{"):
+                out += " "
+    return out[:-2] if out.endswith(", ") else out
+
+
+def transcript_repr(pretty_pinned_vk: str, m: int = o.P) -> int:
+    import hashlib
+    s = compact_debug(pretty_pinned_vk).encode()
+    digest = hashlib.blake2b(len(s).to_bytes(8, "little") + s, digest_size=64, person=b"Halo2-Verify-Key").digest()
+    return int.from_bytes(digest, "little") % m                           # from_uniform_bytes
+
+
+# --- the constraint system of tests/plonk_api.rs:238-330 in the lowered form the restated prover / verifier take ------------
+ADV_E, ADV_A, ADV_B, ADV_C, ADV_D = range(5)
+
+
+def constraint_system(ConstraintSystem):
+    """Query lists in the order the pinned key prints them (plonk_api.rs:740-880); `ConstraintSystem` is the plain record
+    type the caller's prover / verifier uses (halo2_amd.plonk.ConstraintSystem)."""
+    gate0 = lambda q: (q.advice(ADV_A) * q.fixed(SA) + q.advice(ADV_B) * q.fixed(SB) + q.advice(ADV_A) * q.advice(ADV_B) * q.fixed(SM)
+                       - q.advice(ADV_C) * q.fixed(SC) + q.fixed(SF) * (q.advice(ADV_D, 1) * q.advice(ADV_E, -1)))      # :281-296
+    gate1 = lambda q: q.fixed(SP) * (q.advice(ADV_A) - q.instance(0))                                                     # :298-305
+    return ConstraintSystem(
+        num_fixed_columns=7, num_advice_columns=5, num_instance_columns=1, gates=[gate0, gate1],
+        advice_queries=[(ADV_A, 0), (ADV_B, 0), (ADV_C, 0), (ADV_D, 1), (ADV_E, -1), (ADV_E, 0), (ADV_D, 0)],
+        instance_queries=[(0, 0)],
+        fixed_queries=[(SL, 0), (SF, 0), (SA, 0), (SB, 0), (SC, 0), (SM, 0), (SP, 0)],
+        permutation_columns=[("advice", ADV_A), ("advice", ADV_B), ("advice", ADV_C), ("fixed", SF), ("advice", ADV_E), ("advice", ADV_D),
+                             ("instance", 0), ("fixed", SM), ("fixed", SA), ("fixed", SB), ("fixed", SC), ("fixed", SP)],
+        lookups=[([lambda q: q.advice(ADV_A)], [lambda q: q.fixed(SL)])],                                                 # :276-279
+        degree=4, blinding_factors=BLINDING_FACTORS)
+
+
+def witness(m: int = o.P):
+    """The advice columns `MyCircuit { a: Value::known(a) }` assigns (plonk_api.rs:96-212, 372-397) and its public input."""
+    n = 1 << K
+    a = 2834758237 * o.zeta(m) % m
+    a2, a4 = a * a % m, pow(a, 4, m)
+    adv = [[0] * n for _ in range(5)]
+    adv[ADV_A][0] = 2                                                     # public_input: a = 2 at row 0 (:378)
+    row = 1
+    for _ in range(10):
+        mul, add = row, row + 1
+        adv[ADV_A][mul], adv[ADV_B][mul], adv[ADV_C][mul] = a, a, a2      # raw_multiply (a, a, a^2), d = lhs^4, e = rhs^4
+        adv[ADV_D][mul], adv[ADV_E][mul] = a4, a4
+        adv[ADV_A][add], adv[ADV_B][add], adv[ADV_C][add] = a, a2, (a2 + a) % m                           # raw_add (a, a^2, a^2 + a)
+        adv[ADV_D][add], adv[ADV_E][add] = a4, pow(a2, 4, m)
+        row += 2
+    return adv, [[2]]

@@ -103,3 +103,49 @@ def test_group_law_on_reference_pinned_points():
     s0 = co.field_of_curve(h.PALLAS, "scalar")
     got = h.best_multiexp(co.to_mont(s0, co.ints_to_limbs([o.Q - 1])), co.points_to_mont(h.PALLAS, [G]), h.PALLAS)
     assert affine_of(h.PALLAS, got) == o.ec_neg(G, o.P)
+
+
+def test_reference_stored_proof_through_the_device_verifier_and_prover():
+    """The product's keygen (device commits) reproduces the pinned key; its verifier (MSM::eval on the device) accepts the
+    proof the reference stores (tests/plonk_api_proof.bin, two circuit instances) and rejects perturbations; and a fresh proof
+    of the same circuit from the device prover is accepted by both verifiers."""
+    import os
+    from halo2_amd import verifier as hv
+    from halo2_amd.plonk import ConstraintSystem, create_proof_many, keygen_pk
+    from halo2_amd.transcript import Blake2bWrite
+    from oracle import plonk as op
+    from test_reference_goldens import GOLDEN
+    g, _, w, u = pa.params_new("vesta", 5, with_lagrange=False)
+    gm, wm, um = co.points_to_mont(VESTA, g), co.points_to_mont(VESTA, [w])[0], co.points_to_mont(VESTA, [u])[0]
+    params = h.Params.from_generators(VESTA, 5, gm, None, wm, um)
+    cs = pa.constraint_system(ConstraintSystem)
+    fixed, mapping = pa.keygen_columns(o.P)
+    vk_repr = pa.transcript_repr(open(os.path.join(GOLDEN, "plonk_api_pinned_vk.txt")).read())
+    pk = keygen_pk(params, cs, fixed, mapping, vk_repr)
+    dvk = hv.keygen_vk(params, pk)
+    assert dvk.fixed_commitments + dvk.permutation_commitments == PINNED
+    proof = open(os.path.join(GOLDEN, "plonk_api_proof.bin"), "rb").read()
+    instances = [[[2]], [[2]]]
+    assert hv.verify_proof_many(params, dvk, instances, proof)
+    assert not hv.verify_proof_many(params, dvk, [[[2]], [[3]]], proof)
+    for pos in (0, 1000, 2500, len(proof) - 1):
+        bad = bytearray(proof)
+        bad[pos] ^= 1
+        assert not hv.verify_proof_many(params, dvk, instances, bytes(bad))
+    # a fresh two-instance proof of the reference's circuit and witness from the device prover
+    sf = co.field_of_curve(VESTA, "scalar")
+    ctr = [31337]
+
+    def rng(count):
+        ctr[0] += 1
+        return co.random_field(sf, ctr[0], count)
+    adv, inst = pa.witness(o.P)
+    tr = Blake2bWrite(VESTA)
+    create_proof_many(params, pk, [(adv, inst), ([list(c) for c in adv], inst)], rng, tr)
+    fresh = tr.finalize()
+    assert len(fresh) == len(proof)                                   # CircuitCost::proof_size(2), plonk_api.rs:492-497
+    assert hv.verify_proof_many(params, dvk, instances, fresh)
+    ovk = {"cs": cs, "vk_repr": vk_repr, "domain": o.EvaluationDomain(cs.degree, 5, o.P),
+           "fixed_commitments": PINNED[:7], "permutation_commitments": PINNED[7:]}
+    assert op.verify_proof_many(VESTA, 5, gm, wm, um, ovk, instances, fresh)
+    params.close()

@@ -126,3 +126,58 @@ def test_group_law_on_reference_pinned_points_c():
     gm = co.points_to_mont(0, [G])
     s0 = co.field_of_curve(0, "scalar")
     assert co.jac_to_affine_ints(0, co.best_multiexp(0, co.to_mont(s0, co.ints_to_limbs([o.Q - 1])), gm)) == o.ec_neg(G, o.P)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 3. The proof the reference stores (halo2_proofs/tests/plonk_api_proof.bin, verified by its own test at
+#    tests/plonk_api.rs:447-462) is ACCEPTED by the restated verifier with the key recomputed here, and rejected
+#    once anything is perturbed.  This pins the restated transcript, challenges, argument formulas, multi-point opening,
+#    inner-product verification and its multiexp — the checker the device provers / verifiers are compared with — to the reference.
+def _plonk_api_vk(params5):
+    from halo2_amd.plonk import ConstraintSystem                 # the plain record type; nothing of the product runs here
+    from oracle import plonk as op
+    g, g_lagrange, w, u = params5
+    text = open(os.path.join(GOLDEN, "plonk_api_pinned_vk.txt")).read()
+    cs = pa.constraint_system(ConstraintSystem)
+    fixed, perm = pa.pinned_commitments(g_lagrange, w, o.Q, o.P)
+    vk = {"cs": cs, "vk_repr": pa.transcript_repr(text), "domain": o.EvaluationDomain(cs.degree, 5, o.P),
+          "fixed_commitments": fixed, "permutation_commitments": perm}
+    assert vk["domain"].extended_k == PLONK_API["extended_k"]
+    pts = (co.points_to_mont(VESTA, g), co.points_to_mont(VESTA, [w])[0], co.points_to_mont(VESTA, [u])[0])
+    return op, vk, pts
+
+
+def test_reference_stored_proof_verifies(params5):
+    op, vk, (g, w, u) = _plonk_api_vk(params5)
+    proof = open(os.path.join(GOLDEN, "plonk_api_proof.bin"), "rb").read()
+    instances = [[[2]], [[2]]]                                   # two circuit instances, public input 2 (plonk_api.rs:404, 456)
+    assert op.verify_proof_many(VESTA, 5, g, w, u, vk, instances, proof) is True
+    assert op.verify_proof_many(VESTA, 5, g, w, u, vk, [[[2]], [[3]]], proof) is False
+    assert op.verify_proof_many(VESTA, 5, g, w, u, dict(vk, vk_repr=vk["vk_repr"] + 1), instances, proof) is False
+    for pos in (0, 1000, 2500, len(proof) - 1):
+        bad = bytearray(proof)
+        bad[pos] ^= 1
+        assert op.verify_proof_many(VESTA, 5, g, w, u, vk, instances, bytes(bad)) is False
+
+
+def test_restated_prover_on_the_reference_circuit_and_witness(params5):
+    """The sequential restatement of plonk::create_proof, on the reference's circuit + witness (two instances, as its test
+    proves them): the proof has the stored proof's length (CircuitCost::proof_size(2), plonk_api.rs:492-497) and is accepted by
+    the verifier that accepts the stored proof; keygen through the C restatement gives the pinned key."""
+    from oracle import ipa
+    op, vk, (g, w, u) = _plonk_api_vk(params5)
+    fixed, mapping = pa.keygen_columns(o.P)
+    sf = co.field_of_curve(VESTA, "scalar")
+    ctr = [5]
+
+    def rng(count):
+        ctr[0] += 1
+        return co.random_field(sf, ctr[0], count)
+    adv, inst = pa.witness(o.P)
+    ot = ipa.Transcript(VESTA)
+    op.create_proof_many(VESTA, 5, g, w, u, vk["cs"], fixed, mapping, vk["vk_repr"], [(adv, inst), (adv, inst)], rng, ot)
+    proof = bytes(ot.out)
+    assert len(proof) == len(open(os.path.join(GOLDEN, "plonk_api_proof.bin"), "rb").read()) == 4160
+    assert op.verify_proof_many(VESTA, 5, g, w, u, vk, [[[2]], [[2]]], proof)
+    kv = op.keygen_vk(VESTA, 5, g, w, vk["cs"], fixed, mapping, vk["vk_repr"])
+    assert kv["fixed_commitments"] + kv["permutation_commitments"] == PINNED
