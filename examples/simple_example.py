@@ -96,7 +96,7 @@ def main(argv=None):
         return out
 
     t0 = time.perf_counter()
-    pk = keygen_pk(params, cs, fixed, mapping, vk_repr=0)
+    pk = keygen_pk(params, cs, fixed, mapping)          # transcript_repr derived from the key
     vk = keygen_vk(params, pk)
     t1 = time.perf_counter()
     transcript = Blake2bWrite(curve)

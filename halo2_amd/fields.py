@@ -85,3 +85,10 @@ def from_limbs(a: np.ndarray, field: int | None = None, montgomery: bool = True)
 
 def scalar_limbs(v: int, field: int, montgomery: bool = True) -> np.ndarray:
     return to_limbs([v], field, montgomery)[0]
+
+
+def current_device():
+    """The HIP device the C ABI launches on (the caller's current device): one process per GPU sets it once with
+    `torch.cuda.set_device(local_rank)`; every tensor this package allocates follows it."""
+    import torch
+    return torch.device("cuda", torch.cuda.current_device())

@@ -41,7 +41,7 @@ def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, d
     n, k = params.n, params.k
     if p_poly.shape[0] != n:
         raise ValueError("create_proof: polynomial length != params.n")                  # prover.rs:41
-    dev = p_poly.device if hasattr(p_poly, "device") and not isinstance(p_poly, np.ndarray) else torch.device(device or "cuda:0")
+    dev = p_poly.device if hasattr(p_poly, "device") and not isinstance(p_poly, np.ndarray) else (torch.device(device) if device else fields.current_device())
     to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64)).to(dev)
     as_int = lambda limbs: fields.from_limbs(limbs, sf, True)[0]
     as_limbs = lambda v: fields.scalar_limbs(v % m, sf, True)

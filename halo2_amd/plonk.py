@@ -83,12 +83,68 @@ class ProvingKey:
         self.l0, self.l_blind, self.l_last = l0, l_blind, l_last
 
 
-def keygen_pk(params: Params, cs: ConstraintSystem, fixed_columns, mapping, vk_repr: int, device=None) -> ProvingKey:
+class _FingerprintCells:
+    """Lowered expressions are callables, not trees, so they cannot be printed the way `PinnedConstraintSystem`'s Debug does
+    (plonk.rs:81).  Their fingerprint is their value at points derived from the query's identity (Schwartz-Zippel: two
+    different polynomials of degree <= 2^10 collide with probability ~2^-245)."""
+
+    def __init__(self, m: int):
+        self.m = m
+
+    def _pt(self, kind: str, col: int, rot: int) -> int:
+        import hashlib
+        d = hashlib.blake2b(f"{kind}:{col}:{rot}".encode(), digest_size=64, person=b"Halo2-Vk-Queries").digest()
+        return int.from_bytes(d, "little") % self.m
+
+    def fixed(self, col: int, rot: int = 0):
+        return self._pt("fixed", col, rot)
+
+    def advice(self, col: int, rot: int = 0):
+        return self._pt("advice", col, rot)
+
+    def instance(self, col: int, rot: int = 0):
+        return self._pt("instance", col, rot)
+
+
+def derive_vk_repr(params: Params, cs: ConstraintSystem, domain, fixed_commitments, permutation_commitments) -> int:
+    """Default `VerifyingKey::transcript_repr` (plonk.rs:75-98): Blake2b-512, personal "Halo2-Verify-Key", over a canonical
+    serialisation of everything the reference's pinned key holds -- moduli, k, extended_k, omega, the constraint system's
+    counts / query lists / permutation columns / degree / blinding factors, fingerprints of the gate and lookup expressions,
+    and the fixed and permutation commitments -- so the Fiat-Shamir challenges are bound to the circuit.  For byte
+    interoperability with a reference-produced proof pass the reference's own `transcript_repr` as `vk_repr` instead
+    (tests/test_gpu_reference_goldens.py does, from the pinned key's Debug text)."""
+    import hashlib
+    bf_, sf = fields.CURVE_FIELDS[params.curve]
+    m = fields.MODULUS[sf]
+    cells = _FingerprintCells(m)
+    fp = lambda e: int(e(cells)) % m
+    doc = {
+        "base_modulus": hex(fields.MODULUS[bf_]), "scalar_modulus": hex(m),
+        "k": params.k, "extended_k": domain.extended_k, "omega": hex(domain.omega),
+        "num_fixed_columns": cs.num_fixed_columns, "num_advice_columns": cs.num_advice_columns,
+        "num_instance_columns": cs.num_instance_columns,
+        "advice_queries": [list(q) for q in cs.advice_queries], "instance_queries": [list(q) for q in cs.instance_queries],
+        "fixed_queries": [list(q) for q in cs.fixed_queries], "permutation": [list(c) for c in cs.permutation_columns],
+        "degree": cs.degree, "blinding_factors": cs.blinding_factors,
+        "gates": [hex(fp(g)) for g in cs.gates],
+        "lookups": [[[hex(fp(e)) for e in ins], [hex(fp(e)) for e in tabs]] for ins, tabs in cs.lookups],
+        "fixed_commitments": [None if c is None else [hex(c[0]), hex(c[1])] for c in fixed_commitments],
+        "permutation_commitments": [None if c is None else [hex(c[0]), hex(c[1])] for c in permutation_commitments],
+    }
+    import json
+    s = json.dumps(doc, sort_keys=True, separators=(",", ":")).encode()
+    digest = hashlib.blake2b(len(s).to_bytes(8, "little") + s, digest_size=64, person=b"Halo2-Verify-Key").digest()
+    return int.from_bytes(digest, "little") % m
+
+
+def keygen_pk(params: Params, cs: ConstraintSystem, fixed_columns, mapping, vk_repr: int | None = None, device=None) -> ProvingKey:
     """keygen.rs:296-380 after `synthesize`.  fixed_columns: integer lists of n rows; mapping[c][r] = (c', r') the cell that
-    follows (c, r) in its copy-constraint cycle (permutation/keygen.rs:24-107), identity where unconstrained."""
+    follows (c, r) in its copy-constraint cycle (permutation/keygen.rs:24-107), identity where unconstrained.
+    vk_repr=None (the default) derives the key's transcript representation from the key itself (`derive_vk_repr`), as the
+    reference's `VerifyingKey::from_parts` does; an explicit value is for interop with a reference-produced key."""
     import torch
     from .domain import EvaluationDomain
-    dev = torch.device(device or "cuda:0")
+    dev = torch.device(device) if device else fields.current_device()
     sf = fields.CURVE_FIELDS[params.curve][1]
     n, k = params.n, params.k
     domain = EvaluationDomain(cs.degree, k, sf)
@@ -123,6 +179,12 @@ def keygen_pk(params: Params, cs: ConstraintSystem, fixed_columns, mapping, vk_r
     l0 = indicator([0])                                                     # keygen.rs:343-349
     l_blind = indicator(range(usable + 1, n))                               # :353-359
     l_last = indicator([usable])                                            # :363-368
+    if vk_repr is None:
+        from .verifier import _affine
+        blind_one = Blind(field=sf)
+        host = lambda t: t.cpu().numpy().view(np.uint64)
+        commits = [_affine(params, host(params.commit_lagrange(t[0], blind_one))) for t in fixed + perms]
+        vk_repr = derive_vk_repr(params, cs, domain, commits[:len(fixed)], commits[len(fixed):])
     return ProvingKey(cs, domain, vk_repr, [t[0] for t in fixed], [t[1] for t in fixed], [t[2] for t in fixed],
                       [t[0] for t in perms], [t[1] for t in perms], [t[2] for t in perms], l0, l_blind, l_last)
 

@@ -114,7 +114,7 @@ class MSM:
 
     def _dev(self):
         import torch
-        return torch.device("cuda:0")
+        return fields.current_device()
 
     def add_constant_term(self, constant: int) -> None:                                  # msm.rs:86-95
         import torch
@@ -408,7 +408,7 @@ def _verify(params: Params, vk: VerifyingKey, instances, proof: bytes) -> bool:
     sf, m, n = domain.field, domain.m, params.n
     bf = cs.blinding_factors
     usable = n - (bf + 1)
-    dev = torch.device("cuda:0")
+    dev = fields.current_device()
     host = lambda t: t.cpu().numpy().view(np.uint64)
     num_proofs = len(instances)
     instance_commitments = []

@@ -131,3 +131,28 @@ def test_host_point_decoding_matches_the_restatement():
                 assert False, raw.hex()
             except VerificationError:
                 pass
+
+
+def test_default_vk_repr_binds_the_key():
+    """keygen_pk's default transcript_repr (halo2_amd.plonk.derive_vk_repr; plonk.rs:75-98 in the reference) changes with the
+    commitments, the query lists, a gate polynomial, and the domain."""
+    from types import SimpleNamespace as NS
+    from halo2_amd.plonk import derive_vk_repr
+    from plonk_circuits import make_cs
+    params, dom = NS(curve=1, k=5), NS(extended_k=7, omega=0x1234)
+    fc, pc = [(1, 2), (3, 4)], [(5, 6)]
+    base = derive_vk_repr(params, make_cs(), dom, fc, pc)
+    assert base == derive_vk_repr(params, make_cs(), dom, fc, pc) and 0 < base < pasta.P
+    seen = {base}
+    seen.add(derive_vk_repr(params, make_cs(), dom, [(1, 2), (3, 5)], pc))
+    seen.add(derive_vk_repr(params, make_cs(), dom, fc, [None]))
+    seen.add(derive_vk_repr(NS(curve=1, k=6), make_cs(), dom, fc, pc))
+    seen.add(derive_vk_repr(params, make_cs(), NS(extended_k=7, omega=0x1235), fc, pc))
+    seen.add(derive_vk_repr(params, make_cs("two_lookups"), dom, fc, pc))
+    cs = make_cs()
+    cs.gates = [cs.gates[0], lambda q: q.fixed(2) * (q.advice(0) - q.instance(0))]       # sp -> sc in the public-input gate
+    seen.add(derive_vk_repr(params, cs, dom, fc, pc))
+    cs = make_cs()
+    cs.advice_queries = cs.advice_queries[::-1]
+    seen.add(derive_vk_repr(params, cs, dom, fc, pc))
+    assert len(seen) == 8
