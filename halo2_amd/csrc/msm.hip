@@ -1496,6 +1496,25 @@ struct Bases {
     // blind-base maintenance is serialised on one stream of its own, whatever streams the commits come from
     hipStream_t maint = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    int device = 0;            // the HIP device the table lives on (current at registration)
+    // The table is owned here: it goes back to the allocator when the LAST reference drops -- h2_bases_free only removes
+    // the handle, so a commit another host thread is still enqueueing (it holds the shared_ptr from find_bases) keeps the
+    // memory alive, and every error path of h2_bases_register releases what it had allocated.
+    ~Bases() {
+        if (!d_table && !d_blind_tmp && !maint) return;
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != device) (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();
+        if (d_table) (void)hipFree(d_table);
+        if (d_blind_tmp) (void)hipFree(d_blind_tmp);
+        if (maint) {
+            (void)hipStreamDestroy(maint);
+            (void)hipEventDestroy(ev_in);
+            (void)hipEventDestroy(ev_out);
+        }
+        if (cur != device) (void)hipSetDevice(cur);
+    }
 };
 static std::mutex g_bases_mu;
 static std::map<h2_bases_t, std::shared_ptr<Bases>> g_bases;
@@ -1650,6 +1669,7 @@ extern "C" int h2_bases_register(int curve, const uint64_t *bases_xy, size_t n, 
     b->c = choose_c(n ? n : 1, true);
     b->W = 255 / b->c + 1;
     b->stride = (u32)n + 1;
+    H2_HIP(hipGetDevice(&b->device));
     H2_HIP(hipMalloc(&b->d_table, (size_t)b->W * b->stride * 64));
     H2_HIP(hipMemsetAsync(b->d_table, 0, (size_t)b->W * b->stride * 64, 0));
     H2_HIP(hipMalloc(&b->d_blind_tmp, (size_t)b->W * 128 + 64));
@@ -1657,10 +1677,7 @@ extern "C" int h2_bases_register(int curve, const uint64_t *bases_xy, size_t n, 
     if (n) {
         H2_HIP(hipMemcpyAsync(b->d_table, bases_xy, n * 64, hipMemcpyHostToDevice, 0));
         if (form == H2_FORM_CANONICAL) to_mont_async(curve, (u32 *)b->d_table, n * 2, 0);
-        if ((rc = table_fill(*b, 0, (u32)n, 0)) != H2_OK) {
-            (void)hipFree(b->d_table);
-            return rc;
-        }
+        if ((rc = table_fill(*b, 0, (u32)n, 0)) != H2_OK) return rc;   // ~Bases releases the allocations
     }
     H2_HIP(hipStreamSynchronize(0));
     std::lock_guard<std::mutex> lk(g_bases_mu);
@@ -1679,16 +1696,7 @@ extern "C" int h2_bases_free(h2_bases_t handle) {
         b = it->second;
         g_bases.erase(it);
     }
-    if (b->d_table) {
-        H2_HIP(hipDeviceSynchronize());
-        H2_HIP(hipFree(b->d_table));
-        if (b->d_blind_tmp) H2_HIP(hipFree(b->d_blind_tmp));
-        if (b->maint) {
-            (void)hipStreamDestroy(b->maint);
-            (void)hipEventDestroy(b->ev_in);
-            (void)hipEventDestroy(b->ev_out);
-        }
-    }
+    b.reset();   // frees now unless a concurrent commit still holds a reference (then when that call returns)
     return H2_OK;
 }
 
