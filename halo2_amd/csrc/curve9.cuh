@@ -1,0 +1,99 @@
+// XYZZ mixed addition on the carry-free 9 x 29-bit field layer (field9.cuh): the inner loop of the MSM bucket accumulation.
+// Same formulas and the same completeness as curve.cuh's xyzz_madd (madd-2008-s: 8M + 2S; P + P, P - P, O handled by rare
+// divergent branches); coordinates are in M9 form (x * 2^261 mod p), normalised limbs, never conditionally subtracted.
+//
+// Limb / value bounds through one addition (N = normalised: limbs 0..7 in [0, 2^29), |value| < 2^256):
+//   u2, s2, pp, ppp, qq, zz', zzz'   products                       -> N
+//   p = u2 - X1, r = s2 - Y1         N - N: |limbs| < 2^29, |value| < 2^257                  (squared / multiplied by N: fine)
+//   x3 = r^2 - ppp - 2 qq            |limbs| < 3 * 2^29, |value| < 2^258  -> carry pass -> N  (it is multiplied by r below)
+//   y3 = r (qq - x3) - Y1 ppp        N - N                                -> carry pass -> N  (it meets s2 in the next r)
+// so two carry passes (24 plain VALU ops each) per addition, and no other reduction of any kind.
+#pragma once
+#include "curve.cuh"
+#include "field9.cuh"
+
+namespace h2 {
+
+template <int F> struct aff9 {
+    fe9 x, y;
+};
+template <int F> struct xyzz9 {
+    fe9 x, y, zz, zzz;
+};
+
+__device__ __forceinline__ bool fe9_all_zero(const fe9 &a) {
+    i32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= a.v[i];
+    return o == 0;
+}
+template <int F> __device__ __forceinline__ xyzz9<F> xyzz9_identity() { return xyzz9<F>{fe9_zero(), fe9_zero(), fe9_zero(), fe9_zero()}; }
+template <int F> __device__ __forceinline__ bool xyzz9_is_identity(const xyzz9<F> &p) { return fe9_all_zero(p.zz); }
+// Identities are always stored as exact zero limbs (never as the result of a multiplication: a product of value 0 may come out
+// as [2^29, 2^29 - 1, ..., -1]); aff9_unpack / aff9_from_r256 / xyzz9_from_r256 preserve that.
+template <int F> __device__ __forceinline__ bool aff9_is_identity(const aff9<F> &p) { return fe9_all_zero(p.x) && fe9_all_zero(p.y); }
+
+// a table entry stored in M9 form (canonical value packed 8 x 32): repacking only
+template <int F> __device__ __forceinline__ aff9<F> aff9_unpack(const affine<F> &p) { return aff9<F>{fe9_unpack(p.x), fe9_unpack(p.y)}; }
+// a point in the reference's Montgomery form (R = 2^256): one multiplication per coordinate.  (0, 0) stays (0, 0).
+template <int F> __device__ __forceinline__ aff9<F> aff9_from_r256(const affine<F> &p) {
+    if (aff_is_identity(p)) return aff9<F>{fe9_zero(), fe9_zero()};      // a PRODUCT with value 0 need not have all-zero limbs
+    return aff9<F>{fe9_from_r256<F>(p.x), fe9_from_r256<F>(p.y)};
+}
+template <int F> __device__ __forceinline__ xyzz<F> xyzz9_to_r256(const xyzz9<F> &p) {
+    return xyzz<F>{fe9_to_r256<F>(p.x), fe9_to_r256<F>(p.y), fe9_to_r256<F>(p.zz), fe9_to_r256<F>(p.zzz)};
+}
+template <int F> __device__ __forceinline__ xyzz9<F> xyzz9_from_r256(const xyzz<F> &p) {
+    if (xyzz_is_identity(p)) return xyzz9_identity<F>();
+    return xyzz9<F>{fe9_from_r256<F>(p.x), fe9_from_r256<F>(p.y), fe9_from_r256<F>(p.zz), fe9_from_r256<F>(p.zzz)};
+}
+
+// rare: the cheap filter on p = u2 - X1 fired.  Decides whether p really is 0 mod p and, if so, produces the sum (2q or the
+// identity).  Everything goes in and out BY VALUE: handing the accumulator itself to a non-inlined function by reference would
+// make it escape, and the compiler would then keep it in scratch memory through the whole accumulation loop.
+template <int F> __device__ __noinline__ bool xyzz9_madd_rare(fe9 p, fe9 r, aff9<F> q, xyzz9<F> *out) {
+    if (!fe_is_zero(fe9_canonical<F>(p))) return false;
+    if (!fe_is_zero(fe9_canonical<F>(r))) {
+        *out = xyzz9_identity<F>();
+        return true;
+    }
+    affine<F> q256;
+    q256.x = fe9_to_r256<F>(q.x);
+    q256.y = fe9_to_r256<F>(q.y);
+    *out = xyzz9_from_r256<F>(xyzz_dbl_affine<F>(q256));
+    return true;
+}
+
+// acc += q; complete.  acc normalised on entry and exit.
+template <int F> __device__ __forceinline__ void xyzz9_madd(xyzz9<F> &acc, const aff9<F> &q) {
+    if (aff9_is_identity(q)) return;
+    if (xyzz9_is_identity(acc)) {
+        acc.x = q.x;
+        acc.y = q.y;
+        acc.zz = fe9_one<F>();
+        acc.zzz = fe9_one<F>();
+        return;
+    }
+    const fe9 u2 = fe9_mul<F>(q.x, acc.zz);
+    const fe9 s2 = fe9_mul<F>(q.y, acc.zzz);
+    const fe9 p = fe9_sub(u2, acc.x);
+    const fe9 r = fe9_sub(s2, acc.y);
+    if (fe9_maybe_zero_mod_p(p)) {              // 3 instructions; true for 33 of 2^29 residues
+        xyzz9<F> special;
+        if (xyzz9_madd_rare<F>(p, r, q, &special)) {
+            acc = special;
+            return;
+        }
+    }
+    const fe9 pp = fe9_sqr<F>(p);
+    const fe9 ppp = fe9_mul<F>(p, pp);
+    const fe9 qq = fe9_mul<F>(acc.x, pp);
+    const fe9 x3 = fe9_norm(fe9_sub(fe9_sub(fe9_sqr<F>(r), ppp), fe9_dbl(qq)));
+    const fe9 y3 = fe9_norm(fe9_sub(fe9_mul<F>(r, fe9_sub(qq, x3)), fe9_mul<F>(acc.y, ppp)));
+    acc.x = x3;
+    acc.y = y3;
+    acc.zz = fe9_mul<F>(acc.zz, pp);
+    acc.zzz = fe9_mul<F>(acc.zzz, ppp);
+}
+
+}  // namespace h2
