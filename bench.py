@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--columns", type=int, default=4, help="distinct scalar columns resident in HBM")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("H2_BENCH_STREAMS", "3")),
                     help="HIP streams the independent column commits are spread over (per GPU)")
+    ap.add_argument("--prewarm-ms", type=float, default=400.0,
+                    help="untimed commits issued before the W warm-up steps until this much wall time has passed: the chip's clocks "
+                         "take a few hundred ms of sustained load to settle (the first ~20 launches of a cold run are 10-15 %% slower)")
     ap.add_argument("--lane-fraction", type=float, default=None,
                     help="share of the wave slots one accumulate launch claims (default 1)")
     args = ap.parse_args()
@@ -112,6 +115,12 @@ def main():
 
     for i in range(len(sps)):     # one untimed commit per stream: each (device, stream) pair owns a workspace that is
         step(i)                   # allocated on first use (hipMalloc synchronises the device)
+    sync_all()
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:      # clock settling, untimed (not part of W or K)
+        for i in range(2 * len(sps)):
+            step(i)
+        torch.cuda.synchronize()
     sync_all()
     for i in range(args.warmup):
         step(i)

@@ -48,6 +48,41 @@ template <int F> __device__ __forceinline__ xyzz9<F> xyzz9_from_r256(const xyzz<
     return xyzz9<F>{fe9_from_r256<F>(p.x), fe9_from_r256<F>(p.y), fe9_from_r256<F>(p.zz), fe9_from_r256<F>(p.zzz)};
 }
 
+// reference Montgomery form (x * 2^256) -> M9 form (x * 2^261), canonical, in the 8 x 32 layer: one multiplication by 2^5.
+// Used where tables are built (registration, blind base); (0, 0) stays (0, 0).
+template <int F> __device__ __forceinline__ affine<F> aff_to_m9(const affine<F> &p) {
+    return affine<F>{fe_mulx<F>(p.x, fe_k32<F>()), fe_mulx<F>(p.y, fe_k32<F>())};
+}
+
+// raw limbs of an accumulator (36 words, 144 B): what msm_accumulate parks for msm_segments_to_r256
+template <int F> __device__ __forceinline__ void xyzz9_store_raw(u32 *dst, const xyzz9<F> &a) {
+    uint4 *q = reinterpret_cast<uint4 *>(dst);
+    const fe9 *c[4] = {&a.x, &a.y, &a.zz, &a.zzz};
+    u32 w[36];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int i = 0; i < 9; i++) w[9 * k + i] = (u32)c[k]->v[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+template <int F> __device__ __forceinline__ xyzz9<F> xyzz9_load_raw(const u32 *src) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(src);
+    u32 w[36];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const uint4 v = q[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    xyzz9<F> a;
+    fe9 *c[4] = {&a.x, &a.y, &a.zz, &a.zzz};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int i = 0; i < 9; i++) c[k]->v[i] = (i32)w[9 * k + i];
+    return a;
+}
+
 // rare: the cheap filter on p = u2 - X1 fired.  Decides whether p really is 0 mod p and, if so, produces the sum (2q or the
 // identity).  Everything goes in and out BY VALUE: handing the accumulator itself to a non-inlined function by reference would
 // make it escape, and the compiler would then keep it in scratch memory through the whole accumulation loop.

@@ -198,8 +198,27 @@ template <int F> __device__ __forceinline__ fe fe9_canonical(const fe9 &a) {
     return fe9_pack(t);
 }
 
+// the same for a value known to lie in (-p, 2p): what a multiplication by a CANONICAL constant returns (|a| < 2^258 times
+// k < p over 2^261 is below 2^252 in magnitude, plus the quotient's p).  One shift by p and two conditional subtractions.
+template <int F> __device__ __forceinline__ fe fe9_canonical_small(const fe9 &a) {
+    const fe9 pk = fe9_p_shl<F>(0);
+    fe9 t;
+#pragma unroll
+    for (int i = 0; i < 9; i++) t.v[i] = a.v[i] + pk.v[i];
+    t = fe9_norm(t);                            // (0, 3p)
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+        fe9 d;
+#pragma unroll
+        for (int i = 0; i < 9; i++) d.v[i] = t.v[i] - pk.v[i];
+        d = fe9_norm(d);
+        if (d.v[8] >= 0) t = d;
+    }
+    return fe9_pack(t);
+}
+
 template <int F> __device__ __forceinline__ fe9 fe9_from_r256(const fe &x_r256) { return fe9_mul<F>(fe9_unpack(x_r256), fe9_k_in<F>()); }
-template <int F> __device__ __forceinline__ fe fe9_to_r256(const fe9 &x_m9) { return fe9_canonical<F>(fe9_mul<F>(x_m9, fe9_k_out<F>())); }
+template <int F> __device__ __forceinline__ fe fe9_to_r256(const fe9 &x_m9) { return fe9_canonical_small<F>(fe9_mul<F>(x_m9, fe9_k_out<F>())); }
 
 // value = 0 mod p ?  a: limbs below 2^31, |value| < 2^258.  p = 1 mod 2^29, so k p = k mod 2^29: unless the low limb is
 // within +-16 of a multiple of 2^29 the answer is no (the common case costs three instructions).

@@ -43,6 +43,7 @@
 
 #include "common.h"
 #include "curve_wide.cuh"
+#include "curve9.cuh"
 #include "glv.cuh"
 
 namespace h2 {
@@ -753,8 +754,16 @@ __device__ __forceinline__ u32 upper_bucket(const u32 *__restrict__ arr, u32 n, 
 // straight into buckets[b] (zeroed beforehand).  bucket b = buckets[b] + sum of heads[t] for
 // ceil(start_b / chunk) <= t < ceil(start_{b+1} / chunk), which msm_finish_buckets adds up.
 // GLV: entries index 2m columns; column m + i is phi(P_i) = (zeta x_i, y_i), formed on the fly (extra_index = m then)
-template <int FB, bool GLV>
-__global__ void __launch_bounds__(256, 4) msm_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
+#ifndef H2_ACC9_WAVES
+#define H2_ACC9_WAVES 2     // waves per SIMD the M9 accumulate is compiled for: 2, 3 and 4 run the adds equally fast (profiles/r02_ubench_fe9.txt);
+                            // at 2 the register file keeps room for the sort / fold kernels of commits on other streams (3 streams: 903 vs 861 M/s)
+#endif
+// M9: the points come from a registered table, stored in M9 form (x * 2^261 mod p, field9.cuh): the additions run on the
+// carry-free 9 x 29-bit field layer (curve9.cuh, 17.7-18.0 G mixed adds/s against 13.9-15.0 for the 8 x 32 layer,
+// profiles/r02_ubench_fe9.txt) and a flushed segment is converted back to the reference's Montgomery form, canonical, so
+// everything downstream (finish, fold, combine) is unchanged.
+template <int FB, bool GLV, bool M9 = false>
+__global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
                                                       u32 extra_index, const u32 *__restrict__ entries,
                                                       const u32 *__restrict__ starts, u32 *__restrict__ heads,
                                                       u32 *__restrict__ buckets, u32 total_buckets, u32 T) {
@@ -764,6 +773,42 @@ __global__ void __launch_bounds__(256, 4) msm_accumulate(const u32 *__restrict__
     if (t >= T) return;
     const u32 chunk = (M + T - 1) / T;
     const u32 lo = min(M, t * chunk), hi = min(M, lo + chunk);
+    if (M9) {
+        xyzz9<FB> acc = xyzz9_identity<FB>();
+        if (lo < hi) {
+            u32 b = upper_bucket(starts, total_buckets, lo);
+            u32 bend = starts[b + 1];
+            bool first = true;
+            u32 e0 = entries[lo], e1 = lo + 1 < hi ? entries[lo + 1] : 0;
+            affine<FB> nxt = aff_load<FB>(bases + 16 * (size_t)(e0 & 0x7FFFFFFFu));
+            for (u32 i = lo; i < hi; ++i) {
+                const affine<FB> p = nxt;
+                const u32 neg = e0 >> 31;
+                const u32 e2 = i + 2 < hi ? entries[i + 2] : 0;
+                if (i + 1 < hi) nxt = aff_load<FB>(bases + 16 * (size_t)(e1 & 0x7FFFFFFFu));
+                e0 = e1;
+                e1 = e2;
+                if (!aff_is_identity(p)) {
+                    aff9<FB> q = aff9_unpack<FB>(p);
+                    if (neg) q.y = fe9_sub(fe9_zero(), q.y);          // signed limbs: negation is nine subtractions
+                    xyzz9_madd<FB>(acc, q);
+                }
+                if (i + 1 == bend && i + 1 < hi) {
+                    // parked as raw limbs (a few stores): the conversion back to the reference's Montgomery form costs most of a
+                    // mixed addition and would be paid by the whole wave each time one of its lanes crosses a bucket boundary;
+                    // msm_segments_to_r256 does it for all segments at once
+                    xyzz9_store_raw<FB>(first ? heads + 36 * (size_t)t : buckets + 36 * (size_t)b, acc);
+                    first = false;
+                    acc = xyzz9_identity<FB>();
+                    do { ++b; bend = starts[b + 1]; } while (bend <= i + 1);
+                }
+            }
+            xyzz9_store_raw<FB>(first ? heads + 36 * (size_t)t : buckets + 36 * (size_t)b, acc);
+            return;
+        }
+        xyzz9_store_raw<FB>(heads + 36 * (size_t)t, acc);
+        return;
+    }
     xyzz<FB> acc = xyzz_identity<FB>();
     if (lo < hi) {
         u32 b = upper_bucket(starts, total_buckets, lo);
@@ -806,6 +851,19 @@ __global__ void __launch_bounds__(256, 4) msm_accumulate(const u32 *__restrict__
         acc = xyzz_identity<FB>();
     }
     if (lo >= hi) xyzz_store<FB>(heads + 32 * (size_t)t, acc);
+}
+
+// raw M9 segments (heads of the T ranges, then the bucket slots; 36 words each, untouched bucket slots are zero) ->
+// XYZZ in the reference's Montgomery form, canonical, 32 words each: what the finisher and the fold read
+template <int FB>
+__global__ void __launch_bounds__(256) msm_segments_to_r256(const u32 *__restrict__ raw, u32 *__restrict__ heads,
+                                                            u32 *__restrict__ buckets, u32 T, u32 total_buckets) {
+    H2_LATENCY_STAGE();
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= T + total_buckets) return;
+    const xyzz9<FB> a = xyzz9_load_raw<FB>(raw + 36 * (size_t)s);
+    u32 *dst = s < T ? heads + 32 * (size_t)s : buckets + 32 * (size_t)(s - T);
+    xyzz_store<FB>(dst, xyzz9_is_identity(a) ? xyzz_identity<FB>() : xyzz9_to_r256<FB>(a));
 }
 
 // ---- finisher: bucket b = its own non-head segment + the heads of the ranges that begin inside it -----
@@ -1047,13 +1105,13 @@ __global__ void msm_blind_chain(u32 *__restrict__ table, const u32 *__restrict__
                                 u32 *__restrict__ flag, u32 col, u32 stride, int c, int W) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     affine<FB> p = aff_load<FB>(w_xy);
-    affine<FB> cur = aff_load<FB>(table + 16 * (size_t)col);
-    if (fe_eq(p.x, cur.x) && fe_eq(p.y, cur.y)) {
+    const affine<FB> p9 = aff_to_m9<FB>(p), cur = aff_load<FB>(table + 16 * (size_t)col);     // the table holds M9 form
+    if (fe_eq(p9.x, cur.x) && fe_eq(p9.y, cur.y)) {
         *flag = 0;
         return;
     }
-    fe_store(table + 16 * (size_t)col, p.x);
-    fe_store(table + 16 * (size_t)col + 8, p.y);
+    fe_store(table + 16 * (size_t)col, p9.x);
+    fe_store(table + 16 * (size_t)col + 8, p9.y);
     xyzz<FB> r = xyzz_identity<FB>();
     xyzz_madd<FB>(r, p);
     for (int w = 1; w < W; ++w) {
@@ -1069,7 +1127,7 @@ __global__ void msm_blind_normalise(const u32 *__restrict__ tmp, u32 *__restrict
     u32 w = threadIdx.x + 1;
     if (*flag != 1 || (int)w >= W) return;
     xyzz<FB> r = xyzz_load<FB>(tmp + 32 * (size_t)(w - 1));
-    affine<FB> a = xyzz_to_affine<FB>(r);
+    affine<FB> a = aff_to_m9<FB>(xyzz_to_affine<FB>(r));
     u32 *dst = table + 16 * ((size_t)w * stride + col);
     fe_store(dst, a.x);
     fe_store(dst + 8, a.y);
@@ -1083,8 +1141,18 @@ __global__ void __launch_bounds__(256) msm_table_normalise(const u32 *__restrict
     if (t >= (size_t)count * (W - 1)) return;
     u32 w = (u32)(t / count) + 1, i = (u32)(t % count);
     xyzz<FB> r = xyzz_load<FB>(tmp + 32 * t);
-    affine<FB> a = xyzz_to_affine<FB>(r);
+    affine<FB> a = aff_to_m9<FB>(xyzz_to_affine<FB>(r));
     u32 *dst = table + 16 * ((size_t)w * stride + first + i);
+    fe_store(dst, a.x);
+    fe_store(dst + 8, a.y);
+}
+// row 0 (the caller's points, reference Montgomery form) -> M9 form, once the chains have read it
+template <int FB>
+__global__ void __launch_bounds__(256) msm_table_row0_to_m9(u32 *__restrict__ table, u32 count, u32 first) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    u32 *dst = table + 16 * (size_t)(first + i);
+    const affine<FB> a = aff_to_m9<FB>(aff_load<FB>(dst));
     fe_store(dst, a.x);
     fe_store(dst + 8, a.y);
 }
@@ -1151,14 +1219,14 @@ static bool timeline_on() {
 struct MsmContext {
     std::mutex mu;
     DevBuf digits, hist, counts, starts, bsums, entries, heads, heavy, hscratch, buckets, partial, ssums, stage_s, stage_b,
-        out, small, tagged, plan;
+        out, small, tagged, plan, seg9;
     void release_all() {
         for (DevBuf *b : {&digits, &hist, &counts, &starts, &bsums, &entries, &heads, &heavy, &hscratch, &buckets, &partial, &ssums,
-                          &stage_s, &stage_b, &out, &small, &tagged, &plan})
+                          &stage_s, &stage_b, &out, &small, &tagged, &plan, &seg9})
             b->release();
     }
     bool attr_set = false, attr2_set = false;
-    u32 lanes[2][2] = {{0, 0}, {0, 0}};  // resident lanes of msm_accumulate<FP / FQ, plain / GLV> on this device
+    u32 lanes[2][3] = {{0, 0, 0}, {0, 0, 0}};  // resident lanes of msm_accumulate<FP / FQ, plain / GLV> on this device
 };
 
 // One workspace per (device, stream): calls enqueued on different streams never share scratch.
@@ -1225,12 +1293,14 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         H2_HIP(hipFuncSetAttribute((const void *)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         cx.attr_set = true;
     }
-    u32 &lanes = cx.lanes[FB][glv ? 1 : 0];
+    const bool m9 = a.table && !glv;      // registered tables are stored in M9 form (h2_bases_register)
+    u32 &lanes = cx.lanes[FB][glv ? 1 : m9 ? 2 : 0];
     if (!lanes) {  // how many lanes of the accumulate kernel the chip holds at once
         int dev = 0, cus = 0, per_cu = 0;
         H2_HIP(hipGetDevice(&dev));
         H2_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (glv) H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB, true>, 256, 0));
+        else if (m9) H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB, false, true>, 256, 0));
         else H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB, false>, 256, 0));
         lanes = (u32)cus * (u32)std::max(per_cu, 1) * 256u;
     }
@@ -1411,7 +1481,12 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                 first_s != (size_t)-1 ? sb[first_s] : 0, bad_e, first_e);
     }
 #endif
-    H2_HIP(hipMemsetAsync(cx.buckets.ptr, 0, (size_t)tb * 128, st));
+    if (m9) {
+        if ((rc = cx.seg9.reserve(((size_t)T + tb) * 144)) != H2_OK) return rc;
+        H2_HIP(hipMemsetAsync(cx.seg9.as<u32>() + 36 * (size_t)T, 0, (size_t)tb * 144, st));
+    } else {
+        H2_HIP(hipMemsetAsync(cx.buckets.ptr, 0, (size_t)tb * 128, st));
+    }
     H2_HIP(hipMemsetAsync(cx.heavy.ptr, 0, 8, st));
     prof_end(PROF_MSM_SORT, st);
     TL_STAMP(tl_id | 2);
@@ -1419,6 +1494,13 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     if (glv)
         hipLaunchKernelGGL((msm_accumulate<FB, true>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases, (const u32 *)nullptr,
                            (u32)scalars_n, cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T);
+    else if (m9) {
+        hipLaunchKernelGGL((msm_accumulate<FB, false, true>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases,
+                           (const u32 *)nullptr, 0xFFFFFFFFu, cx.entries.as<u32>(), cx.starts.as<u32>(), cx.seg9.as<u32>(),
+                           cx.seg9.as<u32>() + 36 * (size_t)T, tb, T);
+        hipLaunchKernelGGL((msm_segments_to_r256<FB>), dim3((T + tb + 255) / 256), dim3(256), 0, st, cx.seg9.as<u32>(),
+                           cx.heads.as<u32>(), cx.buckets.as<u32>(), T, tb);
+    }
     else
         hipLaunchKernelGGL((msm_accumulate<FB, false>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases,
                            (const u32 *)a.d_extra_base, (!a.table && a.d_extra_base) ? (u32)a.n_used : 0xFFFFFFFFu,
@@ -1550,6 +1632,11 @@ static int table_fill(Bases &b, u32 first, u32 count, hipStream_t st) {
             hipLaunchKernelGGL((msm_table_chain<FQ>), g1, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.stride, b.c, b.W);
             hipLaunchKernelGGL((msm_table_normalise<FQ>), g2, blk, 0, st, (const u32 *)tmp, (u32 *)b.d_table, cnt, first + off, b.stride, b.W);
         }
+    }
+    {
+        dim3 g0((count + 255) / 256), blk(256);
+        if (b.curve == H2_PALLAS) hipLaunchKernelGGL((msm_table_row0_to_m9<FP>), g0, blk, 0, st, (u32 *)b.d_table, count, first);
+        else hipLaunchKernelGGL((msm_table_row0_to_m9<FQ>), g0, blk, 0, st, (u32 *)b.d_table, count, first);
     }
     hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(tmp);
