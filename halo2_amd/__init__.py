@@ -8,3 +8,4 @@ from .arithmetic import (batch_invert, best_fft, best_fft_batch, best_multiexp, 
                          points_sum, powers, scale_add, small_multiexp)
 from .commitment import Blind, Params, lagrange_basis, points_from_bytes, points_to_bytes  # noqa: F401
 from .domain import EvaluationDomain  # noqa: F401
+from .poly import Coeff, ExtendedLagrangeCoeff, LagrangeCoeff, Polynomial  # noqa: F401

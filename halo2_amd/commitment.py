@@ -195,9 +195,11 @@ class Params:
         return out
 
     def commit(self, poly, r: Blind, affine: bool = False):
-        """commitment.rs:119-130: sum poly[i] * g[i] + r * w."""
-        return self._commit(self._h_g, poly, r, affine)
+        """commitment.rs:119-130: sum poly[i] * g[i] + r * w.  `poly`: Polynomial<Coeff> or a raw limb array."""
+        from .poly import Coeff, unwrap
+        return self._commit(self._h_g, unwrap(poly, Coeff, "Params.commit")[0], r, affine)
 
     def commit_lagrange(self, poly, r: Blind, affine: bool = False):
-        """commitment.rs:135-150: sum poly[i] * g_lagrange[i] + r * w."""
-        return self._commit(self._h_gl, poly, r, affine)
+        """commitment.rs:135-150: sum poly[i] * g_lagrange[i] + r * w.  `poly`: Polynomial<LagrangeCoeff> or a raw limb array."""
+        from .poly import LagrangeCoeff, unwrap
+        return self._commit(self._h_gl, unwrap(poly, LagrangeCoeff, "Params.commit_lagrange")[0], r, affine)

@@ -10,6 +10,7 @@ import numpy as np
 from . import fields
 from ._lib import FORM_MONTGOMERY, check, lib
 from .arithmetic import _is_torch, _p, _stream_ptr
+from .poly import Coeff, ExtendedLagrangeCoeff, LagrangeCoeff, Polynomial, rewrap, unwrap
 
 
 class EvaluationDomain:
@@ -58,9 +59,11 @@ class EvaluationDomain:
 
     # -- domain.rs:227-237
     def lagrange_to_coeff(self, a):
+        """Polynomial<LagrangeCoeff> -> Polynomial<Coeff> (raw limb arrays pass through untagged)."""
+        a, tagged = unwrap(a, LagrangeCoeff, "lagrange_to_coeff")
         if a.shape[0] != self.n:
             raise ValueError("lagrange_to_coeff: wrong length")
-        return self._ifft(a, self.omega_inv, self.k, self.ifft_divisor)
+        return rewrap(self._ifft(a, self.omega_inv, self.k, self.ifft_divisor), Coeff, tagged)
 
     def lagrange_to_coeff_batch(self, columns):
         """lagrange_to_coeff over the independent columns of a phase (device tensors, in place) in one call."""
@@ -88,6 +91,11 @@ class EvaluationDomain:
 
     # -- domain.rs:241-255
     def coeff_to_extended(self, a):
+        """Polynomial<Coeff> -> Polynomial<ExtendedLagrangeCoeff>."""
+        a, tagged = unwrap(a, Coeff, "coeff_to_extended")
+        return rewrap(self._coeff_to_extended(a), ExtendedLagrangeCoeff, tagged)
+
+    def _coeff_to_extended(self, a):
         if a.shape[0] != self.n:
             raise ValueError("coeff_to_extended: wrong length")
         args = (_p(self._c(self.g_coset)), _p(self._c(self.g_coset_inv)), _p(self._c(self.extended_omega)))
@@ -105,6 +113,8 @@ class EvaluationDomain:
 
     # -- domain.rs:303-325
     def extended_to_coeff(self, a):
+        """Polynomial<ExtendedLagrangeCoeff> -> the n * (degree - 1) coefficients (a plain vector in the reference too, :303)."""
+        a, _ = unwrap(a, ExtendedLagrangeCoeff, "extended_to_coeff")
         if a.shape[0] != self.extended_len():
             raise ValueError("extended_to_coeff: wrong length")
         args = (_p(self._c(self.g_coset)), _p(self._c(self.g_coset_inv)), _p(self._c(self.extended_omega_inv)),
@@ -121,6 +131,10 @@ class EvaluationDomain:
 
     # -- domain.rs:329-348
     def divide_by_vanishing_poly(self, a):
+        a, tagged = unwrap(a, ExtendedLagrangeCoeff, "divide_by_vanishing_poly")
+        return rewrap(self._divide_by_vanishing_poly(a), ExtendedLagrangeCoeff, tagged)
+
+    def _divide_by_vanishing_poly(self, a):
         if a.shape[0] != self.extended_len():
             raise ValueError("divide_by_vanishing_poly: wrong length")
         t = fields.to_limbs(self.t_evaluations, self.field, True)
@@ -146,30 +160,30 @@ class EvaluationDomain:
     def get_quotient_poly_degree(self) -> int:                     # domain.rs:475
         return self.quotient_poly_degree
 
-    def empty_coeff(self) -> np.ndarray:                           # domain.rs:173
-        return np.zeros((self.n, 4), dtype=np.uint64)
+    def empty_coeff(self) -> Polynomial:                           # domain.rs:173
+        return Polynomial(np.zeros((self.n, 4), dtype=np.uint64), Coeff)
 
-    def empty_lagrange(self) -> np.ndarray:                        # domain.rs:181
-        return np.zeros((self.n, 4), dtype=np.uint64)
+    def empty_lagrange(self) -> Polynomial:                        # domain.rs:181
+        return Polynomial(np.zeros((self.n, 4), dtype=np.uint64), LagrangeCoeff)
 
-    def empty_extended(self) -> np.ndarray:                        # domain.rs:207
-        return np.zeros((self.extended_len(), 4), dtype=np.uint64)
+    def empty_extended(self) -> Polynomial:                        # domain.rs:207
+        return Polynomial(np.zeros((self.extended_len(), 4), dtype=np.uint64), ExtendedLagrangeCoeff)
 
-    def constant_lagrange(self, scalar: int) -> np.ndarray:        # domain.rs:198
-        return np.tile(self._c(scalar), (self.n, 1))
+    def constant_lagrange(self, scalar: int) -> Polynomial:        # domain.rs:198
+        return Polynomial(np.tile(self._c(scalar), (self.n, 1)), LagrangeCoeff)
 
-    def constant_extended(self, scalar: int) -> np.ndarray:        # domain.rs:216
-        return np.tile(self._c(scalar), (self.extended_len(), 1))
+    def constant_extended(self, scalar: int) -> Polynomial:        # domain.rs:216
+        return Polynomial(np.tile(self._c(scalar), (self.extended_len(), 1)), ExtendedLagrangeCoeff)
 
-    def coeff_from_vec(self, values) -> np.ndarray:                # domain.rs:163
+    def coeff_from_vec(self, values) -> Polynomial:                # domain.rs:163
         if values.shape[0] != self.n:
             raise ValueError("coeff_from_vec: wrong length")
-        return values
+        return Polynomial(values, Coeff)
 
-    def lagrange_from_vec(self, values) -> np.ndarray:             # domain.rs:151
+    def lagrange_from_vec(self, values) -> Polynomial:             # domain.rs:151
         if values.shape[0] != self.n:
             raise ValueError("lagrange_from_vec: wrong length")
-        return values
+        return Polynomial(values, LagrangeCoeff)
 
     def rotate_omega(self, value: int, rotation: int) -> int:
         """value * omega^rotation (domain.rs:408-419)."""
@@ -179,6 +193,9 @@ class EvaluationDomain:
     def rotate_extended(self, poly, rotation: int):
         """Rotate an extended-domain polynomial by `rotation` rows of the original domain (domain.rs:258-274):
         rotate_left for rotation >= 0, rotate_right otherwise.  numpy or torch CUDA tensor; returns a new array."""
+        poly, tagged = unwrap(poly, ExtendedLagrangeCoeff, "rotate_extended")
+        if tagged:
+            return Polynomial(self.rotate_extended(poly, rotation), ExtendedLagrangeCoeff)
         if poly.shape[0] != self.extended_len():
             raise ValueError("rotate_extended: wrong length")
         shift = (1 << (self.extended_k - self.k)) * abs(rotation)

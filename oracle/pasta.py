@@ -132,6 +132,20 @@ def msm_naive(scalars, bases, m: int):
     return acc
 
 
+def small_multiexp(scalars, bases, m: int):
+    """`small_multiexp` restated (arithmetic.rs:116-136): double-and-add over the 256 bits of `to_repr()`, most significant
+    first, the doubling shared by all points."""
+    reprs = [int(s).to_bytes(32, "little") for s in scalars]
+    acc = None
+    for byte_idx in range(31, -1, -1):
+        for bit_idx in range(7, -1, -1):
+            acc = ec_add(acc, acc, m)
+            for r, b in zip(reprs, bases):
+                if (r[byte_idx] >> bit_idx) & 1:
+                    acc = ec_add(acc, b, m)
+    return acc
+
+
 # --- best_multiexp restated (arithmetic.rs:143-180) --------------------------
 def window_bits(n: int) -> int:
     """arithmetic.rs:146-152."""

@@ -8,6 +8,7 @@
 #include <vector>
 #define H2_FIELD_EXPERIMENTS 1
 #include "../../halo2_amd/csrc/field.cuh"
+#include "../../halo2_amd/csrc/curve9.cuh"
 
 extern "C" {
 void orc_f_mul(int field, uint64_t *r, const uint64_t *a, const uint64_t *b);
@@ -85,6 +86,58 @@ template <int F, int IMPL> __global__ void __launch_bounds__(256) k_chain(const 
     fe_store(out + 8 * i, fe_add<F>(x, z));
 }
 
+// ---- the carry-free 9 x 29 layer (field9.cuh) against the C oracle.  Inputs / outputs cross in the reference's Montgomery form.
+// op 0: mul   1: sqr   2: (a - b)^2 (a + b - 3a) on signed un-normalised limbs   3: a - b after a carry pass
+// op 4: bridge round trip r256 -> M9 -> r256   5: plain-C multiplier (fe9_mul_c)   6: M9 table form (aff_to_m9 + unpack) times b
+template <int F> __global__ void k_ops9(const u32 *a, const u32 *b, u32 *out, int n, int op) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const fe x = fe_load(a + 8 * i), y = fe_load(b + 8 * i);
+    const fe9 x9 = fe9_from_r256<F>(x), y9 = fe9_from_r256<F>(y);
+    fe r;
+    switch (op) {
+        case 0: r = fe9_to_r256<F>(fe9_mul<F>(x9, y9)); break;
+        case 1: r = fe9_to_r256<F>(fe9_sqr<F>(x9)); break;
+        case 2: r = fe9_to_r256<F>(fe9_mul<F>(fe9_sqr<F>(fe9_sub(x9, y9)), fe9_sub(fe9_add(x9, y9), fe9_add(fe9_dbl(x9), x9)))); break;
+        case 3: r = fe9_to_r256<F>(fe9_norm(fe9_sub(x9, y9))); break;
+        case 4: r = fe9_to_r256<F>(x9); break;
+        case 5: r = fe9_to_r256<F>(fe9_mul_c<F>(x9, y9)); break;
+        default: {
+            affine<F> pt{x, x};
+            const aff9<F> q = aff9_unpack<F>(aff_to_m9<F>(pt));
+            r = fe9_to_r256<F>(fe9_mul<F>(q.x, y9));
+        }
+    }
+    fe_store(out + 8 * i, r);
+}
+template <int F> int run_field9(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b, const u32 *da, const u32 *db, u32 *dout, int n) {
+    std::vector<uint64_t> got(4 * (size_t)n);
+    const char *names[] = {"fe9 mul", "fe9 sqr", "fe9 signed chain", "fe9 sub+norm", "fe9 bridge", "fe9 mul_c", "fe9 table form"};
+    int fails = 0;
+    for (int op = 0; op < 7; ++op) {
+        hipLaunchKernelGGL((k_ops9<F>), dim3((n + 255) / 256), dim3(256), 0, 0, da, db, dout, n, op);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(got.data(), dout, 32 * (size_t)n, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int i = 0; i < n; ++i) {
+            uint64_t w[4], t[4], u[4];
+            const uint64_t *x = &a[4 * i], *y = &b[4 * i];
+            if (op == 0 || op == 5 || op == 6) orc_f_mul(F, w, x, y);
+            else if (op == 1) orc_f_mul(F, w, x, x);
+            else if (op == 2) {
+                orc_f_sub(F, t, x, y); orc_f_mul(F, t, t, t);                    // (a - b)^2
+                orc_f_add(F, u, x, y); orc_f_sub(F, u, u, x); orc_f_sub(F, u, u, x); orc_f_sub(F, u, u, x);
+                orc_f_mul(F, w, t, u);
+            } else if (op == 3) orc_f_sub(F, w, x, y);
+            else memcpy(w, x, 32);
+            if (memcmp(w, &got[4 * i], 32)) { if (!bad) printf("  first mismatch %s idx %d\n", names[op], i); bad++; }
+        }
+        printf("field %d %-16s: %d/%d mismatches\n", F, names[op], bad, n);
+        fails += bad;
+    }
+    return fails;
+}
+
 template <int F> int run_field() {
     const int n = 1 << 14;
     std::vector<uint64_t> a(4 * n), b(4 * n), want(4 * n), got(4 * n);
@@ -141,6 +194,7 @@ template <int F> int run_field() {
                 fails += bad;
             }
     printf("field %d lazy mul / sub / zero-test / 300-step chain over 9 representative pairs: done\n", F);
+    fails += run_field9<F>(a, b, da, db, dout, n);
     CK(hipFree(da)); CK(hipFree(db)); CK(hipFree(dout));
     return fails;
 }

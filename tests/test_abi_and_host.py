@@ -196,3 +196,34 @@ def test_domain_rotations_and_lagrange_basis_evaluations():
         return num * pow(den, -1, m) % m
     rots = [0, 1, 5, -1, -3]
     assert d.l_i_range(x, xn, rots) == [l_direct(r % n) for r in rots]
+
+
+def test_polynomial_basis_tags():
+    """`Polynomial<F, B>` (poly.rs:30-57): the basis marker travels with the values; the domain's constructors hand out tagged
+    polynomials and a transform applied to the wrong basis is refused before anything reaches the device."""
+    import halo2_amd as h
+    d = h.EvaluationDomain(3, 4, h.FP)
+    lag = d.empty_lagrange()
+    assert isinstance(lag, h.Polynomial) and lag.basis is h.LagrangeCoeff and len(lag) == 16 and lag.shape == (16, 4)
+    assert d.empty_coeff().basis is h.Coeff and d.empty_extended().basis is h.ExtendedLagrangeCoeff
+    assert d.constant_extended(7).basis is h.ExtendedLagrangeCoeff and len(d.constant_extended(7)) == d.extended_len()
+    import numpy as np
+    vals = np.zeros((16, 4), dtype=np.uint64)
+    assert d.coeff_from_vec(vals).basis is h.Coeff and d.lagrange_from_vec(vals).basis is h.LagrangeCoeff
+    lag[3] = np.array([1, 2, 3, 4], dtype=np.uint64)
+    assert list(lag[3]) == [1, 2, 3, 4]
+    import pytest
+    with pytest.raises(TypeError):
+        d.lagrange_to_coeff(d.empty_coeff())                   # already coefficients
+    with pytest.raises(TypeError):
+        d.coeff_to_extended(lag)
+    with pytest.raises(TypeError):
+        d.extended_to_coeff(d.empty_coeff())
+    with pytest.raises(TypeError):
+        d.divide_by_vanishing_poly(lag)
+    with pytest.raises(TypeError):
+        h.Polynomial(vals, "Coeff")
+    with pytest.raises(ValueError):
+        h.Polynomial(np.zeros(16, dtype=np.uint64), h.Coeff)
+    with pytest.raises(ValueError):
+        d.coeff_from_vec(np.zeros((15, 4), dtype=np.uint64))

@@ -149,3 +149,44 @@ def test_reference_stored_proof_through_the_device_verifier_and_prover():
            "fixed_commitments": PINNED[:7], "permutation_commitments": PINNED[7:]}
     assert op.verify_proof_many(VESTA, 5, gm, wm, um, ovk, instances, fresh)
     params.close()
+
+
+def test_small_multiexp_on_the_reference_bench_shape(keygen):
+    """benches/arithmetic.rs:15-33 through the product: Params::new(5) generators split in halves, 16 two-point calls of
+    `small_multiexp`; each equals the oracle's double-and-add restatement (and the definition)."""
+    g = keygen[0]
+    sf = co.field_of_curve(VESTA, "scalar")
+    rng = o.SplitMix64(0x736D616C6C)
+    c = [rng.next() * rng.next() * rng.next() * rng.next() % o.P for _ in range(2)]
+    coeffs = co.to_mont(sf, co.ints_to_limbs(c))
+    gm = co.points_to_mont(VESTA, g)
+    for i in range(16):
+        got = affine_of(VESTA, h.small_multiexp(coeffs, np.stack([gm[i], gm[16 + i]]), VESTA))
+        assert got == o.small_multiexp(c, [g[i], g[16 + i]], o.Q)
+    assert affine_of(VESTA, h.small_multiexp(coeffs[:0], gm[:0], VESTA)) is None
+
+
+def test_polynomial_tags_through_the_device_transforms(keygen):
+    """Tagged polynomials through lagrange_to_coeff / coeff_to_extended / commit* return the right basis and the same numbers
+    as raw arrays; commit(iFFT(a)) == commit_lagrange(a) (poly/commitment.rs:258-302) with the typed API."""
+    g, w, u, columns = keygen
+    sf = co.field_of_curve(VESTA, "scalar")
+    dom = h.EvaluationDomain(4, 5, sf)
+    params = h.Params.from_generators(VESTA, 5, co.points_to_mont(VESTA, g), None, co.points_to_mont(VESTA, [w])[0],
+                                      co.points_to_mont(VESTA, [u])[0])
+    lag = dom.lagrange_from_vec(co.to_mont(sf, co.ints_to_limbs(columns[6])))
+    blind = h.Blind(field=sf)
+    c_lag = affine_of(VESTA, params.commit_lagrange(lag, blind))
+    assert c_lag == PINNED_FIXED[6]
+    coeff = dom.lagrange_to_coeff(h.Polynomial(lag.values.copy(), h.LagrangeCoeff))
+    assert coeff.basis is h.Coeff
+    assert affine_of(VESTA, params.commit(coeff, blind)) == c_lag
+    ext = dom.coeff_to_extended(coeff)
+    assert ext.basis is h.ExtendedLagrangeCoeff and len(ext) == dom.extended_len()
+    back = dom.extended_to_coeff(dom.divide_by_vanishing_poly(ext))          # plain vector, as in the reference
+    assert back.shape[0] == dom.n * dom.quotient_poly_degree
+    with pytest.raises(TypeError):
+        params.commit(lag, blind)
+    with pytest.raises(TypeError):
+        params.commit_lagrange(coeff, blind)
+    params.close()

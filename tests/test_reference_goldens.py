@@ -181,3 +181,16 @@ def test_restated_prover_on_the_reference_circuit_and_witness(params5):
     assert op.verify_proof_many(VESTA, 5, g, w, u, vk, [[[2]], [[2]]], proof)
     kv = op.keygen_vk(VESTA, 5, g, w, vk["cs"], fixed, mapping, vk["vk_repr"])
     assert kv["fixed_commitments"] + kv["permutation_commitments"] == PINNED
+
+
+def test_small_multiexp_restated_on_the_reference_bench_shape(params5):
+    """benches/arithmetic.rs:15-33: Params::new(5), g split in halves, small_multiexp(&[c1, c2], &[g_lo[i], g_hi[i]]) for the 16
+    pairs.  The double-and-add restatement equals the definition on the hash-to-curve generators."""
+    g = params5[0]
+    rng = o.SplitMix64(0x736D616C6C)
+    c1, c2 = rng.next_field(o.P) if hasattr(rng, "next_field") else rng.next() * rng.next() * rng.next() * rng.next() % o.P, \
+        rng.next() * rng.next() * rng.next() * rng.next() % o.P
+    for lo, hi in zip(g[:16], g[16:]):
+        assert o.small_multiexp([c1, c2], [lo, hi], o.Q) == o.msm_naive([c1, c2], [lo, hi], o.Q)
+    assert o.small_multiexp([], [], o.Q) is None
+    assert o.small_multiexp([0, o.P - 1], [g[0], g[1]], o.Q) == o.ec_neg(g[1], o.Q)
