@@ -11,11 +11,18 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   -> ONE JSON 
             After the timed region the ranks also run one range-split MSM and sum the 96-byte
             partials exchanged with a single RCCL all_gather (verification, not timed).
   value     total scalar-mults of all ranks / max-over-ranks wall time of the K steps.
+            Each commit carries its blind term (w, r) as Params::commit does (poly/commitment.rs:119-130).
   roofline  dominant kernel = msm_accumulate; achieved = algorithmic bytes per launch (96 B per
-            (scalar, base) pair) / its average duration measured with HIP events on
-            the launching stream inside the timed region (h2_profile_*).
+            (scalar, base) pair) / its device time per launch measured with HIP events on
+            the launching streams inside the timed region (h2_profile_read_busy): launches of different streams
+            overlap on the chip, so the per-launch figure is the UNION of the launch intervals / launches (never
+            more than ms_per_step); `kernel_ms_isolated` is the same kernel alone on one stream.
   cpu_baseline  the C restatement of the reference's best_multiexp (oracle/, "port") timed on the host
-            cores of this box on the same 2^20 workload (1 run), rank 0 at N = 1 only.
+            cores of this box on the same 2^20 workload (median of 5 runs), rank 0 at N = 1 only.
+  extra     first-class companions of the headline: the free function best_multiexp(coeffs, bases) on bases
+            that are NOT registered (BASELINE configs[1] read literally), the Vesta commit (the curve every
+            reference proof uses), the host-pointer h2_commit including the PCIe copy of the scalars, and
+            configs[3]: create_proof of examples/simple_example at k = 20.
 The oracle is used here only as the timed CPU baseline and to generate inputs -- never in the GPU path.
 """
 from __future__ import annotations
@@ -44,6 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--log-n", type=int, default=K_LOG, help="override the MSM size (parity/debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-create-proof", action="store_true", help="skip the configs[3] leg (create_proof simple-example k = 20)")
     ap.add_argument("--columns", type=int, default=4, help="distinct scalar columns resident in HBM")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("H2_BENCH_STREAMS", "3")),
                     help="HIP streams the independent column commits are spread over (per GPU)")
@@ -60,9 +68,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: relaunch one rank per GPU and relay rank 0's JSON line
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", os.environ.get("MASTER_PORT", "29517"), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     ndev = torch.cuda.device_count()
     backend = os.environ.get("H2_BENCH_BACKEND", "nccl")      # "gloo": exercise the N > 1 code path on a 1-GPU box
     if backend == "gloo":
@@ -98,13 +112,19 @@ def main():
     from halo2_amd.arithmetic import _p
     check(lib.h2_bases_register(curve, _p(bases), n, h.FORM_MONTGOMERY, C.byref(params_g)), "h2_bases_register")
     d_cols = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]
+    # the blind term of Params::commit: w = a further seeded point, r = one seeded scalar per column (commitment.rs:119-130)
+    w_host = co.generate_bases(curve, 0x77, 1)[0]
+    blinds_host = co.random_field(sf, 0xB11D + rank, args.columns)
+    d_w = torch.from_numpy(w_host.view(np.int64)).to(dev)
+    d_blinds = torch.from_numpy(blinds_host.view(np.int64)).to(dev)
     d_out = torch.zeros((max(args.steps, 1), 12), dtype=torch.int64, device=dev)
     streams = [torch.cuda.current_stream()] if args.streams <= 1 else [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
     sps = [C.c_void_p(s_.cuda_stream) for s_ in streams]
 
     def step(i):
         # consecutive column commits are independent (plonk/prover.rs:305-309): round-robin them over the streams
-        rc = lib.h2_commit_device(params_g, d_cols[i % len(d_cols)].data_ptr(), n, None, None, h.FORM_MONTGOMERY,
+        c_ = i % len(d_cols)
+        rc = lib.h2_commit_device(params_g, d_cols[c_].data_ptr(), n, d_w.data_ptr(), d_blinds[c_].data_ptr(), h.FORM_MONTGOMERY,
                                   0, d_out[i % d_out.shape[0]].data_ptr(), sps[i % len(sps)])
         check(rc, "h2_commit_device")
 
@@ -140,20 +160,25 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    prof = {}
+    prof, busy = {}, {}
     for name, slot in (("msm_accumulate", 0), ("msm_sort", 2), ("msm_reduce", 3)):
-        ms, cnt = C.c_double(0), C.c_uint64(0)
-        lib.h2_profile_read(slot, C.byref(ms), C.byref(cnt))
+        ms, bz, cnt = C.c_double(0), C.c_double(0), C.c_uint64(0)
+        lib.h2_profile_read_busy(slot, C.byref(ms), C.byref(bz), C.byref(cnt))
         prof[name] = (ms.value, cnt.value)
+        busy[name] = bz.value
     lib.h2_profile_enable(0)
+    first = d_out[0].cpu().numpy().view(np.uint64).copy()   # output of timed step 0 = commit(cols[0], blinds[0]); d_out is reused below
+    sc_full = np.ascontiguousarray(np.concatenate([cols[0], blinds_host[0:1]]))          # what Params::commit hands best_multiexp:
+    bases_full = np.ascontiguousarray(np.concatenate([bases, w_host.reshape(1, 8)]))     # poly ++ [r], g ++ [w] (commitment.rs:120-129)
 
     # ---- the same kernel alone on the chip (one stream, full lane fraction): what the multi-stream figure dilutes ----
     iso = {}
     if rank == 0:
         check(lib.h2_set_option(b"msm_lane_fraction", 1.0), "h2_set_option")
         lib.h2_profile_enable(1)
-        for i in range(5):
-            rc = lib.h2_commit_device(params_g, d_cols[i % len(d_cols)].data_ptr(), n, None, None, h.FORM_MONTGOMERY, 0,
+        for i in range(20):
+            c_ = i % len(d_cols)
+            rc = lib.h2_commit_device(params_g, d_cols[c_].data_ptr(), n, d_w.data_ptr(), d_blinds[c_].data_ptr(), h.FORM_MONTGOMERY, 0,
                                       d_out[0].data_ptr(), sps[0])
             check(rc, "h2_commit_device")
         torch.cuda.synchronize()
@@ -164,25 +189,27 @@ def main():
         lib.h2_profile_enable(0)
         check(lib.h2_set_option(b"msm_lane_fraction", lane_fraction), "h2_set_option")
 
-    first = d_out[0].cpu().numpy().view(np.uint64).copy()   # output of timed step 0, before d_out is reused below
-
     # ---- the same multiexp WITHOUT registered bases (`best_multiexp(coeffs, bases)` as the reference calls it, bases read
     # from HBM each time, endomorphism split instead of the precomputed table): reported beside the headline ----
     generic = None
     if rank == 0:
-        d_bases = torch.from_numpy(bases.view(np.int64)).to(dev)
+        d_bases = torch.from_numpy(bases_full.view(np.int64)).to(dev)
+        d_sc = torch.from_numpy(sc_full.view(np.int64)).to(dev)
         d_gen = torch.zeros(12, dtype=torch.int64, device=dev)
-        for rep_ in range(7):
+        reps_g = 12
+        for rep_ in range(reps_g + 2):
             if rep_ == 2:
                 torch.cuda.synchronize()
                 t6 = time.perf_counter()
-            check(lib.h2_msm_device(curve, d_cols[0].data_ptr(), d_bases.data_ptr(), n, h.FORM_MONTGOMERY, 0, d_gen.data_ptr(), sps[0]),
+            check(lib.h2_msm_device(curve, d_sc.data_ptr(), d_bases.data_ptr(), n + 1, h.FORM_MONTGOMERY, 0, d_gen.data_ptr(), sps[0]),
                   "h2_msm_device")
         torch.cuda.synchronize()
-        g_ms = (time.perf_counter() - t6) / 5 * 1e3
-        generic = {"ms": round(g_ms, 4), "Mscalar_mults_per_s": round(n / g_ms / 1e3, 1),
+        g_ms = (time.perf_counter() - t6) / reps_g * 1e3
+        generic = {"what": "h2_msm_device = best_multiexp(coeffs, bases) (arithmetic.rs:143) on n + 1 device-resident points that are NOT "
+                           "registered (no precomputed table; endomorphism split), one call at a time on one stream",
+                   "ms": round(g_ms, 4), "Mscalar_mults_per_s": round((n + 1) / g_ms / 1e3, 1),
                    "equals_registered_path": bool(co.jac_to_affine_ints(curve, d_gen.cpu().numpy().view(np.uint64)) == co.jac_to_affine_ints(curve, first))}
-        del d_bases
+        del d_bases, d_sc
 
     # ---- skewed columns: 90 % zeros, and every scalar < 2^16 -- same kernels, same partition ----
     skew = {}
@@ -210,6 +237,7 @@ def main():
 
     # ---- parity spot check of the timed outputs (rank 0: first column vs the split-and-sum identity) ----
     parts = [h.best_multiexp(cols[0][i * n // 4:(i + 1) * n // 4], bases[i * n // 4:(i + 1) * n // 4], curve) for i in range(4)]
+    parts.append(h.best_multiexp(blinds_host[0:1], w_host.reshape(1, 8), curve))          # + r * w
     split_ok = co.jac_to_affine_ints(curve, h.points_sum(np.stack(parts), curve)) == co.jac_to_affine_ints(curve, first)
 
     # ---- multi-GPU exchange step: one range-split MSM, partials all-gathered over RCCL, summed locally ----
@@ -298,23 +326,93 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = co.lib().orc_get_threads()
-        t1 = time.perf_counter()
-        ref = co.best_multiexp(curve, cols[0], bases)
-        cpu_s = time.perf_counter() - t1
+        co.best_multiexp(curve, sc_full, bases_full)                      # warm-up run (page faults, thread pool)
+        runs = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            ref = co.best_multiexp(curve, sc_full, bases_full)
+            runs.append(time.perf_counter() - t1)
+        cpu_s = sorted(runs)[len(runs) // 2]
         cpu_ok = co.jac_to_affine_ints(curve, ref) == co.jac_to_affine_ints(curve, first)
-        c = co.lib().orc_window_bits(n)
-        cpu = {"value": round(n / cpu_s / 1e6, 4), "unit": "Mscalar-mults/s", "cores": int(min(cores, 256 // c + 1)),
+        c = co.lib().orc_window_bits(n + 1)
+        cpu = {"value": round((n + 1) / cpu_s / 1e6, 4), "unit": "Mscalar-mults/s", "cores": int(min(cores, 256 // c + 1)),
                "host_cores": int(cores), "kind": "port",
-               "sample": f"1 run of the same 2^{args.log_n}-point Pallas best_multiexp (c={c}, {256 // c + 1} window tasks), "
-                         f"{cpu_s:.2f} s wall; C restatement of arithmetic.rs:143-180, not the Rust reference",
-               "bit_exact_vs_gpu": bool(cpu_ok)}
+               "sample": f"median of 5 runs (after 1 warm-up) of the same commit as best_multiexp over 2^{args.log_n} + 1 Pallas points "
+                         f"(c={c}, {256 // c + 1} window tasks, one thread each), {cpu_s:.3f} s median, {min(runs):.3f}-{max(runs):.3f} s range; "
+                         "C restatement of arithmetic.rs:143-180, not the Rust reference",
+               "runs_s": [round(r, 4) for r in runs], "bit_exact_vs_gpu": bool(cpu_ok)}
+
+    # ---- first-class companions of the headline (the bench line must carry them) ----
+    extra = {}
+    if rank == 0:
+        # (1) the Vesta commit: the curve every reference proof commits on (benches/plonk.rs:6); same kernels, other moduli
+        vs = co.field_of_curve(h.VESTA, "scalar")
+        v_bases = co.generate_bases(h.VESTA, 0x56455354, n)
+        v_cols = [co.random_field(vs, 2000 + c_, n) for c_ in range(2)]
+        v_w = co.generate_bases(h.VESTA, 0x78, 1)[0]
+        v_bl = co.random_field(vs, 0xB11E, 2)
+        hv = C.c_uint64(0)
+        check(lib.h2_bases_register(h.VESTA, _p(v_bases), n, h.FORM_MONTGOMERY, C.byref(hv)), "h2_bases_register")
+        dv_cols = [torch.from_numpy(c_.view(np.int64)).to(dev) for c_ in v_cols]
+        dv_w = torch.from_numpy(v_w.view(np.int64)).to(dev)
+        dv_bl = torch.from_numpy(v_bl.view(np.int64)).to(dev)
+        reps_v = 30
+        for rep_ in range(reps_v + 2 * len(sps)):
+            if rep_ == 2 * len(sps):
+                torch.cuda.synchronize()
+                t7 = time.perf_counter()
+            check(lib.h2_commit_device(hv, dv_cols[rep_ % 2].data_ptr(), n, dv_w.data_ptr(), dv_bl[rep_ % 2].data_ptr(), h.FORM_MONTGOMERY, 0,
+                                       d_out[rep_ % d_out.shape[0]].data_ptr(), sps[rep_ % len(sps)]), "h2_commit_device")
+        torch.cuda.synchronize()
+        v_ms = (time.perf_counter() - t7) / reps_v * 1e3
+        v_last = d_out[(reps_v + 2 * len(sps) - 1) % d_out.shape[0]].cpu().numpy().view(np.uint64).copy()
+        k_ = (reps_v + 2 * len(sps) - 1) % 2
+        v_want = h.best_multiexp(np.ascontiguousarray(np.concatenate([v_cols[k_], v_bl[k_:k_ + 1]])),
+                                 np.ascontiguousarray(np.concatenate([v_bases, v_w.reshape(1, 8)])), h.VESTA)
+        extra["vesta_commit"] = {"ms_per_commit": round(v_ms, 4), "Mscalar_mults_per_s": round(n / v_ms / 1e3, 1), "streams": len(sps),
+                                 "equals_generic_multiexp": bool(co.jac_to_affine_ints(h.VESTA, v_last) == co.jac_to_affine_ints(h.VESTA, v_want))}
+        lib.h2_bases_free(hv)
+        del dv_cols, v_bases
+        # (2) end to end from HOST memory: h2_commit copies the 32 MiB column over PCIe, commits, copies the point back
+        out_h = np.zeros(12, dtype=np.uint64)
+        e2e = []
+        for rep_ in range(6):
+            t8 = time.perf_counter()
+            check(lib.h2_commit(params_g, _p(cols[rep_ % len(cols)]), n, _p(w_host), _p(blinds_host[rep_ % len(cols)]), h.FORM_MONTGOMERY, 0,
+                                _p(out_h)), "h2_commit")
+            e2e.append(time.perf_counter() - t8)
+        e2e_ms = sorted(e2e[1:])[len(e2e[1:]) // 2] * 1e3
+        extra["host_pointer_commit"] = {"what": "h2_commit: pageable host scalars -> PCIe -> commit -> 96 B back, one call at a time (SURVEY 8d 'end-to-end including H2D')",
+                                        "ms": round(e2e_ms, 4), "Mscalar_mults_per_s": round(n / e2e_ms / 1e3, 1)}
+        # (3) BASELINE configs[3]: create_proof of the reference's simple-example circuit at k = 20 (examples/simple_example.py:
+        # product prover + product verifier; columns, quotient FFTs, multi-point opening and the opening argument all on this GPU)
+        if args.log_n == 20 and not args.no_create_proof:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("simple_example", os.path.join(ROOT, "examples", "simple_example.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            pv = co.generate_bases(h.VESTA, 0x56455354, n + 2)          # g (n points), w, u: seeded, as everywhere in this file
+            t9 = time.perf_counter()
+            prm = h.Params.from_generators(h.VESTA, args.log_n, np.ascontiguousarray(pv[:n]), None, pv[n], pv[n + 1])
+            torch.cuda.synchronize()
+            params_s = time.perf_counter() - t9
+            res = mod.prove_and_verify(prm, quiet=True)
+            prm.close()
+            extra["create_proof_simple_example_k20"] = {
+                "accepted_and_wrong_instance_rejected": res["ok"], "create_proof_s": round(res["create_proof_s"], 4),
+                "create_proof_first_call_s": round(res["create_proof_first_s"], 4), "keygen_s": round(res["keygen_s"], 4),
+                "verify_proof_s": round(res["verify_proof_s"], 4), "proof_bytes": res["proof_bytes"],
+                "params_from_generators_s": round(params_s, 3),
+                "what": "examples/simple_example.py: the reference's simple-example circuit (examples/simple-example.rs) at k = 20 on Vesta, "
+                        "columns already assigned; instance / advice commits, permutation, vanishing argument (quotient FFTs at 2^21), "
+                        "multi-point opening and opening argument on this GPU; create_proof_s = second proof of the process"}
 
     if rank == 0:
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # collected separately, corrected as MI355X_MICROARCH.md prescribes); null when the workload differs
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
             if args.log_n == 20:
                 t_ = pmc["msm_accumulate_2^20"]
                 traffic = int(t_["fetch_bytes_reported_max"] + t_["write_bytes_max"])
@@ -323,8 +421,11 @@ def main():
         total_mults = float(n) * args.steps * world
         value = total_mults / elapsed / 1e6
         acc_ms, acc_cnt = prof["msm_accumulate"]
-        avg_ms = acc_ms / max(acc_cnt, 1)
-        achieved = ALGO_BYTES_PER_PAIR * n / (avg_ms * 1e-3) / 1e9 if acc_cnt else None
+        # device time per launch = union of the launch intervals / launches: launches from different streams overlap, and summing
+        # their durations would count shared time once per launch (r1: 1.82 ms "per launch" inside a 1.33 ms step)
+        avg_ms = busy["msm_accumulate"] / max(acc_cnt, 1)
+        sum_ms = acc_ms / max(acc_cnt, 1)
+        achieved = ALGO_BYTES_PER_PAIR * (n + 1) / (avg_ms * 1e-3) / 1e9 if acc_cnt else None
         out = {
             "metric": "Pallas MSM Mscalar-mults/s (+ Fp NTT Gbutterflies/s) at k=20",
             "value": round(value, 3), "unit": "Mscalar-mults/s", "n_gpus": world, "steps": args.steps,
@@ -332,20 +433,26 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u256 (8x32-bit Montgomery limbs)",
             "data": "synthetic",
             "config": {"workload": f"2^{args.log_n}-point Pallas best_multiexp, uniform random Fq scalars, "
-                                   "bases resident (Params::g registered), one column commit per step per GPU",
+                                   "bases resident (Params::g registered), one column commit WITH its blind term per step per GPU",
                        "window_bits": h.msm_window_bits(n), "columns_resident": args.columns, "streams": len(streams),
                        "msm_lane_fraction": lane_fraction,
                        "parallelism": f"{world} GPU(s) x {len(streams)} stream(s) of independent column commits"},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 2) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
                          "traffic": traffic, "avg_kernel_ms": round(avg_ms, 4), "launches": int(acc_cnt),
-                         "valu": {"madd_per_launch": 16 * n, "achieved_Gmadd_per_s": round(16 * n / (avg_ms * 1e-3) / 1e9, 2) if acc_cnt else None,
-                                  "isolated_Gmadd_per_s": round(16 * n / (iso["msm_accumulate"] * 1e-3) / 1e9, 2) if iso.get("msm_accumulate") else None,
-                                  "peak_Gmadd_per_s": 14.4, "peak_source": "bench/ubench_madd.hip on the same chip (XYZZ mixed adds with lazy reduction as the kernel runs them, any memory feed; 13.1 with a conditional subtraction after every product)"},
+                         "avg_kernel_ms_definition": "union of the launch intervals on the device / launches (HIP events on the launching "
+                                                     "streams, timed region only); overlapped_launch_ms = plain mean of the launch durations",
+                         "overlapped_launch_ms": round(sum_ms, 4), "kernel_ms_isolated": iso.get("msm_accumulate"),
+                         "valu": {"madd_per_launch": 16 * (n + 1), "achieved_Gmadd_per_s": round(16 * (n + 1) / (avg_ms * 1e-3) / 1e9, 2) if acc_cnt else None,
+                                  "isolated_Gmadd_per_s": round(16 * (n + 1) / (iso["msm_accumulate"] * 1e-3) / 1e9, 2) if iso.get("msm_accumulate") else None,
+                                  "modmul_per_madd": 10, "v_mad_i64_i32_per_madd": 1188,
+                                  "issue_bound_Gmadd_per_s": 26.5,
+                                  "issue_bound_source": "1188 v_mad_i64_i32 per mixed add at the measured 4.8 cycles per wave-instruction per SIMD "
+                                                        "(profiles/r01_ubench_valu.txt): 1024 SIMDs x 2.4 GHz x 64 lanes / (1188 x 4.8) - the bound if nothing but the "
+                                                        "multiply-adds issued; the whole add is 2135 instructions (profiles/r02_ubench_fe9.txt: 17.7-18.0 G madd/s for the loop alone)"},
                          "note": "VALU integer-multiply bound, not HBM bound (DESIGN.md section 3): the HBM fraction is reported as the contract "
-                                 "asks, the VALU fraction is what tracks kernel quality; avg_kernel_ms is measured inside the timed region, where "
-                                 "launches of several streams share the chip (kernel_ms_isolated = the same kernel alone); traffic = PMC bytes of "
-                                 "the registered-bases path, which gathers 16 precomputed multiples per point from a 1 GiB table by design"},
+                                 "asks, the VALU figures are what track kernel quality; traffic = PMC bytes of the registered-bases path, which "
+                                 "gathers 16 precomputed multiples per point from a 1 GiB table by design"},
             # the HBM-bound part of the path (north star: "bucket-scan kernel"): the two-pass bucket sort streams 320 B per
             # scalar (32 B read twice; 16 entries x 4 B written once, read twice, written once more); time = the sort stage alone
             "roofline_bucket_sort": (lambda ms_, tr_: {
@@ -356,7 +463,7 @@ def main():
                 iso.get("msm_sort"), (pmc or {}).get("msm_bucket_sort_2^20", {}).get("total_hbm_bytes_corrected") if args.log_n == 20 else None),
             "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()},
             "kernel_ms_isolated": iso,
-            "generic_best_multiexp": generic, "skewed_columns": skew, "ntt": ntt, "cpu_baseline": cpu,
+            "generic_best_multiexp": generic, "extra": extra, "skewed_columns": skew, "ntt": ntt, "cpu_baseline": cpu,
             "checks": {"split_sum_identity": bool(split_ok), "split_msm_allgather": split_msm_ok},
             "input_gen_s": round(gen_s, 2),
         }

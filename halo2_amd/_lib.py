@@ -82,6 +82,7 @@ SIGNATURES = {
     "h2_points_decompress_device": ([C.c_int, vp, C.c_size_t, C.c_int, vp, vp], C.c_int),
     "h2_profile_enable": ([C.c_int], C.c_int),
     "h2_profile_read": ([C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),
+    "h2_profile_read_busy": ([C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),
     "h2_debug_timeline": ([C.POINTER(C.c_ulonglong), C.c_uint], C.c_int),
 }
 

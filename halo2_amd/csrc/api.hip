@@ -5,6 +5,7 @@
 #include <mutex>
 #include <vector>
 
+#include <algorithm>
 #include "common.h"
 
 namespace h2 {
@@ -49,6 +50,7 @@ struct ProfState {
     std::vector<Pair> pending[PROF_SLOTS];
     hipEvent_t open[PROF_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     double total_ms[PROF_SLOTS] = {0, 0, 0, 0};
+    double busy_ms[PROF_SLOTS] = {0, 0, 0, 0};     // union of the launch intervals drained so far
     uint64_t count[PROF_SLOTS] = {0, 0, 0, 0};
 };
 static ProfState g_prof;
@@ -80,26 +82,63 @@ extern "C" int h2_profile_enable(int on) {
     if (on) {
         for (int s = 0; s < h2::PROF_SLOTS; ++s) {
             h2::g_prof.total_ms[s] = 0;
+            h2::g_prof.busy_ms[s] = 0;
             h2::g_prof.count[s] = 0;
         }
     }
     return H2_OK;
 }
 
-extern "C" int h2_profile_read(int slot, double *total_ms, uint64_t *launches) {
-    if (slot < 0 || slot >= h2::PROF_SLOTS || !total_ms || !launches) return H2_ERR_ARGS;
-    std::lock_guard<std::mutex> lk(h2::g_prof.mu);
-    for (auto &pr : h2::g_prof.pending[slot]) {
-        float ms = 0;
+// drains the pending event pairs of a slot: sum of the launch durations, and the length of the UNION of the launch intervals
+// (intervals are placed on one clock by measuring every event against the first one drained: hipEventElapsedTime works
+// across streams of a device).  When launches issued on several streams overlap, the union is the time the device spent on
+// this kernel; the sum counts overlapped time once per launch.
+static void prof_drain(int slot) {
+    auto &pend = h2::g_prof.pending[slot];
+    if (pend.empty()) return;
+    std::vector<std::pair<double, double>> iv;
+    hipEvent_t base = pend.front().a;
+    for (auto &pr : pend) {
+        float ms = 0, t0 = 0;
         if (hipEventSynchronize(pr.b) == hipSuccess && hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) {
             h2::g_prof.total_ms[slot] += ms;
             h2::g_prof.count[slot] += 1;
+            if (pr.a == base || hipEventElapsedTime(&t0, base, pr.a) == hipSuccess) iv.push_back({(double)t0, (double)t0 + ms});
         }
+    }
+    std::sort(iv.begin(), iv.end());
+    double busy = 0, lo = 0, hi = -1;
+    for (auto &x : iv) {
+        if (hi < lo || x.first > hi) {
+            if (hi >= lo) busy += hi - lo;
+            lo = x.first;
+            hi = x.second;
+        } else if (x.second > hi) hi = x.second;
+    }
+    if (hi >= lo) busy += hi - lo;
+    h2::g_prof.busy_ms[slot] += busy;
+    for (auto &pr : pend) {
         (void)hipEventDestroy(pr.a);
         (void)hipEventDestroy(pr.b);
     }
-    h2::g_prof.pending[slot].clear();
+    pend.clear();
+}
+
+extern "C" int h2_profile_read(int slot, double *total_ms, uint64_t *launches) {
+    if (slot < 0 || slot >= h2::PROF_SLOTS || !total_ms || !launches) return H2_ERR_ARGS;
+    std::lock_guard<std::mutex> lk(h2::g_prof.mu);
+    prof_drain(slot);
     *total_ms = h2::g_prof.total_ms[slot];
+    *launches = h2::g_prof.count[slot];
+    return H2_OK;
+}
+
+extern "C" int h2_profile_read_busy(int slot, double *total_ms, double *busy_ms, uint64_t *launches) {
+    if (slot < 0 || slot >= h2::PROF_SLOTS || !total_ms || !busy_ms || !launches) return H2_ERR_ARGS;
+    std::lock_guard<std::mutex> lk(h2::g_prof.mu);
+    prof_drain(slot);
+    *total_ms = h2::g_prof.total_ms[slot];
+    *busy_ms = h2::g_prof.busy_ms[slot];
     *launches = h2::g_prof.count[slot];
     return H2_OK;
 }

@@ -1579,22 +1579,25 @@ struct Bases {
     hipStream_t maint = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     int device = 0;            // the HIP device the table lives on (current at registration)
+    // which blind base column n currently holds (ensure_blind_base)
+    bool blind_valid = false, blind_by_content = false;
+    int blind_form = 0;
+    uintptr_t blind_key = 0;
+    unsigned char blind_host[64] = {0};
     // The table is owned here: it goes back to the allocator when the LAST reference drops -- h2_bases_free only removes
     // the handle, so a commit another host thread is still enqueueing (it holds the shared_ptr from find_bases) keeps the
     // memory alive, and every error path of h2_bases_register releases what it had allocated.
     ~Bases() {
-        if (!d_table && !d_blind_tmp && !maint) return;
+        if (!d_table && !d_blind_tmp && !maint && !ev_out) return;
         int cur = 0;
         (void)hipGetDevice(&cur);
         if (cur != device) (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
         if (d_table) (void)hipFree(d_table);
         if (d_blind_tmp) (void)hipFree(d_blind_tmp);
-        if (maint) {
-            (void)hipStreamDestroy(maint);
-            (void)hipEventDestroy(ev_in);
-            (void)hipEventDestroy(ev_out);
-        }
+        if (maint) (void)hipStreamDestroy(maint);
+        if (ev_in) (void)hipEventDestroy(ev_in);
+        if (ev_out) (void)hipEventDestroy(ev_out);
         if (cur != device) (void)hipSetDevice(cur);
     }
 };
@@ -1645,31 +1648,40 @@ static int table_fill(Bases &b, u32 first, u32 count, hipStream_t st) {
     return H2_OK;
 }
 
-// makes column n of the table hold the multiples of `w` (device pointer, Montgomery).  Asynchronous: the check /
-// recompute kernels run on the handle's maintenance stream (so concurrent commits on different streams cannot
-// interleave them), ordered after `st` (which produced w) and before whatever `st` does next.
-// A handle serves ONE blind base at a time (Params::w is fixed per Params, poly/commitment.rs:26-33): switching
-// to a different w while commits with the old one are still in flight is not supported.
-static int ensure_blind_base(Bases &b, const void *d_w_mont, hipStream_t st) {
+// makes column n of the table hold the multiples of `w` (device pointer, Montgomery).  Asynchronous, on the caller's stream.
+// `Params::w` is fixed for the life of a `Params` (poly/commitment.rs:26-33), so the handle remembers which blind base its
+// column holds: by CONTENT for the host-pointer entry points (`host_w`, 64 bytes as passed), by device ADDRESS for the
+// device-pointer ones (`key`; the caller must not change the 64 bytes behind an address it keeps passing while commits
+// are in flight).  A commit that presents the remembered blind base only waits for the event of the rebuild that wrote the
+// column -- no kernel, and nothing that ties the commits of different streams to each other (the round-1 scheme ran a
+// compare kernel per commit on one maintenance stream, which chained every stream's commits through it: 1.12 -> 1.40 ms).
+// Otherwise the compare / chain / normalise kernels run on `st`, ordered after the previous rebuild.
+// Switching to a different w while commits with the old one are still in flight is not supported.
+static int ensure_blind_base(Bases &b, const void *d_w_mont, hipStream_t st, uintptr_t key, const void *host_w, int form) {
     std::lock_guard<std::mutex> lk(b.mu);
-    if (!b.maint) {
-        H2_HIP(hipStreamCreateWithFlags(&b.maint, hipStreamNonBlocking));
-        H2_HIP(hipEventCreateWithFlags(&b.ev_in, hipEventDisableTiming));
-        H2_HIP(hipEventCreateWithFlags(&b.ev_out, hipEventDisableTiming));
+    if (!b.ev_out) H2_HIP(hipEventCreateWithFlags(&b.ev_out, hipEventDisableTiming));
+    const bool same = b.blind_valid && b.blind_form == form &&
+                      (host_w ? (b.blind_by_content && memcmp(b.blind_host, host_w, 64) == 0) : (!b.blind_by_content && b.blind_key == key));
+    if (same) {
+        H2_HIP(hipStreamWaitEvent(st, b.ev_out, 0));
+        return H2_OK;
     }
-    H2_HIP(hipEventRecord(b.ev_in, st));
-    H2_HIP(hipStreamWaitEvent(b.maint, b.ev_in, 0));
+    if (b.blind_valid) H2_HIP(hipStreamWaitEvent(st, b.ev_out, 0));      // rebuilds are ordered one after the other
     u32 *tmp = (u32 *)b.d_blind_tmp, *flag = tmp + 32 * (size_t)b.W;
     if (b.curve == H2_PALLAS) {
-        hipLaunchKernelGGL((msm_blind_chain<FP>), dim3(1), dim3(64), 0, b.maint, (u32 *)b.d_table, (const u32 *)d_w_mont, tmp, flag, (u32)b.n, b.stride, b.c, b.W);
-        hipLaunchKernelGGL((msm_blind_normalise<FP>), dim3(1), dim3(64), 0, b.maint, tmp, (u32 *)b.d_table, flag, (u32)b.n, b.stride, b.W);
+        hipLaunchKernelGGL((msm_blind_chain<FP>), dim3(1), dim3(64), 0, st, (u32 *)b.d_table, (const u32 *)d_w_mont, tmp, flag, (u32)b.n, b.stride, b.c, b.W);
+        hipLaunchKernelGGL((msm_blind_normalise<FP>), dim3(1), dim3(64), 0, st, tmp, (u32 *)b.d_table, flag, (u32)b.n, b.stride, b.W);
     } else {
-        hipLaunchKernelGGL((msm_blind_chain<FQ>), dim3(1), dim3(64), 0, b.maint, (u32 *)b.d_table, (const u32 *)d_w_mont, tmp, flag, (u32)b.n, b.stride, b.c, b.W);
-        hipLaunchKernelGGL((msm_blind_normalise<FQ>), dim3(1), dim3(64), 0, b.maint, tmp, (u32 *)b.d_table, flag, (u32)b.n, b.stride, b.W);
+        hipLaunchKernelGGL((msm_blind_chain<FQ>), dim3(1), dim3(64), 0, st, (u32 *)b.d_table, (const u32 *)d_w_mont, tmp, flag, (u32)b.n, b.stride, b.c, b.W);
+        hipLaunchKernelGGL((msm_blind_normalise<FQ>), dim3(1), dim3(64), 0, st, tmp, (u32 *)b.d_table, flag, (u32)b.n, b.stride, b.W);
     }
     H2_HIP(hipGetLastError());
-    H2_HIP(hipEventRecord(b.ev_out, b.maint));
-    H2_HIP(hipStreamWaitEvent(st, b.ev_out, 0));
+    H2_HIP(hipEventRecord(b.ev_out, st));
+    b.blind_valid = true;
+    b.blind_form = form;
+    b.blind_by_content = host_w != nullptr;
+    b.blind_key = key;
+    if (host_w) memcpy(b.blind_host, host_w, 64);
     return H2_OK;
 }
 
@@ -1814,7 +1826,7 @@ static int commit_device_impl(h2_bases_t g, const void *d_scalars, size_t n, con
             to_mont_async(b->curve, cx.small.as<u32>(), 2, st);
             w = cx.small.ptr;
         }
-        if ((rc = ensure_blind_base(*b, w, st)) != H2_OK) return rc;
+        if ((rc = ensure_blind_base(*b, w, st, (uintptr_t)d_w_xy, nullptr, form)) != H2_OK) return rc;
     }
     MsmArgs a{d_scalars, d_blind, b->d_table, nullptr, n, true, b->c, b->stride, (u32)b->n, form, out_kind, d_out};
     a.lane_fraction = lane_fraction;
@@ -1875,7 +1887,7 @@ extern "C" int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars
             to_mont_async(b->curve, cx.small.as<u32>(), 2, user);
             w = cx.small.ptr;
         }
-        if ((rc = ensure_blind_base(*b, w, user)) != H2_OK) return rc;
+        if ((rc = ensure_blind_base(*b, w, user, (uintptr_t)d_w_xy, nullptr, form)) != H2_OK) return rc;
     }
     H2_HIP(hipEventRecord(bs.fork, user));
     for (size_t i = 0; i < want; ++i) H2_HIP(hipStreamWaitEvent(bs.s[i], bs.fork, 0));
@@ -1942,7 +1954,7 @@ extern "C" int h2_commit(h2_bases_t g, const uint64_t *scalars, size_t n, const 
         H2_HIP(hipMemcpyAsync((char *)cx.small.ptr + 64, blind, 32, hipMemcpyHostToDevice, 0));
         if (form == H2_FORM_CANONICAL) to_mont_async(b->curve, cx.small.as<u32>(), 2, 0);
         d_bl = (char *)cx.small.ptr + 64;
-        if ((rc = ensure_blind_base(*b, cx.small.ptr, 0)) != H2_OK) return rc;
+        if ((rc = ensure_blind_base(*b, cx.small.ptr, 0, 0, w_xy, form)) != H2_OK) return rc;
     }
     MsmArgs a{cx.stage_s.ptr, d_bl, b->d_table, nullptr, n, true, b->c, b->stride, (u32)b->n, form, out_kind, cx.out.ptr};
     if ((rc = msm_dispatch(cx, b->curve, a, 0)) != H2_OK) return rc;

@@ -126,6 +126,11 @@ int h2_divide_by_vanishing_poly(int field, uint64_t *a, unsigned ext_k, const ui
  * memory.  Used by batched provers and by bench.py (inputs resident in HBM before timing starts). */
 int h2_msm_device(int curve, const void *d_scalars, const void *d_bases_xy, size_t n, int form,
                   int out_kind, void *d_out, void *stream);
+/* Blind base: `Params::w` is fixed for the life of a `Params` (poly/commitment.rs:26-33) and the handle keeps its multiples as
+ * one more column of the registered table.  The handle remembers which w that column holds -- by content for the host-pointer
+ * entry points, by device ADDRESS for the device-pointer ones: keep passing the same d_w_xy, and do not change the 64 bytes
+ * behind it while commits are in flight.  A different address (or content) rebuilds the column on `stream`; commits that use the
+ * old w must have been synchronised by then. */
 int h2_commit_device(h2_bases_t g, const void *d_scalars, size_t n, const void *d_w_xy,
                      const void *d_blind, int form, int out_kind, void *d_out, void *stream);
 /* `count` independent commits over one registered basis -- the column commits of a prover phase
@@ -284,6 +289,10 @@ int h2_points_decompress_device(int curve, const void *d_bytes, size_t n, int fo
 #define H2_PROF_MSM_REDUCE 3
 int h2_profile_enable(int on);
 int h2_profile_read(int slot, double *total_ms, uint64_t *launches);
+/* The same, plus `busy_ms`: the length of the union of the launch intervals since h2_profile_enable(1).  With launches
+ * issued on several streams overlapping on the device, total_ms counts shared time once per launch; busy_ms is the time
+ * the device spent on the kernel, so busy_ms / launches never exceeds the wall time per launch. */
+int h2_profile_read_busy(int slot, double *total_ms, double *busy_ms, uint64_t *launches);
 /* With H2_TIMELINE=1 in the environment every commit stamps the device clock (100 MHz) as its sort, accumulate
  * and reduce stages become runnable; this drains up to `cap` {clock, (stream id << 8) | stage} pairs, stage
  * 1 = sort, 2 = accumulate, 3 = reduce, 4 = done.  Returns the pair count, or -1 when the timeline is off. */
