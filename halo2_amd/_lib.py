@@ -81,6 +81,14 @@ SIGNATURES = {
     "h2_points_decompress": ([C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.c_int, u64p], C.c_int),
     "h2_points_decompress_device": ([C.c_int, vp, C.c_size_t, C.c_int, vp, vp], C.c_int),
     "h2_profile_enable": ([C.c_int], C.c_int),
+    "h2_points_sum_device": ([C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p], C.c_int),
+    "h2_commit_batch_multi": ([C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t, C.c_void_p,
+                               C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)], C.c_int),
+    "h2_msm_split_multi": ([C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "h2_rccl_unique_id": ([C.c_void_p], C.c_int),
+    "h2_rccl_init": ([C.c_void_p, C.c_int, C.c_int], C.c_int),
+    "h2_rccl_finalize": ([], C.c_int),
+    "h2_msm_split_rccl_device": ([C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p], C.c_int),
     "h2_profile_read": ([C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),
     "h2_profile_read_busy": ([C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),
     "h2_debug_timeline": ([C.POINTER(C.c_ulonglong), C.c_uint], C.c_int),

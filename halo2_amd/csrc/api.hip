@@ -17,6 +17,8 @@ void set_last_hip_error(hipError_t e, const char *file, int line) {
     snprintf(g_err, sizeof g_err, "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), base ? base + 1 : file, line);
 }
 
+void set_last_error_msg(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
+
 int ensure_device() {
     static thread_local int checked = 0;
     if (checked) return H2_OK;

@@ -24,6 +24,7 @@ namespace h2 {
     } while (0)
 
 void set_last_hip_error(hipError_t e, const char *file, int line);
+void set_last_error_msg(const char *msg);   // what h2_last_error() returns on this thread
 
 // Grow-only device buffer.  One instance per use site, guarded by the owning context's mutex.
 struct DevBuf {

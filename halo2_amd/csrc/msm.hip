@@ -1168,7 +1168,8 @@ template <int F> __global__ void __launch_bounds__(256) k_to_mont(u32 *a, size_t
 // sum of Jacobian points (host helper for the multi-GPU partial sum): Jacobian -> XYZZ is
 // (X, Y, Z^2, Z^3)
 template <int FB>
-__global__ void k_points_sum(const u32 *__restrict__ pts, u32 count, u32 *__restrict__ out) {
+__global__ void k_points_sum(const u32 *__restrict__ pts, u32 count, u32 *__restrict__ out, bool in_mont = true, int out_kind = H2_OUT_JACOBIAN,
+                             bool out_mont = true) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     xyzz<FB> r = xyzz_identity<FB>();
     for (u32 i = 0; i < count; ++i) {
@@ -1178,12 +1179,21 @@ __global__ void k_points_sum(const u32 *__restrict__ pts, u32 count, u32 *__rest
         xyzz<FB> q;
         q.x = fe_load(p);
         q.y = fe_load(p + 8);
+        if (!in_mont) { q.x = fe_to_mont<FB>(q.x); q.y = fe_to_mont<FB>(q.y); Z = fe_to_mont<FB>(Z); }
         q.zz = fe_sqr<FB>(Z);
         q.zzz = fe_mulx<FB>(q.zz, Z);
         xyzz_add<FB>(r, q);
     }
+    if (out_kind == H2_OUT_AFFINE) {
+        affine<FB> a = xyzz_to_affine<FB>(r);
+        if (!out_mont) { a.x = fe_from_mont<FB>(a.x); a.y = fe_from_mont<FB>(a.y); }
+        fe_store(out, a.x);
+        fe_store(out + 8, a.y);
+        return;
+    }
     fe X, Y, Z;
     xyzz_to_jacobian<FB>(r, X, Y, Z);
+    if (!out_mont) { X = fe_from_mont<FB>(X); Y = fe_from_mont<FB>(Y); Z = fe_from_mont<FB>(Z); }
     fe_store(out, X);
     fe_store(out + 8, Y);
     fe_store(out + 16, Z);
@@ -1960,6 +1970,19 @@ extern "C" int h2_commit(h2_bases_t g, const uint64_t *scalars, size_t n, const 
     if ((rc = msm_dispatch(cx, b->curve, a, 0)) != H2_OK) return rc;
     H2_HIP(hipMemcpyAsync(out, cx.out.ptr, out_bytes, hipMemcpyDeviceToHost, 0));
     H2_HIP(hipStreamSynchronize(0));
+    return H2_OK;
+}
+
+// device-resident partials (the landing buffer of an all-gather) -> their sum, on `stream`
+extern "C" int h2_points_sum_device(int curve, const void *d_points_xyz, size_t count, int form, int out_kind, void *d_out, void *stream) {
+    if (bad_common(curve, form, out_kind) || !d_out || (count && !d_points_xyz) || count > (1u << 20)) return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const bool mont = form == H2_FORM_MONTGOMERY;
+    if (curve == H2_PALLAS) hipLaunchKernelGGL((k_points_sum<FP>), dim3(1), dim3(64), 0, st, (const u32 *)d_points_xyz, (u32)count, (u32 *)d_out, mont, out_kind, mont);
+    else hipLaunchKernelGGL((k_points_sum<FQ>), dim3(1), dim3(64), 0, st, (const u32 *)d_points_xyz, (u32)count, (u32 *)d_out, mont, out_kind, mont);
+    H2_HIP(hipGetLastError());
     return H2_OK;
 }
 

@@ -52,3 +52,89 @@ def split_msm(scalars: np.ndarray, bases: np.ndarray, curve: int, rank: int, wor
     partial = msm(scalars[lo:hi], bases[lo:hi])
     gathered = allgather_points(np.asarray(partial), device=device)
     return points_sum(gathered)
+
+
+# ---- one process, several GPUs: the C ABI's own fan-out (csrc/multi.hip) ------------------------------------------------
+def commit_batch_multi(handles, devices, columns, n: int, w=None, blinds=None, affine: bool = False) -> np.ndarray:
+    """h2_commit_batch_multi: `columns` (host limb arrays, (n, 4) each) committed round-robin over `devices`; handles[d] is the
+    h2_bases_t (int, or a Params' registered handle) of the same bases on devices[d].  Returns (len(columns), 12 | 8) limbs."""
+    import ctypes as C
+    from ._lib import FORM_MONTGOMERY, OUT_AFFINE, OUT_JACOBIAN, check, lib
+    count = len(columns)
+    out = np.zeros((count, 8 if affine else 12), dtype=np.uint64)
+    cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in columns]
+    for c in cols:
+        if c.shape != (n, 4):
+            raise ValueError("commit_batch_multi: every column must hold n scalars")
+    if (w is None) != (blinds is None):
+        raise ValueError("commit_batch_multi: w and blinds go together")
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    h_arr = (C.c_uint64 * len(handles))(*[int(getattr(h_, "value", h_)) for h_ in handles])
+    d_arr = (C.c_int * len(devices))(*devices)
+    s_arr = (C.c_void_p * count)(*[ptr(c) for c in cols])
+    o_arr = (C.c_void_p * count)(*[out[i].ctypes.data_as(C.c_void_p) for i in range(count)])
+    if w is not None:
+        w = np.ascontiguousarray(w, dtype=np.uint64).reshape(8)
+        bl = [np.ascontiguousarray(b, dtype=np.uint64).reshape(4) for b in blinds]
+        b_arr = (C.c_void_p * count)(*[ptr(b) for b in bl])
+        check(lib().h2_commit_batch_multi(h_arr, d_arr, len(devices), s_arr, count, n, ptr(w), b_arr, FORM_MONTGOMERY,
+                                          OUT_AFFINE if affine else OUT_JACOBIAN, o_arr), "h2_commit_batch_multi")
+    else:
+        check(lib().h2_commit_batch_multi(h_arr, d_arr, len(devices), s_arr, count, n, None, None, FORM_MONTGOMERY,
+                                          OUT_AFFINE if affine else OUT_JACOBIAN, o_arr), "h2_commit_batch_multi")
+    return out
+
+
+def split_msm_multi(scalars, bases, curve: int, devices, affine: bool = False) -> np.ndarray:
+    """h2_msm_split_multi: one best_multiexp cut into len(devices) point ranges, partials added on devices[0]."""
+    import ctypes as C
+    from ._lib import FORM_MONTGOMERY, OUT_AFFINE, OUT_JACOBIAN, check, lib
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    bases = np.ascontiguousarray(bases, dtype=np.uint64)
+    if scalars.shape[0] != bases.shape[0]:
+        raise ValueError("split_msm_multi: coeffs and bases differ in length")          # arithmetic.rs:144
+    out = np.zeros(8 if affine else 12, dtype=np.uint64)
+    d_arr = (C.c_int * len(devices))(*devices)
+    check(lib().h2_msm_split_multi(curve, scalars.ctypes.data_as(C.c_void_p), bases.ctypes.data_as(C.c_void_p), scalars.shape[0], d_arr,
+                                   len(devices), FORM_MONTGOMERY, OUT_AFFINE if affine else OUT_JACOBIAN, out.ctypes.data_as(C.c_void_p)),
+          "h2_msm_split_multi")
+    return out
+
+
+# ---- one process per GPU, exchange step by RCCL inside the library ------------------------------------------------------------
+def rccl_init(rank: int, world: int) -> None:
+    """Creates the library's own RCCL communicator: rank 0's unique id travels over the caller's torch.distributed group
+    (any backend -- it is 128 bytes), then every rank joins with its GPU current."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from ._lib import check, lib
+    buf = np.zeros(128, dtype=np.uint8)
+    if rank == 0:
+        check(lib().h2_rccl_unique_id(buf.ctypes.data_as(C.c_void_p)), "h2_rccl_unique_id")
+    if world > 1:
+        t = torch.from_numpy(buf.copy())
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.broadcast(t, 0)
+        buf = t.cpu().numpy()
+    check(lib().h2_rccl_init(np.ascontiguousarray(buf).ctypes.data_as(C.c_void_p), rank, world), "h2_rccl_init")
+
+
+def rccl_finalize() -> None:
+    from ._lib import lib
+    lib().h2_rccl_finalize()
+
+
+def split_msm_rccl(d_scalars, d_bases, curve: int, affine: bool = False):
+    """h2_msm_split_rccl_device on CUDA tensors holding the whole problem on every rank: this rank's range, one 96-byte
+    all-gather over xGMI, local sum.  Returns a CUDA tensor (12 | 8 limbs); asynchronous on the current stream."""
+    import torch
+    from ._lib import FORM_MONTGOMERY, OUT_AFFINE, OUT_JACOBIAN, check, lib
+    from .arithmetic import _stream_ptr
+    if d_scalars.shape[0] != d_bases.shape[0]:
+        raise ValueError("split_msm_rccl: coeffs and bases differ in length")
+    out = torch.empty(8 if affine else 12, dtype=torch.int64, device=d_scalars.device)
+    check(lib().h2_msm_split_rccl_device(curve, d_scalars.data_ptr(), d_bases.data_ptr(), d_scalars.shape[0], FORM_MONTGOMERY,
+                                         OUT_AFFINE if affine else OUT_JACOBIAN, out.data_ptr(), _stream_ptr()), "h2_msm_split_rccl_device")
+    return out

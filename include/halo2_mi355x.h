@@ -168,6 +168,32 @@ int h2_divide_by_vanishing_poly_device(int field, void *d_a, unsigned ext_k, con
 /* Sum of `count` Jacobian points laid out contiguously (12 limbs each, Montgomery) -> one Jacobian
  * point.  The local step after the 96-byte all-gather of a range-split MSM (one partial per GPU). */
 int h2_points_sum(int curve, const uint64_t *points_xyz, size_t count, uint64_t *out_xyz);
+/* The same over device memory, asynchronous on `stream`; `form` applies to inputs and output, `out_kind` as for h2_msm. */
+int h2_points_sum_device(int curve, const void *d_points_xyz, size_t count, int form, int out_kind, void *d_out, void *stream);
+
+/* ---- several GPUs (no counterpart in the reference, whose create_proof is one process) ----------- */
+/* The `count` independent column commits of a prover phase (plonk/prover.rs:93-101, 301-313; vanishing/prover.rs:96-108)
+ * spread over `ndev` devices from ONE process: column i goes to devices[i % ndev], which holds handles[i % ndev] -- the same
+ * bases registered once per device (h2_init(dev) + h2_bases_register on each).  Host columns in, host points out; one host
+ * thread and three streams per device, no collective (a result is one point).  Blocking. */
+int h2_commit_batch_multi(const h2_bases_t *handles, const int *devices, int ndev, const uint64_t *const *scalars,
+                          size_t count, size_t n, const uint64_t *w_xy, const uint64_t *const *blinds, int form,
+                          int out_kind, uint64_t *const *outs);
+/* ONE multiexp (best_multiexp, arithmetic.rs:143) cut into ndev contiguous point ranges, one per device; the ndev partial
+ * points (96 bytes each) are brought to devices[0] and added there.  Host pointers, blocking. */
+int h2_msm_split_multi(int curve, const uint64_t *scalars, const uint64_t *bases_xy, size_t n, const int *devices,
+                       int ndev, int form, int out_kind, uint64_t *out);
+/* The same split for the one-process-per-GPU model: RCCL (bound with dlopen at first use) carries the exchange step.
+ * Rank 0 calls h2_rccl_unique_id and hands the 128 bytes to the other ranks by whatever means its launcher offers
+ * (a broadcast of its process group, MPI, a file); every rank then calls h2_rccl_init(id, rank, world) with its GPU current.
+ * h2_msm_split_rccl_device: every rank passes the same device-resident problem; rank r multiplies points
+ * [n r / world, n (r + 1) / world), ONE ncclAllGather of 96 bytes per rank, and every rank writes the total to d_out
+ * (asynchronous on `stream`). */
+int h2_rccl_unique_id(uint8_t id_out[128]);
+int h2_rccl_init(const uint8_t id[128], int rank, int world);
+int h2_rccl_finalize(void);
+int h2_msm_split_rccl_device(int curve, const void *d_scalars, const void *d_bases_xy, size_t n, int form,
+                             int out_kind, void *d_out, void *stream);
 
 /* ---- IPA round kernels (next to the MSMs inside commitment::create_proof) ----------------------- */
 /* replaces parallel_generator_collapse (halo2_proofs/src/poly/commitment/prover.rs:154-166):

@@ -1,0 +1,126 @@
+"""Multi-GPU entry points of the C ABI (csrc/multi.hip) on the one device a test box has: the fan-out code runs with the
+device list [0, 0] (two host threads, round-robin columns) and [0], the range-split multiexp with one to three ranges, the
+RCCL path with a communicator of size 1; and the one-process-per-GPU split (parallel.split_msm) with two gloo ranks sharing
+the GPU, the HIP path as each rank's multiexp.  Expected values come from the oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import halo2_amd as h
+from halo2_amd import parallel
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def aff(curve, out):
+    out = np.ascontiguousarray(out, dtype=np.uint64)
+    return co.jac_to_affine_ints(curve, out) if out.shape[0] == 12 else co.affine_to_ints(curve, out)
+
+
+@pytest.mark.parametrize("curve,n", [(h.VESTA, 1 << 11), (h.PALLAS, 777)])
+def test_commit_batch_multi_two_lanes_on_one_device(curve, n):
+    sf = co.field_of_curve(curve, "scalar")
+    k = max(1, (n - 1).bit_length())
+    g = co.generate_bases(curve, 5150 + n, 1 << k)
+    w = co.generate_bases(curve, 9, 1)[0]
+    params = h.Params(curve, k, g, g, w, w)
+    cols = [co.random_field(sf, 300 + i, n) for i in range(7)]
+    blinds = co.random_field(sf, 77, 7)
+    want = [aff(curve, co.commit(curve, np.ascontiguousarray(g[:n]), w, c, blinds[i])) for i, c in enumerate(cols)]
+    for devices in ([0, 0], [0]):
+        got = parallel.commit_batch_multi([params._h_g] * len(devices), devices, cols, n, w=w, blinds=list(blinds))
+        assert [aff(curve, got[i]) for i in range(7)] == want
+    got = parallel.commit_batch_multi([params._h_g, params._h_g], [0, 0], cols[:3], n, affine=True)        # no blind, affine out
+    assert [aff(curve, got[i]) for i in range(3)] == [aff(curve, co.best_multiexp(curve, c, np.ascontiguousarray(g[:n]))) for c in cols[:3]]
+    assert parallel.commit_batch_multi([params._h_g], [0], [], n).shape == (0, 12)
+    with pytest.raises(ValueError):
+        parallel.commit_batch_multi([params._h_g], [5], cols[:1], n)            # no such device
+    params.close()
+
+
+@pytest.mark.parametrize("ndev", [1, 2, 3])
+def test_msm_split_multi(ndev):
+    curve, n = h.PALLAS, 5000
+    sf = co.field_of_curve(curve, "scalar")
+    sc, bs = co.random_field(sf, 41, n), co.generate_bases(curve, 42, n)
+    want = aff(curve, co.best_multiexp(curve, sc, bs))
+    assert aff(curve, parallel.split_msm_multi(sc, bs, curve, [0] * ndev)) == want
+    assert aff(curve, parallel.split_msm_multi(sc, bs, curve, [0] * ndev, affine=True)) == want
+    assert aff(curve, parallel.split_msm_multi(sc[:2], bs[:2], curve, [0] * ndev)) == aff(curve, co.best_multiexp(curve, sc[:2], bs[:2]))
+
+
+def test_points_sum_device_forms():
+    import torch
+    curve = h.VESTA
+    sf = co.field_of_curve(curve, "scalar")
+    parts = [h.best_multiexp(co.random_field(sf, 60 + i, 50), co.generate_bases(curve, 70 + i, 50), curve) for i in range(4)]
+    want = aff(curve, h.points_sum(np.stack(parts), curve))
+    d = torch.from_numpy(np.stack(parts).view(np.int64)).cuda()
+    out = torch.zeros(8, dtype=torch.int64, device="cuda")
+    from halo2_amd._lib import check, lib
+    check(lib().h2_points_sum_device(curve, d.data_ptr(), 4, h.FORM_MONTGOMERY, 1, out.data_ptr(), None), "h2_points_sum_device")
+    torch.cuda.synchronize()
+    assert aff(curve, out.cpu().numpy().view(np.uint64)) == want
+
+
+def test_split_msm_rccl_world_of_one():
+    """The library's own RCCL communicator (dlopen librccl.so): unique id, init, one all-gather, local sum, finalize."""
+    import torch
+    curve, n = h.PALLAS, 3000
+    sf = co.field_of_curve(curve, "scalar")
+    sc, bs = co.random_field(sf, 91, n), co.generate_bases(curve, 92, n)
+    parallel.rccl_init(0, 1)
+    try:
+        out = parallel.split_msm_rccl(torch.from_numpy(sc.view(np.int64)).cuda(), torch.from_numpy(bs.view(np.int64)).cuda(), curve)
+        torch.cuda.synchronize()
+        assert aff(curve, out.cpu().numpy().view(np.uint64)) == aff(curve, co.best_multiexp(curve, sc, bs))
+    finally:
+        parallel.rccl_finalize()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import halo2_amd as hh
+    from halo2_amd import parallel as par
+    from oracle import c_oracle as oc
+    curve, n = 0, 4097
+    sf = oc.field_of_curve(curve, "scalar")
+    scal, bases = oc.random_field(sf, 11, n), oc.generate_bases(curve, 12, n)
+    total = par.split_msm(scal, bases, curve, rank, world)                     # HIP multiexp per rank, gloo all_gather, HIP sum
+    whole = oc.best_multiexp(curve, scal, bases)
+    q.put((rank, oc.jac_to_affine_ints(curve, total) == oc.jac_to_affine_ints(curve, whole)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_split_msm_two_ranks_hip_path():
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
