@@ -248,6 +248,29 @@ def main():
         whole = h.best_multiexp(shared, bases, curve) if rank == 0 else None
         if rank == 0:
             split_msm_ok = co.jac_to_affine_ints(curve, total) == co.jac_to_affine_ints(curve, whole)
+    # the same exchange step inside the library: its own RCCL communicator (dlopen), one 96-byte ncclAllGather, local sum.
+    # Verification only; guarded by a watchdog so that a communicator that fails to form cannot take the bench line with it.
+    split_rccl_c = None
+    if world > 1 and backend == "nccl" and os.environ.get("H2_BENCH_RCCL_C", "1") != "0":
+        import threading
+        box = {}
+
+        def _rccl_leg():
+            try:
+                torch.cuda.set_device(local_rank)          # the current device is per host thread
+                parallel.rccl_init(rank, world)
+                d_sh = torch.from_numpy(shared.view(np.int64)).to(dev)
+                d_bs = torch.from_numpy(bases.view(np.int64)).to(dev)
+                out_c = parallel.split_msm_rccl(d_sh, d_bs, curve)
+                torch.cuda.synchronize()
+                box["ok"] = bool(co.jac_to_affine_ints(curve, out_c.cpu().numpy().view(np.uint64)) == co.jac_to_affine_ints(curve, total))
+                parallel.rccl_finalize()
+            except Exception as exc:           # reported, never fatal
+                box["ok"] = f"error: {exc}"
+        th = threading.Thread(target=_rccl_leg, daemon=True)
+        th.start()
+        th.join(timeout=90)
+        split_rccl_c = box.get("ok", "timeout after 90 s")
 
     # ---- NTT leg (reported beside the headline value; Fp, k = 20 and 2^22 round trip) ----
     ntt = {}
@@ -464,7 +487,7 @@ def main():
             "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()},
             "kernel_ms_isolated": iso,
             "generic_best_multiexp": generic, "extra": extra, "skewed_columns": skew, "ntt": ntt, "cpu_baseline": cpu,
-            "checks": {"split_sum_identity": bool(split_ok), "split_msm_allgather": split_msm_ok},
+            "checks": {"split_sum_identity": bool(split_ok), "split_msm_allgather": split_msm_ok, "split_msm_rccl_in_library": split_rccl_c},
             "input_gen_s": round(gen_s, 2),
         }
         print(json.dumps(out))
