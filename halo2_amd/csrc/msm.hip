@@ -754,6 +754,25 @@ __device__ __forceinline__ u32 upper_bucket(const u32 *__restrict__ arr, u32 n, 
 // straight into buckets[b] (zeroed beforehand).  bucket b = buckets[b] + sum of heads[t] for
 // ceil(start_b / chunk) <= t < ceil(start_{b+1} / chunk), which msm_finish_buckets adds up.
 // GLV: entries index 2m columns; column m + i is phi(P_i) = (zeta x_i, y_i), formed on the fly (extra_index = m then)
+// generic path (arbitrary bases + endomorphism split): the n caller-supplied points (reference Montgomery form) are converted
+// ONCE per call into M9 form, together with phi(P_i) = (zeta x_i, y_i): column i -> out[i], column n + i -> out[n + i].  The
+// bucket accumulation then runs on the carry-free layer exactly as for a registered table, instead of paying a zeta
+// multiplication and two form conversions on each of the ~9 entries that read a point.
+template <int FB>
+__global__ void __launch_bounds__(256) msm_bases_to_m9_glv(const u32 *__restrict__ bases, u32 *__restrict__ out, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const affine<FB> p = aff_load<FB>(bases + 16 * (size_t)i);
+    const affine<FB> q = aff_to_m9<FB>(p);
+    affine<FB> phi = q;
+    phi.x = fe_mulx<FB>(q.x, glv_zeta<FB>());          // zeta in Montgomery form: (x 2^261)(zeta 2^256) / 2^256
+    u32 *d0 = out + 16 * (size_t)i, *d1 = out + 16 * ((size_t)n + i);
+    fe_store(d0, q.x);
+    fe_store(d0 + 8, q.y);
+    fe_store(d1, phi.x);
+    fe_store(d1 + 8, phi.y);
+}
+
 #ifndef H2_ACC9_WAVES
 #define H2_ACC9_WAVES 2     // waves per SIMD the M9 accumulate is compiled for: 2, 3 and 4 run the adds equally fast (profiles/r02_ubench_fe9.txt);
                             // at 2 the register file keeps room for the sort / fold kernels of commits on other streams (3 streams: 903 vs 861 M/s)
@@ -1229,10 +1248,10 @@ static bool timeline_on() {
 struct MsmContext {
     std::mutex mu;
     DevBuf digits, hist, counts, starts, bsums, entries, heads, heavy, hscratch, buckets, partial, ssums, stage_s, stage_b,
-        out, small, tagged, plan, seg9;
+        out, small, tagged, plan, seg9, bases9;
     void release_all() {
         for (DevBuf *b : {&digits, &hist, &counts, &starts, &bsums, &entries, &heads, &heavy, &hscratch, &buckets, &partial, &ssums,
-                          &stage_s, &stage_b, &out, &small, &tagged, &plan, &seg9})
+                          &stage_s, &stage_b, &out, &small, &tagged, &plan, &seg9, &bases9})
             b->release();
     }
     bool attr_set = false, attr2_set = false;
@@ -1303,14 +1322,17 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         H2_HIP(hipFuncSetAttribute((const void *)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         cx.attr_set = true;
     }
-    const bool m9 = a.table && !glv;      // registered tables are stored in M9 form (h2_bases_register)
-    u32 &lanes = cx.lanes[FB][glv ? 1 : m9 ? 2 : 0];
+    // registered tables are stored in M9 form (h2_bases_register); the generic path converts its bases per call (below)
+    static const bool glv_on_fe9 = [] { const char *e = getenv("H2_GENERIC_FE9"); return !(e && atoi(e) == 0); }();
+    const bool m9 = (a.table && !glv) || (glv && glv_on_fe9);
+    u32 &lanes = cx.lanes[FB][m9 ? 2 : glv ? 1 : 0];
     if (!lanes) {  // how many lanes of the accumulate kernel the chip holds at once
         int dev = 0, cus = 0, per_cu = 0;
         H2_HIP(hipGetDevice(&dev));
         H2_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        if (glv) H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB, true>, 256, 0));
-        else if (m9) H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB, false, true>, 256, 0));
+        if (m9) H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB, false, true>, 256, 0));
+        else if (glv) H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB, true>, 256, 0));
+        else if (false) H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB, false, true>, 256, 0));
         else H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB, false>, 256, 0));
         lanes = (u32)cus * (u32)std::max(per_cu, 1) * 256u;
     }
@@ -1492,6 +1514,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     }
 #endif
     if (m9) {
+        if (glv && (rc = cx.bases9.reserve((size_t)scalars_n * 128 + 64)) != H2_OK) return rc;
         if ((rc = cx.seg9.reserve(((size_t)T + tb) * 144)) != H2_OK) return rc;
         H2_HIP(hipMemsetAsync(cx.seg9.as<u32>() + 36 * (size_t)T, 0, (size_t)tb * 144, st));
     } else {
@@ -1501,11 +1524,17 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     prof_end(PROF_MSM_SORT, st);
     TL_STAMP(tl_id | 2);
     prof_begin(PROF_MSM_ACCUMULATE, st);
-    if (glv)
+    if (glv && !m9)
         hipLaunchKernelGGL((msm_accumulate<FB, true>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases, (const u32 *)nullptr,
                            (u32)scalars_n, cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T);
     else if (m9) {
-        hipLaunchKernelGGL((msm_accumulate<FB, false, true>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases,
+        const u32 *pts = (const u32 *)a.d_bases;
+        if (glv) {
+            hipLaunchKernelGGL((msm_bases_to_m9_glv<FB>), dim3(((u32)scalars_n + 255) / 256), dim3(256), 0, st, (const u32 *)a.d_bases,
+                               cx.bases9.as<u32>(), (u32)scalars_n);
+            pts = cx.bases9.as<u32>();
+        }
+        hipLaunchKernelGGL((msm_accumulate<FB, false, true>), dim3(T / 256), dim3(256), 0, st, pts,
                            (const u32 *)nullptr, 0xFFFFFFFFu, cx.entries.as<u32>(), cx.starts.as<u32>(), cx.seg9.as<u32>(),
                            cx.seg9.as<u32>() + 36 * (size_t)T, tb, T);
         hipLaunchKernelGGL((msm_segments_to_r256<FB>), dim3((T + tb + 255) / 256), dim3(256), 0, st, cx.seg9.as<u32>(),
