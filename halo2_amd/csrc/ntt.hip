@@ -29,7 +29,7 @@
 #include <vector>
 
 #include "common.h"
-#include "field.cuh"
+#include "field9.cuh"
 #include "host_field.h"
 
 namespace h2 {
@@ -271,6 +271,244 @@ __global__ void __launch_bounds__(1024) ntt_pass(const u32 *__restrict__ in, u32
     }
 }
 
+// ---- the same pass on the carry-free 9 x 29-bit field layer (field9.cuh) -----------------------------------------------
+// A butterfly is one multiplication and two additions: on the 8 x 32 layer 248 + 2 x ~35 instructions, here 165 + 2 x 9 plus
+// one "fold" per element and round.  LDS holds nine signed limbs per element (three planes: limbs 0-3, 4-7, 8): nothing is
+// repacked between the stages of a pass.  Twiddles come from a second table flavour, omega^e in M9 form as raw limbs in the same
+// three planes, so data keeps the caller's form: (a 2^256)(w 2^261) / 2^261 = a w 2^256.
+// Bounds: only the LIMBS have to stay small between the stages -- a twiddle is below p < 2^255, so a multiplication tolerates
+// |value| < 2^261 on the data side.  A radix-4 round adds two products (each below 2^256.3 in magnitude) to an element, so
+// after the five rounds of a 10-stage pass |value| < 2^256.4 + 5 x 2^257.3 < 2^260; one carry pass per output and round keeps
+// limbs 0..7 in [0, 2^29) and lets limb 8 absorb the growth.  The value is folded once, when the element leaves the pass:
+// q = round(value / 2^254) from the top limb, minus q p read from a 129-entry LDS table -> |value| < 2^253.1.
+struct Tw9 {
+    const uint4 *a, *b;
+    const u32 *c;
+};
+__device__ __forceinline__ fe9 tw9_load(const Tw9 &t, size_t e) {
+    const uint4 x = t.a[e], y = t.b[e];
+    return fe9{{(i32)x.x, (i32)x.y, (i32)x.z, (i32)x.w, (i32)y.x, (i32)y.y, (i32)y.z, (i32)y.w, (i32)t.c[e]}};
+}
+struct Lds9 {
+    uint4 *a, *b;
+    u32 *c;
+    const i32 *qp;     // q p for q = -64 .. 64, 12 words apart
+};
+__device__ __forceinline__ fe9 lds9_get(const Lds9 &l, u32 s) {
+    const uint4 x = l.a[s], y = l.b[s];
+    return fe9{{(i32)x.x, (i32)x.y, (i32)x.z, (i32)x.w, (i32)y.x, (i32)y.y, (i32)y.z, (i32)y.w, (i32)l.c[s]}};
+}
+__device__ __forceinline__ void lds9_put(const Lds9 &l, u32 s, const fe9 &v) {
+    l.a[s] = make_uint4((u32)v.v[0], (u32)v.v[1], (u32)v.v[2], (u32)v.v[3]);
+    l.b[s] = make_uint4((u32)v.v[4], (u32)v.v[5], (u32)v.v[6], (u32)v.v[7]);
+    l.c[s] = (u32)v.v[8];
+}
+__device__ __forceinline__ fe9 ntt_fold9(const fe9 &v, const i32 *qp) {
+    const i32 q = (v.v[8] + (1 << 21)) >> 22;            // |value| < 2^260: q in [-64, 64]
+    const uint4 *e = reinterpret_cast<const uint4 *>(qp + 12 * (q + 64));
+    const uint4 x = e[0], y = e[1];
+    const i32 z = qp[12 * (q + 64) + 8];
+    fe9 r;
+    r.v[0] = v.v[0] - (i32)x.x; r.v[1] = v.v[1] - (i32)x.y; r.v[2] = v.v[2] - (i32)x.z; r.v[3] = v.v[3] - (i32)x.w;
+    r.v[4] = v.v[4] - (i32)y.x; r.v[5] = v.v[5] - (i32)y.y; r.v[6] = v.v[6] - (i32)y.z; r.v[7] = v.v[7] - (i32)y.w;
+    r.v[8] = v.v[8] - z;
+    return fe9_norm(r);
+}
+// packed, non-negative, below 2^256, same residue (what leaves a pass that is not the last)
+template <int F> __device__ __forceinline__ fe ntt_pack_lazy9(const fe9 &v) {       // |value| < 2^254.2
+    const fe9 pk = fe9_p_shl<F>(0);
+    fe9 t;
+#pragma unroll
+    for (int i = 0; i < 9; i++) t.v[i] = v.v[i] + pk.v[i];
+    return fe9_pack(fe9_norm(t));
+}
+
+template <int F, int R, bool FIRST>
+__global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u32 *__restrict__ out, Tw9 tw, PassArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    constexpr int r = R;
+    const int logT = A.logT, L = A.L, s0 = A.s0;
+    const u32 T = 1u << logT, rows = 1u << r, tile = rows << logT;
+    Lds9 S;
+    S.a = lds;
+    S.b = lds + tile;
+    S.c = reinterpret_cast<u32 *>(lds + 2 * tile);
+    i32 *qp_w = reinterpret_cast<i32 *>(S.c + tile);
+    S.qp = qp_w;
+    const u32 tid = threadIdx.x, nthr = blockDim.x;
+    for (u32 j = tid; j < 129; j += nthr) {     // q p as signed limbs (|q| <= 64: every limb of the product fits 36 bits before the carry pass)
+        const i64 q = (i64)j - 64;
+        const fe9 pk = fe9_p_shl<F>(0);
+        i64 c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const i64 t = q * pk.v[i] + c;
+            qp_w[12 * j + i] = (i32)(t & (i64)M29);
+            c = t >> 29;
+        }
+        qp_w[12 * j + 8] = (i32)(q * pk.v[8] + c);
+    }
+    size_t hi_idx = 0, lo0 = 0;
+    u32 c0 = 0;
+    if (FIRST) {
+        c0 = blockIdx.x << logT;
+    } else {
+        u32 tiles_per_hi = 1u << (s0 - logT);
+        hi_idx = blockIdx.x / tiles_per_hi;
+        lo0 = (size_t)(blockIdx.x % tiles_per_hi) << logT;
+    }
+    // ---- load ----
+    if (FIRST) {
+        const int cb = L - r;
+        fe9 lk0, lk1;
+        if (A.load_mode == 1) {
+            lk0 = fe9_from_r256<F>(from_param(A.lk0));
+            lk1 = fe9_from_r256<F>(from_param(A.lk1));
+        }
+        for (u32 e = tid; e < tile; e += nthr) {
+            u32 col = e & (T - 1), row = e >> logT;
+            size_t j = ((size_t)row << cb) + c0 + col;
+            fe9 v = fe9_zero();
+            if (j < A.n_in) {
+                v = fe9_unpack(fe_load(in + 8 * j));
+                if (A.load_mode == 1) {
+                    u32 m3 = (u32)(j % 3);
+                    if (m3) v = fe9_mul<F>(v, m3 == 1 ? lk0 : lk1);
+                }
+            }
+            lds9_put(S, (bitrev(row, r) << logT) + col, v);
+        }
+    } else {
+        const size_t base = (hi_idx << (s0 + r)) + lo0;
+        for (u32 e = tid; e < tile; e += nthr) {
+            u32 col = e & (T - 1), mid = e >> logT;
+            lds9_put(S, e, fe9_unpack(fe_load(in + 8 * (base + ((size_t)mid << s0) + col))));
+        }
+    }
+        const size_t lo_x = FIRST ? 0 : (lo0 + (tid & (T - 1)));
+    const u32 ngrp = tile >> 2;
+    auto tw_addr = [&](int u, size_t &eA, size_t &eB0, size_t &eB1) {
+        const int t = s0 + u;
+        const u32 q = tid >> logT, low = q & ((1u << u) - 1);
+        const size_t xm = ((size_t)low << s0) + lo_x;
+        eA = xm << (L - t - 1);
+        eB0 = xm << (L - t - 2);
+        eB1 = eB0 + ((size_t)1 << (L - 2));
+    };
+    // the first twiddle of a round (needed at once) is fetched one round ahead; the other two are requested at the top of the
+    // round and first used two multiplications later
+    fe9 wA = fe9_zero();
+    if (R >= 2 && tid < ngrp && !FIRST) {
+        size_t eA, eB0, eB1;
+        tw_addr(0, eA, eB0, eB1);
+        wA = tw9_load(tw, eA);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u + 1 < R; u += 2) {
+        if (tid < ngrp) {
+            size_t eA, eB0, eB1;
+            tw_addr(u, eA, eB0, eB1);
+            const fe9 wB0 = tw9_load(tw, eB0), wB1 = tw9_load(tw, eB1);
+            fe9 nA = fe9_zero();
+            if (u + 3 < R) {
+                size_t nB0, nB1;
+                tw_addr(u + 2, eA, nB0, nB1);
+                nA = tw9_load(tw, eA);
+            }
+            const u32 col = tid & (T - 1), q = tid >> logT;
+            const u32 low = q & ((1u << u) - 1);
+            const u32 mid00 = ((q >> u) << (u + 2)) | low;
+            const u32 s00 = (mid00 << logT) + col, s01 = s00 + (T << u), s10 = s00 + (T << (u + 1)), s11 = s10 + (T << u);
+            fe9 e0 = lds9_get(S, s00), e1 = lds9_get(S, s01), e2 = lds9_get(S, s10), e3 = lds9_get(S, s11);
+            if (!(FIRST && u == 0)) {
+                e1 = fe9_mul<F>(e1, wA);
+                e3 = fe9_mul<F>(e3, wA);
+            }
+            const fe9 a0 = fe9_add(e0, e1), a1 = fe9_sub(e0, e1);
+            const fe9 a2 = fe9_mul<F>(fe9_add(e2, e3), wB0), a3 = fe9_mul<F>(fe9_sub(e2, e3), wB1);
+            lds9_put(S, s00, fe9_norm(fe9_add(a0, a2)));
+            lds9_put(S, s10, fe9_norm(fe9_sub(a0, a2)));
+            lds9_put(S, s01, fe9_norm(fe9_add(a1, a3)));
+            lds9_put(S, s11, fe9_norm(fe9_sub(a1, a3)));
+            wA = nA;
+        }
+        __syncthreads();
+    }
+    if (R & 1) {
+        constexpr int u = R - 1;
+        const int t = s0 + u;
+        const u32 nbf = tile >> 1;
+        for (u32 bfl = tid; bfl < nbf; bfl += nthr) {
+            const u32 col = bfl & (T - 1), q = bfl >> logT;
+            const u32 low = q & ((1u << u) - 1);
+            const u32 mid0 = ((q >> u) << (u + 1)) | low;
+            const u32 s_a = (mid0 << logT) + col, s_b = s_a + (T << u);
+            const size_t xm = ((size_t)low << s0) + (FIRST ? 0 : (lo0 + col));
+            fe9 a = lds9_get(S, s_a), b = lds9_get(S, s_b);
+            if (!(FIRST && u == 0)) b = fe9_mul<F>(b, tw9_load(tw, xm << (L - t - 1)));
+            lds9_put(S, s_a, fe9_norm(fe9_add(a, b)));
+            lds9_put(S, s_b, fe9_norm(fe9_sub(a, b)));
+        }
+        __syncthreads();
+    }
+    // ---- store ----
+    fe9 k0 = fe9_zero(), k1 = k0, k2 = k0;
+    if (A.store_mode) {
+        k0 = fe9_from_r256<F>(from_param(A.k0));
+        if (A.store_mode == 2) {
+            k1 = fe9_from_r256<F>(from_param(A.k1));
+            k2 = fe9_from_r256<F>(from_param(A.k2));
+        }
+    }
+    for (u32 e = tid; e < tile; e += nthr) {
+        u32 col, mid;
+        size_t x;
+        if (FIRST) {
+            mid = e & (rows - 1);
+            col = e >> r;
+            x = ((size_t)bitrev(c0 + col, L - r) << r) + mid;
+        } else {
+            col = e & (T - 1);
+            mid = e >> logT;
+            x = (hi_idx << (s0 + r)) + ((size_t)mid << s0) + lo0 + col;
+        }
+        fe9 v = lds9_get(S, (mid << logT) + col);
+        if (!A.store_mode) v = ntt_fold9(v, S.qp);          // (a multiplication by the store factor takes the unfolded value)
+        fe w;
+        if (A.store_mode) {
+            const u32 m3 = A.store_mode == 2 ? (u32)(x % 3) : 0;
+            w = fe9_canonical_small<F>(fe9_mul<F>(v, m3 == 0 ? k0 : m3 == 1 ? k1 : k2));
+        } else if (A.last) {
+            w = fe9_canonical_small<F>(v);
+        } else {
+            w = ntt_pack_lazy9<F>(v);
+        }
+        fe_store(out + 8 * x, w);
+    }
+}
+
+// twiddle table, M9 flavour: omega^e in M9 form as raw limbs, three planes (limbs 0-3 | 4-7 | 8)
+template <int F>
+__global__ void __launch_bounds__(256) ntt_twiddles9(uint4 *__restrict__ pa, uint4 *__restrict__ pb, u32 *__restrict__ pc, feparam omega_p,
+                                                     feparam step_p, u32 T, size_t count) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    fe omega = from_param(omega_p), step = from_param(step_p);
+    fe cur = fe_one<F>();
+    for (int b = 31 - __clz(t | 1); b >= 0; --b) {
+        cur = fe_sqr<F>(cur);
+        if ((t >> b) & 1) cur = fe_mulx<F>(cur, omega);
+    }
+    for (size_t e = t; e < count; e += T) {
+        const fe9 v = fe9_unpack(fe_mulx<F>(cur, fe_k32<F>()));
+        pa[e] = make_uint4((u32)v.v[0], (u32)v.v[1], (u32)v.v[2], (u32)v.v[3]);
+        pb[e] = make_uint4((u32)v.v[4], (u32)v.v[5], (u32)v.v[6], (u32)v.v[7]);
+        pc[e] = (u32)v.v[8];
+        cur = fe_mulx<F>(cur, step);
+    }
+}
+
 // elementwise multiply for the degenerate log_n = 0 case
 template <int F> __global__ void ntt_scale1(u32 *a, feparam k) {
     if (threadIdx.x == 0 && blockIdx.x == 0) fe_store(a, fe_mulx<F>(fe_load(a), from_param(k)));
@@ -279,14 +517,16 @@ template <int F> __global__ void ntt_scale1(u32 *a, feparam k) {
 // ---- host: twiddle cache + pass plan ---------------------------------------------------------------
 struct TwKey {
     int dev, field, L;
+    int flavour;     // 0: omega^e in the reference's Montgomery form, 32 B each (also read by the curve-point FFT); 1: M9 raw limbs, 36 B
     u64 w[4];
     bool operator==(const TwKey &o) const {
-        return dev == o.dev && field == o.field && L == o.L && memcmp(w, o.w, 32) == 0;
+        return dev == o.dev && field == o.field && L == o.L && flavour == o.flavour && memcmp(w, o.w, 32) == 0;
     }
     bool operator<(const TwKey &o) const {
         if (dev != o.dev) return dev < o.dev;
         if (field != o.field) return field < o.field;
         if (L != o.L) return L < o.L;
+        if (flavour != o.flavour) return flavour < o.flavour;
         return memcmp(w, o.w, 32) < 0;
     }
 };
@@ -322,11 +562,14 @@ void ntt_release_workspaces() {   // h2_trim: scratch vectors and cached twiddle
 }
 
 // returns the device table omega^0..omega^(n/2-1); builds it on `st` when missing
-static int get_twiddles(NttContext &cx, int field, int L, const u64 omega_m[4], hipStream_t st, std::shared_ptr<TwEntry> &out) {
+static int get_twiddles(NttContext &cx, int field, int L, const u64 omega_m[4], hipStream_t st, std::shared_ptr<TwEntry> &out,
+                        int flavour = 0) {
     TwKey key;
     (void)hipGetDevice(&key.dev);
     key.field = field;
     key.L = L;
+    key.flavour = flavour;
+    const size_t esz = flavour ? 36 : 32;
     memcpy(key.w, omega_m, 32);
     auto it = cx.cache.find(key);
     if (it != cx.cache.end()) {
@@ -339,14 +582,19 @@ static int get_twiddles(NttContext &cx, int field, int L, const u64 omega_m[4], 
     }
     size_t count = L >= 1 ? ((size_t)1 << (L - 1)) : 1;
     auto ent = std::make_shared<TwEntry>();
-    H2_HIP(hipMalloc(&ent->d, count * 32));
+    H2_HIP(hipMalloc(&ent->d, count * esz));
     H2_HIP(hipEventCreateWithFlags(&ent->ready, hipEventDisableTiming));
     u32 T = (u32)std::min<size_t>(count, 1u << 16);
     u64 step[4];
     memcpy(step, omega_m, 32);
     for (u32 s = 1; s < T; s <<= 1) host_mul(field, step, step, step);  // omega^T, T a power of two
     dim3 grid((T + 255) / 256), block(256);
-    if (field == H2_FP)
+    if (flavour) {
+        uint4 *pa = (uint4 *)ent->d, *pb = pa + count;
+        u32 *pc = (u32 *)(pb + count);
+        if (field == H2_FP) hipLaunchKernelGGL((ntt_twiddles9<FP>), grid, block, 0, st, pa, pb, pc, to_param(omega_m), to_param(step), T, count);
+        else hipLaunchKernelGGL((ntt_twiddles9<FQ>), grid, block, 0, st, pa, pb, pc, to_param(omega_m), to_param(step), T, count);
+    } else if (field == H2_FP)
         hipLaunchKernelGGL((ntt_twiddles<FP>), grid, block, 0, st, (u32 *)ent->d, to_param(omega_m), to_param(step), T, count);
     else
         hipLaunchKernelGGL((ntt_twiddles<FQ>), grid, block, 0, st, (u32 *)ent->d, to_param(omega_m), to_param(step), T, count);
@@ -354,7 +602,7 @@ static int get_twiddles(NttContext &cx, int field, int L, const u64 omega_m[4], 
     H2_HIP(hipEventRecord(ent->ready, st));
     cx.cache[key] = ent;
     cx.lru.push_front(key);
-    cx.cache_bytes += count * 32;
+    cx.cache_bytes += count * esz;
     while (cx.cache_bytes > kTwCacheBytes && cx.lru.size() > 1) {
         TwKey old = cx.lru.back();
         cx.lru.pop_back();
@@ -363,7 +611,7 @@ static int get_twiddles(NttContext &cx, int field, int L, const u64 omega_m[4], 
             // entries still referenced by in-flight work stay alive through the shared_ptr held by the caller
             H2_HIP(hipEventSynchronize(o->second->ready));
             H2_HIP(hipDeviceSynchronize());
-            cx.cache_bytes -= (old.L >= 1 ? ((size_t)1 << (old.L - 1)) : 1) * 32;
+            cx.cache_bytes -= (old.L >= 1 ? ((size_t)1 << (old.L - 1)) : 1) * (old.flavour ? 36 : 32);
             cx.cache.erase(o);
         }
     }
@@ -371,9 +619,28 @@ static int get_twiddles(NttContext &cx, int field, int L, const u64 omega_m[4], 
     return H2_OK;
 }
 
+static bool ntt_on_fe9() {
+    static const bool on = [] { const char *e = getenv("H2_NTT_FE9"); return !(e && atoi(e) == 0); }();
+    return on;
+}
 template <int F, int R, bool FIRST>
 static int launch_pass_t(const PassArgs &A, unsigned tiles, u32 threads, size_t lds, hipStream_t st, const u32 *src, u32 *dst,
                          const u32 *tw) {
+    if (ntt_on_fe9()) {
+        static bool attr9 = false;
+        if (!attr9) {
+            H2_HIP(hipFuncSetAttribute((const void *)ntt_pass9<F, R, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr9 = true;
+        }
+        const size_t count = A.L >= 1 ? ((size_t)1 << (A.L - 1)) : 1;
+        Tw9 t9;
+        t9.a = (const uint4 *)tw;
+        t9.b = t9.a + count;
+        t9.c = (const u32 *)(t9.b + count);
+        const size_t lds9 = lds / 32 * 36 + 129 * 48;
+        hipLaunchKernelGGL((ntt_pass9<F, R, FIRST>), dim3(tiles), dim3(threads), lds9, st, src, dst, t9, A);
+        return H2_OK;
+    }
     static bool attr = false;  // raise the dynamic-LDS cap once per instantiation
     if (!attr) {
         H2_HIP(hipFuncSetAttribute((const void *)ntt_pass<F, R, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
@@ -447,7 +714,7 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
         return H2_OK;
     }
     std::shared_ptr<TwEntry> tw;
-    int rc = get_twiddles(cx, J.field, L, J.omega, st, tw);
+    int rc = get_twiddles(cx, J.field, L, J.omega, st, tw, ntt_on_fe9() ? 1 : 0);
     if (rc != H2_OK) return rc;
 
     // pass plan: ceil(L / maxr) passes, stages spread evenly (H2_NTT_MAXR / H2_NTT_LOGT / H2_NTT_LDS: tuning sweeps only).
