@@ -6,6 +6,6 @@ from ._lib import (FORM_CANONICAL, FORM_MONTGOMERY, FP, FQ, LIB_PATH, PALLAS, VE
 from .arithmetic import (batch_invert, best_fft, best_fft_batch, best_multiexp, compute_inner_product, eval_polynomial,  # noqa: F401
                          fold_scalars, grand_product, kate_division, msm_window_bits, parallel_generator_collapse,
                          points_sum, powers, scale_add, small_multiexp)
-from .commitment import Blind, Params, lagrange_basis, points_from_bytes, points_to_bytes  # noqa: F401
+from .commitment import Blind, Params, hash_to_curve, lagrange_basis, points_from_bytes, points_to_bytes  # noqa: F401
 from .domain import EvaluationDomain  # noqa: F401
 from .poly import Coeff, ExtendedLagrangeCoeff, LagrangeCoeff, Polynomial  # noqa: F401

@@ -1,9 +1,9 @@
 """`Params` (halo2_proofs/src/poly/commitment.rs:26-205) over the C ABI: `g` and `g_lagrange` are
 registered once and stay in HBM; `commit` / `commit_lagrange` (:119-150) ship only the column.
 
-`Params::new` derives its generators with pasta_curves' hash-to-curve (commitment.rs:51-62), which lives
-in an un-vendored dependency; here a Params is built from caller-supplied generators (`from_generators`),
-which is also what `Params::read` (:184) amounts to."""
+`Params.new(curve, k)` derives the generators as `Params::new` does (commitment.rs:38-114): pasta_curves'
+hash-to-curve (h2_hash_to_curve, csrc/h2c.hip) and the point iFFT, both on the device; `from_generators` takes
+caller-supplied generators, which is also what `Params::read` (:184) amounts to."""
 from __future__ import annotations
 
 import ctypes as C
@@ -52,6 +52,22 @@ def points_from_bytes(raw: bytes, curve: int, form: int = FORM_MONTGOMERY) -> np
     return out
 
 
+def hash_to_curve(curve: int, domain_prefix: str, messages, form: int = FORM_MONTGOMERY) -> np.ndarray:
+    """`C::CurveExt::hash_to_curve(domain_prefix)` applied to each message (bytes objects of equal length, or an (n, len) uint8
+    array) -> (n, 8) affine limbs.  pasta_curves' map (BLAKE2b XMD, simplified SWU, 3-isogeny), computed on the device."""
+    if isinstance(messages, np.ndarray):
+        msgs = np.ascontiguousarray(messages, dtype=np.uint8)
+    else:
+        messages = list(messages)
+        if len({len(m_) for m_ in messages}) > 1:
+            raise ValueError("hash_to_curve: messages must have equal length")
+        msgs = np.frombuffer(b"".join(messages), dtype=np.uint8).reshape(len(messages), -1 if messages and len(messages[0]) else 0).copy()
+    n, mlen = msgs.shape[0], (msgs.shape[1] if msgs.ndim == 2 else 0)
+    out = np.zeros((n, 8), dtype=np.uint64)
+    check(lib().h2_hash_to_curve(curve, domain_prefix.encode(), msgs.ctypes.data_as(C.c_void_p), mlen, n, form, _p(out)), "h2_hash_to_curve")
+    return out
+
+
 class Params:
     def __init__(self, curve: int, k: int, g, g_lagrange, w, u):
         self.curve, self.k, self.n = curve, k, 1 << k
@@ -68,6 +84,21 @@ class Params:
               "h2_bases_register")
         self._w_dev = None
         self._h_gu = C.c_uint64(0)        # g || u, registered on the first opening argument (opening.py)
+
+    @classmethod
+    def new(cls, curve: int, k: int) -> "Params":
+        """`Params::new(k)` (commitment.rs:38-114): g_i = hash_to_curve("Halo2-Parameters")({0, i as LE u32}), g_lagrange by the
+        point iFFT, w = hasher({1}), u = hasher({2}) -- all on the device.  Bit-exact with the reference's generators (the
+        verifying key pinned in tests/plonk_api.rs:958-981 is reproduced from Params.new(5))."""
+        if not 0 <= k < 32:
+            raise ValueError("Params.new: k out of range")                   # assert!(k < 32), commitment.rs:41
+        n = 1 << k
+        msgs = np.zeros((n, 5), dtype=np.uint8)
+        msgs[:, 1:5] = np.arange(n, dtype="<u4").view(np.uint8).reshape(n, 4)
+        g = hash_to_curve(curve, "Halo2-Parameters", msgs)
+        w = hash_to_curve(curve, "Halo2-Parameters", [b"\x01"])[0]
+        u = hash_to_curve(curve, "Halo2-Parameters", [b"\x02"])[0]
+        return cls.from_generators(curve, k, g, None, w, u)
 
     @classmethod
     def from_generators(cls, curve: int, k: int, g, g_lagrange, w, u) -> "Params":

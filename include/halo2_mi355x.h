@@ -305,6 +305,15 @@ int h2_points_compress_device(int curve, const void *d_xy, size_t n, int form, v
 int h2_points_decompress(int curve, const uint8_t *bytes, size_t n, int form, uint64_t *out_xy);
 int h2_points_decompress_device(int curve, const void *d_bytes, size_t n, int form, void *d_out_xy, void *stream);
 
+/* ---- hash-to-curve: `C::CurveExt::hash_to_curve(domain_prefix)` as Params::new calls it (poly/commitment.rs:52-62, :102-104) ---- */
+/* out[i] = hash_to_curve(domain_prefix)(message i), affine; `count` messages of `msg_len` (<= 64) bytes each, contiguous.  The map
+ * is pasta_curves' (BLAKE2b-512 XMD, simplified SWU on iso-Pallas / iso-Vesta, 3-isogeny: Zcash protocol specification 5.4.9.8);
+ * Params::new(k) is count = 2^k messages {0, i as LE u32} plus {1} for w and {2} for u with the prefix "Halo2-Parameters". */
+int h2_hash_to_curve(int curve, const char *domain_prefix, const uint8_t *msgs, size_t msg_len, size_t count, int form,
+                     uint64_t *out_xy);
+int h2_hash_to_curve_device(int curve, const char *domain_prefix, const void *d_msgs, size_t msg_len, size_t count,
+                            int form, void *d_out_xy, void *stream);
+
 /* ---- measurement aid (no reference counterpart) ------------------------------------------------ */
 /* When enabled, the library brackets its dominant kernels with HIP events on the launching stream.
  * h2_profile_read drains them: slot 0 = MSM bucket accumulation, 1 = NTT passes (sum over the passes

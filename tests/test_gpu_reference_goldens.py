@@ -190,3 +190,41 @@ def test_polynomial_tags_through_the_device_transforms(keygen):
     with pytest.raises(TypeError):
         params.commit_lagrange(coeff, blind)
     params.close()
+
+
+def test_hash_to_curve_on_the_device():
+    """h2_hash_to_curve == the restated pasta_curves map, both curves, several prefixes and message lengths (0 .. 64 bytes);
+    w of Params::new is the value the reference pins."""
+    from oracle import hash_to_curve as oh
+    for curve, cid in ((h.VESTA, "vesta"), (h.PALLAS, "pallas")):
+        for prefix, msgs in (("Halo2-Parameters", [b"\x00" + i.to_bytes(4, "little") for i in (0, 1, 2, 31, 0xDEADBEEF)]),
+                             ("z.cash:test", [b"Trans rights now!"]), ("", [b""]), ("x" * 64, [bytes(range(64))])):
+            got = h.hash_to_curve(curve, prefix, msgs)
+            want = [oh.hash_to_curve(cid, prefix)(m_) for m_ in msgs]
+            assert [co.affine_to_ints(curve, got[i]) for i in range(len(msgs))] == want
+    assert co.affine_to_ints(VESTA, h.hash_to_curve(VESTA, "Halo2-Parameters", [b"\x01"])[0]) == PINNED_FIXED[0]
+    can = h.hash_to_curve(VESTA, "Halo2-Parameters", [b"\x01"], form=h.FORM_CANONICAL)[0]
+    assert (int(can[0]) | int(can[1]) << 64 | int(can[2]) << 128 | int(can[3]) << 192) == PINNED_FIXED[0][0]
+    with pytest.raises(ValueError):
+        h.hash_to_curve(VESTA, "y" * 65, [b"\x01"])            # prefix too long for the DST buffer
+
+
+def test_params_new_reproduces_the_pinned_verifying_key():
+    """`Params.new(VESTA, 5)` -- generators hashed on the device, Lagrange basis by the device point FFT -- then commit_lagrange of
+    the reference circuit's keygen columns: all 19 commitments of tests/plonk_api.rs:958-981, with nothing but the column
+    values coming from the test side."""
+    params = h.Params.new(VESTA, 5)
+    g_ref, _, w_ref, u_ref = pa.params_new("vesta", 5, with_lagrange=False)
+    assert [co.affine_to_ints(VESTA, params.g[i]) for i in range(32)] == g_ref
+    assert co.affine_to_ints(VESTA, params.w) == w_ref == PINNED_FIXED[0] and co.affine_to_ints(VESTA, params.u) == u_ref
+    sf = co.field_of_curve(VESTA, "scalar")
+    fixed, mapping = pa.keygen_columns(o.P)
+    om = [pow(o.omega_for(o.P, 5), j, o.P) for j in range(32)]
+    sigmas = [[pow(pa.DELTA[o.P], mapping[i][j][0], o.P) * om[mapping[i][j][1]] % o.P for j in range(32)] for i in range(12)]
+    got = [affine_of(VESTA, params.commit_lagrange(co.to_mont(sf, co.ints_to_limbs(col)), h.Blind(field=sf))) for col in fixed + sigmas]
+    assert got == PINNED
+    params.close()
+    big = h.Params.new(h.PALLAS, 12)                           # a larger one: every generator on the curve and distinct
+    pts = [co.affine_to_ints(h.PALLAS, big.g[i]) for i in range(0, 4096, 97)]
+    assert all(o.on_curve(p_, o.P) for p_ in pts) and len(set(pts)) == len(pts)
+    big.close()
