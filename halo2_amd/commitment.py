@@ -84,6 +84,7 @@ class Params:
               "h2_bases_register")
         self._w_dev = None
         self._h_gu = C.c_uint64(0)        # g || u, registered on the first opening argument (opening.py)
+        self._h_pair = C.c_uint64(0)      # g || u || u || w || w for the paired L_j / R_j commits
 
     @classmethod
     def new(cls, curve: int, k: int) -> "Params":
@@ -131,7 +132,7 @@ class Params:
         return cls(curve, k, pts[:n], pts[n:2 * n], pts[2 * n], pts[2 * n + 1])
 
     def close(self):
-        for h in (self._h_g, self._h_gl, self._h_gu):
+        for h in (self._h_g, self._h_gl, self._h_gu, self._h_pair):
             if h.value:
                 lib().h2_bases_free(h)
                 h.value = 0
@@ -213,6 +214,27 @@ class Params:
                                            arr(*[d_bl[i].data_ptr() for i in range(n_)]), FORM_MONTGOMERY,
                                            OUT_AFFINE if affine else OUT_JACOBIAN, arr(*[out[i].data_ptr() for i in range(n_)]),
                                            _stream_ptr()), "h2_commit_batch_device")
+        return out
+
+    def pair_commit_supported(self) -> bool:
+        """h2_commit_pair_device needs the registered table of n + 4 points to use 16-bit windows (n >= 2^16 or so)."""
+        from .arithmetic import msm_window_bits
+        return self.n >= 8192 and int(lib().h2_commit_window_bits(self.n + 4)) == 16
+
+    def opening_pair_commit(self, column, pair_shift: int, affine: bool = False):
+        """L_j and R_j of an opening-argument round from ONE (n + 4)-row CUDA column over g || u || u || w || w
+        (h2_commit_pair_device): rows i < n belong to output (i >> pair_shift) & 1; rows n, n + 1 are the U scalars of L and R,
+        rows n + 2, n + 3 their W scalars.  Returns a (2, 12 | 8) CUDA tensor."""
+        import torch
+        if not self._h_pair.value:
+            tail = np.stack([self.u, self.u, self.w, self.w])
+            basis = np.ascontiguousarray(np.concatenate([self.g, tail]))
+            check(lib().h2_bases_register(self.curve, _p(basis), self.n + 4, FORM_MONTGOMERY, C.byref(self._h_pair)), "h2_bases_register")
+        if column.shape[0] != self.n + 4 or not column.is_contiguous():
+            raise ValueError("opening_pair_commit: the column must hold n + 4 scalars")
+        out = torch.empty((2, 8 if affine else 12), dtype=torch.int64, device=column.device)
+        check(lib().h2_commit_pair_device(self._h_pair, column.data_ptr(), self.n + 4, pair_shift, FORM_MONTGOMERY,
+                                          OUT_AFFINE if affine else OUT_JACOBIAN, out.data_ptr(), _stream_ptr()), "h2_commit_pair_device")
         return out
 
     def commit_unblinded(self, scalars):

@@ -112,6 +112,10 @@ __global__ void __launch_bounds__(256) ipa_round_scalars(const u32 *__restrict__
     const u32 h = m >> blk, i = m & ((1u << blk) - 1);
     const fe v = fe_mulx<F>(fe_load(p + 8 * (size_t)(i ^ half)), fe_load(s + 8 * (size_t)h));
     const bool lo = i < half;
+    if (cl == cr) {        // merged column for a pair commit (h2_commit_pair_device): L_j and R_j have disjoint supports
+        fe_store(cl + 8 * (size_t)m, v);
+        return;
+    }
     fe_store(cl + 8 * (size_t)m, lo ? v : fe_zero());
     fe_store(cr + 8 * (size_t)m, lo ? fe_zero() : v);
 }

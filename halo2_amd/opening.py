@@ -9,8 +9,11 @@ live on the device for the whole argument; per round the host sees 2 x 32 bytes 
 Two schedules produce the same L_j, R_j (and so the same proof bytes):
 * "collapse": the reference's -- multiexps over the collapsed G' (arbitrary bases each round) + the generator collapse;
 * "original": L_j, R_j as commits over the ORIGINAL, registered generators with scalars p' (x) s_j
-  (`h2_ipa_round_scalars_device`).  Every round is two half-empty registered multiexps; G' never exists.  The default:
-  measured faster at every k (k = 20: 0.047 s against 0.062 s; k = 10: 8.4 ms against 19.8 ms).
+  (`h2_ipa_round_scalars_device`).  Every round is two half-empty registered multiexps; G' never exists
+  (k = 20: 0.042 s against 0.062 s; k = 10: 8.4 ms against 19.8 ms).
+* "paired" (the default where it applies, n >= 8192): the same scalars, but L_j and R_j have disjoint supports in g (the low /
+  high half of every 2^(k-j) block), so they share ONE column and leave ONE sort, ONE bucket accumulation (two bucket slices)
+  and one fold per round (`h2_commit_pair_device` over g || u || u || w || w).
 
 torch is plumbing (device buffers, slicing); all arithmetic goes through the C ABI."""
 from __future__ import annotations
@@ -66,11 +69,17 @@ def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, d
 
     d_b = powers(x3, n, sf, device=dev)                                                   # prover.rs:86-97
     if schedule is None:
-        schedule = "original"
-    if schedule not in ("original", "collapse"):
-        raise ValueError("create_proof: schedule must be 'original' or 'collapse'")
+        schedule = "paired" if n >= 8192 else "original"
+    if schedule not in ("original", "collapse", "paired"):
+        raise ValueError("create_proof: schedule must be 'paired', 'original' or 'collapse'")
+    if schedule == "paired" and (n < 8192 or not params.pair_commit_supported()):
+        schedule = "original"          # small tables use narrower windows, which the paired sort does not take
+    paired = schedule == "paired"
     original = schedule == "original"
-    if original:
+    if paired:
+        d_c = torch.zeros((n + 4, 4), dtype=torch.int64, device=dev)                      # L_j and R_j scalars, one column
+        challenges = []
+    elif original:
         d_cl = torch.zeros((n + 1, 4), dtype=torch.int64, device=dev)                     # L_j / R_j scalars over g || u
         d_cr = torch.zeros((n + 1, 4), dtype=torch.int64, device=dev)
         challenges = []
@@ -86,7 +95,11 @@ def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, d
         value_l, value_r = as_int(values[0]), as_int(values[1])
         l_rand, r_rand = rng(2)
         # L_j = <p'_hi, G'_lo> + [value_l z] U + [l_rand] W as ONE multiexp (the reference's TODO, :108-110)
-        if original:
+        if paired:
+            ipa_round_scalars(d_pp[:2 * half], k, j, challenges, sf, d_c, d_c)
+            d_c[n:] = to_dev(np.stack([as_limbs(value_l * z_i), as_limbs(value_r * z_i), l_rand, r_rand]))
+            lr = _host(params.opening_pair_commit(d_c, k - j - 1))
+        elif original:
             ipa_round_scalars(d_pp[:2 * half], k, j, challenges, sf, d_cl, d_cr)
             tails = to_dev(np.stack([as_limbs(value_l * z_i), as_limbs(value_r * z_i)]))
             d_cl[n] = tails[0]
@@ -105,7 +118,7 @@ def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, d
         u_inv_i = pow(u_i, -1, m)                                                         # prover.rs:125
         d_pp = fold_scalars(d_pp[:2 * half], as_limbs(u_inv_i), sf)                       # prover.rs:128-133
         d_b = fold_scalars(d_b[:2 * half], u_j, sf)
-        if original:
+        if original or paired:
             challenges.append(np.ascontiguousarray(u_j, dtype=np.uint64).reshape(4))
         else:
             d_g = parallel_generator_collapse(d_g[:2 * half], u_j, curve)                 # prover.rs:136-137

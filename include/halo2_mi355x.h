@@ -69,6 +69,8 @@ const char *h2_last_error(void);
 int h2_trim(void);
 /* Window width the MSM would use for n points (informational; the result does not depend on it). */
 int h2_msm_window_bits(size_t n);
+/* The same for a registered basis of n points (h2_bases_register / h2_commit); h2_commit_pair_device needs 16. */
+int h2_commit_window_bits(size_t n);
 /* Tuning knobs (never change results).  "msm_lane_fraction" in (0.05, 1]: share of the resident wave slots
  * one bucket-accumulation launch claims; < 1 lets commits issued on other streams overlap it (default 1). */
 int h2_set_option(const char *key, double value);
@@ -133,6 +135,13 @@ int h2_msm_device(int curve, const void *d_scalars, const void *d_bases_xy, size
  * old w must have been synchronised by then. */
 int h2_commit_device(h2_bases_t g, const void *d_scalars, size_t n, const void *d_w_xy,
                      const void *d_blind, int form, int out_kind, void *d_out, void *stream);
+/* TWO commits from one column over a registered basis of n points: column i < n - 4 feeds output (i >> pair_shift) & 1, the last
+ * four columns feed outputs 0, 1, 0, 1.  This is one round of the opening argument written over the original generators
+ * (poly/commitment/prover.rs:107-114): L_j and R_j have disjoint supports in g, so they share the scalar column produced by
+ * h2_ipa_round_scalars_device (pass the same buffer for d_cl and d_cr), and the basis g || u || u || w || w carries the
+ * [value z] U and [rand] W terms of each.  d_out: output 0 then output 1 (2 x 12 or 2 x 8 limbs).  n >= 8192. */
+int h2_commit_pair_device(h2_bases_t g, const void *d_scalars, size_t n, unsigned pair_shift, int form, int out_kind,
+                          void *d_out, void *stream);
 /* `count` independent commits over one registered basis -- the column commits of a prover phase
  * (plonk/prover.rs:93-101, 301-313; vanishing/prover.rs:96-108).  d_scalars[i] / d_blinds[i] / d_outs[i] are
  * device pointers held in HOST arrays; the commits are spread over internal streams (one column's latency-bound

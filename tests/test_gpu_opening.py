@@ -24,11 +24,13 @@ def _rng(sf, seed):
     return rng
 
 
-@pytest.mark.parametrize("schedule", ["collapse", "original", None])
+@pytest.mark.parametrize("schedule", ["collapse", "original", "paired", None])
 @pytest.mark.parametrize("curve,k", [(h.PALLAS, 1), (h.PALLAS, 4), (h.PALLAS, 6), (h.VESTA, 6), (h.VESTA, 11), (h.VESTA, 13)])
 def test_opening_proof_bytes_and_verification(curve, k, schedule):
     if schedule is None and k != 6:
-        pytest.skip("the default schedule is 'original'; its plumbing is covered once")
+        pytest.skip("the default schedule is 'paired' from n = 8192 on and 'original' below; its plumbing is covered once")
+    if schedule == "paired":
+        pytest.skip("the paired commit needs 16-bit windows (large tables); covered at k = 20 below and at k = 16 in test_paired_commit")
     n = 1 << k
     sf = fields.CURVE_FIELDS[curve][1]
     g = co.generate_bases(curve, 50 + k, n)
@@ -110,6 +112,33 @@ def test_ipa_round_scalars_against_definition(field, k, j):
     assert (d_l[n] == -1).all() and (d_r[n] == -1).all()          # the tail slot belongs to the caller
 
 
+def test_paired_commit_matches_two_commits():
+    """h2_commit_pair_device at k = 16: for every shift, both outputs equal the two commits they stand for (computed by the
+    ordinary registered commit over g || u || u || w || w with the other side's scalars zeroed)."""
+    import torch
+    curve, k = h.PALLAS, 16
+    n = 1 << k
+    sf = fields.CURVE_FIELDS[curve][1]
+    g = co.generate_bases(curve, 91, n)
+    w, u = co.generate_bases(curve, 60, 1)[0], co.generate_bases(curve, 61, 1)[0]
+    params = h.Params(curve, k, g, g, w, u)
+    assert params.pair_commit_supported()
+    col = co.random_field(sf, 92, n + 4)
+    col[::7] = 0
+    basis = np.ascontiguousarray(np.concatenate([g, np.stack([u, u, w, w])]))
+    d_col = torch.from_numpy(col.view(np.int64)).cuda()
+    idx = np.arange(n + 4)
+    for shift in (0, 1, 7, 15):
+        side = np.where(idx < n, (idx >> shift) & 1, (idx - n) & 1)
+        got = params.opening_pair_commit(d_col, shift, affine=True).cpu().numpy().view(np.uint64)
+        for s_ in (0, 1):
+            part = col.copy()
+            part[side != s_] = 0
+            want = co.jac_to_affine_ints(curve, co.best_multiexp(curve, part, basis))
+            assert co.affine_to_ints(curve, got[s_]) == want
+    params.close()
+
+
 def test_opening_proof_full_size_schedules_agree_and_verify():
     """k = 20 (BASELINE's size): the two schedules -- independent device algorithms for L_j, R_j -- write identical proof
     bytes, and the oracle's restatement of the reference verifier (one 2^20 multiexp on the host) accepts them."""
@@ -123,7 +152,7 @@ def test_opening_proof_full_size_schedules_agree_and_verify():
     blind = h.Blind(co.random_field(sf, 70, 1)[0])
     p = params.commit(px, blind, affine=True)
     proofs = []
-    for schedule in ("original", "collapse"):
+    for schedule in ("original", "collapse", "paired"):
         tr = Blake2bWrite(curve)
         tr.write_point(p)
         x = tr.squeeze_challenge_scalar()
@@ -131,7 +160,7 @@ def test_opening_proof_full_size_schedules_agree_and_verify():
         tr.write_scalar(v)
         create_proof(params, _rng(sf, 2000), tr, px, blind, x, schedule=schedule)
         proofs.append(tr.finalize())
-    assert proofs[0] == proofs[1] and len(proofs[0]) == 32 + 32 + 32 + 64 * k + 64
+    assert proofs[0] == proofs[1] == proofs[2] and len(proofs[0]) == 32 + 32 + 32 + 64 * k + 64
     p_int = co.affine_to_ints(curve, p)
     vt = ipa.Transcript(curve, proofs[0])
     assert vt.read_point() == p_int
