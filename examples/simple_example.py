@@ -101,14 +101,20 @@ def prove_and_verify(params, quiet: bool = False) -> dict:
     assert c == 252
 
     gen = np.random.Generator(np.random.PCG64(0x9E3779B97F4A7C15))
+    import torch
+    tgen = torch.Generator(device=fields.current_device())
+    tgen.manual_seed(0x9E3779B97F4A7C15)
 
     def rng(count):                                         # any source of uniform scalars; NOT cryptographic here
+        if count >= 4096:                                   # the n coefficients of a random polynomial: drawn on the device
+            out = torch.randint(-(1 << 63), (1 << 63) - 1, (count, 4), dtype=torch.int64, device=tgen.device, generator=tgen)
+            out[:, 3] &= (1 << 62) - 1
+            return out
         out = gen.integers(0, 1 << 64, size=(count, 4), dtype=np.uint64)
         out[:, 3] &= np.uint64((1 << 62) - 1)               # limbs of a value below 2^254 < p: a valid Montgomery representation
         return out
 
     # the assigned columns go to the device once (synthesis is the host's job; the prover starts from resident columns)
-    import torch
     dev = fields.current_device()
     up = lambda col: torch.from_numpy(fields.to_limbs(col, sf, True).view(np.int64)).to(dev)
     advice, fixed = [up(col) for col in advice], [up(col) for col in fixed]

@@ -92,3 +92,12 @@ def current_device():
     `torch.cuda.set_device(local_rank)`; every tensor this package allocates follows it."""
     import torch
     return torch.device("cuda", torch.cuda.current_device())
+
+
+def to_device_limbs(a, dev):
+    """(count, 4) scalars as an int64 CUDA tensor on `dev`: numpy limbs are uploaded, CUDA tensors pass through (an rng that draws
+    its large vectors on the device -- the n random coefficients of the opening / vanishing arguments -- saves the PCIe copy)."""
+    import torch
+    if isinstance(a, torch.Tensor):
+        return a.to(dev).view(torch.int64) if a.dtype != torch.int64 else a.to(dev)
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64)).to(dev)

@@ -52,7 +52,7 @@ def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, d
     x3 = np.ascontiguousarray(x_3, dtype=np.uint64).reshape(4)
 
     # random polynomial with a root at x_3 (prover.rs:43-53)
-    d_s = to_dev(rng(n))
+    d_s = fields.to_device_limbs(rng(n), dev)
     s_at_x3 = as_int(_host(eval_polynomial(d_s, x3, sf)))
     d_s[0] = to_dev(as_limbs(as_int(_host(d_s[0])) - s_at_x3))
     s_blind = Blind(np.ascontiguousarray(rng(1)[0]))

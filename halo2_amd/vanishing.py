@@ -26,7 +26,7 @@ class Argument:
         """prover.rs:38-61.  rng(count) -> (count, 4) Montgomery limbs: n draws for the polynomial, then one blind."""
         import torch
         dev = torch.device(device) if device else fields.current_device()
-        random_poly = torch.from_numpy(np.ascontiguousarray(rng(params.n), dtype=np.uint64).view(np.int64)).to(dev)
+        random_poly = fields.to_device_limbs(rng(params.n), dev)
         random_blind = Blind(np.ascontiguousarray(rng(1)[0]))
         transcript.write_point(_host(params.commit(random_poly, random_blind)))
         return Committed(random_poly, random_blind)
