@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Turns the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- collected in separate runs, no trace domains) into
-profiles/r01_pmc_traffic.json, the per-launch HBM byte counts bench.py quotes as `roofline.traffic`.
+profiles/r02_pmc_traffic.json, the per-launch HBM byte counts bench.py quotes as `roofline.traffic`.
 
     cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_f -o f --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1
-    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_w -o w --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1
-    python bench/pmc_summary.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv > profiles/r01_pmc_traffic.json
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_f -o f --output-format csv -- python bench.py --steps 3 --warmup 1 --prewarm-ms 0 --minimal --no-cpu-baseline --streams 1
+    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_w -o w --output-format csv -- python bench.py --steps 3 --warmup 1 --prewarm-ms 0 --minimal --no-cpu-baseline --streams 1
+    python bench/pmc_summary.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv > profiles/r02_pmc_traffic.json
 
 Counter values are KiB per dispatch.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide coalesced streaming
 reads by exactly 2x (calibrated for 16 B/lane streams); the x2 is applied to the streaming kernels named in STREAMING and
@@ -17,7 +17,7 @@ import csv
 import json
 import sys
 
-STREAMING = ("ntt_pass", "msm_s1_count", "msm_s1_scatter", "msm_s2_count", "msm_s2_scatter")
+STREAMING = ("ntt_pass", "ntt_pass9", "msm_s1_count", "msm_s1_scatter", "msm_s2_count", "msm_s2_scatter")
 
 
 def collect(path, counter):
@@ -45,10 +45,10 @@ def main():
         return {k: v for k, v in kernels.items() if k.startswith(prefix) and v["FETCH_SIZE_KiB_max"] is not None}
 
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1 "
-                     "--no-cpu-baseline --streams 1, one MI355X; summarised by bench/pmc_summary.py",
+                     "--prewarm-ms 0 --minimal --no-cpu-baseline --streams 1, one MI355X; summarised by bench/pmc_summary.py",
            "units": __doc__.split("Counter values")[1].strip().replace("\n", " "),
            "kernels": kernels}
-    acc = pick("h2::msm_accumulate<0>")
+    acc = pick("h2::msm_accumulate<0, false, true>")
     if acc:
         k = max(acc, key=lambda k_: acc[k_]["FETCH_SIZE_KiB_max"])
         out["msm_accumulate_2^20"] = {
@@ -70,10 +70,10 @@ def main():
                                                 "written by pass 1, read twice and written once by pass 2 = 320 B"}
     ntt = {}
     for k, v in kernels.items():
-        if "ntt_pass" in k and k.endswith("grid=262144") and v["FETCH_SIZE_KiB_max"] is not None:
+        if "ntt_pass9<0, 10" in k and v["FETCH_SIZE_KiB_max"] is not None:
             ntt[k] = {"read_bytes_corrected": int(v["FETCH_SIZE_KiB_max"] * 1024 * 2), "write_bytes": int((v["WRITE_SIZE_KiB_max"] or 0) * 1024)}
     if ntt:
-        out["ntt_2^20"] = {"algorithmic_bytes": 64 << 20, "passes": ntt,
+        out["ntt_2^20"] = {"algorithmic_bytes": 64 << 20, "plan": "two passes of 10 stages (ntt_pass9)", "passes": ntt,
                            "total_hbm_bytes_corrected": sum(v["read_bytes_corrected"] + v["write_bytes"] for v in ntt.values())}
     print(json.dumps(out, indent=1))
 
