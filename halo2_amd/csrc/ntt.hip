@@ -387,13 +387,15 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
     }
         const size_t lo_x = FIRST ? 0 : (lo0 + (tid & (T - 1)));
     const u32 ngrp = tile >> 2;
+    // stage-major table: the 2^t twiddles of stage t, omega^(xm 2^(L-t-1)) for xm < 2^t, sit contiguously at 2^t - 1 + xm, so
+    // the T lanes of a tile row read T consecutive entries (one 128-byte run per plane) instead of entries 2^(L-t-1) apart
     auto tw_addr = [&](int u, size_t &eA, size_t &eB0, size_t &eB1) {
         const int t = s0 + u;
         const u32 q = tid >> logT, low = q & ((1u << u) - 1);
         const size_t xm = ((size_t)low << s0) + lo_x;
-        eA = xm << (L - t - 1);
-        eB0 = xm << (L - t - 2);
-        eB1 = eB0 + ((size_t)1 << (L - 2));
+        eA = (((size_t)1 << t) - 1) + xm;
+        eB0 = (((size_t)2 << t) - 1) + xm;
+        eB1 = eB0 + ((size_t)1 << t);
     };
     // the first twiddle of a round (needed at once) is fetched one round ahead; the other two are requested at the top of the
     // round and first used two multiplications later
@@ -446,7 +448,7 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
             const u32 s_a = (mid0 << logT) + col, s_b = s_a + (T << u);
             const size_t xm = ((size_t)low << s0) + (FIRST ? 0 : (lo0 + col));
             fe9 a = lds9_get(S, s_a), b = lds9_get(S, s_b);
-            if (!(FIRST && u == 0)) b = fe9_mul<F>(b, tw9_load(tw, xm << (L - t - 1)));
+            if (!(FIRST && u == 0)) b = fe9_mul<F>(b, tw9_load(tw, (((size_t)1 << t) - 1) + xm));
             lds9_put(S, s_a, fe9_norm(fe9_add(a, b)));
             lds9_put(S, s_b, fe9_norm(fe9_sub(a, b)));
         }
@@ -488,10 +490,12 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
     }
 }
 
-// twiddle table, M9 flavour: omega^e in M9 form as raw limbs, three planes (limbs 0-3 | 4-7 | 8)
+// twiddle table, M9 flavour: omega^e in M9 form as raw limbs, three planes (limbs 0-3 | 4-7 | 8), STAGE-MAJOR: stage t's
+// entries omega^(xm 2^(L-t-1)), xm < 2^t, at index 2^t - 1 + xm (2^L - 1 entries in all; omega^e is stored once for every
+// stage whose stride divides e).
 template <int F>
 __global__ void __launch_bounds__(256) ntt_twiddles9(uint4 *__restrict__ pa, uint4 *__restrict__ pb, u32 *__restrict__ pc, feparam omega_p,
-                                                     feparam step_p, u32 T, size_t count) {
+                                                     feparam step_p, u32 T, size_t count, int L) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     fe omega = from_param(omega_p), step = from_param(step_p);
@@ -502,9 +506,17 @@ __global__ void __launch_bounds__(256) ntt_twiddles9(uint4 *__restrict__ pa, uin
     }
     for (size_t e = t; e < count; e += T) {
         const fe9 v = fe9_unpack(fe_mulx<F>(cur, fe_k32<F>()));
-        pa[e] = make_uint4((u32)v.v[0], (u32)v.v[1], (u32)v.v[2], (u32)v.v[3]);
-        pb[e] = make_uint4((u32)v.v[4], (u32)v.v[5], (u32)v.v[6], (u32)v.v[7]);
-        pc[e] = (u32)v.v[8];
+        const uint4 va = make_uint4((u32)v.v[0], (u32)v.v[1], (u32)v.v[2], (u32)v.v[3]);
+        const uint4 vb = make_uint4((u32)v.v[4], (u32)v.v[5], (u32)v.v[6], (u32)v.v[7]);
+        // stages st = L - 1 down to the first whose stride 2^(L-st-1) no longer divides e (e = 0: every stage)
+        for (int st = L - 1; st >= 0; --st) {
+            const int sh = L - st - 1;
+            if (e & ((((size_t)1) << sh) - 1)) break;
+            const size_t idx = (((size_t)1 << st) - 1) + (e >> sh);
+            pa[idx] = va;
+            pb[idx] = vb;
+            pc[idx] = (u32)v.v[8];
+        }
         cur = fe_mulx<F>(cur, step);
     }
 }
@@ -569,7 +581,7 @@ static int get_twiddles(NttContext &cx, int field, int L, const u64 omega_m[4], 
     key.field = field;
     key.L = L;
     key.flavour = flavour;
-    const size_t esz = flavour ? 36 : 32;
+    const size_t esz = flavour ? 72 : 32;     // M9 flavour: stage-major, 2^L - 1 entries of 36 B = 72 B per omega^e, e < n / 2
     memcpy(key.w, omega_m, 32);
     auto it = cx.cache.find(key);
     if (it != cx.cache.end()) {
@@ -590,10 +602,10 @@ static int get_twiddles(NttContext &cx, int field, int L, const u64 omega_m[4], 
     for (u32 s = 1; s < T; s <<= 1) host_mul(field, step, step, step);  // omega^T, T a power of two
     dim3 grid((T + 255) / 256), block(256);
     if (flavour) {
-        uint4 *pa = (uint4 *)ent->d, *pb = pa + count;
-        u32 *pc = (u32 *)(pb + count);
-        if (field == H2_FP) hipLaunchKernelGGL((ntt_twiddles9<FP>), grid, block, 0, st, pa, pb, pc, to_param(omega_m), to_param(step), T, count);
-        else hipLaunchKernelGGL((ntt_twiddles9<FQ>), grid, block, 0, st, pa, pb, pc, to_param(omega_m), to_param(step), T, count);
+        uint4 *pa = (uint4 *)ent->d, *pb = pa + 2 * count;
+        u32 *pc = (u32 *)(pb + 2 * count);
+        if (field == H2_FP) hipLaunchKernelGGL((ntt_twiddles9<FP>), grid, block, 0, st, pa, pb, pc, to_param(omega_m), to_param(step), T, count, L);
+        else hipLaunchKernelGGL((ntt_twiddles9<FQ>), grid, block, 0, st, pa, pb, pc, to_param(omega_m), to_param(step), T, count, L);
     } else if (field == H2_FP)
         hipLaunchKernelGGL((ntt_twiddles<FP>), grid, block, 0, st, (u32 *)ent->d, to_param(omega_m), to_param(step), T, count);
     else
@@ -611,7 +623,7 @@ static int get_twiddles(NttContext &cx, int field, int L, const u64 omega_m[4], 
             // entries still referenced by in-flight work stay alive through the shared_ptr held by the caller
             H2_HIP(hipEventSynchronize(o->second->ready));
             H2_HIP(hipDeviceSynchronize());
-            cx.cache_bytes -= (old.L >= 1 ? ((size_t)1 << (old.L - 1)) : 1) * (old.flavour ? 36 : 32);
+            cx.cache_bytes -= (old.L >= 1 ? ((size_t)1 << (old.L - 1)) : 1) * (old.flavour ? 72 : 32);
             cx.cache.erase(o);
         }
     }
@@ -635,8 +647,8 @@ static int launch_pass_t(const PassArgs &A, unsigned tiles, u32 threads, size_t 
         const size_t count = A.L >= 1 ? ((size_t)1 << (A.L - 1)) : 1;
         Tw9 t9;
         t9.a = (const uint4 *)tw;
-        t9.b = t9.a + count;
-        t9.c = (const u32 *)(t9.b + count);
+        t9.b = t9.a + 2 * count;
+        t9.c = (const u32 *)(t9.b + 2 * count);
         const size_t lds9 = lds / 32 * 36 + 129 * 48;
         hipLaunchKernelGGL((ntt_pass9<F, R, FIRST>), dim3(tiles), dim3(threads), lds9, st, src, dst, t9, A);
         return H2_OK;
