@@ -23,6 +23,7 @@ vp = C.c_void_p
 # every symbol include/halo2_mi355x.h declares: name -> (argtypes, restype)
 SIGNATURES = {
     "h2_device_count": ([], C.c_int),
+    "h2_current_device": ([], C.c_int),
     "h2_init": ([C.c_int], C.c_int),
     "h2_last_error": ([], C.c_char_p),
     "h2_trim": ([], C.c_int),

@@ -79,6 +79,7 @@ class Params:
         self.u = np.ascontiguousarray(u, dtype=np.uint64).reshape(8)
         self._h_g = C.c_uint64(0)
         self._h_gl = C.c_uint64(0)
+        self.device_index = int(lib().h2_current_device())     # the registered tables live on the device current now
         check(lib().h2_bases_register(curve, _p(self.g), self.n, FORM_MONTGOMERY, C.byref(self._h_g)), "h2_bases_register")
         check(lib().h2_bases_register(curve, _p(self.g_lagrange), self.n, FORM_MONTGOMERY, C.byref(self._h_gl)),
               "h2_bases_register")
@@ -131,6 +132,12 @@ class Params:
         pts = points_from_bytes(raw, curve)
         return cls(curve, k, pts[:n], pts[n:2 * n], pts[2 * n], pts[2 * n + 1])
 
+    def _check_device(self, t) -> None:
+        """One process may drive several GPUs: a column must live where this Params' tables were registered (a launch on
+        another device would read them through a peer mapping at best)."""
+        if t.device.index != self.device_index:
+            raise ValueError(f"Params registered on cuda:{self.device_index} used with a tensor on {t.device}")
+
     def close(self):
         for h in (self._h_g, self._h_gl, self._h_gu, self._h_pair):
             if h.value:
@@ -153,6 +160,7 @@ class Params:
             raise ValueError("commit: polynomial length != n")
         if _is_torch(poly):
             import torch
+            self._check_device(poly)
             if self._w_dev is None or self._w_dev.device != poly.device:
                 self._w_dev = torch.from_numpy(self.w.view(np.int64)).to(poly.device)
             blind = torch.from_numpy(np.ascontiguousarray(r.value).view(np.int64)).to(poly.device)
@@ -175,6 +183,7 @@ class Params:
         if not polys:
             return None
         dev = polys[0].device
+        self._check_device(polys[0])
         out_len = 8 if affine else 12
         out = torch.empty((len(polys), out_len), dtype=torch.int64, device=dev)
         if self._w_dev is None or self._w_dev.device != dev:

@@ -145,6 +145,15 @@ extern "C" int h2_profile_read_busy(int slot, double *total_ms, double *busy_ms,
     return H2_OK;
 }
 
+extern "C" int h2_current_device(void) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return dev;
+}
+
 extern "C" int h2_device_count(void) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess) {

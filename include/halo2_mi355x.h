@@ -59,6 +59,8 @@ typedef uint64_t h2_bases_t; /* opaque handle to a device-resident basis (Params
 
 /* ---- library ------------------------------------------------------------------------------ */
 int h2_device_count(void);
+/* The HIP device current on the calling thread (what registrations and launches will use), or -1 without a device. */
+int h2_current_device(void);
 /* Binds the calling thread to `device` (hipSetDevice) and warms the per-device context. */
 int h2_init(int device);
 /* Human-readable description of the last failure on this thread (static storage). */
