@@ -7,12 +7,16 @@
 //                                                     halo2_proofs/src/poly/domain.rs:40, :227, :241, :303
 //     arithmetic::{eval_polynomial, compute_inner_product, kate_division}   arithmetic.rs:298, :308, :322
 //     EvaluationDomain::divide_by_vanishing_poly      halo2_proofs/src/poly/domain.rs:329
-//     Params::{commit, commit_lagrange, write, read}, Blind   halo2_proofs/src/poly/commitment.rs:119, :135, :169, :184, :208
+//     Params::{new, commit, commit_lagrange, write, read}, Blind   halo2_proofs/src/poly/commitment.rs:38, :119, :135, :169, :184, :208
+//     CurveExt::hash_to_curve (pasta_curves, as called at commitment.rs:52, :102), arithmetic::small_multiexp (arithmetic.rs:116)
+//     Polynomial<F, B> with the basis markers Coeff / LagrangeCoeff / ExtendedLagrangeCoeff   halo2_proofs/src/poly.rs:30-57
+//     commit_columns_multi: the column loop of a prover phase (plonk/prover.rs:93-101, 301-313) over several GPUs
 // Where the reference panics (assert_eq! on lengths) these throw std::invalid_argument; HIP / device
 // failures throw std::runtime_error with h2_last_error().  All compute happens in libhalo2_mi355x.so.
 #pragma once
 #include <array>
 #include <cstdint>
+#include <functional>
 #include <cstring>
 #include <istream>
 #include <ostream>
@@ -116,6 +120,31 @@ template <int FIELD> inline void best_fft(std::vector<Fe> &a, const Fe &omega, u
     check(h2_ntt(FIELD, a[0].data(), log_n, omega.data(), H2_FORM_MONTGOMERY), "h2_ntt");
 }
 
+// small_multiexp (arithmetic.rs:116-136): the same sum; on the device both are one kernel path
+template <int CURVE>
+inline Jacobian small_multiexp(const std::vector<Fe> &coeffs, const std::vector<Affine> &bases) { return best_multiexp<CURVE>(coeffs, bases); }
+
+// C::CurveExt::hash_to_curve(domain_prefix): returns the hasher closure, as pasta_curves does (commitment.rs:52, :102)
+template <int CURVE> inline std::function<Affine(const std::vector<uint8_t> &)> hash_to_curve(const std::string &domain_prefix) {
+    return [domain_prefix](const std::vector<uint8_t> &message) {
+        Affine out{};
+        check(h2_hash_to_curve(CURVE, domain_prefix.c_str(), message.empty() ? nullptr : message.data(), message.size(), 1, H2_FORM_MONTGOMERY,
+                               out.data()), "h2_hash_to_curve");
+        return out;
+    };
+}
+
+// ---- poly.rs: Polynomial<F, B>; the basis is a type, as in the reference, so mixing bases does not compile -----------------
+struct Coeff {};
+struct LagrangeCoeff {};
+struct ExtendedLagrangeCoeff {};
+template <int FIELD, typename Basis> struct Polynomial {
+    std::vector<Fe> values;
+    size_t len() const { return values.size(); }
+    Fe &operator[](size_t i) { return values[i]; }
+    const Fe &operator[](size_t i) const { return values[i]; }
+};
+
 template <int FIELD> inline Fe eval_polynomial(const std::vector<Fe> &poly, const Fe &point) {                  // arithmetic.rs:298
     Fe out{};
     check(h2_eval_polynomial(FIELD, poly.empty() ? nullptr : poly[0].data(), poly.size(), point.data(), H2_FORM_MONTGOMERY, out.data()),
@@ -192,6 +221,21 @@ template <int FIELD> class EvaluationDomain {
               "h2_divide_by_vanishing_poly");
         return a;
     }
+    // the same transforms on tagged polynomials (domain.rs:151-237 signatures)
+    Polynomial<FIELD, LagrangeCoeff> lagrange_from_vec(std::vector<Fe> v) const {
+        if (v.size() != n) throw std::invalid_argument("lagrange_from_vec: wrong length");
+        return {std::move(v)};
+    }
+    Polynomial<FIELD, Coeff> coeff_from_vec(std::vector<Fe> v) const {
+        if (v.size() != n) throw std::invalid_argument("coeff_from_vec: wrong length");
+        return {std::move(v)};
+    }
+    Polynomial<FIELD, Coeff> lagrange_to_coeff(Polynomial<FIELD, LagrangeCoeff> a) const { return {lagrange_to_coeff(std::move(a.values))}; }
+    Polynomial<FIELD, ExtendedLagrangeCoeff> coeff_to_extended(const Polynomial<FIELD, Coeff> &a) const { return {coeff_to_extended(a.values)}; }
+    std::vector<Fe> extended_to_coeff(Polynomial<FIELD, ExtendedLagrangeCoeff> a) const { return extended_to_coeff(std::move(a.values)); }
+    Polynomial<FIELD, ExtendedLagrangeCoeff> divide_by_vanishing_poly(Polynomial<FIELD, ExtendedLagrangeCoeff> a) const {
+        return {divide_by_vanishing_poly(std::move(a.values))};
+    }
 };
 
 // ---- poly/commitment.rs ------------------------------------------------------------------------------------------
@@ -211,6 +255,26 @@ template <int CURVE> class Params {
         check(h2_bases_register(CURVE, g_lagrange[0].data(), n, H2_FORM_MONTGOMERY, &h_gl), "h2_bases_register");
     }
     ~Params() { if (h_g) h2_bases_free(h_g); if (h_gl) h2_bases_free(h_gl); }
+    // Params::new (commitment.rs:38-114): g_i = hasher({0, i as LE u32}), g_lagrange by the point iFFT, w = hasher({1}), u = hasher({2});
+    // the 2^k + 2 hashes and the point FFT run on the device
+    static Params new_params(uint32_t k_) {
+        if (k_ >= 32) throw std::invalid_argument("Params::new: k < 32");                                              // :41
+        const size_t n_ = (size_t)1 << k_;
+        std::vector<uint8_t> msgs(5 * n_, 0);
+        for (size_t i = 0; i < n_; i++) { const uint32_t le = (uint32_t)i; memcpy(&msgs[5 * i + 1], &le, 4); }         // :57-58 (little-endian host)
+        std::vector<Affine> g_(n_), gl_(n_);
+        check(h2_hash_to_curve(CURVE, "Halo2-Parameters", msgs.data(), 5, n_, H2_FORM_MONTGOMERY, g_[0].data()), "h2_hash_to_curve");
+        check(h2_lagrange_basis(CURVE, g_[0].data(), gl_[0].data(), k_, H2_FORM_MONTGOMERY), "h2_lagrange_basis");       // :77-100
+        auto hasher = hash_to_curve<CURVE>("Halo2-Parameters");
+        return Params(k_, std::move(g_), std::move(gl_), hasher({1}), hasher({2}));
+    }
+    // typed commits: the basis of the polynomial selects the generator set at compile time
+    Jacobian commit(const Polynomial<CURVE == H2_PALLAS ? H2_FQ : H2_FP, Coeff> &poly, const Blind<CURVE> &r) const { return run(h_g, poly.values, r); }
+    Jacobian commit_lagrange(const Polynomial<CURVE == H2_PALLAS ? H2_FQ : H2_FP, LagrangeCoeff> &poly, const Blind<CURVE> &r) const {
+        return run(h_gl, poly.values, r);
+    }
+    h2_bases_t handle_g() const { return h_g; }
+    h2_bases_t handle_g_lagrange() const { return h_gl; }
     Params(const Params &) = delete;
     Params &operator=(const Params &) = delete;
 
@@ -256,5 +320,28 @@ template <int CURVE> class Params {
         return out;
     }
 };
+
+// The independent column commits of a prover phase (plonk/prover.rs:93-101, 301-313; vanishing/prover.rs:96-108) spread over the
+// GPUs of one node from one process: column i -> devices[i % ndev], which holds handles[i % ndev] (the same bases registered on
+// each device: h2_init(d), then construct a Params there).  Blocking; one host thread and three streams per device inside.
+template <int CURVE>
+inline std::vector<Jacobian> commit_columns_multi(const std::vector<h2_bases_t> &handles, const std::vector<int> &devices, const std::vector<std::vector<Fe>> &columns,
+                                                  const Affine &w, const std::vector<Blind<CURVE>> &blinds) {
+    if (handles.size() != devices.size() || columns.size() != blinds.size()) throw std::invalid_argument("commit_columns_multi: sizes differ");
+    std::vector<Jacobian> out(columns.size());
+    if (columns.empty()) return out;
+    const size_t n = columns[0].size();
+    std::vector<const uint64_t *> sc, bl;
+    std::vector<uint64_t *> op;
+    for (size_t i = 0; i < columns.size(); i++) {
+        if (columns[i].size() != n) throw std::invalid_argument("commit_columns_multi: ragged columns");
+        sc.push_back(columns[i][0].data());
+        bl.push_back(blinds[i].value.data());
+        op.push_back(out[i].data());
+    }
+    check(h2_commit_batch_multi(handles.data(), devices.data(), (int)devices.size(), sc.data(), columns.size(), n, w.data(), bl.data(),
+                                H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, op.data()), "h2_commit_batch_multi");
+    return out;
+}
 
 }  // namespace halo2

@@ -129,6 +129,66 @@ int main() {
     threw = false;
     try { Params<CURVE>::read(bad_file); } catch (const std::runtime_error &) { threw = true; }
     EXPECT(threw, "Params::read rejects a non-canonical x");
+    // ---- values the REFERENCE pins (halo2_proofs/tests/plonk_api.rs:958-981): Params::new(5) on Vesta -----------------------
+    {
+        Params<CURVE> p5 = Params<CURVE>::new_params(5);
+        // fixed_commitments[0] commits to a never-assigned column with Blind::default() = 1: it is w = hasher(&[1]) (commitment.rs:102-103)
+        const uint64_t wx[4] = {0x17d45c3e6fd92075ULL, 0x82548b6051713660ULL, 0xf24f9a4b0cc18318ULL, 0x2bbc94ef7b22aebeULL};
+        const uint64_t wy[4] = {0xaf559fde4e3abd97ULL, 0xf47a5c8cc4aa7fa0ULL, 0x943bfb759fb02138ULL, 0x082b801a6e176239ULL};
+        uint64_t pinned[8];
+        memcpy(pinned, wx, 32); memcpy(pinned + 4, wy, 32);
+        orc_to_mont(H2_FQ, pinned, 2);
+        EXPECT(memcmp(p5.w.data(), pinned, 64) == 0, "Params::new(5).w == fixed_commitments[0] of tests/plonk_api.rs:959");
+        auto hasher = hash_to_curve<CURVE>("Halo2-Parameters");
+        EXPECT(hasher({1}) == p5.w && hasher({2}) == p5.u && hasher({0, 3, 0, 0, 0}) == p5.g[3], "hash_to_curve closure == Params::new's generators");
+        // the all-zero Lagrange column with blind 1 commits to w through the registered table; and fixed_commitments[5] (sp: row 0 = 1)
+        EvaluationDomain<FIELD> d5(4, 5);
+        Polynomial<FIELD, LagrangeCoeff> zero = d5.lagrange_from_vec(std::vector<Fe>(32, Fe{0, 0, 0, 0}));
+        Blind<CURVE> one{field::one(FIELD)};
+        Jacobian cz = p5.commit_lagrange(zero, one);
+        uint64_t waff[12];
+        memcpy(waff, p5.w.data(), 64); memcpy(waff + 8, field::one(H2_FQ).data(), 32);
+        EXPECT(same_point(CURVE, cz, waff), "commit_lagrange(0, Blind::default()) == w (typed Polynomial<LagrangeCoeff>)");
+        Polynomial<FIELD, LagrangeCoeff> sp = zero;
+        sp[0] = field::one(FIELD);
+        const uint64_t sx[4] = {0xa89736f5c4b5ae9bULL, 0xbddd35e5929a90a4ULL, 0xd3ee48fb8d769da5ULL, 0x224ef42758215157ULL};
+        const uint64_t sy[4] = {0x9a30ad2febb511c1ULL, 0x6d71e996e2165f7aULL, 0xde764f1492ecef95ULL, 0x11bc3a1e08eb320cULL};
+        uint64_t sp_pinned[12];
+        memcpy(sp_pinned, sx, 32); memcpy(sp_pinned + 4, sy, 32);
+        orc_to_mont(H2_FQ, sp_pinned, 2);
+        memcpy(sp_pinned + 8, field::one(H2_FQ).data(), 32);
+        EXPECT(same_point(CURVE, p5.commit_lagrange(sp, one), sp_pinned), "commit_lagrange(sp column) == fixed_commitments[5] of tests/plonk_api.rs:964");
+        // commit(iFFT(a)) == commit_lagrange(a) (commitment.rs:258-302) with the typed API
+        std::vector<Fe> av(32);
+        orc_random_field(FIELD, 41, av[0].data(), 32);
+        Polynomial<FIELD, LagrangeCoeff> al = d5.lagrange_from_vec(av);
+        Polynomial<FIELD, Coeff> ac = d5.lagrange_to_coeff(al);
+        Jacobian c1 = p5.commit(ac, r), c2 = p5.commit_lagrange(al, r);
+        uint64_t c2a[12];
+        memcpy(c2a, c2.data(), 96);
+        EXPECT(same_point(CURVE, c1, c2a), "commit(lagrange_to_coeff(a)) == commit_lagrange(a) over Params::new(5)");
+        // benches/arithmetic.rs:15-33: small_multiexp on the 16 (g_lo, g_hi) pairs
+        bool sm_ok = true;
+        std::vector<Fe> two_c(2);
+        orc_random_field(FIELD, 42, two_c[0].data(), 2);
+        for (int i = 0; i < 16; i++) {
+            std::vector<Affine> pair = {p5.g[i], p5.g[16 + i]};
+            orc_best_multiexp(CURVE, two_c[0].data(), pair[0].data(), 2, want);
+            sm_ok = sm_ok && same_point(CURVE, small_multiexp<CURVE>(two_c, pair), want);
+        }
+        EXPECT(sm_ok, "small_multiexp on the 16 generator pairs of benches/arithmetic.rs == oracle");
+        // the column loop over "two GPUs" (the one device twice: two host threads inside the library)
+        std::vector<std::vector<Fe>> cols(5, std::vector<Fe>(32));
+        std::vector<Blind<CURVE>> bls(5);
+        for (int i = 0; i < 5; i++) { orc_random_field(FIELD, 50 + i, cols[i][0].data(), 32); orc_random_field(FIELD, 60 + i, bls[i].value.data(), 1); }
+        std::vector<Jacobian> multi = commit_columns_multi<CURVE>({p5.handle_g(), p5.handle_g()}, {0, 0}, cols, p5.w, bls);
+        bool multi_ok = true;
+        for (int i = 0; i < 5; i++) {
+            orc_commit(CURVE, p5.g[0].data(), p5.w.data(), cols[i][0].data(), bls[i].value.data(), 32, want);
+            multi_ok = multi_ok && same_point(CURVE, multi[i], want);
+        }
+        EXPECT(multi_ok, "commit_columns_multi over devices {0, 0} == oracle commits");
+    }
     printf(fails ? "HOST MIRROR CHECK FAILED (%d)\n" : "HOST MIRROR CHECK OK\n", fails);
     return fails ? 1 : 0;
 }
