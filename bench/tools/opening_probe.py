@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Inputs for the opening-argument schedule decision: wall time of every round of the k = 20 argument (stamps taken when the round
+draws its two blinds), and, for a table over 2^m points, the registration time and the time of one registered commit alone."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+
+def main():
+    import torch
+    import halo2_amd as h
+    from halo2_amd import fields
+    from halo2_amd.opening import create_proof
+    from halo2_amd.transcript import Blake2bWrite
+    from oracle import c_oracle as co          # input generation only
+    k, curve = int(os.environ.get("K", "20")), 1
+    n = 1 << k
+    sf = fields.CURVE_FIELDS[curve][1]
+    dev = torch.device("cuda:0")
+    g = co.generate_bases(curve, 1, n)
+    w, u = co.generate_bases(curve, 2, 1)[0], co.generate_bases(curve, 3, 1)[0]
+    res = {"k": k}
+    for m in (12, 13, 15, 17):
+        if m > k:
+            continue
+        t0 = time.perf_counter()
+        p = h.Params(curve, m, g[:1 << m], g[:1 << m], w, u)
+        d = torch.from_numpy(co.random_field(sf, 4, 1 << m).view(np.int64)).to(dev)
+        b = h.Blind(co.random_field(sf, 5, 1)[0])
+        p.commit(d, b).cpu()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ts = []
+        for _ in range(20):
+            t2 = time.perf_counter()
+            p.commit(d, b).cpu()
+            ts.append(time.perf_counter() - t2)
+        res[f"table_2^{m}"] = {"register_plus_first_commit_ms": round((t1 - t0) * 1e3, 2), "commit_alone_ms": round(sorted(ts)[10] * 1e3, 4)}
+    params = h.Params(curve, k, g, g, w, u)
+    px = co.random_field(sf, 4, n)
+    d_px = torch.from_numpy(px.view(np.int64)).to(dev)
+    blind = h.Blind(co.random_field(sf, 5, 1)[0])
+    pool = co.random_field(sf, 6, n + 64)
+    stamps = []
+
+    def rng(count):
+        if count == n:
+            return pool[:n]
+        if count == 2:
+            torch.cuda.synchronize()
+            stamps.append(time.perf_counter())
+        return pool[n: n + count]
+    for rep in range(3):
+        stamps.clear()
+        tr = Blake2bWrite(curve)
+        x = co.random_field(sf, 8, 1)[0]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        create_proof(params, rng, tr, d_px, blind, x, schedule=os.environ.get("SCHEDULE") or None)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+    res["total_ms"] = round((t1 - t0) * 1e3, 3)
+    res["before_round0_ms"] = round((stamps[0] - t0) * 1e3, 3)
+    res["round_ms"] = [round((b_ - a_) * 1e3, 3) for a_, b_ in zip(stamps, stamps[1:] + [t1])]
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -86,6 +86,7 @@ class Params:
         self._w_dev = None
         self._h_gu = C.c_uint64(0)        # g || u, registered on the first opening argument (opening.py)
         self._h_pair = C.c_uint64(0)      # g || u || u || w || w for the paired L_j / R_j commits
+        self._h_guw = C.c_uint64(0)       # g || u || w for the two-commit rounds of small arguments
 
     @classmethod
     def new(cls, curve: int, k: int) -> "Params":
@@ -139,7 +140,7 @@ class Params:
             raise ValueError(f"Params registered on cuda:{self.device_index} used with a tensor on {t.device}")
 
     def close(self):
-        for h in (self._h_g, self._h_gl, self._h_gu, self._h_pair):
+        for h in (self._h_g, self._h_gl, self._h_gu, self._h_pair, self._h_guw):
             if h.value:
                 lib().h2_bases_free(h)
                 h.value = 0
@@ -235,16 +236,109 @@ class Params:
         (h2_commit_pair_device): rows i < n belong to output (i >> pair_shift) & 1; rows n, n + 1 are the U scalars of L and R,
         rows n + 2, n + 3 their W scalars.  Returns a (2, 12 | 8) CUDA tensor."""
         import torch
-        if not self._h_pair.value:
-            tail = np.stack([self.u, self.u, self.w, self.w])
-            basis = np.ascontiguousarray(np.concatenate([self.g, tail]))
-            check(lib().h2_bases_register(self.curve, _p(basis), self.n + 4, FORM_MONTGOMERY, C.byref(self._h_pair)), "h2_bases_register")
+        self._opening_basis(True)
         if column.shape[0] != self.n + 4 or not column.is_contiguous():
             raise ValueError("opening_pair_commit: the column must hold n + 4 scalars")
         out = torch.empty((2, 8 if affine else 12), dtype=torch.int64, device=column.device)
         check(lib().h2_commit_pair_device(self._h_pair, column.data_ptr(), self.n + 4, pair_shift, FORM_MONTGOMERY,
                                           OUT_AFFINE if affine else OUT_JACOBIAN, out.data_ptr(), _stream_ptr()), "h2_commit_pair_device")
         return out
+
+    def _opening_basis(self, paired: bool):
+        """The registered basis of the opening argument's commits: g || u || u || w || w (one paired commit per round) or
+        g || u || w (two commits per round; [value z] U and [rand] W ride in the last two rows of each column)."""
+        if paired:
+            if not self._h_pair.value:
+                tail = np.stack([self.u, self.u, self.w, self.w])
+                basis = np.ascontiguousarray(np.concatenate([self.g, tail]))
+                check(lib().h2_bases_register(self.curve, _p(basis), self.n + 4, FORM_MONTGOMERY, C.byref(self._h_pair)), "h2_bases_register")
+            return self._h_pair
+        if not self._h_guw.value:
+            guw = np.ascontiguousarray(np.concatenate([self.g, self.u.reshape(1, 8), self.w.reshape(1, 8)]))
+            check(lib().h2_bases_register(self.curve, _p(guw), self.n + 2, FORM_MONTGOMERY, C.byref(self._h_guw)), "h2_bases_register")
+        return self._h_guw
+
+    def default_hybrid_rounds(self, paired: bool) -> int:
+        """After how many rounds the opening argument moves to the collapsed generators (0 = never): from k = 17 on, down to a
+        table of 2^14 points -- every round before costs a full-size commit, every round after a small one, the switch itself
+        (h2_ipa_collapsed_generators_device + a small table) about three full-size commits."""
+        if not paired or self.k < 17:
+            return 0
+        return min(self.k - 14, 12)
+
+    def opening_rounds(self, d_p, d_b, z, rands, transcript, paired: bool, hybrid_rounds: int | None = None):
+        """The round loop of the opening argument (poly/commitment/prover.rs:104-142) through h2_ipa_rounds_device: d_p (p') and
+        d_b are (n, 4) CUDA tensors folded in place, `rands` the 2k blinds l_0, r_0, l_1, ... ; the transcript's write_point /
+        squeeze_challenge_scalar are called from inside the loop.  Returns (c, f_delta): the final p'[0] and
+        sum_j (l_j / u_j + r_j u_j), both (4,) Montgomery limbs.
+
+        hybrid_rounds = J > 0: the first J rounds run over the original generators, then G'_J is read off the registered table
+        (h2_ipa_collapsed_generators_device), registered as a table of its own, and the remaining k - J rounds run over it."""
+        import torch
+        from ._lib import IPA_SQUEEZE_FN, IPA_WRITE_POINT_FN
+        n, k = self.n, self.k
+        if d_p.shape[0] != n or d_b.shape[0] != n or not d_p.is_contiguous() or not d_b.is_contiguous():
+            raise ValueError("opening_rounds: p' and b must hold n scalars")
+        rands = np.ascontiguousarray(rands, dtype=np.uint64).reshape(2 * k, 4)
+        z = np.ascontiguousarray(z, dtype=np.uint64).reshape(4)
+        dev = d_p.device
+        J = self.default_hybrid_rounds(paired) if hybrid_rounds is None else int(hybrid_rounds)
+        if J < 0 or J >= k or J > 12 or (J and not paired):
+            raise ValueError("opening_rounds: hybrid_rounds must be in [0, min(k - 1, 12)] and needs the paired schedule")
+        failure = []
+
+        def write_point(_user, xy):
+            try:
+                transcript.write_point(np.ctypeslib.as_array(xy, shape=(8,)).copy())
+                return 0
+            except Exception as e:                      # an exception must not unwind through the C frames
+                failure.append(e)
+                return 1
+
+        def squeeze(_user, out):
+            try:
+                np.ctypeslib.as_array(out, shape=(4,))[:] = np.asarray(transcript.squeeze_challenge_scalar(), dtype=np.uint64).reshape(4)
+                return 0
+            except Exception as e:
+                failure.append(e)
+                return 1
+        cb_w, cb_s = IPA_WRITE_POINT_FN(write_point), IPA_SQUEEZE_FN(squeeze)
+        sf = fields.CURVE_FIELDS[self.curve][1]
+
+        def run(kk, rounds, handle, pair, p_t, b_t, rnd, ch_out):
+            nn = 1 << kk
+            col_l = torch.empty((nn + (4 if pair else 2), 4), dtype=torch.int64, device=dev)
+            col_r = None if pair else torch.empty((nn + 2, 4), dtype=torch.int64, device=dev)
+            c = np.zeros(4, dtype=np.uint64)
+            f = np.zeros(4, dtype=np.uint64)
+            rc = lib().h2_ipa_rounds_device(self.curve, kk, rounds, handle, 1 if pair else 0, p_t.data_ptr(), b_t.data_ptr(), _p(z),
+                                            _p(rnd), col_l.data_ptr(), col_r.data_ptr() if col_r is not None else None, cb_w, cb_s,
+                                            None, _p(ch_out) if ch_out is not None else None, _p(c), _p(f), _stream_ptr())
+            if failure:
+                raise failure[0]
+            check(rc, "h2_ipa_rounds_device")
+            return c, f
+        if not J:
+            return run(k, k, self._opening_basis(paired), paired, d_p, d_b, rands, None)
+        ch = np.zeros((J, 4), dtype=np.uint64)
+        _, f1 = run(k, J, self._opening_basis(True), True, d_p, d_b, rands, ch)
+        kj, nj = k - J, 1 << (k - J)
+        pair2 = int(lib().h2_commit_window_bits(nj + 4)) == 16
+        tail = np.stack([self.u, self.u, self.w, self.w]) if pair2 else np.stack([self.u, self.w])
+        d_gj = torch.empty((nj + tail.shape[0], 8), dtype=torch.int64, device=dev)
+        check(lib().h2_ipa_collapsed_generators_device(self._h_pair, k, J, _p(ch), FORM_MONTGOMERY, d_gj.data_ptr(), _stream_ptr()),
+              "h2_ipa_collapsed_generators_device")
+        d_gj[nj:] = torch.from_numpy(np.ascontiguousarray(tail).view(np.int64)).to(dev)
+        torch.cuda.current_stream(dev).synchronize()          # the registration reads the points on the null stream
+        h_j = C.c_uint64(0)
+        check(lib().h2_bases_register_device(self.curve, d_gj.data_ptr(), d_gj.shape[0], FORM_MONTGOMERY, C.byref(h_j)), "h2_bases_register_device")
+        try:
+            c, f2 = run(kj, kj, h_j, pair2, d_p[:nj], d_b[:nj], rands[2 * J:], None)
+        finally:
+            lib().h2_bases_free(h_j)
+        m = fields.MODULUS[sf]
+        f = (fields.from_limbs(f1, sf, True)[0] + fields.from_limbs(f2, sf, True)[0]) % m
+        return c, fields.scalar_limbs(f, sf, True)
 
     def commit_unblinded(self, scalars):
         """sum_i scalars[i] * g[i] with no blind term, Jacobian: the g part of `MSM::eval` (poly/commitment/msm.rs:163-166)."""

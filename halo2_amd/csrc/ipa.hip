@@ -123,10 +123,18 @@ __global__ void __launch_bounds__(256) ipa_round_scalars(const u32 *__restrict__
 struct IpaContext {
     std::mutex mu;
     DevBuf naf, stage, stab;
+    // the round loop (h2_ipa_rounds_device): its own lock (held for the whole argument; the launches it makes take `mu`),
+    // device scratch { <p'_hi, b_lo>, <p'_lo, b_hi>, L_j, R_j } and the pinned landing pad of L_j, R_j
+    std::mutex rounds_mu;
+    DevBuf rounds;
+    void *rounds_host = nullptr;
     void release_all() {
         naf.release();
         stage.release();
         stab.release();
+        rounds.release();
+        if (rounds_host) (void)hipHostFree(rounds_host);
+        rounds_host = nullptr;
     }
 };
 static StreamContexts<IpaContext> g_ipa_ctxs;
@@ -304,6 +312,59 @@ static int round_scalars_launch(int field, const void *d_p, unsigned k, unsigned
     return H2_OK;
 }
 
+// rows n .. of the round's column(s): [<p'_hi, b_lo> z] and [<p'_lo, b_hi> z] (the U scalars of L_j and R_j,
+// prover.rs:109-113) and the two blinds.  One lane; everything Montgomery.
+template <int F>
+__global__ void ipa_round_tails(const u32 *__restrict__ ip, fe z, fe l_rand, fe r_rand, u32 *__restrict__ vl, u32 *__restrict__ vr,
+                                u32 *__restrict__ bl, u32 *__restrict__ br) {
+    if (blockIdx.x || threadIdx.x) return;
+    fe_store(vl, fe_mulx<F>(fe_load(ip), z));
+    fe_store(vr, fe_mulx<F>(fe_load(ip + 8), z));
+    fe_store(bl, l_rand);
+    fe_store(br, r_rand);
+}
+
+static void host_add(int f, u64 r[4], const u64 a[4], const u64 b[4]) {
+    const HostField &F = kHostField[f];
+    u64 t[4];
+    u128 c = 0;
+    for (int i = 0; i < 4; ++i) {
+        c += (u128)a[i] + b[i];
+        t[i] = (u64)c;
+        c >>= 64;
+    }
+    bool ge = true;                       // both below p < 2^255: no carry out of 256 bits
+    for (int i = 3; i >= 0; --i) {
+        if (t[i] > F.p[i]) break;
+        if (t[i] < F.p[i]) { ge = false; break; }
+    }
+    if (ge) {
+        u128 br = 0;
+        for (int i = 0; i < 4; ++i) {
+            u128 d = (u128)t[i] - F.p[i] - (u64)br;
+            t[i] = (u64)d;
+            br = (d >> 64) & 1;
+        }
+    }
+    memcpy(r, t, 32);
+}
+
+// a^(p - 2), Montgomery in and out (a != 0)
+static void host_inv(int f, u64 r[4], const u64 a[4]) {
+    const HostField &F = kHostField[f];
+    u64 e[4] = {F.p[0] - 2, F.p[1], F.p[2], F.p[3]};      // p[0] ends in ...0001: no borrow
+    u64 acc[4], base[4];
+    memcpy(acc, F.one, 32);
+    memcpy(base, a, 32);
+    for (int i = 0; i < 255; ++i) {
+        if ((e[i >> 6] >> (i & 63)) & 1) host_mul(f, acc, acc, base);
+        host_mul(f, base, base, base);
+    }
+    memcpy(r, acc, 32);
+}
+
+static bool host_is_zero(const u64 a[4]) { return !(a[0] | a[1] | a[2] | a[3]); }
+
 }  // namespace h2
 
 using namespace h2;
@@ -386,4 +447,101 @@ extern "C" int h2_ipa_round_scalars_device(int field, const void *d_p, unsigned 
     int rc = ensure_device();
     if (rc != H2_OK) return rc;
     return round_scalars_launch(field, d_p, k, j, challenges, form, d_cl, d_cr, (hipStream_t)stream);
+}
+
+
+// The round loop of `commitment::create_proof` (poly/commitment/prover.rs:104-142) as ONE call: per round the inner products,
+// the L_j / R_j scalars over the original generators, their commit(s), the two points to the transcript, the challenge, and the
+// p' / b folds.  The host is touched once per round (192 bytes of L_j, R_j in Jacobian form land in pinned memory; the
+// normalisation -- one shared inversion -- and the challenge's inverse are microseconds of 64-bit host arithmetic), through
+// the caller's transcript: `write_point` receives the affine point (8 x u64, Montgomery), `squeeze` returns the challenge
+// scalar (4 x u64, Montgomery) -- the two TranscriptWrite methods the reference's loop uses (:121-124).
+extern "C" int h2_ipa_rounds_device(int curve, unsigned k, unsigned rounds, h2_bases_t basis, int paired, void *d_p, void *d_b,
+                                    const uint64_t *z, const uint64_t *rands, void *d_column_l, void *d_column_r,
+                                    h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze, void *user, uint64_t *challenges_out,
+                                    uint64_t *c_out, uint64_t *f_out, void *stream) {
+    if ((curve != H2_PALLAS && curve != H2_VESTA) || k < 1 || k > 30 || rounds < 1 || rounds > k || !d_p || !d_b || !z || !rands ||
+        !d_column_l || !write_point || !squeeze || !c_out || !f_out || (!paired && !d_column_r))
+        return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int sf = curve == H2_PALLAS ? H2_FQ : H2_FP, bf = curve == H2_PALLAS ? H2_FP : H2_FQ;
+    const size_t n = (size_t)1 << k;
+    IpaContext &cx = g_ipa_ctxs.get(st);
+    std::lock_guard<std::mutex> lk(cx.rounds_mu);
+    if ((rc = cx.rounds.reserve(64 + 192)) != H2_OK) return rc;
+    if (!cx.rounds_host) H2_HIP(hipHostMalloc(&cx.rounds_host, 256, hipHostMallocDefault));
+    u32 *d_ip = cx.rounds.as<u32>(), *d_lr = d_ip + 16;
+    u64 *lr = (u64 *)cx.rounds_host;
+    u64 challenges[32 * 4], f_acc[4] = {0, 0, 0, 0};
+    u32 *col_l = (u32 *)d_column_l, *col_r = paired ? col_l : (u32 *)d_column_r;
+    fe zf;
+    memcpy(zf.v, z, 32);
+    for (unsigned j = 0; j < rounds; ++j) {
+        const size_t half = (size_t)1 << (k - j - 1);
+        char *p8 = (char *)d_p, *b8 = (char *)d_b;
+        if ((rc = h2_inner_product_device(sf, p8 + 32 * half, b8, half, H2_FORM_MONTGOMERY, d_ip, st)) != H2_OK) return rc;
+        if ((rc = h2_inner_product_device(sf, p8, b8 + 32 * half, half, H2_FORM_MONTGOMERY, d_ip + 8, st)) != H2_OK) return rc;
+        if ((rc = round_scalars_launch(sf, d_p, k, j, challenges, H2_FORM_MONTGOMERY, col_l, col_r, st)) != H2_OK) return rc;
+        fe lf, rf;
+        memcpy(lf.v, rands + 8 * j, 32);
+        memcpy(rf.v, rands + 8 * j + 4, 32);
+        u32 *vl = col_l + 8 * n, *vr = paired ? col_l + 8 * (n + 1) : col_r + 8 * n;
+        u32 *bl = paired ? col_l + 8 * (n + 2) : col_l + 8 * (n + 1), *br = paired ? col_l + 8 * (n + 3) : col_r + 8 * (n + 1);
+        if (sf == H2_FP) hipLaunchKernelGGL((ipa_round_tails<FP>), dim3(1), dim3(64), 0, st, d_ip, zf, lf, rf, vl, vr, bl, br);
+        else hipLaunchKernelGGL((ipa_round_tails<FQ>), dim3(1), dim3(64), 0, st, d_ip, zf, lf, rf, vl, vr, bl, br);
+        H2_HIP(hipGetLastError());
+        if (paired) {
+            rc = h2_commit_pair_device(basis, col_l, n + 4, k - j - 1, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_lr, st);
+        } else {
+            const void *cols[2] = {col_l, col_r};
+            void *outs[2] = {d_lr, d_lr + 24};
+            rc = h2_commit_batch_device(basis, cols, 2, n + 2, nullptr, nullptr, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, outs, st);
+        }
+        if (rc != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(lr, d_lr, 192, hipMemcpyDeviceToHost, st));
+        H2_HIP(hipStreamSynchronize(st));
+        // .to_affine() of both points with one inversion (prover.rs:116-117), then the transcript (:121-124)
+        const u64 *zl = lr + 8, *zr = lr + 12 + 8;
+        if (host_is_zero(zl) || host_is_zero(zr)) {
+            set_last_error_msg("h2_ipa_rounds_device: L_j or R_j is the point at infinity, which a transcript cannot absorb");
+            return H2_ERR_ARGS;
+        }
+        u64 zz[4], zi[4], zli[4], zri[4];
+        host_mul(bf, zz, zl, zr);
+        host_inv(bf, zi, zz);
+        host_mul(bf, zli, zi, zr);
+        host_mul(bf, zri, zi, zl);
+        for (int s = 0; s < 2; ++s) {
+            const u64 *pt = lr + 12 * s, *inv = s ? zri : zli;
+            u64 i2[4], i3[4], xy[8];
+            host_mul(bf, i2, inv, inv);
+            host_mul(bf, i3, i2, inv);
+            host_mul(bf, xy, pt, i2);
+            host_mul(bf, xy + 4, pt + 4, i3);
+            if ((rc = write_point(user, xy)) != H2_OK) return rc;
+        }
+        u64 *u = challenges + 4 * j, u_inv[4], t[4];
+        if ((rc = squeeze(user, u)) != H2_OK) return rc;
+        if (host_is_zero(u)) {
+            set_last_error_msg("h2_ipa_rounds_device: zero challenge");       // the reference unwraps the inverse (:125)
+            return H2_ERR_ARGS;
+        }
+        host_inv(sf, u_inv, u);
+        if ((rc = fold_launch(sf, d_p, half, u_inv, H2_FORM_MONTGOMERY, st)) != H2_OK) return rc;      // :128-133
+        if ((rc = fold_launch(sf, d_b, half, u, H2_FORM_MONTGOMERY, st)) != H2_OK) return rc;
+        host_mul(sf, t, rands + 8 * j, u_inv);                                                          // :140-141
+        host_add(sf, f_acc, f_acc, t);
+        host_mul(sf, t, rands + 8 * j + 4, u);
+        host_add(sf, f_acc, f_acc, t);
+    }
+    if (rounds == k) {                   // p' has collapsed to the scalar c (:146)
+        H2_HIP(hipMemcpyAsync(lr, d_p, 32, hipMemcpyDeviceToHost, st));
+        H2_HIP(hipStreamSynchronize(st));
+        memcpy(c_out, lr, 32);
+    }
+    if (challenges_out) memcpy(challenges_out, challenges, 32 * (size_t)rounds);
+    memcpy(f_out, f_acc, 32);
+    return H2_OK;
 }

@@ -45,6 +45,7 @@
 #include "curve_wide.cuh"
 #include "curve9.cuh"
 #include "glv.cuh"
+#include "host_field.h"
 
 namespace h2 {
 
@@ -1126,6 +1127,20 @@ __global__ void __launch_bounds__(256) msm_table_chain(const u32 *__restrict__ r
     }
     (void)stride;
 }
+// the same chain with one point per quad of lanes (curve_wide.cuh): small tables are bound by the (W - 1) c sequential doublings
+template <int FB>
+__global__ void __launch_bounds__(256) msm_table_chain_wide(const u32 *__restrict__ row0, u32 *__restrict__ tmp, u32 count,
+                                                            u32 first, int c, int W) {
+    const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+    if (i >= count) return;
+    const affine<FB> p = aff_load<FB>(row0 + 16 * (size_t)(first + i));
+    xyzz<FB> r = xyzz_identity<FB>();
+    xyzz_madd<FB>(r, p);
+    for (int w = 1; w < W; ++w) {
+        for (int k = 0; k < c; ++k) r = xyzz_dbl_wide<FB>(r);
+        if ((threadIdx.x & (kGroup - 1)) == 0) xyzz_store<FB>(tmp + 32 * ((size_t)(w - 1) * count + i), r);
+    }
+}
 // blind base: column `col` of the table must hold the multiples of `w`.  One lane compares w with what row 0
 // already holds; only when it differs does it store w, redo the chain into `tmp` and raise `flag` so that
 // msm_blind_normalise refreshes rows 1..W-1.  Entirely on the stream: no host round trip per commit.
@@ -1184,6 +1199,73 @@ __global__ void __launch_bounds__(256) msm_table_row0_to_m9(u32 *__restrict__ ta
     const affine<FB> a = aff_to_m9<FB>(aff_load<FB>(dst));
     fe_store(dst, a.x);
     fe_store(dst + 8, a.y);
+}
+
+// ---- the collapsed generators of the opening argument, straight from a registered table ------------------------------------
+// After J rounds G'_J[i] = sum_{h < 2^J} s(h) * G[i + h * nJ] (nJ = 2^(k-J); s(h) = the challenge products of
+// h2_ipa_round_scalars_device), i.e. nJ multiexps of 2^J terms that SHARE their scalars.  Each s(h) is cut into the table's
+// 16-bit signed digits d_w and every d_w into four signed 4-bit digits e_v in [-7, 8]:
+//     s(h) G[m] = sum_w sum_v 16^v e_{h,w,v} T[w][m],          T[w][m] = 2^(16w) G[m] (the table's row w)
+// so bucket (v, b) of output i collects +-T[w][i + h nJ] over the (h, w) with |e_{h,w,v}| = b -- the SAME (h, w, sign) list for
+// every i.  The host writes the 32 lists once (2^J * 64 entries in all); lane i of workgroup row (v, b) walks list (v, b) with
+// no divergence and perfectly coalesced 64-byte gathers (consecutive lanes read consecutive table columns), 2^J * 64 mixed
+// additions per output in the carry-free field layer.  ipa_collapse_windows then forms sum_b b * bucket per (i, v) by running
+// sums and ipa_collapse_finish the Horner step over v (12 doublings) and the affine result.
+template <int FB>
+__global__ void __launch_bounds__(256, H2_ACC9_WAVES) ipa_collapse_buckets(const u32 *__restrict__ table, const u32 *__restrict__ list,
+                                                                         const u32 *__restrict__ list_start, u32 nJ, u32 *__restrict__ sums) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x, lb = blockIdx.y;
+    if (i >= nJ) return;
+    const u32 lo = list_start[lb], hi = list_start[lb + 1];
+    xyzz9<FB> acc = xyzz9_identity<FB>();
+    if (lo < hi) {
+        u32 e0 = list[lo], e1 = lo + 1 < hi ? list[lo + 1] : 0;
+        affine<FB> nxt = aff_load<FB>(table + 16 * ((size_t)(e0 & 0x7FFFFFFFu) + i));
+        for (u32 t = lo; t < hi; ++t) {
+            const affine<FB> p = nxt;
+            const u32 neg = e0 >> 31;
+            const u32 e2 = t + 2 < hi ? list[t + 2] : 0;
+            if (t + 1 < hi) nxt = aff_load<FB>(table + 16 * ((size_t)(e1 & 0x7FFFFFFFu) + i));
+            e0 = e1;
+            e1 = e2;
+            if (!aff_is_identity(p)) {
+                aff9<FB> q = aff9_unpack<FB>(p);
+                if (neg) q.y = fe9_sub(fe9_zero(), q.y);
+                xyzz9_madd<FB>(acc, q);
+            }
+        }
+    }
+    xyzz_store<FB>(sums + 32 * ((size_t)lb * nJ + i), xyzz9_is_identity(acc) ? xyzz_identity<FB>() : xyzz9_to_r256<FB>(acc));
+}
+
+// lane (i, v): sums[v * 8][i] <- sum_{b = 1..8} b * sums[v * 8 + b - 1][i]
+template <int FB>
+__global__ void __launch_bounds__(256) ipa_collapse_windows(u32 *__restrict__ sums, u32 nJ) {
+    H2_LATENCY_STAGE();
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 4 * nJ) return;
+    const u32 v = t / nJ, i = t % nJ;
+    xyzz<FB> run = xyzz_identity<FB>(), tot = xyzz_identity<FB>();
+    for (int b = 8; b >= 1; --b) {
+        xyzz_add<FB>(run, xyzz_load<FB>(sums + 32 * ((size_t)(v * 8 + b - 1) * nJ + i)));
+        xyzz_add<FB>(tot, run);
+    }
+    xyzz_store<FB>(sums + 32 * ((size_t)(v * 8) * nJ + i), tot);
+}
+
+template <int FB>
+__global__ void __launch_bounds__(256) ipa_collapse_finish(const u32 *__restrict__ sums, u32 nJ, u32 *__restrict__ out_xy) {
+    H2_LATENCY_STAGE();
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nJ) return;
+    xyzz<FB> acc = xyzz_load<FB>(sums + 32 * ((size_t)24 * nJ + i));
+    for (int v = 2; v >= 0; --v) {
+        for (int d = 0; d < 4; ++d) acc = xyzz_dbl<FB>(acc);
+        xyzz_add<FB>(acc, xyzz_load<FB>(sums + 32 * ((size_t)(v * 8) * nJ + i)));
+    }
+    const affine<FB> a = xyzz_to_affine<FB>(acc);
+    fe_store(out_xy + 16 * (size_t)i, a.x);
+    fe_store(out_xy + 16 * (size_t)i + 8, a.y);
 }
 
 // ---- small helpers -----------------------------------------------------------------------------
@@ -1258,10 +1340,10 @@ static bool timeline_on() {
 struct MsmContext {
     std::mutex mu;
     DevBuf digits, hist, counts, starts, bsums, entries, heads, heavy, hscratch, buckets, partial, ssums, stage_s, stage_b,
-        out, small, tagged, plan, seg9, bases9;
+        out, small, tagged, plan, seg9, bases9, collapse, collapse_list;
     void release_all() {
         for (DevBuf *b : {&digits, &hist, &counts, &starts, &bsums, &entries, &heads, &heavy, &hscratch, &buckets, &partial, &ssums,
-                          &stage_s, &stage_b, &out, &small, &tagged, &plan, &seg9, &bases9})
+                          &stage_s, &stage_b, &out, &small, &tagged, &plan, &seg9, &bases9, &collapse, &collapse_list})
             b->release();
     }
     bool attr_set = false, attr2_set = false;
@@ -1707,11 +1789,15 @@ static int table_fill(Bases &b, u32 first, u32 count, hipStream_t st) {
         dim3 g1((cnt + 255) / 256), blk(256);
         size_t tot = (size_t)cnt * (b.W - 1);
         dim3 g2((unsigned)((tot + 255) / 256));
+        const bool wide = count <= 65536;           // few points: the doubling chain is pure latency
+        dim3 g1w((cnt * kGroup + 255) / 256);
         if (b.curve == H2_PALLAS) {
-            hipLaunchKernelGGL((msm_table_chain<FP>), g1, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.stride, b.c, b.W);
+            if (wide) hipLaunchKernelGGL((msm_table_chain_wide<FP>), g1w, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.c, b.W);
+            else hipLaunchKernelGGL((msm_table_chain<FP>), g1, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.stride, b.c, b.W);
             hipLaunchKernelGGL((msm_table_normalise<FP>), g2, blk, 0, st, (const u32 *)tmp, (u32 *)b.d_table, cnt, first + off, b.stride, b.W);
         } else {
-            hipLaunchKernelGGL((msm_table_chain<FQ>), g1, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.stride, b.c, b.W);
+            if (wide) hipLaunchKernelGGL((msm_table_chain_wide<FQ>), g1w, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.c, b.W);
+            else hipLaunchKernelGGL((msm_table_chain<FQ>), g1, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.stride, b.c, b.W);
             hipLaunchKernelGGL((msm_table_normalise<FQ>), g2, blk, 0, st, (const u32 *)tmp, (u32 *)b.d_table, cnt, first + off, b.stride, b.W);
         }
     }
@@ -1836,7 +1922,7 @@ extern "C" int h2_msm(int curve, const uint64_t *scalars, const uint64_t *bases_
     return H2_OK;
 }
 
-extern "C" int h2_bases_register(int curve, const uint64_t *bases_xy, size_t n, int form, h2_bases_t *handle) {
+static int bases_register_impl(int curve, const void *bases_xy, bool on_device, size_t n, int form, h2_bases_t *handle) {
     if ((curve != H2_PALLAS && curve != H2_VESTA) || (form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY) ||
         !handle || (n && !bases_xy) || n > (1u << 26))
         return H2_ERR_ARGS;
@@ -1854,7 +1940,7 @@ extern "C" int h2_bases_register(int curve, const uint64_t *bases_xy, size_t n, 
     H2_HIP(hipMalloc(&b->d_blind_tmp, (size_t)b->W * 128 + 64));
     H2_HIP(hipMemsetAsync(b->d_blind_tmp, 0, (size_t)b->W * 128 + 64, 0));
     if (n) {
-        H2_HIP(hipMemcpyAsync(b->d_table, bases_xy, n * 64, hipMemcpyHostToDevice, 0));
+        H2_HIP(hipMemcpyAsync(b->d_table, bases_xy, n * 64, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, 0));
         if (form == H2_FORM_CANONICAL) to_mont_async(curve, (u32 *)b->d_table, n * 2, 0);
         if ((rc = table_fill(*b, 0, (u32)n, 0)) != H2_OK) return rc;   // ~Bases releases the allocations
     }
@@ -1863,6 +1949,92 @@ extern "C" int h2_bases_register(int curve, const uint64_t *bases_xy, size_t n, 
     h2_bases_t h = g_next_handle++;
     g_bases[h] = b;
     *handle = h;
+    return H2_OK;
+}
+
+extern "C" int h2_bases_register(int curve, const uint64_t *bases_xy, size_t n, int form, h2_bases_t *handle) {
+    return bases_register_impl(curve, bases_xy, false, n, form, handle);
+}
+
+// the same from points already in HBM (work queued on other streams that produces them must have completed: the copy runs on
+// the null stream).  What the opening argument registers its collapsed generators with (h2_ipa_collapsed_generators_device).
+extern "C" int h2_bases_register_device(int curve, const void *d_bases_xy, size_t n, int form, h2_bases_t *handle) {
+    return bases_register_impl(curve, d_bases_xy, true, n, form, handle);
+}
+
+extern "C" int h2_ipa_collapsed_generators_device(h2_bases_t basis, unsigned k, unsigned rounds, const uint64_t *challenges, int form,
+                                                  void *d_out_xy, void *stream) {
+    auto b = find_bases(basis);
+    if (!b) return H2_ERR_HANDLE;
+    if ((form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY) || !challenges || !d_out_xy || k < 1 || k > 26 || rounds < 1 ||
+        rounds > k || rounds > 12 || b->n < ((size_t)1 << k) || b->c != 16 || b->W != 16)
+        return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int sf = b->curve == H2_PALLAS ? H2_FQ : H2_FP;
+    const u32 J = rounds, nJ = 1u << (k - J);
+    u64 um[12 * 4];
+    for (u32 r = 0; r < J; ++r) host_to_mont(sf, um + 4 * r, challenges + 4 * r, form);
+    std::vector<u32> lists[32];
+    for (u32 h = 0; h < (1u << J); ++h) {
+        u64 s[4], canon[4];
+        memcpy(s, kHostField[sf].one, 32);
+        for (u32 r = 0; r < J; ++r)
+            if ((h >> (J - 1 - r)) & 1) host_mul(sf, s, s, um + 4 * r);          // the products of ipa_s_table
+        host_from_mont(sf, canon, s);
+        u32 carry = 0;
+        for (u32 w = 0; w < 16; ++w) {
+            u32 raw = (u32)((canon[w >> 2] >> (16 * (w & 3))) & 0xFFFFu) + carry;   // signed 16-bit digits, as msm_recode cuts them
+            const bool neg = raw > 0x8000u;
+            carry = neg ? 1 : 0;
+            u32 mag = neg ? 0x10000u - raw : raw;                                 // |d| <= 2^15
+            const u32 off = w * b->stride + h * nJ;
+            u32 c4 = 0;
+            for (u32 v = 0; v < 4; ++v) {                                         // |d| = sum_v 16^v e_v, e_v in [-7, 8]
+                u32 e = ((mag >> (4 * v)) & 15u) + c4;
+                bool eneg = false;
+                c4 = 0;
+                if (e > 8) {
+                    e = 16 - e;
+                    eneg = true;
+                    c4 = 1;
+                }
+                if (e) lists[v * 8 + e - 1].push_back(off | ((neg != eneg) ? 0x80000000u : 0u));
+            }
+            // c4 is 0 here: the top nibble of |d| <= 0x8000 is at most 8 with its carry
+        }
+        // carry is 0 here: the scalar is below 2^255, so the top digit takes it
+    }
+    std::vector<u32> flat, start(33, 0);
+    for (int l = 0; l < 32; ++l) {
+        start[l] = (u32)flat.size();
+        flat.insert(flat.end(), lists[l].begin(), lists[l].end());
+    }
+    start[32] = (u32)flat.size();
+    if (flat.empty()) flat.push_back(0);
+    MsmContext &cx = msm_ctx(st);
+    std::lock_guard<std::mutex> lk(cx.mu);
+    if ((rc = cx.collapse.reserve((size_t)32 * nJ * 128)) != H2_OK) return rc;
+    if ((rc = cx.collapse_list.reserve(33 * 4 + flat.size() * 4)) != H2_OK) return rc;
+    u32 *d_start = cx.collapse_list.as<u32>(), *d_list = d_start + 33;
+    // pageable sources: consumed when hipMemcpyAsync returns; stream-ordered after the previous call's kernels
+    H2_HIP(hipMemcpyAsync(d_start, start.data(), 33 * 4, hipMemcpyHostToDevice, st));
+    H2_HIP(hipMemcpyAsync(d_list, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, st));
+    {   // the table's columns must be complete (a registration runs on the null stream and synchronises; nothing to wait for)
+        dim3 blk(256), g1((nJ + 255) / 256, 32), g2((4 * nJ + 255) / 256), g3((nJ + 255) / 256);
+        u32 *sums = cx.collapse.as<u32>();
+        if (b->curve == H2_PALLAS) {
+            hipLaunchKernelGGL((ipa_collapse_buckets<FP>), g1, blk, 0, st, (const u32 *)b->d_table, d_list, d_start, nJ, sums);
+            hipLaunchKernelGGL((ipa_collapse_windows<FP>), g2, blk, 0, st, sums, nJ);
+            hipLaunchKernelGGL((ipa_collapse_finish<FP>), g3, blk, 0, st, (const u32 *)sums, nJ, (u32 *)d_out_xy);
+        } else {
+            hipLaunchKernelGGL((ipa_collapse_buckets<FQ>), g1, blk, 0, st, (const u32 *)b->d_table, d_list, d_start, nJ, sums);
+            hipLaunchKernelGGL((ipa_collapse_windows<FQ>), g2, blk, 0, st, sums, nJ);
+            hipLaunchKernelGGL((ipa_collapse_finish<FQ>), g3, blk, 0, st, (const u32 *)sums, nJ, (u32 *)d_out_xy);
+        }
+    }
+    H2_HIP(hipGetLastError());
     return H2_OK;
 }
 

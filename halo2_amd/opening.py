@@ -31,7 +31,8 @@ def _host(t) -> np.ndarray:
     return t.cpu().numpy().view(np.uint64)
 
 
-def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, device=None, schedule: str | None = None) -> None:
+def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, device=None, schedule: str | None = None,
+                 hybrid_rounds: int | None = None) -> None:
     """Writes the opening proof of `p_poly` at `x_3` to `transcript`.
 
     rng(count) -> (count, 4) uniformly random scalars, Montgomery limbs (the reference draws `C::Scalar::random`
@@ -74,19 +75,15 @@ def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, d
         raise ValueError("create_proof: schedule must be 'paired', 'original' or 'collapse'")
     if schedule == "paired" and (n < 8192 or not params.pair_commit_supported()):
         schedule = "original"          # small tables use narrower windows, which the paired sort does not take
-    paired = schedule == "paired"
-    original = schedule == "original"
-    if paired:
-        d_c = torch.zeros((n + 4, 4), dtype=torch.int64, device=dev)                      # L_j and R_j scalars, one column
-        challenges = []
-    elif original:
-        d_cl = torch.zeros((n + 1, 4), dtype=torch.int64, device=dev)                     # L_j / R_j scalars over g || u
-        d_cr = torch.zeros((n + 1, 4), dtype=torch.int64, device=dev)
-        challenges = []
-    else:
-        d_g = to_dev(params.g)                                                            # G' (prover.rs:101)
-        d_uw = to_dev(np.stack([params.u, params.w]))
-
+    if schedule != "collapse":
+        # the round loop as one C-ABI call (h2_ipa_rounds_device): the host sees L_j, R_j once per round and answers with the challenge
+        rands = np.ascontiguousarray(np.concatenate([np.asarray(rng(2), dtype=np.uint64).reshape(2, 4) for _ in range(k)]))
+        c, f_delta = params.opening_rounds(d_pp, d_b, z, rands, transcript, paired=schedule == "paired", hybrid_rounds=hybrid_rounds)
+        transcript.write_scalar(c)                                                        # prover.rs:146-148
+        transcript.write_scalar(as_limbs(f + as_int(f_delta)))
+        return
+    d_g = to_dev(params.g)                                                                # G' (prover.rs:101)
+    d_uw = to_dev(np.stack([params.u, params.w]))
     for j in range(k):                                                                    # prover.rs:104-142
         half = 1 << (k - j - 1)
         lo_p, hi_p = d_pp[:half], d_pp[half:2 * half]
@@ -95,22 +92,11 @@ def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, d
         value_l, value_r = as_int(values[0]), as_int(values[1])
         l_rand, r_rand = rng(2)
         # L_j = <p'_hi, G'_lo> + [value_l z] U + [l_rand] W as ONE multiexp (the reference's TODO, :108-110)
-        if paired:
-            ipa_round_scalars(d_pp[:2 * half], k, j, challenges, sf, d_c, d_c)
-            d_c[n:] = to_dev(np.stack([as_limbs(value_l * z_i), as_limbs(value_r * z_i), l_rand, r_rand]))
-            lr = _host(params.opening_pair_commit(d_c, k - j - 1))
-        elif original:
-            ipa_round_scalars(d_pp[:2 * half], k, j, challenges, sf, d_cl, d_cr)
-            tails = to_dev(np.stack([as_limbs(value_l * z_i), as_limbs(value_r * z_i)]))
-            d_cl[n] = tails[0]
-            d_cr[n] = tails[1]
-            lr = _host(params.opening_columns_commit([d_cl, d_cr], [l_rand, r_rand], affine=False))
-        else:
-            tail_l = to_dev(np.stack([as_limbs(value_l * z_i), l_rand]))
-            tail_r = to_dev(np.stack([as_limbs(value_r * z_i), r_rand]))
-            lr = _host(best_multiexp_batch([(torch.cat([hi_p, tail_l]), torch.cat([d_g[:half], d_uw])),
-                                            (torch.cat([lo_p, tail_r]), torch.cat([d_g[half:2 * half], d_uw]))],
-                                           curve, FORM_MONTGOMERY, affine=False))
+        tail_l = to_dev(np.stack([as_limbs(value_l * z_i), l_rand]))
+        tail_r = to_dev(np.stack([as_limbs(value_r * z_i), r_rand]))
+        lr = _host(best_multiexp_batch([(torch.cat([hi_p, tail_l]), torch.cat([d_g[:half], d_uw])),
+                                        (torch.cat([lo_p, tail_r]), torch.cat([d_g[half:2 * half], d_uw]))],
+                                       curve, FORM_MONTGOMERY, affine=False))
         transcript.write_point(lr[0])                                                     # prover.rs:121-122
         transcript.write_point(lr[1])
         u_j = transcript.squeeze_challenge_scalar()                                       # prover.rs:124
@@ -118,10 +104,7 @@ def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, d
         u_inv_i = pow(u_i, -1, m)                                                         # prover.rs:125
         d_pp = fold_scalars(d_pp[:2 * half], as_limbs(u_inv_i), sf)                       # prover.rs:128-133
         d_b = fold_scalars(d_b[:2 * half], u_j, sf)
-        if original or paired:
-            challenges.append(np.ascontiguousarray(u_j, dtype=np.uint64).reshape(4))
-        else:
-            d_g = parallel_generator_collapse(d_g[:2 * half], u_j, curve)                 # prover.rs:136-137
+        d_g = parallel_generator_collapse(d_g[:2 * half], u_j, curve)                     # prover.rs:136-137
         f = (f + as_int(l_rand) * u_inv_i + as_int(r_rand) * u_i) % m                     # prover.rs:140-141
 
     transcript.write_scalar(_host(d_pp[0]))                                               # c  (prover.rs:146-148)

@@ -85,6 +85,8 @@ int h2_msm(int curve, const uint64_t *scalars, const uint64_t *bases_xy, size_t 
 /* Params::{new,read} keep `g` / `g_lagrange` for the life of the Params (poly/commitment.rs:26-33):
  * register them once, commit many times. */
 int h2_bases_register(int curve, const uint64_t *bases_xy, size_t n, int form, h2_bases_t *handle);
+/* the same from `n` affine points already in device memory (work that produces them must have completed) */
+int h2_bases_register_device(int curve, const void *d_bases_xy, size_t n, int form, h2_bases_t *handle);
 int h2_bases_free(h2_bases_t handle);
 
 /* replaces Params::commit / commit_lagrange (halo2_proofs/src/poly/commitment.rs:119-150):
@@ -228,6 +230,40 @@ int h2_fold_scalars_device(int field, void *d_a, size_t half, const uint64_t *fa
  * d_cl, d_cr: 2^k elements each, in the form of d_p.  1 <= k <= 30, j < k. */
 int h2_ipa_round_scalars_device(int field, const void *d_p, unsigned k, unsigned j, const uint64_t *challenges, int form,
                                 void *d_cl, void *d_cr, void *stream);
+/* The whole round loop of commitment::create_proof (prover.rs:104-142) in one call, p' and b resident: per round the two inner
+ * products (:109-110), the L_j / R_j scalars over the original generators (above), their commit, the two points to the
+ * transcript (:121-122), the challenge and its inverse (:124-125), the p' / b folds (:128-133) and the blind bookkeeping
+ * (:140-141).  The host is visited once per round -- L_j and R_j (192 bytes) land in pinned memory, are normalised with one
+ * shared inversion and handed to the caller's transcript through the two TranscriptWrite methods the loop uses:
+ *     write_point(user, xy)  the affine point, 8 x u64 Montgomery; returns H2_OK or an error the call passes on
+ *     squeeze(user, out)     the next challenge scalar, 4 x u64 Montgomery, into out
+ * Everything here is Montgomery form (the working form of resident vectors).
+ *   paired != 0: `basis` is a registered g || u || u || w || w (2^k + 4 points, 16-bit windows: h2_commit_window_bits) and each
+ *                round is ONE h2_commit_pair_device over d_column_l (2^k + 4 scalars of scratch); d_column_r unused
+ *   paired == 0: `basis` is a registered g || u || w (2^k + 2 points), each round two commits (h2_commit_batch_device) over
+ *                d_column_l / d_column_r (2^k + 2 scalars of scratch each): any table size
+ * d_p: p' (2^k scalars, folded in place; c_out receives the final p'[0]);  d_b: b, likewise;  z: the challenge of :66;
+ * rands: l_0, r_0, l_1, r_1, ... (2k scalars, the order the reference draws them, :111-112);
+ * f_out: sum_j (l_j u_j^-1 + r_j u_j), the amount the synthetic blinding factor grows by (:140-141).
+ * rounds: how many rounds to run (1 .. k); with rounds < k the call stops there -- p' and b hold 2^(k-rounds) live entries,
+ *         challenges_out (if not NULL) the challenges drawn, c_out is not written -- and the caller continues with another call
+ *         over the collapsed generators (h2_ipa_collapsed_generators_device) as a k - rounds argument.
+ * Returns H2_ERR_ARGS if an L_j / R_j is the point at infinity or a challenge is zero (the reference errors / panics). */
+typedef int (*h2_ipa_write_point_fn)(void *user, const uint64_t *xy);
+typedef int (*h2_ipa_squeeze_fn)(void *user, uint64_t *challenge);
+int h2_ipa_rounds_device(int curve, unsigned k, unsigned rounds, h2_bases_t basis, int paired, void *d_p, void *d_b,
+                         const uint64_t *z, const uint64_t *rands, void *d_column_l, void *d_column_r,
+                         h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze, void *user, uint64_t *challenges_out,
+                         uint64_t *c_out, uint64_t *f_out, void *stream);
+/* The generators after `rounds` collapses, without collapsing: G'[i] = sum_{h < 2^rounds} s(h) * G[i + h * 2^(k-rounds)] for
+ * i < 2^(k-rounds), s(h) the challenge products of h2_ipa_round_scalars_device, read off the registered table of `basis` (its
+ * first 2^k points are G; the table must use 16-bit windows, h2_commit_window_bits) as 2^(k-rounds) multiexps that share their
+ * scalars: 64 * 2^k mixed additions in all, no sort.  With h2_bases_register_device this lets the
+ * opening argument switch to a 2^rounds times smaller table after its first rounds: L_j / R_j written over the ORIGINAL generators
+ * cost a full-size commit in every round, over G' a commit of 2^(k-rounds) points.
+ * challenges: u_0 .. u_{rounds-1} in `form` (host); d_out_xy: 2^(k-rounds) affine points, Montgomery form.  rounds <= 12. */
+int h2_ipa_collapsed_generators_device(h2_bases_t basis, unsigned k, unsigned rounds, const uint64_t *challenges, int form,
+                                       void *d_out_xy, void *stream);
 
 /* ---- Params set-up: Lagrange basis by an FFT over curve points -------------------------------- */
 /* replaces the point FFT + 2^-k scaling + batch_normalize of Params::new

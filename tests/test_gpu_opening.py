@@ -152,20 +152,106 @@ def test_opening_proof_full_size_schedules_agree_and_verify():
     blind = h.Blind(co.random_field(sf, 70, 1)[0])
     p = params.commit(px, blind, affine=True)
     proofs = []
-    for schedule in ("original", "collapse", "paired"):
+    assert params.default_hybrid_rounds(True) == 6
+    # "paired" alone moves to the collapsed generators after 6 rounds (the default); 0 keeps every round on the original ones
+    for schedule, hybrid in (("original", None), ("collapse", None), ("paired", 0), ("paired", None), ("paired", 9)):
         tr = Blake2bWrite(curve)
         tr.write_point(p)
         x = tr.squeeze_challenge_scalar()
         v = h.eval_polynomial(px, x, sf)
         tr.write_scalar(v)
-        create_proof(params, _rng(sf, 2000), tr, px, blind, x, schedule=schedule)
+        create_proof(params, _rng(sf, 2000), tr, px, blind, x, schedule=schedule, hybrid_rounds=hybrid)
         proofs.append(tr.finalize())
-    assert proofs[0] == proofs[1] == proofs[2] and len(proofs[0]) == 32 + 32 + 32 + 64 * k + 64
+    assert all(pr == proofs[0] for pr in proofs) and len(proofs[0]) == 32 + 32 + 32 + 64 * k + 64
     p_int = co.affine_to_ints(curve, p)
     vt = ipa.Transcript(curve, proofs[0])
     assert vt.read_point() == p_int
     ox = vt.squeeze_challenge()
     ov = vt.read_scalar()
     assert ox == fields.from_limbs(x, sf, True)[0] and ov == fields.from_limbs(v, sf, True)[0]
+    assert ipa.verify_proof(curve, k, g, w, u, vt, p_int, ox, ov)
+    params.close()
+
+
+@pytest.mark.parametrize("curve,k,rounds", [(h.PALLAS, 16, 1), (h.VESTA, 16, 3), (h.PALLAS, 16, 6), (h.VESTA, 17, 12)])
+def test_collapsed_generators_against_definition(curve, k, rounds):
+    """h2_ipa_collapsed_generators_device: G'[i] = sum_h s(h) G[i + h 2^(k - rounds)] with s(h) the product of the challenges
+    picked by the bits of h (bit rounds-1-r <-> u_r), checked at sampled i against the oracle's multiexp; and a table registered
+    from the device copy (h2_bases_register_device) commits like one registered from the host."""
+    import ctypes as C
+    import torch
+    from halo2_amd._lib import FORM_MONTGOMERY, check, lib
+    n, nj = 1 << k, 1 << (k - rounds)
+    sf = fields.CURVE_FIELDS[curve][1]
+    m_ = fields.MODULUS[sf]
+    g = co.generate_bases(curve, 93, n)
+    w, u = co.generate_bases(curve, 60, 1)[0], co.generate_bases(curve, 61, 1)[0]
+    params = h.Params(curve, k, g, g, w, u)
+    assert params.pair_commit_supported()
+    handle = params._opening_basis(True)
+    ch = co.random_field(sf, 94, rounds)
+    if rounds >= 3:
+        ch[1] = fields.scalar_limbs(m_ - 1, sf, True)              # every 16-bit digit at its extreme
+        ch[2] = fields.scalar_limbs(0x8000800080008000, sf, True)
+    u_i = fields.from_limbs(ch, sf, True)
+    d_out = torch.empty((nj, 8), dtype=torch.int64, device="cuda:0")
+    check(lib().h2_ipa_collapsed_generators_device(handle, k, rounds, ch.ctypes.data_as(C.POINTER(C.c_uint64)), FORM_MONTGOMERY,
+                                                   d_out.data_ptr(), None), "h2_ipa_collapsed_generators_device")
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(np.uint64)
+    s_ = []
+    for hh in range(1 << rounds):
+        v = 1
+        for r in range(rounds):
+            if (hh >> (rounds - 1 - r)) & 1:
+                v = v * u_i[r] % m_
+        s_.append(v)
+    s_l = fields.to_limbs(s_, sf, True)
+    for i in sorted({0, 1, nj - 1, nj // 2, (12345 * 7) % nj}):
+        pts = np.ascontiguousarray(g[i::nj])
+        assert pts.shape[0] == 1 << rounds
+        want = co.jac_to_affine_ints(curve, co.best_multiexp(curve, s_l, pts))
+        assert co.affine_to_ints(curve, got[i]) == want, i
+    # registration from device memory
+    hj = C.c_uint64(0)
+    check(lib().h2_bases_register_device(curve, d_out.data_ptr(), nj, FORM_MONTGOMERY, C.byref(hj)), "h2_bases_register_device")
+    col = co.random_field(sf, 95, nj)
+    d_col = torch.from_numpy(col.view(np.int64)).cuda()
+    out = torch.empty(8, dtype=torch.int64, device="cuda:0")
+    check(lib().h2_commit_device(hj, d_col.data_ptr(), nj, None, None, FORM_MONTGOMERY, 1, out.data_ptr(), None), "h2_commit_device")
+    torch.cuda.synchronize()
+    want = co.jac_to_affine_ints(curve, co.best_multiexp(curve, col, np.ascontiguousarray(got)))
+    assert co.affine_to_ints(curve, out.cpu().numpy().view(np.uint64)) == want
+    lib().h2_bases_free(hj)
+    params.close()
+
+
+@pytest.mark.parametrize("curve,k,hybrid", [(h.VESTA, 16, 1), (h.PALLAS, 16, 3), (h.VESTA, 16, 9), (h.PALLAS, 17, None)])
+def test_opening_hybrid_schedule_same_bytes(curve, k, hybrid):
+    """The opening argument that moves to the collapsed generators after `hybrid` rounds writes the bytes of the one that stays on
+    the original generators, and the restated verifier accepts them."""
+    n = 1 << k
+    sf = fields.CURVE_FIELDS[curve][1]
+    g = co.generate_bases(curve, 96, n)
+    w, u = co.generate_bases(curve, 60, 1)[0], co.generate_bases(curve, 61, 1)[0]
+    params = h.Params(curve, k, g, g, w, u)
+    px = co.random_field(sf, 97, n)
+    blind = h.Blind(co.random_field(sf, 70, 1)[0])
+    p = params.commit(px, blind, affine=True)
+    proofs = []
+    for schedule, hy in (("original", None), ("paired", hybrid)):
+        tr = Blake2bWrite(curve)
+        tr.write_point(p)
+        x = tr.squeeze_challenge_scalar()
+        v = h.eval_polynomial(px, x, sf)
+        tr.write_scalar(v)
+        create_proof(params, _rng(sf, 3000), tr, px, blind, x, schedule=schedule, hybrid_rounds=hy)
+        proofs.append(tr.finalize())
+    assert proofs[0] == proofs[1]
+    p_int = co.affine_to_ints(curve, p)
+    vt = ipa.Transcript(curve, proofs[1])
+    assert vt.read_point() == p_int
+    ox = vt.squeeze_challenge()
+    ov = vt.read_scalar()
     assert ipa.verify_proof(curve, k, g, w, u, vt, p_int, ox, ov)
     params.close()
