@@ -99,6 +99,7 @@ SIGNATURES = {
     "h2_hash_to_curve": ([C.c_int, C.c_char_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p], C.c_int),
     "h2_hash_to_curve_device": ([C.c_int, C.c_char_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p], C.c_int),
     "h2_commit_window_bits": ([C.c_size_t], C.c_int),
+    "h2_commit_pair_supported": ([C.c_size_t], C.c_int),
     "h2_commit_pair_device": ([C.c_uint64, C.c_void_p, C.c_size_t, C.c_uint, C.c_int, C.c_int, C.c_void_p, C.c_void_p], C.c_int),
     "h2_profile_read": ([C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),
     "h2_profile_read_busy": ([C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),

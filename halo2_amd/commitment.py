@@ -227,9 +227,9 @@ class Params:
         return out
 
     def pair_commit_supported(self) -> bool:
-        """h2_commit_pair_device needs the registered table of n + 4 points to use 16-bit windows (n >= 2^16 or so)."""
-        from .arithmetic import msm_window_bits
-        return self.n >= 8192 and int(lib().h2_commit_window_bits(self.n + 4)) == 16
+        """Whether L_j and R_j of a round can share one commit (h2_commit_pair_device over g || u || u || w || w): tables from
+        8192 points on."""
+        return bool(lib().h2_commit_pair_supported(self.n + 4))
 
     def opening_pair_commit(self, column, pair_shift: int, affine: bool = False):
         """L_j and R_j of an opening-argument round from ONE (n + 4)-row CUDA column over g || u || u || w || w
@@ -323,7 +323,7 @@ class Params:
         ch = np.zeros((J, 4), dtype=np.uint64)
         _, f1 = run(k, J, self._opening_basis(True), True, d_p, d_b, rands, ch)
         kj, nj = k - J, 1 << (k - J)
-        pair2 = int(lib().h2_commit_window_bits(nj + 4)) == 16
+        pair2 = bool(lib().h2_commit_pair_supported(nj + 4))
         tail = np.stack([self.u, self.u, self.w, self.w]) if pair2 else np.stack([self.u, self.w])
         d_gj = torch.empty((nj + tail.shape[0], 8), dtype=torch.int64, device=dev)
         check(lib().h2_ipa_collapsed_generators_device(self._h_pair, k, J, _p(ch), FORM_MONTGOMERY, d_gj.data_ptr(), _stream_ptr()),

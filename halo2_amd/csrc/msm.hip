@@ -74,6 +74,31 @@ static bool sort2_geometry(u32 stride, int c, int *lowb_out, int *lb_out) {
     *lb_out = lb;
     return true;
 }
+// The paired commit (h2_commit_pair_device): two bucket slices, key = side * NB + bucket.  Pass 1 stages s1 scalars' digits per
+// workgroup in LDS: 2048 for 16 windows, 1024 when narrower windows (smaller tables: more digits per scalar) would not fit.
+static bool pair_geometry(size_t m, int c, u32 stride, int *lowb_out, int *lb_out, u32 *nh_out, u32 *s1_out) {
+    if (c > kMaxC || c < 2 || m < 8192) return false;
+    const int W = 255 / c + 1;
+    const u32 tb = 2u << (c - 1);
+    const uint64_t top = (uint64_t)W * stride - 1;
+    if (top >= ((uint64_t)1 << 31)) return false;
+    int lb = 0, kb = 0;
+    while ((top >> lb) != 0) ++lb;
+    while (((u64)(tb - 1) >> kb) != 0) ++kb;
+    const int lowb = std::min(31 - lb, std::max(1, kb - 9));
+    if (lowb < 1) return false;
+    const u32 nh = (tb + (1u << lowb) - 1) >> lowb;
+    if (nh > 4096) return false;
+    u32 s1 = kS1Scalars;
+    while (s1 >= 1024 && ((size_t)nh * 3 + 1 + (size_t)s1 * W) * 4 > kLdsCap) s1 /= 2;
+    if (s1 < 1024) return false;
+    *lowb_out = lowb;
+    *lb_out = lb;
+    *nh_out = nh;
+    *s1_out = s1;
+    return true;
+}
+
 static constexpr int kSeg = 8;     // buckets per reduce segment
 static constexpr u32 kScanBlock = 1024;
 
@@ -1449,21 +1474,16 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     bool use_sort2 = false;
     if (pair) {
         // key = side * NB + bucket over both slices (the generic path's multi-slice geometry), entry = table index
-        int lb = 0, kb = 0;
-        const uint64_t top = (uint64_t)sh.W * a.stride - 1;
-        while ((top >> lb) != 0) ++lb;
-        while (((u64)(tb - 1) >> kb) != 0) ++kb;
-        const int lowb = std::min(31 - lb, std::max(1, kb - 9));
-        const u32 nh = lowb >= 1 ? (tb + (1u << lowb) - 1) >> lowb : 0;
-        const bool fits = ((size_t)nh * 3 + 1 + (size_t)kS1Scalars * sh.W) * 4 <= kLdsCap;
-        if (top >= ((uint64_t)1 << 31) || sh.c > kMaxC || lowb < 1 || nh > 4096 || !fits || m < 8192) return H2_ERR_ARGS;
+        int lb = 0, lowb = 0;
+        u32 nh = 0, s1 = 0;
+        if (!pair_geometry(m, sh.c, a.stride, &lowb, &lb, &nh, &s1)) return H2_ERR_ARGS;
         use_sort2 = true;
         S2.m = (u32)m; S2.c = sh.c; S2.W = sh.W; S2.mont = a.form == H2_FORM_MONTGOMERY;
         S2.stride = a.stride; S2.extra_col = 0xFFFFFFFFu;
         S2.lowb = lowb; S2.lb = lb; S2.nh = nh;
-        S2.s1_scalars = kS1Scalars;
+        S2.s1_scalars = s1;
         S2.nb = sh.NB;
-        S2.B1 = (u32)((m + kS1Scalars - 1) / kS1Scalars);
+        S2.B1 = (u32)((m + s1 - 1) / s1);
         S2.K2 = kS2Chunk;
         S2.B2 = (u32)((all_items + kS2Chunk - 1) / kS2Chunk);
         S2.lds_window = std::min<u32>(tb, 32768u);
@@ -1856,6 +1876,11 @@ using namespace h2;
 
 extern "C" int h2_msm_window_bits(size_t n) { return choose_c(n ? n : 1, false); }
 extern "C" int h2_commit_window_bits(size_t n) { return choose_c(n ? n : 1, true); }
+extern "C" int h2_commit_pair_supported(size_t n) {
+    int lowb, lb;
+    u32 nh, s1;
+    return n >= 8 && n <= (1u << 26) && pair_geometry(n, choose_c(n, true), (u32)n + 1, &lowb, &lb, &nh, &s1) ? 1 : 0;
+}
 
 // copies up to `cap` {clock, tag} pairs recorded under H2_TIMELINE=1 (measurement aid, see the header)
 extern "C" int h2_debug_timeline(unsigned long long *out, unsigned cap) {

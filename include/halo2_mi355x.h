@@ -71,8 +71,10 @@ const char *h2_last_error(void);
 int h2_trim(void);
 /* Window width the MSM would use for n points (informational; the result does not depend on it). */
 int h2_msm_window_bits(size_t n);
-/* The same for a registered basis of n points (h2_bases_register / h2_commit); h2_commit_pair_device needs 16. */
+/* The same for a registered basis of n points (h2_bases_register / h2_commit); h2_commit_pair_device: see h2_commit_pair_supported. */
 int h2_commit_window_bits(size_t n);
+/* 1 if h2_commit_pair_device accepts a registered basis of n points (n >= 8192 and the sort geometry fits), else 0. */
+int h2_commit_pair_supported(size_t n);
 /* Tuning knobs (never change results).  "msm_lane_fraction" in (0.05, 1]: share of the resident wave slots
  * one bucket-accumulation launch claims; < 1 lets commits issued on other streams overlap it (default 1). */
 int h2_set_option(const char *key, double value);
@@ -238,7 +240,7 @@ int h2_ipa_round_scalars_device(int field, const void *d_p, unsigned k, unsigned
  *     write_point(user, xy)  the affine point, 8 x u64 Montgomery; returns H2_OK or an error the call passes on
  *     squeeze(user, out)     the next challenge scalar, 4 x u64 Montgomery, into out
  * Everything here is Montgomery form (the working form of resident vectors).
- *   paired != 0: `basis` is a registered g || u || u || w || w (2^k + 4 points, 16-bit windows: h2_commit_window_bits) and each
+ *   paired != 0: `basis` is a registered g || u || u || w || w (2^k + 4 points; h2_commit_pair_supported) and each
  *                round is ONE h2_commit_pair_device over d_column_l (2^k + 4 scalars of scratch); d_column_r unused
  *   paired == 0: `basis` is a registered g || u || w (2^k + 2 points), each round two commits (h2_commit_batch_device) over
  *                d_column_l / d_column_r (2^k + 2 scalars of scratch each): any table size

@@ -29,9 +29,9 @@ def _rng(sf, seed):
 def test_opening_proof_bytes_and_verification(curve, k, schedule):
     if schedule is None and k != 6:
         pytest.skip("the default schedule is 'paired' from n = 8192 on and 'original' below; its plumbing is covered once")
-    if schedule == "paired":
-        pytest.skip("the paired commit needs 16-bit windows (large tables); covered at k = 20 below and at k = 16 in test_paired_commit")
     n = 1 << k
+    if schedule == "paired" and n < 8192:
+        pytest.skip("the paired commit takes tables from 8192 points on")
     sf = fields.CURVE_FIELDS[curve][1]
     g = co.generate_bases(curve, 50 + k, n)
     w, u = co.generate_bases(curve, 60, 1)[0], co.generate_bases(curve, 61, 1)[0]
@@ -112,11 +112,11 @@ def test_ipa_round_scalars_against_definition(field, k, j):
     assert (d_l[n] == -1).all() and (d_r[n] == -1).all()          # the tail slot belongs to the caller
 
 
-def test_paired_commit_matches_two_commits():
-    """h2_commit_pair_device at k = 16: for every shift, both outputs equal the two commits they stand for (computed by the
-    ordinary registered commit over g || u || u || w || w with the other side's scalars zeroed)."""
+@pytest.mark.parametrize("curve,k", [(h.PALLAS, 16), (h.VESTA, 13), (h.PALLAS, 14), (h.VESTA, 15)])
+def test_paired_commit_matches_two_commits(curve, k):
+    """h2_commit_pair_device at k = 13 .. 16 (13- to 16-bit windows): for every shift, both outputs equal the two commits they
+    stand for (the oracle's multiexp over g || u || u || w || w with the other side's scalars zeroed)."""
     import torch
-    curve, k = h.PALLAS, 16
     n = 1 << k
     sf = fields.CURVE_FIELDS[curve][1]
     g = co.generate_bases(curve, 91, n)
@@ -128,7 +128,7 @@ def test_paired_commit_matches_two_commits():
     basis = np.ascontiguousarray(np.concatenate([g, np.stack([u, u, w, w])]))
     d_col = torch.from_numpy(col.view(np.int64)).cuda()
     idx = np.arange(n + 4)
-    for shift in (0, 1, 7, 15):
+    for shift in (0, 1, 7, k - 1):
         side = np.where(idx < n, (idx >> shift) & 1, (idx - n) & 1)
         got = params.opening_pair_commit(d_col, shift, affine=True).cpu().numpy().view(np.uint64)
         for s_ in (0, 1):
