@@ -41,7 +41,10 @@ def main():
             p.commit(d, b).cpu()
             ts.append(time.perf_counter() - t2)
         res[f"table_2^{m}"] = {"register_plus_first_commit_ms": round((t1 - t0) * 1e3, 2), "commit_alone_ms": round(sorted(ts)[10] * 1e3, 4)}
+    t0 = time.perf_counter()
     params = h.Params(curve, k, g, g, w, u)
+    torch.cuda.synchronize()
+    res["params_two_tables_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
     px = co.random_field(sf, 4, n)
     d_px = torch.from_numpy(px.view(np.int64)).to(dev)
     blind = h.Blind(co.random_field(sf, 5, 1)[0])

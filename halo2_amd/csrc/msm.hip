@@ -1202,18 +1202,37 @@ __global__ void msm_blind_normalise(const u32 *__restrict__ tmp, u32 *__restrict
     fe_store(dst + 8, a.y);
 }
 
-// normalise: one lane per (w, i): XYZZ -> affine into table row w
+// rows 1 .. W-1 of the table from the chains' XYZZ results, affine and in M9 form, with ONE inversion per point: the W - 1
+// multiples of a point are normalised together (Montgomery's trick over
+// d_w = ZZ_w ZZZ_w; the running products wait in `pre`), ~8 multiplications per entry instead of a 255-step inversion each
 template <int FB>
-__global__ void __launch_bounds__(256) msm_table_normalise(const u32 *__restrict__ tmp, u32 *__restrict__ table, u32 count,
-                                                           u32 first, u32 stride, int W) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)count * (W - 1)) return;
-    u32 w = (u32)(t / count) + 1, i = (u32)(t % count);
-    xyzz<FB> r = xyzz_load<FB>(tmp + 32 * t);
-    affine<FB> a = aff_to_m9<FB>(xyzz_to_affine<FB>(r));
-    u32 *dst = table + 16 * ((size_t)w * stride + first + i);
-    fe_store(dst, a.x);
-    fe_store(dst + 8, a.y);
+__global__ void __launch_bounds__(256) msm_table_normalise_batch(const u32 *__restrict__ tmp, u32 *__restrict__ pre, u32 *__restrict__ table,
+                                                                 u32 count, u32 first, u32 stride, int W) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    fe acc = fe_one<FB>();
+    for (int w = 1; w < W; ++w) {
+        const size_t t = (size_t)(w - 1) * count + i;
+        const fe zz = fe_load(tmp + 32 * t + 16), zzz = fe_load(tmp + 32 * t + 24);
+        fe_store(pre + 8 * t, acc);
+        if (!fe_is_zero(zz)) acc = fe_mulx<FB>(acc, fe_mulx<FB>(zz, zzz));       // the identity (exact zeros) sits the product out
+    }
+    fe inv = fe_inv<FB>(acc);
+    for (int w = W - 1; w >= 1; --w) {
+        const size_t t = (size_t)(w - 1) * count + i;
+        const xyzz<FB> r = xyzz_load<FB>(tmp + 32 * t);
+        u32 *dst = table + 16 * ((size_t)w * stride + first + i);
+        if (fe_is_zero(r.zz)) {
+            fe_store(dst, fe_zero());
+            fe_store(dst + 8, fe_zero());
+            continue;
+        }
+        const fe di = fe_mulx<FB>(inv, fe_load(pre + 8 * t));                      // 1 / (ZZ ZZZ)
+        inv = fe_mulx<FB>(inv, fe_mulx<FB>(r.zz, r.zzz));
+        const affine<FB> a = aff_to_m9<FB>(affine<FB>{fe_mulx<FB>(r.x, fe_mulx<FB>(di, r.zzz)), fe_mulx<FB>(r.y, fe_mulx<FB>(di, r.zz))});
+        fe_store(dst, a.x);
+        fe_store(dst + 8, a.y);
+    }
 }
 // row 0 (the caller's points, reference Montgomery form) -> M9 form, once the chains have read it
 template <int FB>
@@ -1803,22 +1822,22 @@ static int table_fill(Bases &b, u32 first, u32 count, hipStream_t st) {
     void *tmp = nullptr;
     // worked in slabs so the XYZZ staging stays modest
     const u32 slab = 1u << 18;
-    H2_HIP(hipMalloc(&tmp, (size_t)std::min(count, slab) * (b.W - 1) * 128));
+    H2_HIP(hipMalloc(&tmp, (size_t)std::min(count, slab) * (b.W - 1) * 160));      // XYZZ staging + the running products
     for (u32 off = 0; off < count; off += slab) {
         u32 cnt = std::min(slab, count - off);
         dim3 g1((cnt + 255) / 256), blk(256);
         size_t tot = (size_t)cnt * (b.W - 1);
-        dim3 g2((unsigned)((tot + 255) / 256));
+        u32 *pre = (u32 *)tmp + 32 * tot;
         const bool wide = count <= 65536;           // few points: the doubling chain is pure latency
         dim3 g1w((cnt * kGroup + 255) / 256);
         if (b.curve == H2_PALLAS) {
             if (wide) hipLaunchKernelGGL((msm_table_chain_wide<FP>), g1w, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.c, b.W);
             else hipLaunchKernelGGL((msm_table_chain<FP>), g1, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.stride, b.c, b.W);
-            hipLaunchKernelGGL((msm_table_normalise<FP>), g2, blk, 0, st, (const u32 *)tmp, (u32 *)b.d_table, cnt, first + off, b.stride, b.W);
+            hipLaunchKernelGGL((msm_table_normalise_batch<FP>), g1, blk, 0, st, (const u32 *)tmp, pre, (u32 *)b.d_table, cnt, first + off, b.stride, b.W);
         } else {
             if (wide) hipLaunchKernelGGL((msm_table_chain_wide<FQ>), g1w, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.c, b.W);
             else hipLaunchKernelGGL((msm_table_chain<FQ>), g1, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.stride, b.c, b.W);
-            hipLaunchKernelGGL((msm_table_normalise<FQ>), g2, blk, 0, st, (const u32 *)tmp, (u32 *)b.d_table, cnt, first + off, b.stride, b.W);
+            hipLaunchKernelGGL((msm_table_normalise_batch<FQ>), g1, blk, 0, st, (const u32 *)tmp, pre, (u32 *)b.d_table, cnt, first + off, b.stride, b.W);
         }
     }
     {
