@@ -259,10 +259,11 @@ class Params:
         return self._h_guw
 
     def default_hybrid_rounds(self, paired: bool) -> int:
-        """After how many rounds the opening argument moves to the collapsed generators (0 = never): from k = 17 on, down to a
-        table of 2^14 points -- every round before costs a full-size commit, every round after a small one, the switch itself
-        (h2_ipa_collapsed_generators_device + a small table) about three full-size commits."""
-        if not paired or self.k < 17:
+        """After how many rounds the opening argument moves to the collapsed generators (0 = never): from k = 16 on (the table
+        must use 16-bit windows), down to a table of 2^14 points -- every round before costs a full-size commit, every round
+        after a small one, the switch itself (h2_ipa_collapsed_generators_device + a small table) about four full-size rounds
+        at k = 20."""
+        if not paired or self.k < 16 or int(lib().h2_commit_window_bits(self.n + 4)) != 16:
             return 0
         return min(self.k - 14, 12)
 
