@@ -19,6 +19,7 @@ _lib = None
 
 u64p = C.POINTER(C.c_uint64)
 vp = C.c_void_p
+IPA_SWITCH_DEFAULT = 0xFFFFFFFF
 IPA_WRITE_POINT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64))     # h2_ipa_write_point_fn
 IPA_SQUEEZE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64))         # h2_ipa_squeeze_fn
 
@@ -59,8 +60,11 @@ SIGNATURES = {
     "h2_fold_scalars": ([C.c_int, u64p, C.c_size_t, u64p, C.c_int], C.c_int),
     "h2_fold_scalars_device": ([C.c_int, vp, C.c_size_t, u64p, C.c_int, vp], C.c_int),
     "h2_ipa_round_scalars_device": ([C.c_int, vp, C.c_uint, C.c_uint, u64p, C.c_int, vp, vp, vp], C.c_int),
-    "h2_ipa_rounds_device": ([C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_int, vp, vp, u64p, u64p, vp, vp, IPA_WRITE_POINT_FN,
-                             IPA_SQUEEZE_FN, vp, u64p, u64p, u64p, vp], C.c_int),
+    "h2_ipa_rounds_device": ([C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_int, vp, vp, u64p, u64p, u64p, vp, vp, IPA_WRITE_POINT_FN,
+                             IPA_SQUEEZE_FN, vp, u64p, u64p, vp], C.c_int),
+    "h2_ipa_rounds": ([C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_int, u64p, u64p, u64p, u64p, u64p, IPA_WRITE_POINT_FN, IPA_SQUEEZE_FN, vp,
+                      u64p, u64p], C.c_int),
+    "h2_ipa_default_switch_rounds": ([C.c_uint, C.c_int], C.c_uint),
     "h2_ipa_collapsed_generators_device": ([C.c_uint64, C.c_uint, C.c_uint, u64p, C.c_int, vp, vp], C.c_int),
     "h2_bases_register_device": ([C.c_int, vp, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)], C.c_int),
     "h2_lagrange_basis": ([C.c_int, u64p, u64p, C.c_uint, C.c_int], C.c_int),

@@ -259,13 +259,9 @@ class Params:
         return self._h_guw
 
     def default_hybrid_rounds(self, paired: bool) -> int:
-        """After how many rounds the opening argument moves to the collapsed generators (0 = never): from k = 16 on (the table
-        must use 16-bit windows), down to a table of 2^14 points -- every round before costs a full-size commit, every round
-        after a small one, the switch itself (h2_ipa_collapsed_generators_device + a small table) about four full-size rounds
-        at k = 20."""
-        if not paired or self.k < 16 or int(lib().h2_commit_window_bits(self.n + 4)) != 16:
-            return 0
-        return min(self.k - 14, 12)
+        """After how many rounds the opening argument moves to the collapsed generators (0 = never): the library's choice,
+        k - 14 from k = 16 on (h2_ipa_default_switch_rounds)."""
+        return int(lib().h2_ipa_default_switch_rounds(self.k, 1 if paired else 0))
 
     def opening_rounds(self, d_p, d_b, z, rands, transcript, paired: bool, hybrid_rounds: int | None = None):
         """The round loop of the opening argument (poly/commitment/prover.rs:104-142) through h2_ipa_rounds_device: d_p (p') and
@@ -273,18 +269,18 @@ class Params:
         squeeze_challenge_scalar are called from inside the loop.  Returns (c, f_delta): the final p'[0] and
         sum_j (l_j / u_j + r_j u_j), both (4,) Montgomery limbs.
 
-        hybrid_rounds = J > 0: the first J rounds run over the original generators, then G'_J is read off the registered table
-        (h2_ipa_collapsed_generators_device), registered as a table of its own, and the remaining k - J rounds run over it."""
+        hybrid_rounds = J > 0: the first J rounds run over the original generators, then the library reads G'_J off the
+        registered table and runs the remaining k - J rounds over it (None: the library's choice)."""
         import torch
-        from ._lib import IPA_SQUEEZE_FN, IPA_WRITE_POINT_FN
+        from ._lib import IPA_SQUEEZE_FN, IPA_SWITCH_DEFAULT, IPA_WRITE_POINT_FN
         n, k = self.n, self.k
         if d_p.shape[0] != n or d_b.shape[0] != n or not d_p.is_contiguous() or not d_b.is_contiguous():
             raise ValueError("opening_rounds: p' and b must hold n scalars")
         rands = np.ascontiguousarray(rands, dtype=np.uint64).reshape(2 * k, 4)
         z = np.ascontiguousarray(z, dtype=np.uint64).reshape(4)
         dev = d_p.device
-        J = self.default_hybrid_rounds(paired) if hybrid_rounds is None else int(hybrid_rounds)
-        if J < 0 or J >= k or J > 12 or (J and not paired):
+        J = IPA_SWITCH_DEFAULT if hybrid_rounds is None else int(hybrid_rounds)
+        if J != IPA_SWITCH_DEFAULT and (J < 0 or J >= k or J > 12 or (J and not paired)):
             raise ValueError("opening_rounds: hybrid_rounds must be in [0, min(k - 1, 12)] and needs the paired schedule")
         failure = []
 
@@ -303,43 +299,18 @@ class Params:
             except Exception as e:
                 failure.append(e)
                 return 1
-        cb_w, cb_s = IPA_WRITE_POINT_FN(write_point), IPA_SQUEEZE_FN(squeeze)
-        sf = fields.CURVE_FIELDS[self.curve][1]
-
-        def run(kk, rounds, handle, pair, p_t, b_t, rnd, ch_out):
-            nn = 1 << kk
-            col_l = torch.empty((nn + (4 if pair else 2), 4), dtype=torch.int64, device=dev)
-            col_r = None if pair else torch.empty((nn + 2, 4), dtype=torch.int64, device=dev)
-            c = np.zeros(4, dtype=np.uint64)
-            f = np.zeros(4, dtype=np.uint64)
-            rc = lib().h2_ipa_rounds_device(self.curve, kk, rounds, handle, 1 if pair else 0, p_t.data_ptr(), b_t.data_ptr(), _p(z),
-                                            _p(rnd), col_l.data_ptr(), col_r.data_ptr() if col_r is not None else None, cb_w, cb_s,
-                                            None, _p(ch_out) if ch_out is not None else None, _p(c), _p(f), _stream_ptr())
-            if failure:
-                raise failure[0]
-            check(rc, "h2_ipa_rounds_device")
-            return c, f
-        if not J:
-            return run(k, k, self._opening_basis(paired), paired, d_p, d_b, rands, None)
-        ch = np.zeros((J, 4), dtype=np.uint64)
-        _, f1 = run(k, J, self._opening_basis(True), True, d_p, d_b, rands, ch)
-        kj, nj = k - J, 1 << (k - J)
-        pair2 = bool(lib().h2_commit_pair_supported(nj + 4))
-        tail = np.stack([self.u, self.u, self.w, self.w]) if pair2 else np.stack([self.u, self.w])
-        d_gj = torch.empty((nj + tail.shape[0], 8), dtype=torch.int64, device=dev)
-        check(lib().h2_ipa_collapsed_generators_device(self._h_pair, k, J, _p(ch), FORM_MONTGOMERY, d_gj.data_ptr(), _stream_ptr()),
-              "h2_ipa_collapsed_generators_device")
-        d_gj[nj:] = torch.from_numpy(np.ascontiguousarray(tail).view(np.int64)).to(dev)
-        torch.cuda.current_stream(dev).synchronize()          # the registration reads the points on the null stream
-        h_j = C.c_uint64(0)
-        check(lib().h2_bases_register_device(self.curve, d_gj.data_ptr(), d_gj.shape[0], FORM_MONTGOMERY, C.byref(h_j)), "h2_bases_register_device")
-        try:
-            c, f2 = run(kj, kj, h_j, pair2, d_p[:nj], d_b[:nj], rands[2 * J:], None)
-        finally:
-            lib().h2_bases_free(h_j)
-        m = fields.MODULUS[sf]
-        f = (fields.from_limbs(f1, sf, True)[0] + fields.from_limbs(f2, sf, True)[0]) % m
-        return c, fields.scalar_limbs(f, sf, True)
+        col_l = torch.empty((n + (4 if paired else 2), 4), dtype=torch.int64, device=dev)
+        col_r = None if paired else torch.empty((n + 2, 4), dtype=torch.int64, device=dev)
+        c = np.zeros(4, dtype=np.uint64)
+        f = np.zeros(4, dtype=np.uint64)
+        uw = np.ascontiguousarray(np.stack([self.u, self.w]), dtype=np.uint64)
+        rc = lib().h2_ipa_rounds_device(self.curve, k, J, self._opening_basis(paired), 1 if paired else 0, d_p.data_ptr(), d_b.data_ptr(),
+                                        _p(z), _p(rands), _p(uw), col_l.data_ptr(), col_r.data_ptr() if col_r is not None else None,
+                                        IPA_WRITE_POINT_FN(write_point), IPA_SQUEEZE_FN(squeeze), None, _p(c), _p(f), _stream_ptr())
+        if failure:
+            raise failure[0]
+        check(rc, "h2_ipa_rounds_device")
+        return c, f
 
     def commit_unblinded(self, scalars):
         """sum_i scalars[i] * g[i] with no blind term, Jacobian: the g part of `MSM::eval` (poly/commitment/msm.rs:163-166)."""

@@ -126,13 +126,14 @@ struct IpaContext {
     // the round loop (h2_ipa_rounds_device): its own lock (held for the whole argument; the launches it makes take `mu`),
     // device scratch { <p'_hi, b_lo>, <p'_lo, b_hi>, L_j, R_j } and the pinned landing pad of L_j, R_j
     std::mutex rounds_mu;
-    DevBuf rounds;
+    DevBuf rounds, gprime;
     void *rounds_host = nullptr;
     void release_all() {
         naf.release();
         stage.release();
         stab.release();
         rounds.release();
+        gprime.release();
         if (rounds_host) (void)hipHostFree(rounds_host);
         rounds_host = nullptr;
     }
@@ -450,31 +451,21 @@ extern "C" int h2_ipa_round_scalars_device(int field, const void *d_p, unsigned 
 }
 
 
-// The round loop of `commitment::create_proof` (poly/commitment/prover.rs:104-142) as ONE call: per round the inner products,
-// the L_j / R_j scalars over the original generators, their commit(s), the two points to the transcript, the challenge, and the
-// p' / b folds.  The host is touched once per round (192 bytes of L_j, R_j in Jacobian form land in pinned memory; the
-// normalisation -- one shared inversion -- and the challenge's inverse are microseconds of 64-bit host arithmetic), through
-// the caller's transcript: `write_point` receives the affine point (8 x u64, Montgomery), `squeeze` returns the challenge
-// scalar (4 x u64, Montgomery) -- the two TranscriptWrite methods the reference's loop uses (:121-124).
-extern "C" int h2_ipa_rounds_device(int curve, unsigned k, unsigned rounds, h2_bases_t basis, int paired, void *d_p, void *d_b,
-                                    const uint64_t *z, const uint64_t *rands, void *d_column_l, void *d_column_r,
-                                    h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze, void *user, uint64_t *challenges_out,
-                                    uint64_t *c_out, uint64_t *f_out, void *stream) {
-    if ((curve != H2_PALLAS && curve != H2_VESTA) || k < 1 || k > 30 || rounds < 1 || rounds > k || !d_p || !d_b || !z || !rands ||
-        !d_column_l || !write_point || !squeeze || !c_out || !f_out || (!paired && !d_column_r))
-        return H2_ERR_ARGS;
+// `rounds` rounds of the loop below over ONE registered basis (the public entry switches bases in between)
+static int ipa_rounds_impl(int curve, unsigned k, unsigned rounds, h2_bases_t basis, int paired, void *d_p, void *d_b, const uint64_t *z,
+                           const uint64_t *rands, void *d_column_l, void *d_column_r, h2_ipa_write_point_fn write_point,
+                           h2_ipa_squeeze_fn squeeze, void *user, uint64_t *challenges_out, uint64_t *c_out, uint64_t *f_acc, void *stream) {
     int rc = ensure_device();
     if (rc != H2_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int sf = curve == H2_PALLAS ? H2_FQ : H2_FP, bf = curve == H2_PALLAS ? H2_FP : H2_FQ;
     const size_t n = (size_t)1 << k;
-    IpaContext &cx = g_ipa_ctxs.get(st);
-    std::lock_guard<std::mutex> lk(cx.rounds_mu);
+    IpaContext &cx = g_ipa_ctxs.get(st);           // the caller holds cx.rounds_mu
     if ((rc = cx.rounds.reserve(64 + 192)) != H2_OK) return rc;
     if (!cx.rounds_host) H2_HIP(hipHostMalloc(&cx.rounds_host, 256, hipHostMallocDefault));
     u32 *d_ip = cx.rounds.as<u32>(), *d_lr = d_ip + 16;
     u64 *lr = (u64 *)cx.rounds_host;
-    u64 challenges[32 * 4], f_acc[4] = {0, 0, 0, 0};
+    u64 challenges[32 * 4];
     u32 *col_l = (u32 *)d_column_l, *col_r = paired ? col_l : (u32 *)d_column_r;
     fe zf;
     memcpy(zf.v, z, 32);
@@ -542,6 +533,87 @@ extern "C" int h2_ipa_rounds_device(int curve, unsigned k, unsigned rounds, h2_b
         memcpy(c_out, lr, 32);
     }
     if (challenges_out) memcpy(challenges_out, challenges, 32 * (size_t)rounds);
-    memcpy(f_out, f_acc, 32);
     return H2_OK;
+}
+
+// The round loop of `commitment::create_proof` (poly/commitment/prover.rs:104-142) as ONE call: per round the inner products,
+// the L_j / R_j scalars over the original generators, their commit(s), the two points to the transcript, the challenge, and the
+// p' / b folds.  The host is touched once per round (192 bytes of L_j, R_j in Jacobian form land in pinned memory; the
+// normalisation -- one shared inversion -- and the challenge's inverse are microseconds of 64-bit host arithmetic), through
+// the caller's transcript: `write_point` receives the affine point (8 x u64, Montgomery), `squeeze` returns the challenge
+// scalar (4 x u64, Montgomery) -- the two TranscriptWrite methods the reference's loop uses (:121-124).
+// With switch_rounds = J > 0 the first J rounds run over `basis` (the original generators), then G'_J is read off its table
+// (h2_ipa_collapsed_generators_device), registered as a table of its own next to u and w, and the remaining k - J rounds run as a
+// (k - J)-round argument over it: a round over the original generators costs a full-size commit whatever j, a round over G'_J a
+// commit of 2^(k-J) points.
+extern "C" unsigned h2_ipa_default_switch_rounds(unsigned k, int paired) {
+    if (!paired || k < 16 || k > 26 || h2_commit_window_bits(((size_t)1 << k) + 4) != 16) return 0;
+    return k - 14 < 12 ? k - 14 : 12;
+}
+
+extern "C" int h2_ipa_rounds_device(int curve, unsigned k, unsigned switch_rounds, h2_bases_t basis, int paired, void *d_p, void *d_b,
+                                    const uint64_t *z, const uint64_t *rands, const uint64_t *uw_xy, void *d_column_l, void *d_column_r,
+                                    h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze, void *user, uint64_t *c_out,
+                                    uint64_t *f_out, void *stream) {
+    if ((curve != H2_PALLAS && curve != H2_VESTA) || k < 1 || k > 30 || !d_p || !d_b || !z || !rands || !d_column_l || !write_point ||
+        !squeeze || !c_out || !f_out || (!paired && !d_column_r))
+        return H2_ERR_ARGS;
+    unsigned J = switch_rounds == H2_IPA_SWITCH_DEFAULT ? h2_ipa_default_switch_rounds(k, paired) : switch_rounds;
+    if (J && (!paired || J >= k || J > 12 || !uw_xy)) return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    IpaContext &cx = g_ipa_ctxs.get(st);
+    std::lock_guard<std::mutex> lk(cx.rounds_mu);
+    u64 f_acc[4] = {0, 0, 0, 0};
+    if (!J) {
+        rc = ipa_rounds_impl(curve, k, k, basis, paired, d_p, d_b, z, rands, d_column_l, d_column_r, write_point, squeeze, user, nullptr,
+                             c_out, f_acc, stream);
+        if (rc == H2_OK) memcpy(f_out, f_acc, 32);
+        return rc;
+    }
+    u64 challenges[12 * 4];
+    if ((rc = ipa_rounds_impl(curve, k, J, basis, 1, d_p, d_b, z, rands, d_column_l, nullptr, write_point, squeeze, user, challenges, c_out,
+                              f_acc, stream)) != H2_OK)
+        return rc;
+    const unsigned kj = k - J;
+    const size_t nj = (size_t)1 << kj;
+    const bool pair2 = h2_commit_pair_supported(nj + 4) != 0;
+    const size_t tail = pair2 ? 4 : 2;
+    if ((rc = cx.gprime.reserve((nj + tail) * 64)) != H2_OK) return rc;
+    char *d_g = cx.gprime.as<char>();
+    if ((rc = h2_ipa_collapsed_generators_device(basis, k, J, challenges, H2_FORM_MONTGOMERY, d_g, st)) != H2_OK) return rc;
+    u64 tails[4 * 8];                                                 // u, u, w, w  or  u, w
+    for (size_t t = 0; t < tail; ++t) memcpy(tails + 8 * t, uw_xy + 8 * (pair2 ? t / 2 : t), 64);
+    H2_HIP(hipMemcpyAsync(d_g + nj * 64, tails, tail * 64, hipMemcpyHostToDevice, st));
+    H2_HIP(hipStreamSynchronize(st));                                // the registration reads the points on the null stream
+    h2_bases_t hj = 0;
+    if ((rc = h2_bases_register_device(curve, d_g, nj + tail, H2_FORM_MONTGOMERY, &hj)) != H2_OK) return rc;
+    // the columns of the second phase fit in the first phase's scratch (2 (nj + 2) <= 2^k + 4)
+    void *col_l = d_column_l, *col_r = pair2 ? nullptr : (void *)((char *)d_column_l + 32 * (nj + 2));
+    rc = ipa_rounds_impl(curve, kj, kj, hj, pair2 ? 1 : 0, d_p, d_b, z, rands + 8 * J, col_l, col_r, write_point, squeeze, user, nullptr,
+                         c_out, f_acc, stream);
+    (void)h2_bases_free(hj);
+    if (rc == H2_OK) memcpy(f_out, f_acc, 32);
+    return rc;
+}
+
+// the same with p' and b in host memory (copied in; the folded vectors are not copied back: only c and f leave the argument)
+extern "C" int h2_ipa_rounds(int curve, unsigned k, unsigned switch_rounds, h2_bases_t basis, int paired, const uint64_t *p, const uint64_t *b,
+                             const uint64_t *z, const uint64_t *rands, const uint64_t *uw_xy, h2_ipa_write_point_fn write_point,
+                             h2_ipa_squeeze_fn squeeze, void *user, uint64_t *c_out, uint64_t *f_out) {
+    if (k < 1 || k > 30 || !p || !b) return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    const size_t n = (size_t)1 << k, col = (n + 4) * 32;
+    char *d = nullptr;
+    H2_HIP(hipMalloc((void **)&d, 2 * n * 32 + 2 * col));
+    hipError_t e = hipMemcpy(d, p, n * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n * 32, b, n * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        rc = h2_ipa_rounds_device(curve, k, switch_rounds, basis, paired, d, d + n * 32, z, rands, uw_xy, d + 2 * n * 32, d + 2 * n * 32 + col,
+                                  write_point, squeeze, user, c_out, f_out, nullptr);
+    (void)hipFree(d);
+    if (e != hipSuccess) { set_last_hip_error(e, __FILE__, __LINE__); return H2_ERR_HIP; }
+    return rc;
 }

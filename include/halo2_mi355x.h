@@ -247,22 +247,29 @@ int h2_ipa_round_scalars_device(int field, const void *d_p, unsigned k, unsigned
  * d_p: p' (2^k scalars, folded in place; c_out receives the final p'[0]);  d_b: b, likewise;  z: the challenge of :66;
  * rands: l_0, r_0, l_1, r_1, ... (2k scalars, the order the reference draws them, :111-112);
  * f_out: sum_j (l_j u_j^-1 + r_j u_j), the amount the synthetic blinding factor grows by (:140-141).
- * rounds: how many rounds to run (1 .. k); with rounds < k the call stops there -- p' and b hold 2^(k-rounds) live entries,
- *         challenges_out (if not NULL) the challenges drawn, c_out is not written -- and the caller continues with another call
- *         over the collapsed generators (h2_ipa_collapsed_generators_device) as a k - rounds argument.
- * Returns H2_ERR_ARGS if an L_j / R_j is the point at infinity or a challenge is zero (the reference errors / panics). */
+ * switch_rounds = J > 0 (paired only, J < k, J <= 12, 16-bit window table): after J rounds the argument leaves the original
+ *   generators -- G'_J is read off the table (h2_ipa_collapsed_generators_device), registered next to u and w (uw_xy: u then w,
+ *   host, affine Montgomery) as a table of 2^(k-J) points, and the remaining rounds run over it: a round over the original
+ *   generators costs a full-size commit whatever j, a round over G'_J a small one.  0 = never; H2_IPA_SWITCH_DEFAULT = the
+ *   library's choice (h2_ipa_default_switch_rounds: k - 14 from k = 16 on).  Same L_j, R_j, so the same proof bytes.
+ * Returns H2_ERR_ARGS if an L_j / R_j is the point at infinity or a challenge is zero (the reference errors / panics).
+ * h2_ipa_rounds: the same with p' and b in host memory (copied in; only c and f leave the argument). */
+#define H2_IPA_SWITCH_DEFAULT 0xFFFFFFFFu
 typedef int (*h2_ipa_write_point_fn)(void *user, const uint64_t *xy);
 typedef int (*h2_ipa_squeeze_fn)(void *user, uint64_t *challenge);
-int h2_ipa_rounds_device(int curve, unsigned k, unsigned rounds, h2_bases_t basis, int paired, void *d_p, void *d_b,
-                         const uint64_t *z, const uint64_t *rands, void *d_column_l, void *d_column_r,
-                         h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze, void *user, uint64_t *challenges_out,
-                         uint64_t *c_out, uint64_t *f_out, void *stream);
+unsigned h2_ipa_default_switch_rounds(unsigned k, int paired);
+int h2_ipa_rounds_device(int curve, unsigned k, unsigned switch_rounds, h2_bases_t basis, int paired, void *d_p, void *d_b,
+                         const uint64_t *z, const uint64_t *rands, const uint64_t *uw_xy, void *d_column_l, void *d_column_r,
+                         h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze, void *user, uint64_t *c_out,
+                         uint64_t *f_out, void *stream);
+int h2_ipa_rounds(int curve, unsigned k, unsigned switch_rounds, h2_bases_t basis, int paired, const uint64_t *p, const uint64_t *b,
+                  const uint64_t *z, const uint64_t *rands, const uint64_t *uw_xy, h2_ipa_write_point_fn write_point,
+                  h2_ipa_squeeze_fn squeeze, void *user, uint64_t *c_out, uint64_t *f_out);
 /* The generators after `rounds` collapses, without collapsing: G'[i] = sum_{h < 2^rounds} s(h) * G[i + h * 2^(k-rounds)] for
  * i < 2^(k-rounds), s(h) the challenge products of h2_ipa_round_scalars_device, read off the registered table of `basis` (its
  * first 2^k points are G; the table must use 16-bit windows, h2_commit_window_bits) as 2^(k-rounds) multiexps that share their
- * scalars: 64 * 2^k mixed additions in all, no sort.  With h2_bases_register_device this lets the
- * opening argument switch to a 2^rounds times smaller table after its first rounds: L_j / R_j written over the ORIGINAL generators
- * cost a full-size commit in every round, over G' a commit of 2^(k-rounds) points.
+ * scalars: 64 * 2^k mixed additions in all, no sort (DESIGN.md section 8, step ao).  With h2_bases_register_device this is how
+ * h2_ipa_rounds_device moves to a 2^rounds times smaller table after its first rounds.
  * challenges: u_0 .. u_{rounds-1} in `form` (host); d_out_xy: 2^(k-rounds) affine points, Montgomery form.  rounds <= 12. */
 int h2_ipa_collapsed_generators_device(h2_bases_t basis, unsigned k, unsigned rounds, const uint64_t *challenges, int form,
                                        void *d_out_xy, void *stream);
