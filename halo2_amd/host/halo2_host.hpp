@@ -11,9 +11,12 @@
 //     CurveExt::hash_to_curve (pasta_curves, as called at commitment.rs:52, :102), arithmetic::small_multiexp (arithmetic.rs:116)
 //     Polynomial<F, B> with the basis markers Coeff / LagrangeCoeff / ExtendedLagrangeCoeff   halo2_proofs/src/poly.rs:30-57
 //     commit_columns_multi: the column loop of a prover phase (plonk/prover.rs:93-101, 301-313) over several GPUs
+//     Blake2bWrite + Challenge255 (transcript.rs:150-300) and poly::commitment::create_proof, the opening argument
+//                                                     halo2_proofs/src/poly/commitment/prover.rs:26-151
 // Where the reference panics (assert_eq! on lengths) these throw std::invalid_argument; HIP / device
 // failures throw std::runtime_error with h2_last_error().  All compute happens in libhalo2_mi355x.so.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <functional>
@@ -88,6 +91,17 @@ inline Fe sub(int f, const Fe &a, const Fe &b) {
     if (br) { u128 c = 0; for (int i = 0; i < 4; i++) { c += (u128)t[i] + F.p[i]; t[i] = (uint64_t)c; c >>= 64; } }
     return Fe{t[0], t[1], t[2], t[3]};
 }
+inline Fe add(int f, const Fe &a, const Fe &b) {
+    const Params &F = params(f);
+    uint64_t t[4]; u128 c = 0;
+    for (int i = 0; i < 4; i++) { c += (u128)a[i] + b[i]; t[i] = (uint64_t)c; c >>= 64; }
+    Fe r{t[0], t[1], t[2], t[3]};
+    bool ge = true;
+    for (int i = 3; i >= 0; i--) { if (t[i] > F.p[i]) break; if (t[i] < F.p[i]) { ge = false; break; } }
+    return ge ? sub(f, r, Fe{F.p[0], F.p[1], F.p[2], F.p[3]}) : r;
+}
+inline Fe from_mont(int f, const Fe &a) { return mul(f, a, Fe{1, 0, 0, 0}); }            // canonical limbs
+inline Fe to_mont(int f, const Fe &raw) { const Params &F = params(f); return mul(f, raw, Fe{F.r2[0], F.r2[1], F.r2[2], F.r2[3]}); }   // any raw < 2^256
 // ROOT_OF_UNITY = 5^((p-1)/2^32): multiplicative generator 5, S = 32 for both fields
 inline Fe root_of_unity(int f) {
     const Params &F = params(f);
@@ -254,7 +268,7 @@ template <int CURVE> class Params {
         check(h2_bases_register(CURVE, g[0].data(), n, H2_FORM_MONTGOMERY, &h_g), "h2_bases_register");
         check(h2_bases_register(CURVE, g_lagrange[0].data(), n, H2_FORM_MONTGOMERY, &h_gl), "h2_bases_register");
     }
-    ~Params() { if (h_g) h2_bases_free(h_g); if (h_gl) h2_bases_free(h_gl); }
+    ~Params() { for (h2_bases_t h : {h_g, h_gl, h_open}) if (h) h2_bases_free(h); }
     // Params::new (commitment.rs:38-114): g_i = hasher({0, i as LE u32}), g_lagrange by the point iFFT, w = hasher({1}), u = hasher({2});
     // the 2^k + 2 hashes and the point FFT run on the device
     static Params new_params(uint32_t k_) {
@@ -275,6 +289,18 @@ template <int CURVE> class Params {
     }
     h2_bases_t handle_g() const { return h_g; }
     h2_bases_t handle_g_lagrange() const { return h_gl; }
+    // the registered basis of the opening argument's commits (prover.rs:107-114): g || u || u || w || w when one paired commit per
+    // round is possible (h2_commit_pair_supported), else g || u || w; registered on first use
+    h2_bases_t opening_basis(bool *paired) const {
+        *paired = h2_commit_pair_supported(n + 4) != 0;
+        if (!h_open) {
+            std::vector<Affine> basis(g);
+            if (*paired) basis.insert(basis.end(), {u, u, w, w});
+            else basis.insert(basis.end(), {u, w});
+            check(h2_bases_register(CURVE, basis[0].data(), basis.size(), H2_FORM_MONTGOMERY, &h_open), "h2_bases_register");
+        }
+        return h_open;
+    }
     Params(const Params &) = delete;
     Params &operator=(const Params &) = delete;
 
@@ -307,12 +333,14 @@ template <int CURVE> class Params {
         return Params(k_le, std::vector<Affine>(pts.begin(), pts.begin() + n_), std::vector<Affine>(pts.begin() + n_, pts.begin() + 2 * n_),
                       pts[2 * n_], pts[2 * n_ + 1]);
     }
-    Params(Params &&o) noexcept : k(o.k), n(o.n), g(std::move(o.g)), g_lagrange(std::move(o.g_lagrange)), w(o.w), u(o.u), h_g(o.h_g), h_gl(o.h_gl) {
-        o.h_g = o.h_gl = 0;
+    Params(Params &&o) noexcept
+        : k(o.k), n(o.n), g(std::move(o.g)), g_lagrange(std::move(o.g_lagrange)), w(o.w), u(o.u), h_g(o.h_g), h_gl(o.h_gl), h_open(o.h_open) {
+        o.h_g = o.h_gl = o.h_open = 0;
     }
 
   private:
     h2_bases_t h_g = 0, h_gl = 0;
+    mutable h2_bases_t h_open = 0;
     Jacobian run(h2_bases_t h, const std::vector<Fe> &poly, const Blind<CURVE> &r) const {
         if (poly.size() != n) throw std::invalid_argument("commit: poly.len() != n");
         Jacobian out{};
@@ -320,6 +348,191 @@ template <int CURVE> class Params {
         return out;
     }
 };
+
+// ---- transcript.rs -----------------------------------------------------------------------------------------------
+// BLAKE2b-512 (RFC 7693) with a personalisation string, as blake2b_simd::Params::new().hash_length(64).personal(..) builds it
+class Blake2bState {
+  public:
+    explicit Blake2bState(const char personal[16]) {
+        static const uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                       0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+        uint64_t pw[2];
+        memcpy(pw, personal, 16);
+        for (int i = 0; i < 8; i++) h[i] = IV[i];
+        h[0] ^= 0x01010000ULL ^ 64;          // digest length 64, no key, fanout 1, depth 1
+        h[6] ^= pw[0];
+        h[7] ^= pw[1];
+    }
+    void update(const uint8_t *in, size_t len) {
+        while (len) {
+            if (fill == 128) { t += 128; compress(false); fill = 0; }     // only once more input is known to follow
+            const size_t take = std::min(len, (size_t)128 - fill);
+            memcpy(buf + fill, in, take);
+            fill += take; in += take; len -= take;
+        }
+    }
+    std::array<uint8_t, 64> finalize() const {                            // on a copy: the transcript keeps absorbing (transcript.rs:202)
+        Blake2bState c = *this;
+        c.t += c.fill;
+        memset(c.buf + c.fill, 0, 128 - c.fill);
+        c.compress(true);
+        std::array<uint8_t, 64> out;
+        memcpy(out.data(), c.h, 64);
+        return out;
+    }
+
+  private:
+    uint64_t h[8], t = 0;
+    uint8_t buf[128];
+    size_t fill = 0;
+    static uint64_t rotr(uint64_t x, int r) { return (x >> r) | (x << (64 - r)); }
+    void compress(bool last) {
+        static const uint8_t S[12][16] = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+                                          {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+                                          {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+                                          {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+                                          {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+                                          {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+        static const uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                       0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+        uint64_t m[16], v[16];
+        memcpy(m, buf, 128);
+        for (int i = 0; i < 8; i++) { v[i] = h[i]; v[8 + i] = IV[i]; }
+        v[12] ^= t;
+        if (last) v[14] = ~v[14];
+        auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
+            v[a] = v[a] + v[b] + x; v[d] = rotr(v[d] ^ v[a], 32);
+            v[c] = v[c] + v[d];     v[b] = rotr(v[b] ^ v[c], 24);
+            v[a] = v[a] + v[b] + y; v[d] = rotr(v[d] ^ v[a], 16);
+            v[c] = v[c] + v[d];     v[b] = rotr(v[b] ^ v[c], 63);
+        };
+        for (int r = 0; r < 12; r++) {
+            const uint8_t *s = S[r];
+            G(0, 4, 8, 12, m[s[0]], m[s[1]]);   G(1, 5, 9, 13, m[s[2]], m[s[3]]);
+            G(2, 6, 10, 14, m[s[4]], m[s[5]]);  G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+            G(0, 5, 10, 15, m[s[8]], m[s[9]]);  G(1, 6, 11, 12, m[s[10]], m[s[11]]);
+            G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+        }
+        for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[8 + i];
+    }
+};
+
+// Blake2bWrite<_, C, Challenge255<C>> (transcript.rs:150-198, 286-296): points are absorbed as (x, y) canonical little-endian and
+// written compressed; a challenge is the 64-byte digest of a copy of the state, reduced into the scalar field
+template <int CURVE> class Blake2bWrite {
+    static constexpr int BF = CURVE == H2_PALLAS ? H2_FP : H2_FQ, SF = CURVE == H2_PALLAS ? H2_FQ : H2_FP;
+
+  public:
+    Blake2bWrite() : state("Halo2-Transcript") {}
+    void common_point(const Affine &p) {                                                                               // :206-219
+        if (!(p[0] | p[1] | p[2] | p[3] | p[4] | p[5] | p[6] | p[7])) throw std::invalid_argument("cannot write points at infinity to the transcript");
+        const uint8_t prefix = 1;
+        state.update(&prefix, 1);
+        const Fe x = field::from_mont(BF, {p[0], p[1], p[2], p[3]}), y = field::from_mont(BF, {p[4], p[5], p[6], p[7]});
+        state.update(reinterpret_cast<const uint8_t *>(x.data()), 32);
+        state.update(reinterpret_cast<const uint8_t *>(y.data()), 32);
+    }
+    void write_point(const Affine &p) {                                                                                // :183-187
+        common_point(p);
+        const Fe x = field::from_mont(BF, {p[0], p[1], p[2], p[3]}), y = field::from_mont(BF, {p[4], p[5], p[6], p[7]});
+        uint8_t enc[32];
+        memcpy(enc, x.data(), 32);
+        enc[31] |= (uint8_t)((y[0] & 1) << 7);                   // pasta_curves to_bytes: the sign of y in the top bit
+        writer.insert(writer.end(), enc, enc + 32);
+    }
+    void common_scalar(const Fe &s) {                                                                                  // :221-227
+        const uint8_t prefix = 2;
+        state.update(&prefix, 1);
+        const Fe c = field::from_mont(SF, s);
+        state.update(reinterpret_cast<const uint8_t *>(c.data()), 32);
+    }
+    void write_scalar(const Fe &s) {                                                                                   // :188-192
+        common_scalar(s);
+        const Fe c = field::from_mont(SF, s);
+        const uint8_t *b = reinterpret_cast<const uint8_t *>(c.data());
+        writer.insert(writer.end(), b, b + 32);
+    }
+    Fe squeeze_challenge_scalar() {                                                                                    // :200-205, :286-296
+        const uint8_t prefix = 0;
+        state.update(&prefix, 1);
+        const std::array<uint8_t, 64> d = state.finalize();
+        Fe lo, hi;
+        memcpy(lo.data(), d.data(), 32);
+        memcpy(hi.data(), d.data() + 32, 32);
+        // from_bytes_wide: (lo + hi 2^256) mod q; r2 read as a Montgomery element IS 2^256
+        const field::Params &F = field::params(SF);
+        return field::add(SF, field::to_mont(SF, lo), field::mul(SF, field::to_mont(SF, hi), Fe{F.r2[0], F.r2[1], F.r2[2], F.r2[3]}));
+    }
+    std::vector<uint8_t> finalize() const { return writer; }
+
+  private:
+    Blake2bState state;
+    std::vector<uint8_t> writer;
+};
+
+template <int CURVE> inline Affine to_affine(const Jacobian &p) {
+    constexpr int BF = CURVE == H2_PALLAS ? H2_FP : H2_FQ;
+    const Fe X{p[0], p[1], p[2], p[3]}, Y{p[4], p[5], p[6], p[7]}, Z{p[8], p[9], p[10], p[11]};
+    if (!(Z[0] | Z[1] | Z[2] | Z[3])) return Affine{};
+    const Fe zi = field::inv(BF, Z), zi2 = field::mul(BF, zi, zi);
+    const Fe x = field::mul(BF, X, zi2), y = field::mul(BF, Y, field::mul(BF, zi2, zi));
+    return Affine{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+}
+
+// ---- poly/commitment/prover.rs:26-151 ------------------------------------------------------------------------------
+// create_proof: the opening argument for `p_poly` at `x_3`, written to `transcript`.  rng() -> one uniformly random scalar
+// (C::Scalar::random); it is drawn n + 1 + 2k times in the reference's order (s_poly coefficients, s_poly_blind, then l_j, r_j
+// per round).  The O(n) steps and the round loop run on the GPU through the host-pointer entry points; the proof bytes are the
+// reference's for the same randomness (tests/test_gpu_parity.py::test_native_drivers compares them with the Python mirror's).
+template <int CURVE, class Rng>
+inline void create_proof(const Params<CURVE> &params, Rng &&rng, Blake2bWrite<CURVE> &transcript, const std::vector<Fe> &p_poly,
+                         const Blind<CURVE> &p_blind, const Fe &x_3) {
+    constexpr int SF = CURVE == H2_PALLAS ? H2_FQ : H2_FP;
+    const size_t n = params.n;
+    const uint32_t k = params.k;
+    if (p_poly.size() != n) throw std::invalid_argument("create_proof: p_poly.len() != params.n");                      // :41
+    // a random polynomial with a root at x_3, and its commitment (:43-57)
+    std::vector<Fe> s_poly(n);
+    for (Fe &c : s_poly) c = rng();
+    const Fe s_at_x3 = eval_polynomial<SF>(s_poly, x_3);
+    s_poly[0] = field::sub(SF, s_poly[0], s_at_x3);
+    const Blind<CURVE> s_poly_blind{rng()};
+    transcript.write_point(to_affine<CURVE>(params.commit(s_poly, s_poly_blind)));
+    const Fe xi = transcript.squeeze_challenge_scalar();                                                              // :62
+    const Fe z = transcript.squeeze_challenge_scalar();                                                               // :66
+    // P' = P - [v] G_0 + [xi] S (:70-78)
+    std::vector<Fe> p_prime(std::move(s_poly));
+    check(h2_scale_add(SF, p_prime[0].data(), xi.data(), p_poly[0].data(), n, H2_FORM_MONTGOMERY), "h2_scale_add");
+    const Fe v = eval_polynomial<SF>(p_prime, x_3);
+    p_prime[0] = field::sub(SF, p_prime[0], v);
+    Fe f = field::add(SF, field::mul(SF, s_poly_blind.value, xi), p_blind.value);
+    std::vector<Fe> b(n);                                                                                              // :86-97
+    check(h2_powers(SF, x_3.data(), n, H2_FORM_MONTGOMERY, b[0].data()), "h2_powers");
+    std::vector<Fe> rands(2 * (size_t)k);                                                                              // :111-112
+    for (Fe &r : rands) r = rng();
+    bool paired = false;
+    const h2_bases_t basis = params.opening_basis(&paired);
+    struct Ctx { Blake2bWrite<CURVE> *t; std::string err; } ctx{&transcript, {}};
+    auto write_point = [](void *user, const uint64_t *xy) -> int {
+        Ctx *c = static_cast<Ctx *>(user);
+        try { Affine p; memcpy(p.data(), xy, 64); c->t->write_point(p); return H2_OK; }
+        catch (const std::exception &e) { c->err = e.what(); return H2_ERR_ARGS; }
+    };
+    auto squeeze = [](void *user, uint64_t *out) -> int {
+        Ctx *c = static_cast<Ctx *>(user);
+        const Fe u = c->t->squeeze_challenge_scalar();
+        memcpy(out, u.data(), 32);
+        return H2_OK;
+    };
+    const Affine uw[2] = {params.u, params.w};
+    Fe c_final{}, f_delta{};
+    const int rc = h2_ipa_rounds(CURVE, k, H2_IPA_SWITCH_DEFAULT, basis, paired ? 1 : 0, p_prime[0].data(), b[0].data(), z.data(), rands[0].data(),
+                                 uw[0].data(), write_point, squeeze, &ctx, c_final.data(), f_delta.data());                // :104-142
+    if (!ctx.err.empty()) throw std::invalid_argument(ctx.err);
+    check(rc, "h2_ipa_rounds");
+    transcript.write_scalar(c_final);                                                                                  // :146-148
+    transcript.write_scalar(field::add(SF, f, f_delta));
+}
 
 // The independent column commits of a prover phase (plonk/prover.rs:93-101, 301-313; vanishing/prover.rs:96-108) spread over the
 // GPUs of one node from one process: column i -> devices[i % ndev], which holds handles[i % ndev] (the same bases registered on

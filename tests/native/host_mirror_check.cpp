@@ -36,8 +36,30 @@ static bool same_point(int curve, const Jacobian &a, const uint64_t *b_xyz) {
     return memcmp(x, y, 64) == 0;
 }
 
-int main() {
+// `host_mirror_check opening <k>`: the reference's test_opening_proof (poly/commitment.rs:305-379) through the C++ mirror -- Params::new(k),
+// a_i = i, a counter-driven rng -- printing the transcript bytes in hex; tests/test_gpu_opening.py compares them with the Python
+// mirror's for the same inputs (which is in turn pinned to the sequential restatement of the reference prover).
+static int opening_mode(uint32_t k) {
+    constexpr int CURVE = H2_VESTA, SF = H2_FP;
+    Params<CURVE> params = Params<CURVE>::new_params(k);
+    std::vector<Fe> px(params.n);
+    for (size_t i = 0; i < params.n; i++) px[i] = field::from_u64(SF, i);
+    const Blind<CURVE> blind{field::from_u64(SF, 7)};
+    uint64_t ctr = 0;
+    auto rng = [&]() { ++ctr; return field::from_u64(SF, ctr * 0x9E3779B97F4A7C15ULL + 1); };
+    Blake2bWrite<CURVE> tr;
+    tr.write_point(to_affine<CURVE>(params.commit(px, blind)));
+    const Fe x = tr.squeeze_challenge_scalar();
+    tr.write_scalar(eval_polynomial<SF>(px, x));
+    create_proof<CURVE>(params, rng, tr, px, blind, x);
+    for (uint8_t b : tr.finalize()) printf("%02x", b);
+    printf("\n");
+    return 0;
+}
+
+int main(int argc, char **argv) {
     if (h2_device_count() <= 0) { printf("no GPU: host mirror check needs an MI355X\n"); return 2; }
+    if (argc == 3 && std::string(argv[1]) == "opening") return opening_mode((uint32_t)atoi(argv[2]));
     constexpr int CURVE = H2_VESTA, FIELD = H2_FP;   // every proof in the reference runs on Vesta / Fp
     const uint32_t k = 8;
     const size_t n = (size_t)1 << k;

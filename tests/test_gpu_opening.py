@@ -255,3 +255,37 @@ def test_opening_hybrid_schedule_same_bytes(curve, k, hybrid):
     ov = vt.read_scalar()
     assert ipa.verify_proof(curve, k, g, w, u, vt, p_int, ox, ov)
     params.close()
+
+
+@pytest.mark.parametrize("k", [5, 13, 16])
+def test_native_host_mirror_opening_same_bytes(k):
+    """The C++ host mirror's create_proof + Blake2bWrite (halo2_amd/host/halo2_host.hpp, plain g++ over the C ABI: h2_commit,
+    h2_scale_add, h2_powers, h2_ipa_rounds) writes the bytes of the Python mirror for the same Params::new(k), polynomial and
+    randomness (k = 16 switches to the collapsed generators inside the library)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "host_mirror_check")
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} not built (run __graft_entry__.build())")
+    out = subprocess.run([exe, "opening", str(k)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    native = bytes.fromhex(out.stdout.strip().splitlines()[-1])
+    curve = h.VESTA
+    sf = fields.CURVE_FIELDS[curve][1]
+    n = 1 << k
+    params = h.Params.new(curve, k)
+    px = fields.to_limbs(range(n), sf, True)
+    blind = h.Blind(fields.scalar_limbs(7, sf, True))
+    ctr = [0]
+
+    def rng(count):
+        vals = [((ctr[0] + i + 1) * 0x9E3779B97F4A7C15 + 1) % (1 << 64) for i in range(count)]
+        ctr[0] += count
+        return fields.to_limbs(vals, sf, True)
+    tr = Blake2bWrite(curve)
+    tr.write_point(params.commit(px, blind, affine=True))
+    x = tr.squeeze_challenge_scalar()
+    tr.write_scalar(h.eval_polynomial(px, x, sf))
+    create_proof(params, rng, tr, px, blind, x)
+    assert tr.finalize() == native
+    params.close()
