@@ -25,10 +25,15 @@ template <int SRC> __device__ __forceinline__ fe g_bcast(const fe &r) {
 // lane-indexed operand pick, spelt with masks: a chain of `l == k ? a_k : ...` selects makes hipcc build a
 // lookup table in scratch memory and index it per lane
 __device__ __forceinline__ fe g_sel(int l, const fe &a0, const fe &a1, const fe &a2, const fe &a3) {
-    const u32 m0 = l == 0 ? ~0u : 0u, m1 = l == 1 ? ~0u : 0u, m2 = l == 2 ? ~0u : 0u, m3 = l >= 3 ? ~0u : 0u;
+    // three bit-field inserts per limb: (m & a) | (~m & b) is one v_bfi_b32
+    const u32 m0 = l == 0 ? ~0u : 0u, m1 = l == 1 ? ~0u : 0u, m2 = l == 2 ? ~0u : 0u;
     fe o;
 #pragma unroll
-    for (int i = 0; i < 8; i++) o.v[i] = (a0.v[i] & m0) | (a1.v[i] & m1) | (a2.v[i] & m2) | (a3.v[i] & m3);
+    for (int i = 0; i < 8; i++) {
+        const u32 t2 = (a2.v[i] & m2) | (a3.v[i] & ~m2);
+        const u32 t1 = (a1.v[i] & m1) | (t2 & ~m1);
+        o.v[i] = (a0.v[i] & m0) | (t1 & ~m0);
+    }
     return o;
 }
 // 2 * p; every lane of the group passes the same p and receives the same result (dbl-2008-s-1, a = 0)

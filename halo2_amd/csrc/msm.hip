@@ -997,14 +997,32 @@ template <int FB>
 __global__ void __launch_bounds__(64) msm_finish_heavy2(const u32 *__restrict__ scratch, u32 *__restrict__ buckets,
                                                         const u32 *__restrict__ heavy) {
     H2_LATENCY_STAGE();
-    if (blockIdx.x >= min(heavy[1], kMaxHeavy) || threadIdx.x >= kGroup) return;
-    const u32 b = heavy[2 + blockIdx.x];
-    xyzz<FB> acc = xyzz_load<FB>(buckets + 32 * (size_t)b);
-    for (u32 i = 0; i < kHeavyBlocks; ++i) {
-        xyzz<FB> p = xyzz_load<FB>(scratch + 32 * ((size_t)blockIdx.x * kHeavyBlocks + i));
+    __shared__ __attribute__((aligned(16))) u32 sh[32 * 16];
+    if (blockIdx.x >= min(heavy[1], kMaxHeavy)) return;
+    // one wave = 16 quads: quad q adds partials q and q + 16, then a 4-level tree (5 dependent additions instead of 32)
+    const u32 b = heavy[2 + blockIdx.x], q = threadIdx.x / kGroup;
+    const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
+    const u32 *src = scratch + 32 * ((size_t)blockIdx.x * kHeavyBlocks);
+    xyzz<FB> acc = xyzz_load<FB>(src + 32 * q);
+    for (u32 i = q + 16; i < kHeavyBlocks; i += 16) {
+        xyzz<FB> p = xyzz_load<FB>(src + 32 * i);
         xyzz_add_wide<FB>(acc, p);
     }
-    if (threadIdx.x == 0) xyzz_store<FB>(buckets + 32 * (size_t)b, acc);
+    if (lead) xyzz_store<FB>(sh + 32 * q, acc);
+    __syncthreads();
+    for (u32 off = 8; off > 0; off >>= 1) {
+        if (q < off) {
+            xyzz<FB> x = xyzz_load<FB>(sh + 32 * q), y = xyzz_load<FB>(sh + 32 * (q + off));
+            xyzz_add_wide<FB>(x, y);
+            if (lead) xyzz_store<FB>(sh + 32 * q, x);
+        }
+        __syncthreads();
+    }
+    if (q == 0) {
+        xyzz<FB> r = xyzz_load<FB>(sh), own = xyzz_load<FB>(buckets + 32 * (size_t)b);
+        xyzz_add_wide<FB>(r, own);
+        if (lead) xyzz_store<FB>(buckets + 32 * (size_t)b, r);
+    }
 }
 
 // The three tail kernels below run each logical lane as a quad of 4 hardware lanes (curve_wide.cuh): the chip
