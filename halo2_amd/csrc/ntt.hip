@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
             lds9_put(S, e, fe9_unpack(fe_load(in + 8 * (base + ((size_t)mid << s0) + col))));
         }
     }
-        const size_t lo_x = FIRST ? 0 : (lo0 + (tid & (T - 1)));
+    const size_t lo_x = FIRST ? 0 : (lo0 + (tid & (T - 1)));
     const u32 ngrp = tile >> 2;
     // stage-major table: the 2^t twiddles of stage t, omega^(xm 2^(L-t-1)) for xm < 2^t, sit contiguously at 2^t - 1 + xm, so
     // the T lanes of a tile row read T consecutive entries (one 128-byte run per plane) instead of entries 2^(L-t-1) apart
