@@ -4,7 +4,7 @@ import numpy as np, torch
 import halo2_amd as h
 from halo2_amd import fields
 from oracle import c_oracle as co, pasta as o
-for L in (16, 18, 20, 22, 24):
+for L in [int(x) for x in os.environ.get("NTT_SIZES", "16,18,20,22,24").split(",")]:
     a = co.random_field(h.FP, 3, 1 << L)
     d = torch.from_numpy(a.view(np.int64)).cuda()
     omega = fields.scalar_limbs(o.omega_for(o.P, L), h.FP, True)
