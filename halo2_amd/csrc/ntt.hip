@@ -357,42 +357,83 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
         hi_idx = blockIdx.x / tiles_per_hi;
         lo0 = (size_t)(blockIdx.x % tiles_per_hi) << logT;
     }
-    // ---- load ----
-    if (FIRST) {
-        const int cb = L - r;
-        fe9 lk0, lk1;
-        if (A.load_mode == 1) {
-            lk0 = fe9_from_r256<F>(from_param(A.lk0));
-            lk1 = fe9_from_r256<F>(from_param(A.lk1));
-        }
-        for (u32 e = tid; e < tile; e += nthr) {
-            u32 col = e & (T - 1), row = e >> logT;
-            size_t j = ((size_t)row << cb) + c0 + col;
+    // With an even number of stages the first radix-4 round takes its four elements straight from global memory and the last
+    // one stores straight to it: no load-all / barrier / store-all phases, a wave starts multiplying as soon as ITS loads are
+    // back, and two of the LDS round trips disappear.  (An odd stage count ends in a radix-2 round and keeps the store loop.)
+    constexpr bool FUSE_LOAD = R >= 2, FUSE_STORE = R >= 2 && (R % 2 == 0);
+    const u32 ngrp = tile >> 2;
+    // the element that sits in LDS row `row` (after the first pass's bit reversal), column `col`
+    auto load_elem = [&](u32 row, u32 col, const fe9 &lk0, const fe9 &lk1) -> fe9 {
+        if (FIRST) {
+            const size_t j = ((size_t)bitrev(row, r) << (L - r)) + c0 + col;
             fe9 v = fe9_zero();
             if (j < A.n_in) {
                 v = fe9_unpack(fe_load(in + 8 * j));
                 if (A.load_mode == 1) {
-                    u32 m3 = (u32)(j % 3);
+                    const u32 m3 = (u32)(j % 3);
                     if (m3) v = fe9_mul<F>(v, m3 == 1 ? lk0 : lk1);
                 }
             }
-            lds9_put(S, (bitrev(row, r) << logT) + col, v);
+            return v;
         }
-    } else {
-        const size_t base = (hi_idx << (s0 + r)) + lo0;
-        for (u32 e = tid; e < tile; e += nthr) {
-            u32 col = e & (T - 1), mid = e >> logT;
-            lds9_put(S, e, fe9_unpack(fe_load(in + 8 * (base + ((size_t)mid << s0) + col))));
+        return fe9_unpack(fe_load(in + 8 * ((hi_idx << (s0 + r)) + lo0 + ((size_t)row << s0) + col)));
+    };
+    auto load_factors = [&](fe9 &lk0, fe9 &lk1) {
+        lk0 = lk1 = fe9_zero();
+        if (FIRST && A.load_mode == 1) {
+            lk0 = fe9_from_r256<F>(from_param(A.lk0));
+            lk1 = fe9_from_r256<F>(from_param(A.lk1));
         }
+    };
+    auto store_factors = [&](fe9 &k0, fe9 &k1, fe9 &k2) {
+        k0 = k1 = k2 = fe9_zero();
+        if (A.store_mode) {
+            k0 = fe9_from_r256<F>(from_param(A.k0));
+            if (A.store_mode == 2) {
+                k1 = fe9_from_r256<F>(from_param(A.k1));
+                k2 = fe9_from_r256<F>(from_param(A.k2));
+            }
+        }
+    };
+    // the element of LDS row `mid`, column `col` leaves the pass
+    auto store_elem = [&](u32 mid, u32 col, fe9 v, const fe9 &k0, const fe9 &k1, const fe9 &k2) {
+        const size_t x = FIRST ? ((size_t)bitrev(c0 + col, L - r) << r) + mid : (hi_idx << (s0 + r)) + ((size_t)mid << s0) + lo0 + col;
+        if (!A.store_mode) v = ntt_fold9(v, S.qp);          // (a multiplication by the store factor takes the unfolded value)
+        fe w;
+        if (A.store_mode) {
+            const u32 m3 = A.store_mode == 2 ? (u32)(x % 3) : 0;
+            w = fe9_canonical_small<F>(fe9_mul<F>(v, m3 == 0 ? k0 : m3 == 1 ? k1 : k2));
+        } else if (A.last) {
+            w = fe9_canonical_small<F>(v);
+        } else {
+            w = ntt_pack_lazy9<F>(v);
+        }
+        fe_store(out + 8 * x, w);
+    };
+    if (!FUSE_LOAD) {
+        fe9 lk0, lk1;
+        load_factors(lk0, lk1);
+        for (u32 e = tid; e < tile; e += nthr) lds9_put(S, e, load_elem(e >> logT, e & (T - 1), lk0, lk1));
     }
-    const size_t lo_x = FIRST ? 0 : (lo0 + (tid & (T - 1)));
-    const u32 ngrp = tile >> 2;
+    // group q of round u in column col: rows mid00 + {0, 2^u, 2^(u+1), 3 2^u}; lanes take col fastest, except in a transposing
+    // (first-pass) fused store, where q runs fastest so that a wave writes one contiguous run of its column
+    auto lane_of = [&](int u, u32 &q, u32 &col) {
+        if (FIRST && FUSE_STORE && u == R - 2) {
+            q = tid & ((1u << (r - 2)) - 1);
+            col = tid >> (r - 2);
+        } else {
+            q = tid >> logT;
+            col = tid & (T - 1);
+        }
+    };
     // stage-major table: the 2^t twiddles of stage t, omega^(xm 2^(L-t-1)) for xm < 2^t, sit contiguously at 2^t - 1 + xm, so
     // the T lanes of a tile row read T consecutive entries (one 128-byte run per plane) instead of entries 2^(L-t-1) apart
     auto tw_addr = [&](int u, size_t &eA, size_t &eB0, size_t &eB1) {
+        u32 q, col;
+        lane_of(u, q, col);
         const int t = s0 + u;
-        const u32 q = tid >> logT, low = q & ((1u << u) - 1);
-        const size_t xm = ((size_t)low << s0) + lo_x;
+        const u32 low = q & ((1u << u) - 1);
+        const size_t xm = ((size_t)low << s0) + (FIRST ? 0 : lo0 + col);
         eA = (((size_t)1 << t) - 1) + xm;
         eB0 = (((size_t)2 << t) - 1) + xm;
         eB1 = eB0 + ((size_t)1 << t);
@@ -405,7 +446,7 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
         tw_addr(0, eA, eB0, eB1);
         wA = tw9_load(tw, eA);
     }
-    __syncthreads();
+    __syncthreads();                                   // the q p table (and, unfused, the tile) is in LDS
 #pragma unroll
     for (int u = 0; u + 1 < R; u += 2) {
         if (tid < ngrp) {
@@ -418,24 +459,46 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
                 tw_addr(u + 2, eA, nB0, nB1);
                 nA = tw9_load(tw, eA);
             }
-            const u32 col = tid & (T - 1), q = tid >> logT;
+            u32 q, col;
+            lane_of(u, q, col);
             const u32 low = q & ((1u << u) - 1);
             const u32 mid00 = ((q >> u) << (u + 2)) | low;
             const u32 s00 = (mid00 << logT) + col, s01 = s00 + (T << u), s10 = s00 + (T << (u + 1)), s11 = s10 + (T << u);
-            fe9 e0 = lds9_get(S, s00), e1 = lds9_get(S, s01), e2 = lds9_get(S, s10), e3 = lds9_get(S, s11);
+            fe9 e0, e1, e2, e3;
+            if (FUSE_LOAD && u == 0) {
+                fe9 lk0, lk1;
+                load_factors(lk0, lk1);
+                e0 = load_elem(mid00, col, lk0, lk1);
+                e1 = load_elem(mid00 + 1, col, lk0, lk1);
+                e2 = load_elem(mid00 + 2, col, lk0, lk1);
+                e3 = load_elem(mid00 + 3, col, lk0, lk1);
+            } else {
+                e0 = lds9_get(S, s00), e1 = lds9_get(S, s01), e2 = lds9_get(S, s10), e3 = lds9_get(S, s11);
+            }
             if (!(FIRST && u == 0)) {
                 e1 = fe9_mul<F>(e1, wA);
                 e3 = fe9_mul<F>(e3, wA);
             }
             const fe9 a0 = fe9_add(e0, e1), a1 = fe9_sub(e0, e1);
             const fe9 a2 = fe9_mul<F>(fe9_add(e2, e3), wB0), a3 = fe9_mul<F>(fe9_sub(e2, e3), wB1);
-            lds9_put(S, s00, fe9_norm(fe9_add(a0, a2)));
-            lds9_put(S, s10, fe9_norm(fe9_sub(a0, a2)));
-            lds9_put(S, s01, fe9_norm(fe9_add(a1, a3)));
-            lds9_put(S, s11, fe9_norm(fe9_sub(a1, a3)));
+            const fe9 o00 = fe9_norm(fe9_add(a0, a2)), o10 = fe9_norm(fe9_sub(a0, a2));
+            const fe9 o01 = fe9_norm(fe9_add(a1, a3)), o11 = fe9_norm(fe9_sub(a1, a3));
+            if (FUSE_STORE && u == R - 2) {
+                fe9 k0, k1, k2;
+                store_factors(k0, k1, k2);
+                store_elem(mid00, col, o00, k0, k1, k2);
+                store_elem(mid00 + (1u << u), col, o01, k0, k1, k2);
+                store_elem(mid00 + (2u << u), col, o10, k0, k1, k2);
+                store_elem(mid00 + (3u << u), col, o11, k0, k1, k2);
+            } else {
+                lds9_put(S, s00, o00);
+                lds9_put(S, s10, o10);
+                lds9_put(S, s01, o01);
+                lds9_put(S, s11, o11);
+            }
             wA = nA;
         }
-        __syncthreads();
+        if (!(FUSE_STORE && u == R - 2)) __syncthreads();
     }
     if (R & 1) {
         constexpr int u = R - 1;
@@ -454,39 +517,21 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
         }
         __syncthreads();
     }
-    // ---- store ----
-    fe9 k0 = fe9_zero(), k1 = k0, k2 = k0;
-    if (A.store_mode) {
-        k0 = fe9_from_r256<F>(from_param(A.k0));
-        if (A.store_mode == 2) {
-            k1 = fe9_from_r256<F>(from_param(A.k1));
-            k2 = fe9_from_r256<F>(from_param(A.k2));
+    // ---- store (passes that end in a radix-2 round) ----
+    if (!FUSE_STORE) {
+        fe9 k0, k1, k2;
+        store_factors(k0, k1, k2);
+        for (u32 e = tid; e < tile; e += nthr) {
+            u32 col, mid;
+            if (FIRST) {
+                mid = e & (rows - 1);
+                col = e >> r;
+            } else {
+                col = e & (T - 1);
+                mid = e >> logT;
+            }
+            store_elem(mid, col, lds9_get(S, (mid << logT) + col), k0, k1, k2);
         }
-    }
-    for (u32 e = tid; e < tile; e += nthr) {
-        u32 col, mid;
-        size_t x;
-        if (FIRST) {
-            mid = e & (rows - 1);
-            col = e >> r;
-            x = ((size_t)bitrev(c0 + col, L - r) << r) + mid;
-        } else {
-            col = e & (T - 1);
-            mid = e >> logT;
-            x = (hi_idx << (s0 + r)) + ((size_t)mid << s0) + lo0 + col;
-        }
-        fe9 v = lds9_get(S, (mid << logT) + col);
-        if (!A.store_mode) v = ntt_fold9(v, S.qp);          // (a multiplication by the store factor takes the unfolded value)
-        fe w;
-        if (A.store_mode) {
-            const u32 m3 = A.store_mode == 2 ? (u32)(x % 3) : 0;
-            w = fe9_canonical_small<F>(fe9_mul<F>(v, m3 == 0 ? k0 : m3 == 1 ? k1 : k2));
-        } else if (A.last) {
-            w = fe9_canonical_small<F>(v);
-        } else {
-            w = ntt_pack_lazy9<F>(v);
-        }
-        fe_store(out + 8 * x, w);
     }
 }
 
