@@ -790,6 +790,16 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
     const int P = (L + maxr - 1) / maxr;
     int stages[40];
     for (int i = 0; i < P; ++i) stages[i] = L / P + (i < L % P ? 1 : 0);
+    // passes with an even stage count fuse their loads and stores into the first and last radix-4 round: pair up odd counts
+    for (int i = 0; i < P; ++i) {
+        if (!(stages[i] & 1)) continue;
+        for (int j = i + 1; j < P; ++j)
+            if ((stages[j] & 1) && stages[i] + 1 <= maxr && stages[j] >= 2) {
+                stages[i] += 1;
+                stages[j] -= 1;
+                break;
+            }
+    }
     const size_t n = (size_t)1 << L;
     int dev = 0;
     (void)hipGetDevice(&dev);
