@@ -283,15 +283,19 @@ def main():
             a = co.random_field(h.FP, 7 + log_n, 1 << log_n)
             d_a = torch.from_numpy(a.view(np.int64)).to(dev)
             omega = fields.scalar_limbs(pasta.omega_for(pasta.P, log_n), h.FP)
-            for _ in range(25):                      # clocks settle over a few hundred microseconds of sustained load
-                h.best_fft(d_a, omega, log_n, h.FP)
-            torch.cuda.synchronize()
-            reps = 40
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                h.best_fft(d_a, omega, log_n, h.FP)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / reps
+            t_w = time.perf_counter()                # clocks settle over tens of milliseconds of sustained load (the GPU idled
+            while time.perf_counter() - t_w < 0.05:  # through the CPU baseline): warm up by time, not by count
+                for _ in range(25):
+                    h.best_fft(d_a, omega, log_n, h.FP)
+                torch.cuda.synchronize()
+            reps, runs = 40, []
+            for _run in range(3):
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    h.best_fft(d_a, omega, log_n, h.FP)
+                torch.cuda.synchronize()
+                runs.append((time.perf_counter() - t1) / reps)
+            dt = sorted(runs)[1]                     # median of three runs of 40 transforms
             lib.h2_profile_enable(1)                 # per-pass HIP events (they cost ~20 us per transform: not in `ms`)
             for _ in range(reps):
                 h.best_fft(d_a, omega, log_n, h.FP)
@@ -318,10 +322,12 @@ def main():
                 d_cols_ntt = [torch.from_numpy(a.view(np.int64)).to(dev) for _ in range(2 * len(streams))]
                 torch.cuda.synchronize()
                 reps_b = 8
-                for rep_ in range(reps_b + 3):
-                    if rep_ == 3:
-                        torch.cuda.synchronize()
-                        t3 = time.perf_counter()
+                t_w = time.perf_counter()
+                while time.perf_counter() - t_w < 0.05:          # the CPU transform above left the GPU idle: warm up by time
+                    h.best_fft_batch(d_cols_ntt, omega, log_n, h.FP)
+                    torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                for rep_ in range(reps_b):
                     h.best_fft_batch(d_cols_ntt, omega, log_n, h.FP)
                 torch.cuda.synchronize()
                 ms_dt = (time.perf_counter() - t3) / (reps_b * len(d_cols_ntt))
