@@ -136,8 +136,9 @@ static int choose_c(size_t n, bool shared_buckets) {
     // bits: 2 for c = 14, 8 for c = 12 or 15 -- every entry of that window then lands in a few hundred buckets, which are
     // summed by the (slow) heavy-bucket path.  c = 10, 13 and 16 fill their top window (8 of 10, 11 of 13, 16 of 16 bits).
     // Small multiexps are pure latency (a chain of ~128 doublings plus the per-slice folds); measured over c = 4..14
-    // (bench/tools/c_sweep_small.py): 0.67-0.72 ms at c = 10 up to 2^12 points, c = 13 up to 2^17, c = 16 beyond.
-    if (glv) return n <= 4096 ? 10 : n <= 131072 ? 13 : 16;
+    // (bench/tools/c_sweep_small.py): 0.67-0.72 ms at c = 10 up to 2^12 points, c = 13 up to 2^19 (2^18: 1.08 against 1.20 ms at
+    // c = 16, 2^19: 1.43 against 1.52; 2^20: equal, and the accumulate is shorter with 16), c = 16 beyond.
+    if (glv) return n <= 4096 ? 10 : n <= 524288 ? 13 : 16;
     double best = 1e300;
     int bc = 4;
     for (int c = 4; c <= kMaxC; ++c) {
