@@ -139,6 +139,12 @@ static int choose_c(size_t n, bool shared_buckets) {
     // (bench/tools/c_sweep_small.py): 0.67-0.72 ms at c = 10 up to 2^12 points, c = 13 up to 2^19 (2^18: 1.08 against 1.20 ms at
     // c = 16, 2^19: 1.43 against 1.52; 2^20: equal, and the accumulate is shorter with 16), c = 16 beyond.
     if (glv) return n <= 4096 ? 10 : n <= 524288 ? 13 : 16;
+    // Registered tables: a commit below ~2^17 points is a chain of latency-bound kernels, not bucket arithmetic, and the widths
+    // whose top window is nearly empty (255 mod c small: 12, 14) send that window through the heavy-bucket path.  Measured, one
+    // commit alone (bench/tools/c_sweep_registered.py): 8 bits up to 2^9 points (0.21-0.27 ms), 10 up to 2^10 (0.32), 13 up to
+    // 2^13 (0.35-0.39; 12 bits at 2^12: 0.59; a paired commit at 2^13: 0.39 against 0.44 with 16), 16 from 2^14 on (0.41-0.49;
+    // the cost model below picked 13-14 bits there: 2^15 0.48 -> 0.42).
+    if (shared_buckets) return n <= 512 ? 8 : n <= 1536 ? 10 : n <= 12288 ? 13 : 16;
     double best = 1e300;
     int bc = 4;
     for (int c = 4; c <= kMaxC; ++c) {
