@@ -769,8 +769,9 @@ __global__ void __launch_bounds__(256) msm_s2_prefix(u32 *__restrict__ hist2, co
 }
 
 // lanes actually used for M sorted entries: the launch is sized for the worst case (no zero digits); sparse or tiny
-// columns use fewer lanes so that a lane's range keeps >= 16 entries
-__device__ __forceinline__ u32 eff_lanes(u32 M, u32 T) { return min(T, max(256u, (M + 15) / 16)); }
+// columns use fewer lanes so that a lane's range keeps >= `div` entries
+// (16 entries for full-size columns; 8 for small ones, which are latency-bound: more, shorter lanes -- `div`)
+__device__ __forceinline__ u32 eff_lanes(u32 M, u32 T, u32 div) { return min(T, max(256u, (M + div - 1) / div)); }
 
 // largest b in [0, n) with arr[b] <= t  (arr non-decreasing, arr[0] = 0)
 __device__ __forceinline__ u32 upper_bucket(const u32 *__restrict__ arr, u32 n, u32 t) {
@@ -822,10 +823,10 @@ template <int FB, bool GLV, bool M9 = false>
 __global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
                                                       u32 extra_index, const u32 *__restrict__ entries,
                                                       const u32 *__restrict__ starts, u32 *__restrict__ heads,
-                                                      u32 *__restrict__ buckets, u32 total_buckets, u32 T) {
+                                                      u32 *__restrict__ buckets, u32 total_buckets, u32 T, u32 div) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 M = starts[total_buckets];
-    T = eff_lanes(M, T);
+    T = eff_lanes(M, T, div);
     if (t >= T) return;
     const u32 chunk = (M + T - 1) / T;
     const u32 lo = min(M, t * chunk), hi = min(M, lo + chunk);
@@ -930,14 +931,14 @@ static constexpr u32 kMaxHeavy = 512;   // heavy buckets handed to the workgroup
 template <int FB>
 __global__ void __launch_bounds__(256) msm_finish_buckets(const u32 *__restrict__ heads, const u32 *__restrict__ starts,
                                                           u32 *__restrict__ buckets, u32 *__restrict__ heavy,
-                                                          u32 total_buckets, u32 T) {
+                                                          u32 total_buckets, u32 T, u32 div) {
     H2_LATENCY_STAGE();
     // one quad of lanes per bucket (curve_wide.cuh)
     const u32 b = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
     if (b >= total_buckets) return;
     const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
     const u32 M = starts[total_buckets];
-    T = eff_lanes(M, T);
+    T = eff_lanes(M, T, div);
     const u32 chunk = max(1u, (M + T - 1) / T);
     const u32 h0 = (starts[b] + chunk - 1) / chunk, h1 = (starts[b + 1] + chunk - 1) / chunk;
     if (h1 <= h0) return;
@@ -968,14 +969,14 @@ static constexpr u32 kHeavyBlocks = 32;
 template <int FB>
 __global__ void __launch_bounds__(256) msm_finish_heavy(const u32 *__restrict__ heads, const u32 *__restrict__ starts,
                                                         u32 *__restrict__ scratch, const u32 *__restrict__ heavy,
-                                                        u32 total_buckets, u32 T) {
+                                                        u32 total_buckets, u32 T, u32 div) {
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
     if (blockIdx.y >= min(heavy[1], kMaxHeavy)) return;
     const u32 b = heavy[2 + blockIdx.y], t = threadIdx.x / kGroup, nl = blockDim.x / kGroup;
     const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
     const u32 M = starts[total_buckets];
-    T = eff_lanes(M, T);
+    T = eff_lanes(M, T, div);
     const u32 chunk = max(1u, (M + T - 1) / T);
     const u32 h0 = (starts[b] + chunk - 1) / chunk, h1 = (starts[b + 1] + chunk - 1) / chunk;
     const u32 share = (h1 - h0 + kHeavyBlocks - 1) / kHeavyBlocks;
@@ -1509,7 +1510,11 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     // of a commit running on ANOTHER stream can overlap this kernel (independent column commits)
     const double fraction = a.lane_fraction > 0.0 ? a.lane_fraction : g_lane_fraction.load();
     const u32 usable = std::max(256u, (u32)(lanes * fraction) / 256u * 256u);
-    u32 T = (u32)std::min<size_t>(usable, std::max<size_t>(256, (all_items / 16 + 255) / 256 * 256));
+    // entries per lane of the accumulate: 16 for full-size columns; small commits are chains of latency-bound kernels and run
+    // shorter with more, shorter lanes (one registered commit at 2^11 .. 2^15 points: 3-7 % faster at 8; H2_MSM_DIV: sweeps only)
+    static const u32 env_div = [] { const char *e = getenv("H2_MSM_DIV"); int v = e ? atoi(e) : 0; return (u32)(v >= 1 && v <= 64 ? v : 0); }();
+    const u32 lane_div = env_div ? env_div : (all_items < ((size_t)1 << 20) ? 8u : 16u);
+    u32 T = (u32)std::min<size_t>(usable, std::max<size_t>(256, (all_items / lane_div + 255) / 256 * 256));
     const u32 max_heavy = kMaxHeavy;
     // two-pass sort (registered path): always for windows beyond 16 bits, else for large bucket counts
     Sort2 S2;
@@ -1712,7 +1717,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     prof_begin(PROF_MSM_ACCUMULATE, st);
     if (glv && !m9)
         hipLaunchKernelGGL((msm_accumulate<FB, true>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases, (const u32 *)nullptr,
-                           (u32)scalars_n, cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T);
+                           (u32)scalars_n, cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T, lane_div);
     else if (m9) {
         const u32 *pts = (const u32 *)a.d_bases;
         if (glv) {
@@ -1722,21 +1727,21 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         }
         hipLaunchKernelGGL((msm_accumulate<FB, false, true>), dim3(T / 256), dim3(256), 0, st, pts,
                            (const u32 *)nullptr, 0xFFFFFFFFu, cx.entries.as<u32>(), cx.starts.as<u32>(), cx.seg9.as<u32>(),
-                           cx.seg9.as<u32>() + 36 * (size_t)T, tb, T);
+                           cx.seg9.as<u32>() + 36 * (size_t)T, tb, T, lane_div);
         hipLaunchKernelGGL((msm_segments_to_r256<FB>), dim3((T + tb + 255) / 256), dim3(256), 0, st, cx.seg9.as<u32>(),
                            cx.heads.as<u32>(), cx.buckets.as<u32>(), T, tb);
     }
     else
         hipLaunchKernelGGL((msm_accumulate<FB, false>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases,
                            (const u32 *)a.d_extra_base, (!a.table && a.d_extra_base) ? (u32)a.n_used : 0xFFFFFFFFu,
-                           cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T);
+                           cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T, lane_div);
     prof_end(PROF_MSM_ACCUMULATE, st);
     TL_STAMP(tl_id | 3);
     prof_begin(PROF_MSM_REDUCE, st);
     hipLaunchKernelGGL((msm_finish_buckets<FB>), dim3((tb * kGroup + 255) / 256), dim3(256), 0, st, cx.heads.as<u32>(),
-                       cx.starts.as<u32>(), cx.buckets.as<u32>(), cx.heavy.as<u32>(), tb, T);
+                       cx.starts.as<u32>(), cx.buckets.as<u32>(), cx.heavy.as<u32>(), tb, T, lane_div);
     hipLaunchKernelGGL((msm_finish_heavy<FB>), dim3(kHeavyBlocks, max_heavy), dim3(256), (256 / kGroup) * 128, st,
-                       cx.heads.as<u32>(), cx.starts.as<u32>(), cx.hscratch.as<u32>(), cx.heavy.as<u32>(), tb, T);
+                       cx.heads.as<u32>(), cx.starts.as<u32>(), cx.hscratch.as<u32>(), cx.heavy.as<u32>(), tb, T, lane_div);
     hipLaunchKernelGGL((msm_finish_heavy2<FB>), dim3(max_heavy), dim3(64), 0, st, cx.hscratch.as<u32>(), cx.buckets.as<u32>(),
                        cx.heavy.as<u32>());
     {
