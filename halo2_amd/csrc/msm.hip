@@ -99,7 +99,7 @@ static bool pair_geometry(size_t m, int c, u32 stride, int *lowb_out, int *lb_ou
     return true;
 }
 
-static constexpr int kSeg = 8;     // buckets per reduce segment
+static constexpr int kSeg = 4;     // buckets per reduce segment when the fold is latency-bound (few segments), else 2 kSeg
 static constexpr u32 kScanBlock = 1024;
 
 struct MsmShape {
@@ -1039,21 +1039,21 @@ __global__ void __launch_bounds__(64) msm_finish_heavy2(const u32 *__restrict__ 
 // ---- reduce level 1: segment of kSeg buckets -> sum_j (j+1) * B_j restricted to the segment ------
 template <int FB>
 __global__ void __launch_bounds__(256) msm_reduce_segments(const u32 *__restrict__ buckets, u32 *__restrict__ partial,
-                                                           u32 NB, u32 total_segments) {
+                                                           u32 NB, u32 total_segments, int seg) {
     H2_LATENCY_STAGE();
     const u32 t = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
     if (t >= total_segments) return;
-    u32 segs_per_slice = NB / kSeg;
+    u32 segs_per_slice = NB / seg;
     u32 sl = t / segs_per_slice, sg = t % segs_per_slice;
-    const u32 *base = buckets + 32 * ((size_t)sl * NB + (size_t)sg * kSeg);
+    const u32 *base = buckets + 32 * ((size_t)sl * NB + (size_t)sg * seg);
     xyzz<FB> run = xyzz_identity<FB>(), acc = xyzz_identity<FB>();
-    for (int j = kSeg - 1; j >= 0; --j) {
+    for (int j = seg - 1; j >= 0; --j) {
         xyzz<FB> bk = xyzz_load<FB>(base + 32 * j);
         xyzz_add_wide<FB>(run, bk);
         xyzz_add_wide<FB>(acc, run);
     }
-    // buckets of this segment carry weights sg*kSeg + (j+1): add (sg*kSeg) * run
-    xyzz<FB> sh = xyzz_mul_small_wide<FB>(run, sg * kSeg);
+    // buckets of this segment carry weights sg*seg + (j+1): add (sg*seg) * run
+    xyzz<FB> sh = xyzz_mul_small_wide<FB>(run, sg * seg);
     xyzz_add_wide<FB>(acc, sh);
     if ((threadIdx.x & (kGroup - 1)) == 0) xyzz_store<FB>(partial + 32 * (size_t)t, acc);
 }
@@ -1759,11 +1759,15 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
             fold_slices = 2;
             fold_c = (sh.c - 1) / 2;      // log2 S
         }
-        const u32 fold_segs = fold_slices * fold_nb / kSeg;
+        // A segment is 2 seg running-sum additions + a small-scalar multiple (~23 more dependent operations) on one quad of lanes:
+        // 4 buckets while the segments fit the chip a few times over (the fold is their latency: one commit 0.235 -> 0.218 ms,
+        // small commits 5-8 %), 8 when there are many slices (generic multiexps of 2^20 points: the multiples are throughput)
+        const int seg = (size_t)fold_slices * fold_nb / kSeg <= 32768 ? kSeg : 2 * kSeg;
+        const u32 fold_segs = fold_slices * fold_nb / seg;
         hipLaunchKernelGGL((msm_reduce_segments<FB>), dim3((fold_segs * kGroup + 255) / 256), dim3(256), 0, st, fold_src,
-                           cx.partial.as<u32>(), fold_nb, fold_segs);
+                           cx.partial.as<u32>(), fold_nb, fold_segs, seg);
         // 64 logical lanes per workgroup; first level leaves <= 32 block sums per slice
-        const u32 per_slice = fold_nb / kSeg, nl = 256 / kGroup;
+        const u32 per_slice = fold_nb / seg, nl = 256 / kGroup;
         const u32 bps = std::max(1u, std::min(32u, per_slice / (2 * nl)));
         const u32 share = (per_slice + bps - 1) / bps;
         if (bps > 1) {
