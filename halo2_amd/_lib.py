@@ -65,6 +65,16 @@ SIGNATURES = {
     "h2_ipa_rounds": ([C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_int, u64p, u64p, u64p, u64p, u64p, IPA_WRITE_POINT_FN, IPA_SQUEEZE_FN, vp,
                       u64p, u64p], C.c_int),
     "h2_ipa_default_switch_rounds": ([C.c_uint, C.c_int], C.c_uint),
+    "h2_transcript_new": ([C.c_int, C.POINTER(C.c_uint64)], C.c_int),
+    "h2_transcript_free": ([C.c_uint64], C.c_int),
+    "h2_transcript_common_point": ([C.c_uint64, u64p, C.c_int], C.c_int),
+    "h2_transcript_write_point": ([C.c_uint64, u64p, C.c_int], C.c_int),
+    "h2_transcript_common_scalar": ([C.c_uint64, u64p], C.c_int),
+    "h2_transcript_write_scalar": ([C.c_uint64, u64p], C.c_int),
+    "h2_transcript_squeeze_challenge": ([C.c_uint64, u64p], C.c_int),
+    "h2_transcript_bytes": ([C.c_uint64, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t)], C.c_int),
+    "h2_transcript_cb_write_point": ([vp, u64p], C.c_int),
+    "h2_transcript_cb_squeeze": ([vp, u64p], C.c_int),
     "h2_ipa_collapsed_generators_device": ([C.c_uint64, C.c_uint, C.c_uint, u64p, C.c_int, vp, vp], C.c_int),
     "h2_bases_register_device": ([C.c_int, vp, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)], C.c_int),
     "h2_lagrange_basis": ([C.c_int, u64p, u64p, C.c_uint, C.c_int], C.c_int),

@@ -283,22 +283,28 @@ class Params:
         if J != IPA_SWITCH_DEFAULT and (J < 0 or J >= k or J > 12 or (J and not paired)):
             raise ValueError("opening_rounds: hybrid_rounds must be in [0, min(k - 1, 12)] and needs the paired schedule")
         failure = []
+        if getattr(transcript, "handle", 0):
+            # a transcript of the library (halo2_amd.transcript): the loop calls it natively, no Python in between
+            cb_w = C.cast(lib().h2_transcript_cb_write_point, IPA_WRITE_POINT_FN)
+            cb_s = C.cast(lib().h2_transcript_cb_squeeze, IPA_SQUEEZE_FN)
+            user = C.c_void_p(transcript.handle)
+        else:
+            def write_point(_user, xy):
+                try:
+                    transcript.write_point(np.ctypeslib.as_array(xy, shape=(8,)).copy())
+                    return 0
+                except Exception as e:                      # an exception must not unwind through the C frames
+                    failure.append(e)
+                    return 1
 
-        def write_point(_user, xy):
-            try:
-                transcript.write_point(np.ctypeslib.as_array(xy, shape=(8,)).copy())
-                return 0
-            except Exception as e:                      # an exception must not unwind through the C frames
-                failure.append(e)
-                return 1
-
-        def squeeze(_user, out):
-            try:
-                np.ctypeslib.as_array(out, shape=(4,))[:] = np.asarray(transcript.squeeze_challenge_scalar(), dtype=np.uint64).reshape(4)
-                return 0
-            except Exception as e:
-                failure.append(e)
-                return 1
+            def squeeze(_user, out):
+                try:
+                    np.ctypeslib.as_array(out, shape=(4,))[:] = np.asarray(transcript.squeeze_challenge_scalar(), dtype=np.uint64).reshape(4)
+                    return 0
+                except Exception as e:
+                    failure.append(e)
+                    return 1
+            cb_w, cb_s, user = IPA_WRITE_POINT_FN(write_point), IPA_SQUEEZE_FN(squeeze), None
         col_l = torch.empty((n + (4 if paired else 2), 4), dtype=torch.int64, device=dev)
         col_r = None if paired else torch.empty((n + 2, 4), dtype=torch.int64, device=dev)
         c = np.zeros(4, dtype=np.uint64)
@@ -306,7 +312,7 @@ class Params:
         uw = np.ascontiguousarray(np.stack([self.u, self.w]), dtype=np.uint64)
         rc = lib().h2_ipa_rounds_device(self.curve, k, J, self._opening_basis(paired), 1 if paired else 0, d_p.data_ptr(), d_b.data_ptr(),
                                         _p(z), _p(rands), _p(uw), col_l.data_ptr(), col_r.data_ptr() if col_r is not None else None,
-                                        IPA_WRITE_POINT_FN(write_point), IPA_SQUEEZE_FN(squeeze), None, _p(c), _p(f), _stream_ptr())
+                                        cb_w, cb_s, user, _p(c), _p(f), _stream_ptr())
         if failure:
             raise failure[0]
         check(rc, "h2_ipa_rounds_device")

@@ -325,47 +325,6 @@ __global__ void ipa_round_tails(const u32 *__restrict__ ip, fe z, fe l_rand, fe 
     fe_store(br, r_rand);
 }
 
-static void host_add(int f, u64 r[4], const u64 a[4], const u64 b[4]) {
-    const HostField &F = kHostField[f];
-    u64 t[4];
-    u128 c = 0;
-    for (int i = 0; i < 4; ++i) {
-        c += (u128)a[i] + b[i];
-        t[i] = (u64)c;
-        c >>= 64;
-    }
-    bool ge = true;                       // both below p < 2^255: no carry out of 256 bits
-    for (int i = 3; i >= 0; --i) {
-        if (t[i] > F.p[i]) break;
-        if (t[i] < F.p[i]) { ge = false; break; }
-    }
-    if (ge) {
-        u128 br = 0;
-        for (int i = 0; i < 4; ++i) {
-            u128 d = (u128)t[i] - F.p[i] - (u64)br;
-            t[i] = (u64)d;
-            br = (d >> 64) & 1;
-        }
-    }
-    memcpy(r, t, 32);
-}
-
-// a^(p - 2), Montgomery in and out (a != 0)
-static void host_inv(int f, u64 r[4], const u64 a[4]) {
-    const HostField &F = kHostField[f];
-    u64 e[4] = {F.p[0] - 2, F.p[1], F.p[2], F.p[3]};      // p[0] ends in ...0001: no borrow
-    u64 acc[4], base[4];
-    memcpy(acc, F.one, 32);
-    memcpy(base, a, 32);
-    for (int i = 0; i < 255; ++i) {
-        if ((e[i >> 6] >> (i & 63)) & 1) host_mul(f, acc, acc, base);
-        host_mul(f, base, base, base);
-    }
-    memcpy(r, acc, 32);
-}
-
-static bool host_is_zero(const u64 a[4]) { return !(a[0] | a[1] | a[2] | a[3]); }
-
 }  // namespace h2
 
 using namespace h2;

@@ -350,124 +350,41 @@ template <int CURVE> class Params {
 };
 
 // ---- transcript.rs -----------------------------------------------------------------------------------------------
-// BLAKE2b-512 (RFC 7693) with a personalisation string, as blake2b_simd::Params::new().hash_length(64).personal(..) builds it
-class Blake2bState {
+// Blake2bWrite<_, C, Challenge255<C>> (transcript.rs:150-198, 286-296) over the library's transcript object (h2_transcript_*:
+// BLAKE2b-512 personalised "Halo2-Transcript"; points absorbed as canonical (x, y) and written compressed; a challenge is the
+// 64-byte digest of a copy of the state reduced into the scalar field).  Keeping the state in the library lets the opening
+// argument's round loop (h2_ipa_rounds) absorb L_j, R_j and squeeze its challenges without a callback into this header.
+template <int CURVE> class Blake2bWrite {
   public:
-    explicit Blake2bState(const char personal[16]) {
-        static const uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
-                                       0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
-        uint64_t pw[2];
-        memcpy(pw, personal, 16);
-        for (int i = 0; i < 8; i++) h[i] = IV[i];
-        h[0] ^= 0x01010000ULL ^ 64;          // digest length 64, no key, fanout 1, depth 1
-        h[6] ^= pw[0];
-        h[7] ^= pw[1];
+    Blake2bWrite() { check(h2_transcript_new(CURVE, &h), "h2_transcript_new"); }
+    ~Blake2bWrite() { if (h) h2_transcript_free(h); }
+    Blake2bWrite(const Blake2bWrite &) = delete;
+    Blake2bWrite &operator=(const Blake2bWrite &) = delete;
+    void common_point(const Affine &p) { point(h2_transcript_common_point(h, p.data(), 0)); }                          // :206-219
+    void write_point(const Affine &p) { point(h2_transcript_write_point(h, p.data(), 0)); }                            // :183-187
+    void write_point(const Jacobian &p) { point(h2_transcript_write_point(h, p.data(), 1)); }                          // .to_affine() first
+    void common_scalar(const Fe &s) { check(h2_transcript_common_scalar(h, s.data()), "h2_transcript_common_scalar"); } // :221-227
+    void write_scalar(const Fe &s) { check(h2_transcript_write_scalar(h, s.data()), "h2_transcript_write_scalar"); }    // :188-192
+    Fe squeeze_challenge_scalar() {                                                                                    // :200-205, :286-296
+        Fe u{};
+        check(h2_transcript_squeeze_challenge(h, u.data()), "h2_transcript_squeeze_challenge");
+        return u;
     }
-    void update(const uint8_t *in, size_t len) {
-        while (len) {
-            if (fill == 128) { t += 128; compress(false); fill = 0; }     // only once more input is known to follow
-            const size_t take = std::min(len, (size_t)128 - fill);
-            memcpy(buf + fill, in, take);
-            fill += take; in += take; len -= take;
-        }
-    }
-    std::array<uint8_t, 64> finalize() const {                            // on a copy: the transcript keeps absorbing (transcript.rs:202)
-        Blake2bState c = *this;
-        c.t += c.fill;
-        memset(c.buf + c.fill, 0, 128 - c.fill);
-        c.compress(true);
-        std::array<uint8_t, 64> out;
-        memcpy(out.data(), c.h, 64);
+    std::vector<uint8_t> finalize() const {
+        size_t len = 0;
+        check(h2_transcript_bytes(h, nullptr, 0, &len), "h2_transcript_bytes");
+        std::vector<uint8_t> out(len);
+        check(h2_transcript_bytes(h, out.data(), out.size(), &len), "h2_transcript_bytes");
         return out;
     }
+    h2_transcript_t handle() const { return h; }
 
   private:
-    uint64_t h[8], t = 0;
-    uint8_t buf[128];
-    size_t fill = 0;
-    static uint64_t rotr(uint64_t x, int r) { return (x >> r) | (x << (64 - r)); }
-    void compress(bool last) {
-        static const uint8_t S[12][16] = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
-                                          {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
-                                          {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
-                                          {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
-                                          {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
-                                          {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
-        static const uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
-                                       0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
-        uint64_t m[16], v[16];
-        memcpy(m, buf, 128);
-        for (int i = 0; i < 8; i++) { v[i] = h[i]; v[8 + i] = IV[i]; }
-        v[12] ^= t;
-        if (last) v[14] = ~v[14];
-        auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
-            v[a] = v[a] + v[b] + x; v[d] = rotr(v[d] ^ v[a], 32);
-            v[c] = v[c] + v[d];     v[b] = rotr(v[b] ^ v[c], 24);
-            v[a] = v[a] + v[b] + y; v[d] = rotr(v[d] ^ v[a], 16);
-            v[c] = v[c] + v[d];     v[b] = rotr(v[b] ^ v[c], 63);
-        };
-        for (int r = 0; r < 12; r++) {
-            const uint8_t *s = S[r];
-            G(0, 4, 8, 12, m[s[0]], m[s[1]]);   G(1, 5, 9, 13, m[s[2]], m[s[3]]);
-            G(2, 6, 10, 14, m[s[4]], m[s[5]]);  G(3, 7, 11, 15, m[s[6]], m[s[7]]);
-            G(0, 5, 10, 15, m[s[8]], m[s[9]]);  G(1, 6, 11, 12, m[s[10]], m[s[11]]);
-            G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
-        }
-        for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[8 + i];
+    h2_transcript_t h = 0;
+    static void point(int rc) {
+        if (rc == H2_ERR_ARGS) throw std::invalid_argument("cannot write points at infinity to the transcript");           // :209-214
+        check(rc, "h2_transcript_write_point");
     }
-};
-
-// Blake2bWrite<_, C, Challenge255<C>> (transcript.rs:150-198, 286-296): points are absorbed as (x, y) canonical little-endian and
-// written compressed; a challenge is the 64-byte digest of a copy of the state, reduced into the scalar field
-template <int CURVE> class Blake2bWrite {
-    static constexpr int BF = CURVE == H2_PALLAS ? H2_FP : H2_FQ, SF = CURVE == H2_PALLAS ? H2_FQ : H2_FP;
-
-  public:
-    Blake2bWrite() : state("Halo2-Transcript") {}
-    void common_point(const Affine &p) {                                                                               // :206-219
-        if (!(p[0] | p[1] | p[2] | p[3] | p[4] | p[5] | p[6] | p[7])) throw std::invalid_argument("cannot write points at infinity to the transcript");
-        const uint8_t prefix = 1;
-        state.update(&prefix, 1);
-        const Fe x = field::from_mont(BF, {p[0], p[1], p[2], p[3]}), y = field::from_mont(BF, {p[4], p[5], p[6], p[7]});
-        state.update(reinterpret_cast<const uint8_t *>(x.data()), 32);
-        state.update(reinterpret_cast<const uint8_t *>(y.data()), 32);
-    }
-    void write_point(const Affine &p) {                                                                                // :183-187
-        common_point(p);
-        const Fe x = field::from_mont(BF, {p[0], p[1], p[2], p[3]}), y = field::from_mont(BF, {p[4], p[5], p[6], p[7]});
-        uint8_t enc[32];
-        memcpy(enc, x.data(), 32);
-        enc[31] |= (uint8_t)((y[0] & 1) << 7);                   // pasta_curves to_bytes: the sign of y in the top bit
-        writer.insert(writer.end(), enc, enc + 32);
-    }
-    void common_scalar(const Fe &s) {                                                                                  // :221-227
-        const uint8_t prefix = 2;
-        state.update(&prefix, 1);
-        const Fe c = field::from_mont(SF, s);
-        state.update(reinterpret_cast<const uint8_t *>(c.data()), 32);
-    }
-    void write_scalar(const Fe &s) {                                                                                   // :188-192
-        common_scalar(s);
-        const Fe c = field::from_mont(SF, s);
-        const uint8_t *b = reinterpret_cast<const uint8_t *>(c.data());
-        writer.insert(writer.end(), b, b + 32);
-    }
-    Fe squeeze_challenge_scalar() {                                                                                    // :200-205, :286-296
-        const uint8_t prefix = 0;
-        state.update(&prefix, 1);
-        const std::array<uint8_t, 64> d = state.finalize();
-        Fe lo, hi;
-        memcpy(lo.data(), d.data(), 32);
-        memcpy(hi.data(), d.data() + 32, 32);
-        // from_bytes_wide: (lo + hi 2^256) mod q; r2 read as a Montgomery element IS 2^256
-        const field::Params &F = field::params(SF);
-        return field::add(SF, field::to_mont(SF, lo), field::mul(SF, field::to_mont(SF, hi), Fe{F.r2[0], F.r2[1], F.r2[2], F.r2[3]}));
-    }
-    std::vector<uint8_t> finalize() const { return writer; }
-
-  private:
-    Blake2bState state;
-    std::vector<uint8_t> writer;
 };
 
 template <int CURVE> inline Affine to_affine(const Jacobian &p) {
@@ -497,7 +414,7 @@ inline void create_proof(const Params<CURVE> &params, Rng &&rng, Blake2bWrite<CU
     const Fe s_at_x3 = eval_polynomial<SF>(s_poly, x_3);
     s_poly[0] = field::sub(SF, s_poly[0], s_at_x3);
     const Blind<CURVE> s_poly_blind{rng()};
-    transcript.write_point(to_affine<CURVE>(params.commit(s_poly, s_poly_blind)));
+    transcript.write_point(params.commit(s_poly, s_poly_blind));
     const Fe xi = transcript.squeeze_challenge_scalar();                                                              // :62
     const Fe z = transcript.squeeze_challenge_scalar();                                                               // :66
     // P' = P - [v] G_0 + [xi] S (:70-78)
@@ -512,24 +429,11 @@ inline void create_proof(const Params<CURVE> &params, Rng &&rng, Blake2bWrite<CU
     for (Fe &r : rands) r = rng();
     bool paired = false;
     const h2_bases_t basis = params.opening_basis(&paired);
-    struct Ctx { Blake2bWrite<CURVE> *t; std::string err; } ctx{&transcript, {}};
-    auto write_point = [](void *user, const uint64_t *xy) -> int {
-        Ctx *c = static_cast<Ctx *>(user);
-        try { Affine p; memcpy(p.data(), xy, 64); c->t->write_point(p); return H2_OK; }
-        catch (const std::exception &e) { c->err = e.what(); return H2_ERR_ARGS; }
-    };
-    auto squeeze = [](void *user, uint64_t *out) -> int {
-        Ctx *c = static_cast<Ctx *>(user);
-        const Fe u = c->t->squeeze_challenge_scalar();
-        memcpy(out, u.data(), 32);
-        return H2_OK;
-    };
     const Affine uw[2] = {params.u, params.w};
     Fe c_final{}, f_delta{};
-    const int rc = h2_ipa_rounds(CURVE, k, H2_IPA_SWITCH_DEFAULT, basis, paired ? 1 : 0, p_prime[0].data(), b[0].data(), z.data(), rands[0].data(),
-                                 uw[0].data(), write_point, squeeze, &ctx, c_final.data(), f_delta.data());                // :104-142
-    if (!ctx.err.empty()) throw std::invalid_argument(ctx.err);
-    check(rc, "h2_ipa_rounds");
+    check(h2_ipa_rounds(CURVE, k, H2_IPA_SWITCH_DEFAULT, basis, paired ? 1 : 0, p_prime[0].data(), b[0].data(), z.data(), rands[0].data(),
+                        uw[0].data(), h2_transcript_cb_write_point, h2_transcript_cb_squeeze, (void *)(uintptr_t)transcript.handle(),
+                        c_final.data(), f_delta.data()), "h2_ipa_rounds");                                             // :104-142
     transcript.write_scalar(c_final);                                                                                  // :146-148
     transcript.write_scalar(field::add(SF, f, f_delta));
 }

@@ -1,16 +1,17 @@
 """Host-side mirror of the reference's Fiat-Shamir transcript (halo2_proofs/src/transcript.rs:150-300):
-`Blake2bWrite` / `Blake2bRead` with `Challenge255`.  Pure host logic (hashing a few hundred bytes per proof);
-it exists so the device-resident opening argument (halo2_amd/opening.py) can be driven exactly as the reference
-drives `create_proof`, and so tests read like the reference's `test_opening_proof` (poly/commitment.rs:305-379).
+`Blake2bWrite` / `Blake2bRead` with `Challenge255`.  Pure host logic (hashing a few hundred bytes per proof), kept in the
+library (h2_transcript_*) so that the opening argument's native round loop reaches it without a Python callback;
+this module is the reference-shaped front: tests read like `test_opening_proof` (poly/commitment.rs:305-379).
 
 Points are affine (8,) and scalars (4,) uint64 Montgomery limbs, as everywhere in this package."""
 from __future__ import annotations
 
-import hashlib
+import ctypes as C
 
 import numpy as np
 
 from . import fields
+from ._lib import H2_ERR_ARGS, check, lib, u64p
 
 _PREFIX_CHALLENGE, _PREFIX_POINT, _PREFIX_SCALAR = b"\x00", b"\x01", b"\x02"     # transcript.rs:14-20
 
@@ -27,62 +28,68 @@ def point_to_bytes(x: int, y: int) -> bytes:
 
 
 class _Blake2bTranscript:
+    """State and hashing live in the library (h2_transcript_*: BLAKE2b-512, `Halo2-Transcript`), so the opening argument's
+    round loop can absorb L_j / R_j and squeeze its challenges without coming back to Python."""
+
     def __init__(self, curve: int):
         self.curve = curve
         self.base, self.scalar = fields.CURVE_FIELDS[curve]
-        self.state = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")    # transcript.rs:162-166
+        self._h = C.c_uint64(0)
+        check(lib().h2_transcript_new(curve, C.byref(self._h)), "h2_transcript_new")                 # transcript.rs:162-166
+
+    def __del__(self):
+        try:
+            if self._h.value:
+                lib().h2_transcript_free(self._h)
+                self._h.value = 0
+        except Exception:
+            pass
+
+    @property
+    def handle(self) -> int:
+        return int(self._h.value)
 
     # -- Transcript -------------------------------------------------------------------------------
-    def squeeze_challenge(self) -> int:
-        """transcript.rs:200-205 + Challenge255::new (:286-296): 64 hash bytes reduced into the scalar field."""
-        self.state.update(_PREFIX_CHALLENGE)
-        digest = self.state.copy().digest()
-        return int.from_bytes(digest, "little") % fields.MODULUS[self.scalar]
-
     def squeeze_challenge_scalar(self) -> np.ndarray:
-        return fields.scalar_limbs(self.squeeze_challenge(), self.scalar, True)
+        """transcript.rs:200-205 + Challenge255::new (:286-296): 64 hash bytes reduced into the scalar field."""
+        out = np.zeros(4, dtype=np.uint64)
+        check(lib().h2_transcript_squeeze_challenge(self._h, out.ctypes.data_as(u64p)), "h2_transcript_squeeze_challenge")
+        return out
 
-    def _coords(self, point) -> tuple[int, int]:
-        """Affine (8 limbs) or Jacobian (12 limbs, what `C::Curve` is) -> canonical affine integers.  The Jacobian case is
-        the prover's `.to_affine()` before `write_point` (poly/commitment/prover.rs:116-117): one modular inversion on the
-        host costs microseconds, on the device a 255-step dependent chain on a single lane."""
+    def squeeze_challenge(self) -> int:
+        return fields.from_limbs(self.squeeze_challenge_scalar(), self.scalar, True)[0]
+
+    def _absorb_point(self, point, write: bool):
+        """Affine (8 limbs) or Jacobian (12 limbs, what `C::Curve` is: the prover's `.to_affine()` before `write_point`,
+        poly/commitment/prover.rs:116-117)."""
         point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1)
-        if point.shape[0] == 12:
-            xj, yj, zj = fields.from_limbs(point.reshape(3, 4), self.base, True)
-            m = fields.MODULUS[self.base]
-            if zj == 0:
-                raise ValueError("cannot write points at infinity to the transcript")    # transcript.rs:209-214
-            zi = pow(zj, -1, m)
-            zi2 = zi * zi % m
-            return xj * zi2 % m, yj * zi2 * zi % m
-        x, y = fields.from_limbs(point.reshape(2, 4), self.base, True)
-        if x == 0 and y == 0:
-            raise ValueError("cannot write points at infinity to the transcript")        # transcript.rs:209-214
-        return x, y
+        if point.shape[0] not in (8, 12):
+            raise ValueError("transcript: a point is 8 (affine) or 12 (Jacobian) limbs")
+        fn = lib().h2_transcript_write_point if write else lib().h2_transcript_common_point
+        rc = fn(self._h, point.ctypes.data_as(u64p), 1 if point.shape[0] == 12 else 0)
+        if rc == H2_ERR_ARGS:
+            raise ValueError("cannot write points at infinity to the transcript")            # transcript.rs:209-214
+        check(rc, "h2_transcript_write_point")
 
     def common_point(self, point):
-        x, y = self._coords(point)
-        self.state.update(_PREFIX_POINT)
-        self.state.update(_le32(x))
-        self.state.update(_le32(y))
+        self._absorb_point(point, False)
 
     def common_scalar(self, scalar):
-        self.state.update(_PREFIX_SCALAR)
-        self.state.update(_le32(fields.from_limbs(scalar, self.scalar, True)[0]))
+        s = np.ascontiguousarray(scalar, dtype=np.uint64).reshape(4)
+        check(lib().h2_transcript_common_scalar(self._h, s.ctypes.data_as(u64p)), "h2_transcript_common_scalar")
 
 
 class Blake2bWrite(_Blake2bTranscript):
-    def __init__(self, curve: int):
-        super().__init__(curve)
-        self.writer = bytearray()
-
     def write_point(self, point):
-        self.common_point(point)
-        self.writer += point_to_bytes(*self._coords(point))                          # transcript.rs:183-187
+        self._absorb_point(point, True)                                                  # transcript.rs:183-187
 
     def write_scalar(self, scalar):
-        self.common_scalar(scalar)
-        self.writer += _le32(fields.from_limbs(scalar, self.scalar, True)[0])        # transcript.rs:188-192
+        s = np.ascontiguousarray(scalar, dtype=np.uint64).reshape(4)
+        check(lib().h2_transcript_write_scalar(self._h, s.ctypes.data_as(u64p)), "h2_transcript_write_scalar")   # :188-192
 
     def finalize(self) -> bytes:
-        return bytes(self.writer)
+        n = C.c_size_t(0)
+        check(lib().h2_transcript_bytes(self._h, None, 0, C.byref(n)), "h2_transcript_bytes")
+        buf = (C.c_uint8 * max(n.value, 1))()
+        check(lib().h2_transcript_bytes(self._h, buf, n.value, C.byref(n)), "h2_transcript_bytes")
+        return bytes(buf[:n.value])

@@ -274,6 +274,27 @@ int h2_ipa_rounds(int curve, unsigned k, unsigned switch_rounds, h2_bases_t basi
 int h2_ipa_collapsed_generators_device(h2_bases_t basis, unsigned k, unsigned rounds, const uint64_t *challenges, int form,
                                        void *d_out_xy, void *stream);
 
+/* ---- the Fiat-Shamir transcript (host side) ------------------------------------------------------- */
+/* replaces Blake2bWrite<_, C, Challenge255<C>> (halo2_proofs/src/transcript.rs:150-198, 286-296) for callers that want the
+ * round loop above to stay in native code: BLAKE2b-512 personalised "Halo2-Transcript"; points are absorbed as canonical
+ * (x, y) and written compressed (x with the sign of y in the top bit), scalars canonical little-endian; a challenge is the
+ * digest of a copy of the state reduced from 512 bits into the curve's scalar field.  Inputs and challenges are Montgomery
+ * limbs; `jacobian` != 0: the point is (X, Y, Z), 12 limbs, and is normalised first (the prover's .to_affine()).  Writing the
+ * point at infinity returns H2_ERR_ARGS (the reference returns an io::Error, :209-214).  Host arithmetic only. */
+typedef uint64_t h2_transcript_t;
+int h2_transcript_new(int curve, h2_transcript_t *t);
+int h2_transcript_free(h2_transcript_t t);
+int h2_transcript_common_point(h2_transcript_t t, const uint64_t *point, int jacobian);
+int h2_transcript_write_point(h2_transcript_t t, const uint64_t *point, int jacobian);
+int h2_transcript_common_scalar(h2_transcript_t t, const uint64_t *scalar);
+int h2_transcript_write_scalar(h2_transcript_t t, const uint64_t *scalar);
+int h2_transcript_squeeze_challenge(h2_transcript_t t, uint64_t *challenge);
+/* the bytes written so far (the proof): *len always receives their count, out is filled when cap >= *len */
+int h2_transcript_bytes(h2_transcript_t t, uint8_t *out, size_t cap, size_t *len);
+/* write_point / squeeze of h2_ipa_rounds_device over such a transcript: pass these with user = (void *)(uintptr_t)t */
+int h2_transcript_cb_write_point(void *user, const uint64_t *xy);
+int h2_transcript_cb_squeeze(void *user, uint64_t *challenge);
+
 /* ---- Params set-up: Lagrange basis by an FFT over curve points -------------------------------- */
 /* replaces the point FFT + 2^-k scaling + batch_normalize of Params::new
  * (halo2_proofs/src/poly/commitment.rs:77-100): out[j] = 2^-k * sum_i alpha_inv^(i*j) * g[i], affine, where
