@@ -100,18 +100,83 @@ static inline void host_add(int f, u64 r[4], const u64 a[4], const u64 b[4]) {
     memcpy(r, t, 32);
 }
 
-// a^(p - 2), Montgomery in and out (a != 0)
+// 256-bit helpers of the inversion below
+static inline bool host_ge(const u64 a[4], const u64 b[4]) {
+    for (int i = 3; i >= 0; --i) {
+        if (a[i] > b[i]) return true;
+        if (a[i] < b[i]) return false;
+    }
+    return true;
+}
+static inline u64 host_sub_raw(u64 r[4], const u64 a[4], const u64 b[4]) {        // returns the borrow
+    u128 br = 0;
+    for (int i = 0; i < 4; ++i) {
+        u128 d = (u128)a[i] - b[i] - (u64)br;
+        r[i] = (u64)d;
+        br = (d >> 64) & 1;
+    }
+    return (u64)br;
+}
+static inline void host_halve_mod(const u64 p[4], u64 x[4]) {                      // x / 2 mod p (p odd), x < p
+    u64 carry = 0;
+    if (x[0] & 1) {
+        u128 c = 0;
+        for (int i = 0; i < 4; ++i) {
+            c += (u128)x[i] + p[i];
+            x[i] = (u64)c;
+            c >>= 64;
+        }
+        carry = (u64)c;
+    }
+    for (int i = 0; i < 4; ++i) x[i] = (x[i] >> 1) | ((i < 3 ? x[i + 1] : carry) << 63);
+}
+static inline void host_shr1(u64 x[4]) {
+    for (int i = 0; i < 4; ++i) x[i] = (x[i] >> 1) | ((i < 3 ? x[i + 1] : 0) << 63);
+}
+
+// 1 / a, Montgomery in and out (a != 0): binary extended Euclid on the raw limbs (~500 shift / subtract steps, a few
+// microseconds, against ~380 Montgomery products for a^(p - 2)), then two products by R^2 to land back in Montgomery form:
+// (a R)^-1 = a^-1 R^-1  ->  a^-1 R
 static inline void host_inv(int f, u64 r[4], const u64 a[4]) {
     const HostField &F = kHostField[f];
-    u64 e[4] = {F.p[0] - 2, F.p[1], F.p[2], F.p[3]};      // p[0] ends in ...0001: no borrow
-    u64 acc[4], base[4];
-    memcpy(acc, F.one, 32);
-    memcpy(base, a, 32);
-    for (int i = 0; i < 255; ++i) {
-        if ((e[i >> 6] >> (i & 63)) & 1) host_mul(f, acc, acc, base);
-        host_mul(f, base, base, base);
+    u64 u[4], v[4], x1[4] = {1, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
+    memcpy(u, a, 32);
+    memcpy(v, F.p, 32);
+    auto is_one = [](const u64 t[4]) { return t[0] == 1 && !(t[1] | t[2] | t[3]); };
+    while (!is_one(u) && !is_one(v)) {
+        while (!(u[0] & 1)) {
+            host_shr1(u);
+            host_halve_mod(F.p, x1);
+        }
+        while (!(v[0] & 1)) {
+            host_shr1(v);
+            host_halve_mod(F.p, x2);
+        }
+        if (host_ge(u, v)) {
+            host_sub_raw(u, u, v);
+            if (host_sub_raw(x1, x1, x2)) {            // x1 - x2 mod p
+                u128 c = 0;
+                for (int i = 0; i < 4; ++i) {
+                    c += (u128)x1[i] + F.p[i];
+                    x1[i] = (u64)c;
+                    c >>= 64;
+                }
+            }
+        } else {
+            host_sub_raw(v, v, u);
+            if (host_sub_raw(x2, x2, x1)) {
+                u128 c = 0;
+                for (int i = 0; i < 4; ++i) {
+                    c += (u128)x2[i] + F.p[i];
+                    x2[i] = (u64)c;
+                    c >>= 64;
+                }
+            }
+        }
     }
-    memcpy(r, acc, 32);
+    u64 t[4];
+    host_mul(f, t, is_one(u) ? x1 : x2, F.r2);
+    host_mul(f, r, t, F.r2);
 }
 
 static inline bool host_is_zero(const u64 a[4]) { return !(a[0] | a[1] | a[2] | a[3]); }
