@@ -64,7 +64,8 @@ def main():
         x = co.random_field(sf, 8, 1)[0]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        create_proof(params, rng, tr, d_px, blind, x, schedule=os.environ.get("SCHEDULE") or None)
+        create_proof(params, rng, tr, d_px, blind, x, schedule=os.environ.get("SCHEDULE") or None,
+                     hybrid_rounds=int(os.environ["HYBRID"]) if "HYBRID" in os.environ else None)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
     res["total_ms"] = round((t1 - t0) * 1e3, 3)
