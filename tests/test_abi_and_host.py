@@ -227,3 +227,46 @@ def test_polynomial_basis_tags():
         h.Polynomial(np.zeros(16, dtype=np.uint64), h.Coeff)
     with pytest.raises(ValueError):
         d.coeff_from_vec(np.zeros((15, 4), dtype=np.uint64))
+
+
+@pytest.mark.parametrize("curve", [h.PALLAS, h.VESTA])
+def test_library_transcript_matches_hashlib_restatement(curve):
+    """h2_transcript_* (the library's Blake2bWrite / Challenge255, host arithmetic only) against the oracle's hashlib restatement
+    of transcript.rs: a few hundred mixed operations -- affine and Jacobian points, scalars, challenges at block boundaries of the
+    128-byte BLAKE2b buffer -- give the same challenges and the same written bytes; the identity is refused."""
+    from halo2_amd import fields
+    from halo2_amd.transcript import Blake2bWrite
+    from oracle import c_oracle as co
+    from oracle import ipa
+    bf, sf = fields.CURVE_FIELDS[curve]
+    bm, sm = fields.MODULUS[bf], fields.MODULUS[sf]
+    pts = co.generate_bases(curve, 5, 24)
+    ints = [co.affine_to_ints(curve, p) for p in pts]
+    rs = np.random.RandomState(11)
+    tr, ot = Blake2bWrite(curve), ipa.Transcript(curve)
+    for step in range(300):
+        op = int(rs.randint(0, 5))
+        i = int(rs.randint(0, len(pts)))
+        if op == 0:
+            tr.write_point(pts[i])
+            ot.write_point(ints[i])
+        elif op == 1:                                   # Jacobian (x z^2, y z^3, z): the prover's .to_affine() happens inside
+            z = int(rs.randint(2, 1 << 30))
+            jac = fields.to_limbs([ints[i][0] * z * z % bm, ints[i][1] * z * z * z % bm, z], bf, True).reshape(12)
+            tr.write_point(jac)
+            ot.write_point(ints[i])
+        elif op == 2:
+            s = int(rs.randint(0, 1 << 62)) * int(rs.randint(1, 1 << 62)) % sm
+            tr.write_scalar(fields.scalar_limbs(s, sf, True))
+            ot.write_scalar(s)
+        elif op == 3:
+            tr.common_point(pts[i])
+            ot.common_point(ints[i])
+        else:
+            assert tr.squeeze_challenge() == ot.squeeze_challenge(), step
+    assert tr.squeeze_challenge() == ot.squeeze_challenge()
+    assert tr.finalize() == bytes(ot.out) and len(tr.finalize()) > 1000
+    with pytest.raises(ValueError):
+        tr.write_point(np.zeros(8, dtype=np.uint64))
+    with pytest.raises(ValueError):
+        tr.write_point(np.zeros(12, dtype=np.uint64))
