@@ -112,7 +112,8 @@ def main():
     gen_s = time.time() - t0
     params_g = C.c_uint64(0)
     from halo2_amd.arithmetic import _p
-    check(lib.h2_bases_register(curve, _p(bases), n, h.FORM_MONTGOMERY, C.byref(params_g)), "h2_bases_register")
+    col_bits = int(lib.h2_commit_column_window_bits(n))       # Params::g as halo2_amd.Params registers it (17-bit windows at 2^20)
+    check(lib.h2_bases_register_ex(curve, _p(bases), n, h.FORM_MONTGOMERY, col_bits, C.byref(params_g)), "h2_bases_register_ex")
     d_cols = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]
     # the blind term of Params::commit: w = a further seeded point, r = one seeded scalar per column (commitment.rs:119-130)
     w_host = co.generate_bases(curve, 0x77, 1)[0]
@@ -385,7 +386,7 @@ def main():
         v_w = co.generate_bases(h.VESTA, 0x78, 1)[0]
         v_bl = co.random_field(vs, 0xB11E, 2)
         hv = C.c_uint64(0)
-        check(lib.h2_bases_register(h.VESTA, _p(v_bases), n, h.FORM_MONTGOMERY, C.byref(hv)), "h2_bases_register")
+        check(lib.h2_bases_register_ex(h.VESTA, _p(v_bases), n, h.FORM_MONTGOMERY, col_bits, C.byref(hv)), "h2_bases_register_ex")
         dv_cols = [torch.from_numpy(c_.view(np.int64)).to(dev) for c_ in v_cols]
         dv_w = torch.from_numpy(v_w.view(np.int64)).to(dev)
         dv_bl = torch.from_numpy(v_bl.view(np.int64)).to(dev)
@@ -459,6 +460,7 @@ def main():
         avg_ms = busy["msm_accumulate"] / max(acc_cnt, 1)
         sum_ms = acc_ms / max(acc_cnt, 1)
         achieved = ALGO_BYTES_PER_PAIR * (n + 1) / (avg_ms * 1e-3) / 1e9 if acc_cnt else None
+        madds = 16 * (n + 1) if col_bits <= 16 else int(15.5 * (n + 1))
         out = {
             "metric": "Pallas MSM Mscalar-mults/s (+ Fp NTT Gbutterflies/s) at k=20",
             "value": round(value, 3), "unit": "Mscalar-mults/s", "n_gpus": world, "steps": args.steps,
@@ -467,7 +469,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"2^{args.log_n}-point Pallas best_multiexp, uniform random Fq scalars, "
                                    "bases resident (Params::g registered), one column commit WITH its blind term per step per GPU",
-                       "window_bits": h.msm_window_bits(n), "columns_resident": args.columns, "streams": len(streams),
+                       "window_bits": col_bits, "columns_resident": args.columns, "streams": len(streams),
                        "msm_lane_fraction": lane_fraction,
                        "parallelism": f"{world} GPU(s) x {len(streams)} stream(s) of independent column commits"},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 2) if achieved else None,
@@ -476,13 +478,15 @@ def main():
                          "avg_kernel_ms_definition": "union of the launch intervals on the device / launches (HIP events on the launching "
                                                      "streams, timed region only); overlapped_launch_ms = plain mean of the launch durations",
                          "overlapped_launch_ms": round(sum_ms, 4), "kernel_ms_isolated": iso.get("msm_accumulate"),
-                         "valu": {"madd_per_launch": 16 * (n + 1), "achieved_Gmadd_per_s": round(16 * (n + 1) / (avg_ms * 1e-3) / 1e9, 2) if acc_cnt else None,
-                                  "isolated_Gmadd_per_s": round(16 * (n + 1) / (iso["msm_accumulate"] * 1e-3) / 1e9, 2) if iso.get("msm_accumulate") else None,
+                         "valu": {"madd_per_launch": madds, "madd_per_launch_definition": "non-zero digits of the column: 16 per scalar at 16-bit windows; "
+                                  "15 + the recode carry out of the top window (every second scalar) at 17 bits",
+                                  "achieved_Gmadd_per_s": round(madds / (avg_ms * 1e-3) / 1e9, 2) if acc_cnt else None,
+                                  "isolated_Gmadd_per_s": round(madds / (iso["msm_accumulate"] * 1e-3) / 1e9, 2) if iso.get("msm_accumulate") else None,
                                   "modmul_per_madd": 10, "v_mad_i64_i32_per_madd": 1188,
                                   "issue_bound_Gmadd_per_s": 26.5,
                                   "issue_bound_source": "1188 v_mad_i64_i32 per mixed add at the measured 4.8 cycles per wave-instruction per SIMD "
                                                         "(profiles/r01_ubench_valu.txt): 1024 SIMDs x 2.4 GHz x 64 lanes / (1188 x 4.8) - the bound if nothing but the "
-                                                        "multiply-adds issued; the whole add is 2135 instructions (profiles/r02_ubench_fe9.txt: 17.7-18.0 G madd/s for the loop alone)"},
+                                                        "multiply-adds issued; the whole add is 2031 instructions (DESIGN.md section 9.1; profiles/r02_ubench_fe9.txt: 17.7-18.0 G madd/s for the loop alone)"},
                          "note": "VALU integer-multiply bound, not HBM bound (DESIGN.md section 3): the HBM fraction is reported as the contract "
                                  "asks, the VALU figures are what track kernel quality; traffic = PMC bytes of the registered-bases path, which "
                                  "gathers 16 precomputed multiples per point from a 1 GiB table by design"},

@@ -2000,7 +2000,7 @@ extern "C" int h2_msm(int curve, const uint64_t *scalars, const uint64_t *bases_
     return H2_OK;
 }
 
-static int bases_register_impl(int curve, const void *bases_xy, bool on_device, size_t n, int form, h2_bases_t *handle) {
+static int bases_register_impl(int curve, const void *bases_xy, bool on_device, size_t n, int form, h2_bases_t *handle, int want_c = 0) {
     if ((curve != H2_PALLAS && curve != H2_VESTA) || (form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY) ||
         !handle || (n && !bases_xy) || n > (1u << 26))
         return H2_ERR_ARGS;
@@ -2009,7 +2009,7 @@ static int bases_register_impl(int curve, const void *bases_xy, bool on_device, 
     auto b = std::make_shared<Bases>();
     b->curve = curve;
     b->n = n;
-    b->c = choose_c(n ? n : 1, true);
+    b->c = want_c ? want_c : choose_c(n ? n : 1, true);
     b->W = 255 / b->c + 1;
     b->stride = (u32)n + 1;
     H2_HIP(hipGetDevice(&b->device));
@@ -2032,6 +2032,27 @@ static int bases_register_impl(int curve, const void *bases_xy, bool on_device, 
 
 extern "C" int h2_bases_register(int curve, const uint64_t *bases_xy, size_t n, int form, h2_bases_t *handle) {
     return bases_register_impl(curve, bases_xy, false, n, form, handle);
+}
+
+// Window width for a table that only serves independent column commits (Params::g, g_lagrange): from 2^20 points on 17 bits --
+// 255 = 15 x 17, so a scalar leaves 15 digits plus the recode carry instead of 16: the accumulate is ~6 % shorter, the sort and
+// the fold (2^16 buckets) ~0.07 ms longer, which independent commits hide (953-966 against 925-939 M scalar-mults/s, one box,
+// one lone commit unchanged).  The paired commit and the collapsed-generator read-out of the opening argument take 16-bit
+// tables, which is what h2_bases_register keeps building.
+extern "C" int h2_commit_column_window_bits(size_t n) {
+    const int c = choose_c(n ? n : 1, true);
+    int lowb, lb;
+    return c == 16 && n >= ((size_t)1 << 20) && n + 1 < ((size_t)1 << 31) && sort2_geometry((u32)n + 1, 17, &lowb, &lb) ? 17 : c;
+}
+
+extern "C" int h2_bases_register_ex(int curve, const uint64_t *bases_xy, size_t n, int form, int window_bits, h2_bases_t *handle) {
+    if (window_bits) {
+        int lowb, lb;
+        if (window_bits < 4 || window_bits > kMaxCShared ||
+            (window_bits > kMaxC && !(n + 1 < ((size_t)1 << 31) && sort2_geometry((u32)n + 1, window_bits, &lowb, &lb))))
+            return H2_ERR_ARGS;
+    }
+    return bases_register_impl(curve, bases_xy, false, n, form, handle, window_bits);
 }
 
 // the same from points already in HBM (work queued on other streams that produces them must have completed: the copy runs on

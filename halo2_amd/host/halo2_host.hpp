@@ -265,8 +265,9 @@ template <int CURVE> class Params {
     Params(uint32_t k_, std::vector<Affine> g_, std::vector<Affine> g_lagrange_, const Affine &w_, const Affine &u_)
         : k(k_), n((uint64_t)1 << k_), g(std::move(g_)), g_lagrange(std::move(g_lagrange_)), w(w_), u(u_) {
         if (g.size() != n || g_lagrange.size() != n) throw std::invalid_argument("Params: need 2^k generators");
-        check(h2_bases_register(CURVE, g[0].data(), n, H2_FORM_MONTGOMERY, &h_g), "h2_bases_register");
-        check(h2_bases_register(CURVE, g_lagrange[0].data(), n, H2_FORM_MONTGOMERY, &h_gl), "h2_bases_register");
+        const int wb = h2_commit_column_window_bits(n);        // tables of column commits: 17-bit windows from 2^20 points on
+        check(h2_bases_register_ex(CURVE, g[0].data(), n, H2_FORM_MONTGOMERY, wb, &h_g), "h2_bases_register_ex");
+        check(h2_bases_register_ex(CURVE, g_lagrange[0].data(), n, H2_FORM_MONTGOMERY, wb, &h_gl), "h2_bases_register_ex");
     }
     ~Params() { for (h2_bases_t h : {h_g, h_gl, h_open}) if (h) h2_bases_free(h); }
     // Params::new (commitment.rs:38-114): g_i = hasher({0, i as LE u32}), g_lagrange by the point iFFT, w = hasher({1}), u = hasher({2});
