@@ -460,7 +460,7 @@ def main():
         avg_ms = busy["msm_accumulate"] / max(acc_cnt, 1)
         sum_ms = acc_ms / max(acc_cnt, 1)
         achieved = ALGO_BYTES_PER_PAIR * (n + 1) / (avg_ms * 1e-3) / 1e9 if acc_cnt else None
-        madds = 16 * (n + 1) if col_bits <= 16 else int(15.5 * (n + 1))
+        madds = (255 // col_bits + (1 if 255 % col_bits else 0)) * (n + 1)      # non-zero digits per scalar: 16 at 16 bits, 15 at 17 (255 = 15 x 17)
         out = {
             "metric": "Pallas MSM Mscalar-mults/s (+ Fp NTT Gbutterflies/s) at k=20",
             "value": round(value, 3), "unit": "Mscalar-mults/s", "n_gpus": world, "steps": args.steps,
@@ -478,8 +478,8 @@ def main():
                          "avg_kernel_ms_definition": "union of the launch intervals on the device / launches (HIP events on the launching "
                                                      "streams, timed region only); overlapped_launch_ms = plain mean of the launch durations",
                          "overlapped_launch_ms": round(sum_ms, 4), "kernel_ms_isolated": iso.get("msm_accumulate"),
-                         "valu": {"madd_per_launch": madds, "madd_per_launch_definition": "non-zero digits of the column: 16 per scalar at 16-bit windows; "
-                                  "15 + the recode carry out of the top window (every second scalar) at 17 bits",
+                         "valu": {"madd_per_launch": madds, "madd_per_launch_definition": "non-zero digits of the column: 16 per scalar at 16-bit windows, 15 at 17 bits (255 = 15 x 17; the "
+                                  "top window of a scalar below q < 2^254 + 2^126 never exceeds 2^16, so the recode carries nothing out of it)",
                                   "achieved_Gmadd_per_s": round(madds / (avg_ms * 1e-3) / 1e9, 2) if acc_cnt else None,
                                   "isolated_Gmadd_per_s": round(madds / (iso["msm_accumulate"] * 1e-3) / 1e9, 2) if iso.get("msm_accumulate") else None,
                                   "modmul_per_madd": 10, "v_mad_i64_i32_per_madd": 1188,

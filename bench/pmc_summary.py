@@ -54,7 +54,7 @@ def main():
         out["msm_accumulate_2^20"] = {
             "algorithmic_bytes": 96 << 20, "fetch_bytes_reported_max": int(acc[k]["FETCH_SIZE_KiB_max"] * 1024),
             "write_bytes_max": int((acc[k]["WRITE_SIZE_KiB_max"] or 0) * 1024),
-            "note": "the registered-bases path gathers one 64-B point per non-zero digit (15.5 per scalar with the 17-bit windows of a column table, 16 with 16-bit ones) from the table of precomputed 2^(c w) multiples: ~1 GiB of gathers + 64 MiB of sorted entries by design; bench/ubench_madd "
+            "note": "the registered-bases path gathers one 64-B point per non-zero digit (15 per scalar with the 17-bit windows of a column table, 16 with 16-bit ones) from the table of precomputed 2^(c w) multiples: ~1 GiB of gathers + 64 MiB of sorted entries by design; bench/ubench_madd "
                     "shows the kernel runs at the same speed when the table is L2-resident, i.e. this traffic is not what bounds it"}
     sort = {}
     for k, v in kernels.items():

@@ -2035,7 +2035,8 @@ extern "C" int h2_bases_register(int curve, const uint64_t *bases_xy, size_t n, 
 }
 
 // Window width for a table that only serves independent column commits (Params::g, g_lagrange): from 2^20 points on 17 bits --
-// 255 = 15 x 17, so a scalar leaves 15 digits plus the recode carry instead of 16: the accumulate is ~6 % shorter, the sort and
+// 255 = 15 x 17, so a scalar leaves 15 digits instead of 16 (the top window of a scalar below q never exceeds 2^16, half the
+// window, so the signed recode carries nothing out of it): the accumulate is ~6 % shorter, the sort and
 // the fold (2^16 buckets) ~0.07 ms longer, which independent commits hide (953-966 against 925-939 M scalar-mults/s, one box,
 // one lone commit unchanged).  The paired commit and the collapsed-generator read-out of the opening argument take 16-bit
 // tables, which is what h2_bases_register keeps building.
