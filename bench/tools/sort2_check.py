@@ -10,7 +10,7 @@ for logn in (14, 18, 19, 20):
     n = 1 << logn
     g = co.generate_bases(curve, 55, n)
     hd = C.c_uint64(0)
-    assert lib.h2_bases_register(curve, _p(g), n, 1, C.byref(hd)) == 0
+    assert lib.h2_bases_register_ex(curve, _p(g), n, 1, int(os.environ.get("WINDOW_BITS", lib.h2_commit_column_window_bits(n))), C.byref(hd)) == 0
     for name in ("dense", "zeros90", "small"):
         col = co.random_field(sf, 600 + logn, n)
         if name == "zeros90": col[np.arange(n) % 10 != 0] = 0
