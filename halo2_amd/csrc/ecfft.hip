@@ -10,6 +10,7 @@
 // come from the field NTT's cached table.  One-off set-up work per Params (minutes on the CPU path).
 #include "common.h"
 #include "curve.cuh"
+#include "glv.cuh"
 #include "host_field.h"
 
 namespace h2 {
@@ -61,6 +62,56 @@ __global__ void __launch_bounds__(256) ec_stage(u32 *__restrict__ p, const u32 *
     if (e != 0) {
         fe w = fe_from_mont<FS>(fe_load(tw + 8 * e));
         b = ec_scalar_mul<FB>(b, w);
+    }
+    xyzz<FB> s = a, d = a;
+    xyzz_add<FB>(s, b);
+    b.y = fe_neg<FB>(b.y);
+    xyzz_add<FB>(d, b);
+    xyzz_store<FB>(p + 32 * (size_t)x0, s);
+    xyzz_store<FB>(p + 32 * (size_t)x1, d);
+}
+
+// The same stage with one twiddle per WAVE (stages where a twiddle serves >= 64 butterflies, t <= L - 7): the 64 lanes of a
+// wave take butterflies (hi, low) with a common `low`, so the scalar is wave-uniform and the walk has no divergence -- a lane of
+// ec_stage pays every addition any lane of its wave needs, i.e. 255 doublings + ~255 additions; here the scalar is split with the
+// curve endomorphism (k = k1 + k2 lambda, 128-bit halves, glv.cuh; phi(X, Y, ZZ, ZZZ) = (zeta X, Y, ZZ, ZZZ)) and walked as
+// 129 doublings + the set bits of |k1| and |k2| (~128 additions).  The points of a wave are 2^(t+1) apart: 128-byte lines either way.
+template <int FB, int FS>
+__global__ void __launch_bounds__(256) ec_stage_uniform(u32 *__restrict__ p, const u32 *__restrict__ tw, int L, int t) {
+    const u32 per_low = 1u << (L - 1 - t - 6);                       // waves per twiddle
+    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const u32 low = wave / per_low, hi = (wave % per_low) * 64 + lane;
+    const u32 x0 = (hi << (t + 1)) | low, x1 = x0 + (1u << t);
+    xyzz<FB> a = xyzz_load<FB>(p + 32 * (size_t)x0), b = xyzz_load<FB>(p + 32 * (size_t)x1);
+    if (low != 0) {
+        const fe w = fe_from_mont<FS>(fe_load(tw + 8 * ((size_t)low << (L - t - 1))));
+        u32 m1[5], m2[5], n1, n2;
+        glv_split<FS>(w, m1, n1, m2, n2);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {                                // identical in every lane: say so (scalar registers, uniform branches)
+            m1[i] = (u32)__builtin_amdgcn_readfirstlane((int)m1[i]);
+            m2[i] = (u32)__builtin_amdgcn_readfirstlane((int)m2[i]);
+        }
+        n1 = (u32)__builtin_amdgcn_readfirstlane((int)n1);
+        n2 = (u32)__builtin_amdgcn_readfirstlane((int)n2);
+        xyzz<FB> b1 = b, b2 = b;
+        if (n1) b1.y = fe_neg<FB>(b.y);
+        b2.x = fe_mulx<FB>(b.x, glv_zeta<FB>());
+        if (n2) b2.y = fe_neg<FB>(b.y);
+        xyzz<FB> r = xyzz_identity<FB>();
+        for (int bit = 129; bit >= 0; --bit) {
+            r = xyzz_dbl<FB>(r);
+            const u32 w_ = (u32)bit >> 5, s_ = (u32)bit & 31;
+            u32 l1 = 0, l2 = 0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                l1 = w_ == (u32)i ? m1[i] : l1;
+                l2 = w_ == (u32)i ? m2[i] : l2;
+            }
+            if ((l1 >> s_) & 1) xyzz_add<FB>(r, b1);
+            if ((l2 >> s_) & 1) xyzz_add<FB>(r, b2);
+        }
+        b = r;
     }
     xyzz<FB> s = a, d = a;
     xyzz_add<FB>(s, b);
@@ -167,8 +218,12 @@ static int lagrange_basis_run(int field_s, const void *d_g, void *d_out, unsigne
         if (k >= 1 && (rc = ntt_twiddle_table(field_s, (int)k, inv, st, &d_tw)) != H2_OK) break;
         dim3 block(256), gn((n + 255) / 256), gh((n / 2 + 255) / 256);
         hipLaunchKernelGGL((ec_load_bitrev<FB>), gn, block, 0, st, (const u32 *)d_g, (u32 *)d_p, n, (int)k, form == H2_FORM_MONTGOMERY);
-        for (unsigned t = 0; t < k; ++t)
-            hipLaunchKernelGGL((ec_stage<FB, FS>), gh, block, 0, st, (u32 *)d_p, d_tw, n / 2, (int)k, (int)t);
+        for (unsigned t = 0; t < k; ++t) {
+            if (t + 7 <= k && k >= 9)      // a twiddle serves >= 64 butterflies: one twiddle per wave (n / 2 is a multiple of 256)
+                hipLaunchKernelGGL((ec_stage_uniform<FB, FS>), dim3(n / 2 / 256), block, 0, st, (u32 *)d_p, d_tw, (int)k, (int)t);
+            else
+                hipLaunchKernelGGL((ec_stage<FB, FS>), gh, block, 0, st, (u32 *)d_p, d_tw, n / 2, (int)k, (int)t);
+        }
         hipLaunchKernelGGL((ec_scale_normalise<FB>), gn, block, 0, st, (const u32 *)d_p, (u32 *)d_out, n, (const int8_t *)d_naf, top,
                            form == H2_FORM_MONTGOMERY);
         e = hipStreamSynchronize(st);

@@ -430,7 +430,7 @@ def test_lagrange_basis_and_commit_lagrange_identity(curve):
     reference's own test_commit_lagrange_{epaffine,eqaffine} (:258-302) at k = 6:
     commit(lagrange_to_coeff(a)) == commit_lagrange(a), which ties the MSM, the field iFFT and the point FFT together."""
     sf = co.field_of_curve(curve, "scalar")
-    for k in (0, 1, 3, 6):
+    for k in (0, 1, 3, 6, 8, 9, 10):          # from k = 9 on the early stages run one twiddle per wave with the endomorphism split
         g = co.generate_bases(curve, 300 + k, 1 << k)
         assert np.array_equal(h.lagrange_basis(g, curve, k), co.lagrange_basis(curve, g, k)), k
     k = 6
