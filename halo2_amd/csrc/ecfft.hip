@@ -76,24 +76,37 @@ __global__ void __launch_bounds__(256) ec_stage(u32 *__restrict__ p, const u32 *
 // ec_stage pays every addition any lane of its wave needs, i.e. 255 doublings + ~255 additions; here the scalar is split with the
 // curve endomorphism (k = k1 + k2 lambda, 128-bit halves, glv.cuh; phi(X, Y, ZZ, ZZZ) = (zeta X, Y, ZZ, ZZZ)) and walked as
 // 129 doublings + the set bits of |k1| and |k2| (~128 additions).  The points of a wave are 2^(t+1) apart: 128-byte lines either way.
-template <int FB, int FS>
-__global__ void __launch_bounds__(256) ec_stage_uniform(u32 *__restrict__ p, const u32 *__restrict__ tw, int L, int t) {
-    const u32 per_low = 1u << (L - 1 - t - 6);                       // waves per twiddle
-    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    const u32 low = wave / per_low, hi = (wave % per_low) * 64 + lane;
+// UNIFORM = false: the last stages, one twiddle per lane -- the same split walk (130 doublings and, with 64 different scalars in
+// a wave, practically every one of the 2 x 130 additions) against 255 + 255 for the plain walk.
+template <int FB, int FS, bool UNIFORM>
+__global__ void __launch_bounds__(256) ec_stage_glv(u32 *__restrict__ p, const u32 *__restrict__ tw, u32 half_n, int L, int t) {
+    u32 low, hi;
+    if (UNIFORM) {
+        const u32 per_low = 1u << (L - 1 - t - 6);                   // waves per twiddle
+        const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+        low = wave / per_low;
+        hi = (wave % per_low) * 64 + lane;
+    } else {
+        const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+        if (q >= half_n) return;
+        low = q & ((1u << t) - 1);
+        hi = q >> t;
+    }
     const u32 x0 = (hi << (t + 1)) | low, x1 = x0 + (1u << t);
     xyzz<FB> a = xyzz_load<FB>(p + 32 * (size_t)x0), b = xyzz_load<FB>(p + 32 * (size_t)x1);
     if (low != 0) {
         const fe w = fe_from_mont<FS>(fe_load(tw + 8 * ((size_t)low << (L - t - 1))));
         u32 m1[5], m2[5], n1, n2;
         glv_split<FS>(w, m1, n1, m2, n2);
+        if (UNIFORM) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {                                // identical in every lane: say so (scalar registers, uniform branches)
-            m1[i] = (u32)__builtin_amdgcn_readfirstlane((int)m1[i]);
-            m2[i] = (u32)__builtin_amdgcn_readfirstlane((int)m2[i]);
+            for (int i = 0; i < 5; ++i) {                            // identical in every lane: say so (scalar registers, uniform branches)
+                m1[i] = (u32)__builtin_amdgcn_readfirstlane((int)m1[i]);
+                m2[i] = (u32)__builtin_amdgcn_readfirstlane((int)m2[i]);
+            }
+            n1 = (u32)__builtin_amdgcn_readfirstlane((int)n1);
+            n2 = (u32)__builtin_amdgcn_readfirstlane((int)n2);
         }
-        n1 = (u32)__builtin_amdgcn_readfirstlane((int)n1);
-        n2 = (u32)__builtin_amdgcn_readfirstlane((int)n2);
         xyzz<FB> b1 = b, b2 = b;
         if (n1) b1.y = fe_neg<FB>(b.y);
         b2.x = fe_mulx<FB>(b.x, glv_zeta<FB>());
@@ -220,7 +233,9 @@ static int lagrange_basis_run(int field_s, const void *d_g, void *d_out, unsigne
         hipLaunchKernelGGL((ec_load_bitrev<FB>), gn, block, 0, st, (const u32 *)d_g, (u32 *)d_p, n, (int)k, form == H2_FORM_MONTGOMERY);
         for (unsigned t = 0; t < k; ++t) {
             if (t + 7 <= k && k >= 9)      // a twiddle serves >= 64 butterflies: one twiddle per wave (n / 2 is a multiple of 256)
-                hipLaunchKernelGGL((ec_stage_uniform<FB, FS>), dim3(n / 2 / 256), block, 0, st, (u32 *)d_p, d_tw, (int)k, (int)t);
+                hipLaunchKernelGGL((ec_stage_glv<FB, FS, true>), dim3(n / 2 / 256), block, 0, st, (u32 *)d_p, d_tw, n / 2, (int)k, (int)t);
+            else if (t >= 2)     // per-lane twiddles; stages 0 and 1 multiply by 1 and by a fourth root of unity only
+                hipLaunchKernelGGL((ec_stage_glv<FB, FS, false>), gh, block, 0, st, (u32 *)d_p, d_tw, n / 2, (int)k, (int)t);
             else
                 hipLaunchKernelGGL((ec_stage<FB, FS>), gh, block, 0, st, (u32 *)d_p, d_tw, n / 2, (int)k, (int)t);
         }
