@@ -118,7 +118,8 @@ def main():
     # the blind term of Params::commit: w = a further seeded point, r = one seeded scalar per column (commitment.rs:119-130)
     w_host = co.generate_bases(curve, 0x77, 1)[0]
     blinds_host = co.random_field(sf, 0xB11D + rank, args.columns)
-    d_w = torch.from_numpy(w_host.view(np.int64)).to(dev)
+    # `w` is a field of Params: installed once as the table's blind column, as halo2_amd.Params does (commits pass only r)
+    check(lib.h2_bases_set_blind_base(params_g, _p(w_host), h.FORM_MONTGOMERY), "h2_bases_set_blind_base")
     d_blinds = torch.from_numpy(blinds_host.view(np.int64)).to(dev)
     d_out = torch.zeros((max(args.steps, 1), 12), dtype=torch.int64, device=dev)
     streams = [torch.cuda.current_stream()] if args.streams <= 1 else [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
@@ -127,7 +128,7 @@ def main():
     def step(i):
         # consecutive column commits are independent (plonk/prover.rs:305-309): round-robin them over the streams
         c_ = i % len(d_cols)
-        rc = lib.h2_commit_device(params_g, d_cols[c_].data_ptr(), n, d_w.data_ptr(), d_blinds[c_].data_ptr(), h.FORM_MONTGOMERY,
+        rc = lib.h2_commit_device(params_g, d_cols[c_].data_ptr(), n, None, d_blinds[c_].data_ptr(), h.FORM_MONTGOMERY,
                                   0, d_out[i % d_out.shape[0]].data_ptr(), sps[i % len(sps)])
         check(rc, "h2_commit_device")
 
@@ -181,7 +182,7 @@ def main():
         lib.h2_profile_enable(1)
         for i in range(20):
             c_ = i % len(d_cols)
-            rc = lib.h2_commit_device(params_g, d_cols[c_].data_ptr(), n, d_w.data_ptr(), d_blinds[c_].data_ptr(), h.FORM_MONTGOMERY, 0,
+            rc = lib.h2_commit_device(params_g, d_cols[c_].data_ptr(), n, None, d_blinds[c_].data_ptr(), h.FORM_MONTGOMERY, 0,
                                       d_out[0].data_ptr(), sps[0])
             check(rc, "h2_commit_device")
         torch.cuda.synchronize()
@@ -388,12 +389,12 @@ def main():
         hv = C.c_uint64(0)
         check(lib.h2_bases_register_ex(h.VESTA, _p(v_bases), n, h.FORM_MONTGOMERY, col_bits, C.byref(hv)), "h2_bases_register_ex")
         dv_cols = [torch.from_numpy(c_.view(np.int64)).to(dev) for c_ in v_cols]
-        dv_w = torch.from_numpy(v_w.view(np.int64)).to(dev)
+        check(lib.h2_bases_set_blind_base(hv, _p(v_w), h.FORM_MONTGOMERY), "h2_bases_set_blind_base")
         dv_bl = torch.from_numpy(v_bl.view(np.int64)).to(dev)
         reps_v, rep_ = 60, 0
 
         def v_commit(r_):
-            check(lib.h2_commit_device(hv, dv_cols[r_ % 2].data_ptr(), n, dv_w.data_ptr(), dv_bl[r_ % 2].data_ptr(), h.FORM_MONTGOMERY, 0,
+            check(lib.h2_commit_device(hv, dv_cols[r_ % 2].data_ptr(), n, None, dv_bl[r_ % 2].data_ptr(), h.FORM_MONTGOMERY, 0,
                                        d_out[r_ % d_out.shape[0]].data_ptr(), sps[r_ % len(sps)]), "h2_commit_device")
         t_w = time.perf_counter()                  # the GPU idled through the CPU baseline: warm up by time, as the headline does
         while time.perf_counter() - t_w < max(args.prewarm_ms, 50) * 1e-3:

@@ -85,7 +85,9 @@ class Params:
         check(lib().h2_bases_register_ex(curve, _p(self.g), self.n, FORM_MONTGOMERY, wb, C.byref(self._h_g)), "h2_bases_register_ex")
         check(lib().h2_bases_register_ex(curve, _p(self.g_lagrange), self.n, FORM_MONTGOMERY, wb, C.byref(self._h_gl)),
               "h2_bases_register_ex")
-        self._w_dev = None
+        # `w` is a field of Params (commitment.rs:26-33): installed once per table, commits then pass only their blind scalar
+        for h_ in (self._h_g, self._h_gl):
+            check(lib().h2_bases_set_blind_base(h_, _p(self.w), FORM_MONTGOMERY), "h2_bases_set_blind_base")
         self._h_gu = C.c_uint64(0)        # g || u, registered on the first opening argument (opening.py)
         self._h_pair = C.c_uint64(0)      # g || u || u || w || w for the paired L_j / R_j commits
         self._h_guw = C.c_uint64(0)       # g || u || w for the two-commit rounds of small arguments
@@ -164,16 +166,14 @@ class Params:
         if _is_torch(poly):
             import torch
             self._check_device(poly)
-            if self._w_dev is None or self._w_dev.device != poly.device:
-                self._w_dev = torch.from_numpy(self.w.view(np.int64)).to(poly.device)
             blind = torch.from_numpy(np.ascontiguousarray(r.value).view(np.int64)).to(poly.device)
             out = torch.empty(out_len, dtype=torch.int64, device=poly.device)
-            check(lib().h2_commit_device(handle, poly.data_ptr(), self.n, self._w_dev.data_ptr(), blind.data_ptr(),
+            check(lib().h2_commit_device(handle, poly.data_ptr(), self.n, None, blind.data_ptr(),
                                          FORM_MONTGOMERY, out_kind, out.data_ptr(), _stream_ptr()), "h2_commit_device")
             return out
         poly = _np(poly, 4)
         out = np.zeros(out_len, dtype=np.uint64)
-        check(lib().h2_commit(handle, _p(poly), self.n, _p(self.w), _p(np.ascontiguousarray(r.value)), FORM_MONTGOMERY,
+        check(lib().h2_commit(handle, _p(poly), self.n, None, _p(np.ascontiguousarray(r.value)), FORM_MONTGOMERY,
                               out_kind, _p(out)), "h2_commit")
         return out
 
@@ -189,8 +189,6 @@ class Params:
         self._check_device(polys[0])
         out_len = 8 if affine else 12
         out = torch.empty((len(polys), out_len), dtype=torch.int64, device=dev)
-        if self._w_dev is None or self._w_dev.device != dev:
-            self._w_dev = torch.from_numpy(self.w.view(np.int64)).to(dev)
         d_bl = torch.from_numpy(np.stack([np.ascontiguousarray(b.value) for b in blinds]).view(np.int64)).to(dev)
         n_ = len(polys)
         arr = C.c_void_p * n_
@@ -200,7 +198,7 @@ class Params:
         sc = arr(*[p_.data_ptr() for p_ in polys])
         bl = arr(*[d_bl[i].data_ptr() for i in range(n_)])
         outs = arr(*[out[i].data_ptr() for i in range(n_)])
-        check(lib().h2_commit_batch_device(self._h_gl if lagrange else self._h_g, sc, n_, self.n, self._w_dev.data_ptr(), bl,
+        check(lib().h2_commit_batch_device(self._h_gl if lagrange else self._h_g, sc, n_, self.n, None, bl,
                                            FORM_MONTGOMERY, OUT_AFFINE if affine else OUT_JACOBIAN, outs, _stream_ptr()),
               "h2_commit_batch_device")
         return out
@@ -212,17 +210,16 @@ class Params:
         if not self._h_gu.value:
             gu = np.ascontiguousarray(np.concatenate([self.g, self.u.reshape(1, 8)]))
             check(lib().h2_bases_register(self.curve, _p(gu), self.n + 1, FORM_MONTGOMERY, C.byref(self._h_gu)), "h2_bases_register")
+            check(lib().h2_bases_set_blind_base(self._h_gu, _p(self.w), FORM_MONTGOMERY), "h2_bases_set_blind_base")
         dev = cols[0].device
         n_ = len(cols)
         out = torch.empty((n_, 8 if affine else 12), dtype=torch.int64, device=dev)
-        if self._w_dev is None or self._w_dev.device != dev:
-            self._w_dev = torch.from_numpy(self.w.view(np.int64)).to(dev)
         d_bl = torch.from_numpy(np.stack([np.ascontiguousarray(b, dtype=np.uint64).reshape(4) for b in blinds]).view(np.int64)).to(dev)
         arr = C.c_void_p * n_
         for c_ in cols:
             if c_.shape[0] != self.n + 1 or not c_.is_contiguous():
                 raise ValueError("opening_columns_commit: columns must hold n + 1 scalars")
-        check(lib().h2_commit_batch_device(self._h_gu, arr(*[c_.data_ptr() for c_ in cols]), n_, self.n + 1, self._w_dev.data_ptr(),
+        check(lib().h2_commit_batch_device(self._h_gu, arr(*[c_.data_ptr() for c_ in cols]), n_, self.n + 1, None,
                                            arr(*[d_bl[i].data_ptr() for i in range(n_)]), FORM_MONTGOMERY,
                                            OUT_AFFINE if affine else OUT_JACOBIAN, arr(*[out[i].data_ptr() for i in range(n_)]),
                                            _stream_ptr()), "h2_commit_batch_device")

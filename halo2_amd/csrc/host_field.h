@@ -142,6 +142,11 @@ static inline void host_inv(int f, u64 r[4], const u64 a[4]) {
     u64 u[4], v[4], x1[4] = {1, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
     memcpy(u, a, 32);
     memcpy(v, F.p, 32);
+    while (host_ge(u, v)) host_sub_raw(u, u, v);                     // raw limbs at or above p (at most 3 p < 2^256): reduce first
+    if (!(u[0] | u[1] | u[2] | u[3])) {                               // 0 has no inverse: return 0 (as ff's `invert().unwrap_or(0)`
+        memset(r, 0, 32);                                             // callers do) instead of halving 0 for ever
+        return;
+    }
     auto is_one = [](const u64 t[4]) { return t[0] == 1 && !(t[1] | t[2] | t[3]); };
     while (!is_one(u) && !is_one(v)) {
         while (!(u[0] & 1)) {

@@ -132,6 +132,10 @@ struct IpaContext {
         naf.release();
         stage.release();
         stab.release();
+        // h2_trim must not take the round loop's scratch from under a running argument (which holds rounds_mu for its whole
+        // length and takes `mu` inside: try, never wait -- the lock order is the other way round there)
+        std::unique_lock<std::mutex> rl(rounds_mu, std::try_to_lock);
+        if (!rl.owns_lock()) return;
         rounds.release();
         gprime.release();
         if (rounds_host) (void)hipHostFree(rounds_host);
@@ -517,8 +521,15 @@ extern "C" int h2_ipa_rounds_device(int curve, unsigned k, unsigned switch_round
     if ((curve != H2_PALLAS && curve != H2_VESTA) || k < 1 || k > 30 || !d_p || !d_b || !z || !rands || !d_column_l || !write_point ||
         !squeeze || !c_out || !f_out || (!paired && !d_column_r))
         return H2_ERR_ARGS;
-    unsigned J = switch_rounds == H2_IPA_SWITCH_DEFAULT ? h2_ipa_default_switch_rounds(k, paired) : switch_rounds;
-    if (J && (!paired || J >= k || J > 12 || !uw_xy)) return H2_ERR_ARGS;
+    // everything that can be refused is refused HERE, before round 0 writes L_0 / R_0 into the caller's transcript and folds p' / b:
+    // the read-out of the collapsed generators (h2_ipa_collapsed_generators_device) takes a 16-bit table over g || u || u || w || w
+    size_t basis_n = 0;
+    int basis_c = 0, basis_curve = -1;
+    if ((h2_bases_info(basis, &basis_n, &basis_c, &basis_curve)) != H2_OK) return H2_ERR_HANDLE;
+    if (basis_curve != curve || basis_n < ((size_t)1 << k)) return H2_ERR_ARGS;
+    const bool can_switch = paired && basis_c == 16 && k <= 26 && basis_n == ((size_t)1 << k) + 4;
+    unsigned J = switch_rounds == H2_IPA_SWITCH_DEFAULT ? (can_switch ? h2_ipa_default_switch_rounds(k, paired) : 0) : switch_rounds;
+    if (J && (!can_switch || J >= k || J > 12 || !uw_xy)) return H2_ERR_ARGS;
     int rc = ensure_device();
     if (rc != H2_OK) return rc;
     hipStream_t st = (hipStream_t)stream;

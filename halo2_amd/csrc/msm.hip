@@ -50,6 +50,7 @@
 namespace h2 {
 
 static std::atomic<double> g_lane_fraction{1.0};
+static std::atomic<size_t> g_pipe_chunk{0};   // h2_set_option("host_commit_chunk"): sweeps only
 static constexpr int kMaxC = 16;          // generic path (and the 16-bit digit codes of the one-pass sort)
 static constexpr int kMaxCShared = 20;    // registered path: one bucket slice, two-pass sort, 32-bit digit codes
 static constexpr u32 kZeroCode = 0xFFFFu;
@@ -349,7 +350,7 @@ __global__ void __launch_bounds__(kScanBlock) msm_scan_apply(const u32 *__restri
 __global__ void __launch_bounds__(1024) msm_scatter(const uint16_t *__restrict__ digits, const u32 *__restrict__ hist,
                                                     const u32 *__restrict__ starts, u32 *__restrict__ entries,
                                                     size_t items, u32 chunk, u32 NB, u32 m, u32 stride, u32 extra_col,
-                                                    int table) {
+                                                    int table, u32 col0) {
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 off[];
     const u32 b = blockIdx.x, sl = blockIdx.y, B = gridDim.x;
@@ -366,6 +367,7 @@ __global__ void __launch_bounds__(1024) msm_scatter(const uint16_t *__restrict__
             const u32 i32 = (u32)i;  // items < 2^31
             u32 w = table ? i32 / m : 0, col = table ? i32 % m : i32;
             if (col == m - 1 && extra_col != 0xFFFFFFFFu) col = extra_col;
+            else col += col0;
             entries[pos] = (w * stride + col) | ((code & 0x8000u) << 16);
         }
     }
@@ -392,6 +394,7 @@ struct Sort2 {
     u32 lds_window;   // widest pass-2 window (buckets) whose counters fit LDS; wider ones count in HBM
     u32 s1_scalars;   // scalars per pass-1 workgroup (a multiple of 1024)
     u32 nb;           // buckets per slice; generic path: sort key = window * nb + bucket, entry = digit column
+    u32 col0;         // registered path: scalar i sits in table column col0 + i (a column RANGE of the table: the chunks of a pipelined host commit)
     int pair_shift;   // >= 0: registered PAIR commit -- column i < pair_n feeds output (i >> pair_shift) & 1, a tail column
     u32 pair_n;       //       i >= pair_n feeds output (i - pair_n) & 1; sort key = side * nb + bucket (two bucket slices)
 };
@@ -436,7 +439,7 @@ template <typename Fn> __device__ __forceinline__ void for_each_digit(const fe &
 template <int FS, bool GLV, typename Fn>
 __device__ __forceinline__ void emit_entries(const fe &s, u32 i, const Sort2 &P, Fn f) {
     if (!GLV) {
-        u32 col = i;
+        u32 col = P.col0 + i;
         if (i == P.m - 1 && P.extra_col != 0xFFFFFFFFu) col = P.extra_col;
         u32 side_key = 0;
         if (P.pair_shift >= 0) side_key = (i < P.pair_n ? (i >> P.pair_shift) & 1u : (i - P.pair_n) & 1u) * P.nb;
@@ -1192,40 +1195,47 @@ __global__ void __launch_bounds__(256) msm_table_chain_wide(const u32 *__restric
         if ((threadIdx.x & (kGroup - 1)) == 0) xyzz_store<FB>(tmp + 32 * ((size_t)(w - 1) * count + i), r);
     }
 }
-// blind base: column `col` of the table must hold the multiples of `w`.  One lane compares w with what row 0
-// already holds; only when it differs does it store w, redo the chain into `tmp` and raise `flag` so that
-// msm_blind_normalise refreshes rows 1..W-1.  Entirely on the stream: no host round trip per commit.
+// blind base: column `col` of the table must hold the multiples of `w` (Params::w, poly/commitment.rs:26-33).  ONE workgroup of
+// 64 lanes: lane 0 compares w with what row 0 of the column holds (the CONTENT, not an address) and leaves when they agree.
+// Otherwise it walks the doubling chain, parking 2^(c w) * w in LDS, lanes 1 .. W-1 normalise one row each, and row 0 -- the
+// word later calls compare against -- is written LAST, after a fence: a column whose row 0 shows w is complete.
 template <int FB>
-__global__ void msm_blind_chain(u32 *__restrict__ table, const u32 *__restrict__ w_xy, u32 *__restrict__ tmp,
-                                u32 *__restrict__ flag, u32 col, u32 stride, int c, int W) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    affine<FB> p = aff_load<FB>(w_xy);
-    const affine<FB> p9 = aff_to_m9<FB>(p), cur = aff_load<FB>(table + 16 * (size_t)col);     // the table holds M9 form
-    if (fe_eq(p9.x, cur.x) && fe_eq(p9.y, cur.y)) {
-        *flag = 0;
-        return;
+__global__ void __launch_bounds__(64) msm_blind_install(u32 *__restrict__ table, const u32 *__restrict__ w_xy, u32 col, u32 stride, int c, int W,
+                                                        int mont) {
+    __shared__ __attribute__((aligned(16))) u32 chain[63 * 32];
+    __shared__ u32 differs;
+    affine<FB> p9;
+    if (threadIdx.x == 0) {
+        affine<FB> p = aff_load<FB>(w_xy);
+        if (!mont) { p.x = fe_to_mont<FB>(p.x); p.y = fe_to_mont<FB>(p.y); }
+        p9 = aff_to_m9<FB>(p);                                                                   // the table holds M9 form
+        const affine<FB> cur = aff_load<FB>(table + 16 * (size_t)col);
+        differs = (fe_eq(p9.x, cur.x) && fe_eq(p9.y, cur.y)) ? 0u : 1u;
+        if (differs) {
+            xyzz<FB> r = xyzz_identity<FB>();
+            xyzz_madd<FB>(r, p);
+            for (int w = 1; w < W; ++w) {
+                for (int k = 0; k < c; ++k) r = xyzz_dbl<FB>(r);
+                xyzz_store<FB>(chain + 32 * (size_t)(w - 1), r);
+            }
+        }
     }
-    fe_store(table + 16 * (size_t)col, p9.x);
-    fe_store(table + 16 * (size_t)col + 8, p9.y);
-    xyzz<FB> r = xyzz_identity<FB>();
-    xyzz_madd<FB>(r, p);
-    for (int w = 1; w < W; ++w) {
-        for (int k = 0; k < c; ++k) r = xyzz_dbl<FB>(r);
-        xyzz_store<FB>(tmp + 32 * (size_t)(w - 1), r);
+    __syncthreads();
+    if (!differs) return;
+    const u32 w = threadIdx.x;
+    if (w >= 1 && (int)w < W) {
+        const xyzz<FB> r = xyzz_load<FB>(chain + 32 * (size_t)(w - 1));
+        const affine<FB> a = aff_to_m9<FB>(xyzz_to_affine<FB>(r));
+        u32 *dst = table + 16 * ((size_t)w * stride + col);
+        fe_store(dst, a.x);
+        fe_store(dst + 8, a.y);
     }
-    *flag = 1;
-    (void)stride;
-}
-template <int FB>
-__global__ void msm_blind_normalise(const u32 *__restrict__ tmp, u32 *__restrict__ table, const u32 *__restrict__ flag,
-                                    u32 col, u32 stride, int W) {
-    u32 w = threadIdx.x + 1;
-    if (*flag != 1 || (int)w >= W) return;
-    xyzz<FB> r = xyzz_load<FB>(tmp + 32 * (size_t)(w - 1));
-    affine<FB> a = aff_to_m9<FB>(xyzz_to_affine<FB>(r));
-    u32 *dst = table + 16 * ((size_t)w * stride + col);
-    fe_store(dst, a.x);
-    fe_store(dst + 8, a.y);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        fe_store(table + 16 * (size_t)col, p9.x);
+        fe_store(table + 16 * (size_t)col + 8, p9.y);
+    }
 }
 
 // rows 1 .. W-1 of the table from the chains' XYZZ results, affine and in M9 form, with ONE inversion per point: the W - 1
@@ -1458,6 +1468,7 @@ struct MsmArgs {
     double lane_fraction = 0.0;  // 0 = the process-wide option; the batch entry point narrows its commits
     int pair_shift = -1;         // >= 0 (registered only): two outputs from one column, see Sort2::pair_shift; d_out holds both
     u32 pair_n = 0;
+    u32 col0 = 0;                // registered only: the scalars are table columns [col0, col0 + n_used)
 };
 
 template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a, hipStream_t st) {
@@ -1552,6 +1563,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
             S2.K2 = kS2Chunk;
             S2.B2 = (u32)((all_items + kS2Chunk - 1) / kS2Chunk);
             S2.lds_window = std::min<u32>(sh.NB, 32768u);
+            S2.col0 = a.col0;
         }
     } else if (glv && scalars_n >= 65536) {
         // generic path, large: sort key = window * NB + bucket over all slices, entry = digit column (< 2 * scalars)
@@ -1667,7 +1679,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                            cx.starts.as<u32>(), tb);
         hipLaunchKernelGGL(msm_scatter, dim3(sh.B, sh.slices), dim3(1024), sh.NB * 4, st, cx.digits.as<uint16_t>(),
                            cx.hist.as<u32>(), cx.starts.as<u32>(), cx.entries.as<u32>(), sh.items, sh.chunk, sh.NB, m32,
-                           a.table ? a.stride : 0u, extra_col, a.table ? 1 : 0);
+                           a.table ? a.stride : 0u, extra_col, a.table ? 1 : 0, a.table ? a.col0 : 0u);
     }
 #ifdef H2_SORT_DEBUG
     if (use_sort2 && sh.c <= kMaxC && a.table) {
@@ -1686,7 +1698,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         hipLaunchKernelGGL(msm_scan_top, dim3(1), dim3(kScanBlock), 0, st, cx.bsums.as<u32>(), nblocks, grand);
         hipLaunchKernelGGL(msm_scan_apply, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), grand, cx.starts.as<u32>(), tb);
         hipLaunchKernelGGL(msm_scatter, dim3(sh.B, sh.slices), dim3(1024), sh.NB * 4, st, cx.digits.as<uint16_t>(), h2b.as<u32>(), cx.starts.as<u32>(),
-                           cx.entries.as<u32>(), sh.items, sh.chunk, sh.NB, m32, a.table ? a.stride : 0u, extra_col, a.table ? 1 : 0);
+                           cx.entries.as<u32>(), sh.items, sh.chunk, sh.NB, m32, a.table ? a.stride : 0u, extra_col, a.table ? 1 : 0, a.table ? a.col0 : 0u);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(sb.data(), cx.starts.ptr, (tb + 1) * 4, hipMemcpyDeviceToHost);
         (void)hipMemcpy(eb.data(), cx.entries.ptr, (size_t)sb[tb] * 4, hipMemcpyDeviceToHost);
@@ -1808,30 +1820,25 @@ struct Bases {
     int c = 16, W = 16;
     u32 stride = 0;            // n + 1: column n is the blind's base
     void *d_table = nullptr;   // [W][stride] affine Montgomery points, row w = 2^(c*w) * P
-    void *d_blind_tmp = nullptr;  // (W-1) XYZZ + flag word, scratch of msm_blind_chain
-    // blind-base maintenance is serialised on one stream of its own, whatever streams the commits come from
-    hipStream_t maint = nullptr;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    void *d_blind_tmp = nullptr;  // 64-byte staging slot for a blind base that arrives through a host pointer
     int device = 0;            // the HIP device the table lives on (current at registration)
-    // which blind base column n currently holds (ensure_blind_base)
-    bool blind_valid = false, blind_by_content = false;
+    // `Params::w` (poly/commitment.rs:26-33) belongs to the handle: h2_bases_set_blind_base installs its multiples as column n.
+    // blind_set: the column holds SOME w.  blind_host_known: `blind_host` / `blind_form` are the 64 bytes it was installed from
+    // (false after a device-pointer override, whose content the host never sees).
+    bool blind_set = false, blind_host_known = false;
     int blind_form = 0;
-    uintptr_t blind_key = 0;
     unsigned char blind_host[64] = {0};
     // The table is owned here: it goes back to the allocator when the LAST reference drops -- h2_bases_free only removes
     // the handle, so a commit another host thread is still enqueueing (it holds the shared_ptr from find_bases) keeps the
     // memory alive, and every error path of h2_bases_register releases what it had allocated.
     ~Bases() {
-        if (!d_table && !d_blind_tmp && !maint && !ev_out) return;
+        if (!d_table && !d_blind_tmp) return;
         int cur = 0;
         (void)hipGetDevice(&cur);
         if (cur != device) (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
         if (d_table) (void)hipFree(d_table);
         if (d_blind_tmp) (void)hipFree(d_blind_tmp);
-        if (maint) (void)hipStreamDestroy(maint);
-        if (ev_in) (void)hipEventDestroy(ev_in);
-        if (ev_out) (void)hipEventDestroy(ev_out);
         if (cur != device) (void)hipSetDevice(cur);
     }
 };
@@ -1886,40 +1893,53 @@ static int table_fill(Bases &b, u32 first, u32 count, hipStream_t st) {
     return H2_OK;
 }
 
-// makes column n of the table hold the multiples of `w` (device pointer, Montgomery).  Asynchronous, on the caller's stream.
-// `Params::w` is fixed for the life of a `Params` (poly/commitment.rs:26-33), so the handle remembers which blind base its
-// column holds: by CONTENT for the host-pointer entry points (`host_w`, 64 bytes as passed), by device ADDRESS for the
-// device-pointer ones (`key`; the caller must not change the 64 bytes behind an address it keeps passing while commits
-// are in flight).  A commit that presents the remembered blind base only waits for the event of the rebuild that wrote the
-// column -- no kernel, and nothing that ties the commits of different streams to each other (the round-1 scheme ran a
-// compare kernel per commit on one maintenance stream, which chained every stream's commits through it: 1.12 -> 1.40 ms).
-// Otherwise the compare / chain / normalise kernels run on `st`, ordered after the previous rebuild.
-// Switching to a different w while commits with the old one are still in flight is not supported.
-static int ensure_blind_base(Bases &b, const void *d_w_mont, hipStream_t st, uintptr_t key, const void *host_w, int form) {
+// ---- the blind base ---------------------------------------------------------------------------------------------------
+// `Params::w` is a field of `Params`, fixed for its life (poly/commitment.rs:26-33, set at :102-103), so it is a property of
+// the HANDLE: h2_bases_set_blind_base installs the multiples of w as column n of the table once, and a commit that passes a
+// blind scalar but no w uses that column -- no kernel, no event, nothing that ties the commits of different streams together.
+// A commit may still present a w of its own: the 64 BYTES are compared (never an address) -- on the host for host pointers,
+// by msm_blind_install on the commit's stream for device pointers -- and only a different point rebuilds the column.
+static void launch_blind_install(Bases &b, const void *d_w_xy, int form, hipStream_t st) {
+    if (b.curve == H2_PALLAS)
+        hipLaunchKernelGGL((msm_blind_install<FP>), dim3(1), dim3(64), 0, st, (u32 *)b.d_table, (const u32 *)d_w_xy, (u32)b.n, b.stride, b.c, b.W,
+                           form == H2_FORM_MONTGOMERY);
+    else
+        hipLaunchKernelGGL((msm_blind_install<FQ>), dim3(1), dim3(64), 0, st, (u32 *)b.d_table, (const u32 *)d_w_xy, (u32)b.n, b.stride, b.c, b.W,
+                           form == H2_FORM_MONTGOMERY);
+}
+
+// host pointer: compared by content against what the handle was last given; a different point waits for the device to drain
+// (commits with the old w may be in flight on any stream), installs the new one and returns when the column is complete.
+static int set_blind_base_host(Bases &b, const void *host_w_xy, int form) {
     std::lock_guard<std::mutex> lk(b.mu);
-    if (!b.ev_out) H2_HIP(hipEventCreateWithFlags(&b.ev_out, hipEventDisableTiming));
-    const bool same = b.blind_valid && b.blind_form == form &&
-                      (host_w ? (b.blind_by_content && memcmp(b.blind_host, host_w, 64) == 0) : (!b.blind_by_content && b.blind_key == key));
-    if (same) {
-        H2_HIP(hipStreamWaitEvent(st, b.ev_out, 0));
-        return H2_OK;
+    if (b.blind_set && b.blind_host_known && b.blind_form == form && memcmp(b.blind_host, host_w_xy, 64) == 0) return H2_OK;
+    int cur = 0;
+    H2_HIP(hipGetDevice(&cur));
+    if (cur != b.device) H2_HIP(hipSetDevice(b.device));
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(b.d_blind_tmp, host_w_xy, 64, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_blind_install(b, b.d_blind_tmp, form, 0);
+        e = hipGetLastError();
     }
-    if (b.blind_valid) H2_HIP(hipStreamWaitEvent(st, b.ev_out, 0));      // rebuilds are ordered one after the other
-    u32 *tmp = (u32 *)b.d_blind_tmp, *flag = tmp + 32 * (size_t)b.W;
-    if (b.curve == H2_PALLAS) {
-        hipLaunchKernelGGL((msm_blind_chain<FP>), dim3(1), dim3(64), 0, st, (u32 *)b.d_table, (const u32 *)d_w_mont, tmp, flag, (u32)b.n, b.stride, b.c, b.W);
-        hipLaunchKernelGGL((msm_blind_normalise<FP>), dim3(1), dim3(64), 0, st, tmp, (u32 *)b.d_table, flag, (u32)b.n, b.stride, b.W);
-    } else {
-        hipLaunchKernelGGL((msm_blind_chain<FQ>), dim3(1), dim3(64), 0, st, (u32 *)b.d_table, (const u32 *)d_w_mont, tmp, flag, (u32)b.n, b.stride, b.c, b.W);
-        hipLaunchKernelGGL((msm_blind_normalise<FQ>), dim3(1), dim3(64), 0, st, tmp, (u32 *)b.d_table, flag, (u32)b.n, b.stride, b.W);
-    }
-    H2_HIP(hipGetLastError());
-    H2_HIP(hipEventRecord(b.ev_out, st));
-    b.blind_valid = true;
+    if (e == hipSuccess) e = hipStreamSynchronize(0);
+    if (cur != b.device) (void)hipSetDevice(cur);
+    if (e != hipSuccess) { set_last_hip_error(e, __FILE__, __LINE__); return H2_ERR_HIP; }
+    b.blind_set = b.blind_host_known = true;
     b.blind_form = form;
-    b.blind_by_content = host_w != nullptr;
-    b.blind_key = key;
-    if (host_w) memcpy(b.blind_host, host_w, 64);
+    memcpy(b.blind_host, host_w_xy, 64);
+    return H2_OK;
+}
+
+// device pointer presented by a commit: one 64-lane kernel on the commit's stream compares the bytes with row 0 of the column
+// and rebuilds it only when they differ (then this w becomes the handle's).  Commits that use another w on other streams
+// must have completed by then, as for any change of `Params`.
+static int override_blind_base_device(Bases &b, const void *d_w_xy, int form, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(b.mu);
+    launch_blind_install(b, d_w_xy, form, st);
+    H2_HIP(hipGetLastError());
+    b.blind_set = true;
+    b.blind_host_known = false;
     return H2_OK;
 }
 
@@ -1951,6 +1971,11 @@ extern "C" int h2_set_option(const char *key, double value) {
     if (strcmp(key, "msm_lane_fraction") == 0) {
         if (!(value > 0.05 && value <= 1.0)) return H2_ERR_ARGS;
         g_lane_fraction.store(value);
+        return H2_OK;
+    }
+    if (strcmp(key, "host_commit_chunk") == 0) {        // scalars per range of a pipelined host commit (0 = default); sweeps only
+        if (!(value >= 0 && value <= (double)(1u << 26))) return H2_ERR_ARGS;
+        g_pipe_chunk.store((size_t)value);
         return H2_OK;
     }
     return H2_ERR_ARGS;
@@ -2015,8 +2040,7 @@ static int bases_register_impl(int curve, const void *bases_xy, bool on_device, 
     H2_HIP(hipGetDevice(&b->device));
     H2_HIP(hipMalloc(&b->d_table, (size_t)b->W * b->stride * 64));
     H2_HIP(hipMemsetAsync(b->d_table, 0, (size_t)b->W * b->stride * 64, 0));
-    H2_HIP(hipMalloc(&b->d_blind_tmp, (size_t)b->W * 128 + 64));
-    H2_HIP(hipMemsetAsync(b->d_blind_tmp, 0, (size_t)b->W * 128 + 64, 0));
+    H2_HIP(hipMalloc(&b->d_blind_tmp, 64));
     if (n) {
         H2_HIP(hipMemcpyAsync(b->d_table, bases_xy, n * 64, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, 0));
         if (form == H2_FORM_CANONICAL) to_mont_async(curve, (u32 *)b->d_table, n * 2, 0);
@@ -2138,6 +2162,15 @@ extern "C" int h2_ipa_collapsed_generators_device(h2_bases_t basis, unsigned k, 
     return H2_OK;
 }
 
+extern "C" int h2_bases_info(h2_bases_t handle, size_t *n, int *window_bits, int *curve) {
+    auto b = find_bases(handle);
+    if (!b) return H2_ERR_HANDLE;
+    if (n) *n = b->n;
+    if (window_bits) *window_bits = b->c;
+    if (curve) *curve = b->curve;
+    return H2_OK;
+}
+
 extern "C" int h2_bases_free(h2_bases_t handle) {
     std::shared_ptr<Bases> b;
     {
@@ -2163,26 +2196,36 @@ static int commit_device_impl(h2_bases_t g, const void *d_scalars, size_t n, con
                               int out_kind, void *d_out, void *stream, bool blind_base_ready, double lane_fraction) {
     auto b = find_bases(g);
     if (!b) return H2_ERR_HANDLE;
-    if (bad_common(b->curve, form, out_kind) || !d_out || (n && !d_scalars) || n > b->n || ((d_w_xy == nullptr) != (d_blind == nullptr)))
-        return H2_ERR_ARGS;
+    // d_blind without d_w_xy: the handle's own blind base (h2_bases_set_blind_base).  d_w_xy without d_blind: nothing to multiply.
+    if (bad_common(b->curve, form, out_kind) || !d_out || (n && !d_scalars) || n > b->n || (d_w_xy && !d_blind)) return H2_ERR_ARGS;
     int rc = ensure_device();
     if (rc != H2_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     MsmContext &cx = msm_ctx(st);
     std::lock_guard<std::mutex> lk(cx.mu);
-    if (d_w_xy && !blind_base_ready) {
-        const void *w = d_w_xy;
-        if (form == H2_FORM_CANONICAL) {
-            if ((rc = cx.small.reserve(64)) != H2_OK) return rc;
-            H2_HIP(hipMemcpyAsync(cx.small.ptr, d_w_xy, 64, hipMemcpyDeviceToDevice, st));
-            to_mont_async(b->curve, cx.small.as<u32>(), 2, st);
-            w = cx.small.ptr;
+    if (d_blind && !blind_base_ready) {
+        if (d_w_xy) {
+            if ((rc = override_blind_base_device(*b, d_w_xy, form, st)) != H2_OK) return rc;
+        } else {
+            std::lock_guard<std::mutex> bl(b->mu);
+            if (!b->blind_set) {
+                set_last_error_msg("commit with a blind but the handle has no blind base: call h2_bases_set_blind_base, or pass d_w_xy");
+                return H2_ERR_ARGS;
+            }
         }
-        if ((rc = ensure_blind_base(*b, w, st, (uintptr_t)d_w_xy, nullptr, form)) != H2_OK) return rc;
     }
     MsmArgs a{d_scalars, d_blind, b->d_table, nullptr, n, true, b->c, b->stride, (u32)b->n, form, out_kind, d_out};
     a.lane_fraction = lane_fraction;
     return msm_dispatch(cx, b->curve, a, st);
+}
+
+extern "C" int h2_bases_set_blind_base(h2_bases_t g, const uint64_t *w_xy, int form) {
+    auto b = find_bases(g);
+    if (!b) return H2_ERR_HANDLE;
+    if (!w_xy || (form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY)) return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    return set_blind_base_host(*b, w_xy, form);
 }
 
 // Two commits from ONE column over a registered basis: column i < n - 4 belongs to output (i >> pair_shift) & 1, the last four
@@ -2230,7 +2273,7 @@ BatchStreams &batch_streams() {
 
 extern "C" int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars, size_t count, size_t n, const void *d_w_xy,
                                       const void *const *d_blinds, int form, int out_kind, void *const *d_outs, void *stream) {
-    if (!d_scalars || !d_outs || (d_w_xy && !d_blinds)) return H2_ERR_ARGS;
+    if (!d_scalars || !d_outs || (d_w_xy && !d_blinds)) return H2_ERR_ARGS;      // d_blinds without d_w_xy: the handle's blind base
     if (count == 0) return H2_OK;
     int rc = ensure_device();
     if (rc != H2_OK) return rc;
@@ -2248,25 +2291,24 @@ extern "C" int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars
     }
     if (!bs.fork) H2_HIP(hipEventCreateWithFlags(&bs.fork, hipEventDisableTiming));
     hipStream_t user = (hipStream_t)stream;
-    if (d_w_xy) {  // bring the blind base up to date ONCE, on the caller's stream, before forking
+    if (d_blinds) {  // a presented w is checked (and installed if it differs) ONCE, on the caller's stream, before forking
         auto b = find_bases(g);
         if (!b) return H2_ERR_HANDLE;
         if (form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY) return H2_ERR_ARGS;
-        const void *w = d_w_xy;
-        MsmContext &cx = msm_ctx(user);
-        std::lock_guard<std::mutex> cl(cx.mu);
-        if (form == H2_FORM_CANONICAL) {
-            if ((rc = cx.small.reserve(64)) != H2_OK) return rc;
-            H2_HIP(hipMemcpyAsync(cx.small.ptr, d_w_xy, 64, hipMemcpyDeviceToDevice, user));
-            to_mont_async(b->curve, cx.small.as<u32>(), 2, user);
-            w = cx.small.ptr;
+        if (d_w_xy) {
+            if ((rc = override_blind_base_device(*b, d_w_xy, form, user)) != H2_OK) return rc;
+        } else {
+            std::lock_guard<std::mutex> bl(b->mu);
+            if (!b->blind_set) {
+                set_last_error_msg("batch commit with blinds but the handle has no blind base: call h2_bases_set_blind_base, or pass d_w_xy");
+                return H2_ERR_ARGS;
+            }
         }
-        if ((rc = ensure_blind_base(*b, w, user, (uintptr_t)d_w_xy, nullptr, form)) != H2_OK) return rc;
     }
     H2_HIP(hipEventRecord(bs.fork, user));
     for (size_t i = 0; i < want; ++i) H2_HIP(hipStreamWaitEvent(bs.s[i], bs.fork, 0));
     for (size_t i = 0; i < count && rc == H2_OK; ++i)
-        rc = commit_device_impl(g, d_scalars[i], n, d_w_xy, d_w_xy ? d_blinds[i] : nullptr, form, out_kind, d_outs[i], bs.s[i % want], true, fraction);
+        rc = commit_device_impl(g, d_scalars[i], n, nullptr, d_blinds ? d_blinds[i] : nullptr, form, out_kind, d_outs[i], bs.s[i % want], true, fraction);
     for (size_t i = 0; i < want; ++i) {
         H2_HIP(hipEventRecord(bs.done[i], bs.s[i]));
         H2_HIP(hipStreamWaitEvent(user, bs.done[i], 0));
@@ -2307,34 +2349,105 @@ extern "C" int h2_msm_batch_device(int curve, const void *const *d_scalars, cons
     return rc;
 }
 
+// ---- Params::commit from a HOST column (the literal seam: the reference's `poly` is a Vec in host memory,
+// poly/commitment.rs:119-130).  The column is cut into ranges of the registered table's columns; range r is copied on a copy
+// stream and, as soon as it has landed, committed on one of two compute streams as a multiexp of its own over table columns
+// [lo, hi) (MsmArgs::col0) -- so PCIe runs beside the bucket arithmetic of the ranges before it, and only the first range's
+// copy and the last range's fold stay exposed.  The partial points are added by k_points_sum (a group element: any order).
+namespace {
+constexpr int kPipeMaxChunks = 16;
+constexpr size_t kPipeChunk = (size_t)1 << 17;      // 4 MiB of scalars: ~0.08 ms of PCIe, 0.13 ms of bucket additions
+struct HostPipe {
+    std::mutex mu;
+    bool ready = false;
+    hipStream_t copy = nullptr, comp[2] = {nullptr, nullptr};
+    hipEvent_t landed[kPipeMaxChunks] = {nullptr}, done[2] = {nullptr, nullptr};
+    DevBuf stage, parts;
+    int prepare() {
+        if (ready) return H2_OK;
+        H2_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+        for (auto &c : comp) H2_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+        for (auto &e : landed) H2_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : done) H2_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ready = true;
+        return H2_OK;
+    }
+};
+HostPipe &host_pipe() {
+    static HostPipe p[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return p[dev & 15];
+}
+}  // namespace
+
+
+static int commit_host_pipelined(Bases &b, const uint64_t *scalars, size_t n, const uint64_t *blind, int form, int out_kind, uint64_t *out) {
+    HostPipe &hp = host_pipe();
+    std::lock_guard<std::mutex> lk(hp.mu);
+    int rc = hp.prepare();
+    if (rc != H2_OK) return rc;
+    size_t chunk = g_pipe_chunk.load() ? g_pipe_chunk.load() : kPipeChunk;
+    if (n < 2 * chunk) chunk = std::max<size_t>(n, 1);                       // small columns: one range, nothing to overlap
+    chunk = std::max(chunk, (n + kPipeMaxChunks - 1) / kPipeMaxChunks);
+    const int chunks = (int)std::max<size_t>(1, (n + chunk - 1) / chunk);
+    if ((rc = hp.stage.reserve(n * 32 + 64)) != H2_OK) return rc;
+    if ((rc = hp.parts.reserve((size_t)(chunks + 1) * 96)) != H2_OK) return rc;
+    char *d_s = hp.stage.as<char>(), *d_blind = d_s + n * 32, *d_parts = hp.parts.as<char>();
+    if (blind) H2_HIP(hipMemcpyAsync(d_blind, blind, 32, hipMemcpyHostToDevice, hp.copy));
+    for (int i = 0; i < chunks; ++i) {
+        const size_t lo = (size_t)i * chunk, len = std::min(chunk, n - lo);
+        if (len) H2_HIP(hipMemcpyAsync(d_s + lo * 32, (const char *)scalars + lo * 32, len * 32, hipMemcpyHostToDevice, hp.copy));
+        H2_HIP(hipEventRecord(hp.landed[i], hp.copy));
+        hipStream_t st = hp.comp[i & 1];
+        H2_HIP(hipStreamWaitEvent(st, hp.landed[i], 0));
+        MsmContext &cx = msm_ctx(st);
+        std::lock_guard<std::mutex> cl(cx.mu);
+        // the blind rides with the last range (its base is column n of the table whatever the range)
+        MsmArgs a{d_s + lo * 32, (blind && i == chunks - 1) ? d_blind : nullptr, b.d_table, nullptr, len, true, b.c, b.stride, (u32)b.n, form,
+                  H2_OUT_JACOBIAN, d_parts + (size_t)i * 96};
+        a.col0 = (u32)lo;
+        if ((rc = msm_dispatch(cx, b.curve, a, st)) != H2_OK) break;
+    }
+    for (int j = 0; j < 2; ++j) {
+        H2_HIP(hipEventRecord(hp.done[j], hp.comp[j]));
+        H2_HIP(hipStreamWaitEvent(hp.copy, hp.done[j], 0));
+    }
+    if (rc != H2_OK) {
+        (void)hipStreamSynchronize(hp.copy);
+        return rc;
+    }
+    const bool mont = form == H2_FORM_MONTGOMERY;
+    char *d_res = d_parts + (size_t)chunks * 96;
+    if (b.curve == H2_PALLAS)
+        hipLaunchKernelGGL((k_points_sum<FP>), dim3(1), dim3(64), 0, hp.copy, (const u32 *)d_parts, (u32)chunks, (u32 *)d_res, mont, out_kind, mont);
+    else
+        hipLaunchKernelGGL((k_points_sum<FQ>), dim3(1), dim3(64), 0, hp.copy, (const u32 *)d_parts, (u32)chunks, (u32 *)d_res, mont, out_kind, mont);
+    H2_HIP(hipGetLastError());
+    H2_HIP(hipMemcpyAsync(out, d_res, out_kind == H2_OUT_AFFINE ? 64 : 96, hipMemcpyDeviceToHost, hp.copy));
+    H2_HIP(hipStreamSynchronize(hp.copy));
+    return H2_OK;
+}
+
 extern "C" int h2_commit(h2_bases_t g, const uint64_t *scalars, size_t n, const uint64_t *w_xy, const uint64_t *blind,
                          int form, int out_kind, uint64_t *out) {
     auto b = find_bases(g);
     if (!b) return H2_ERR_HANDLE;
-    if (bad_common(b->curve, form, out_kind) || !out || (n && !scalars) || n > b->n || ((w_xy == nullptr) != (blind == nullptr)))
-        return H2_ERR_ARGS;
+    if (bad_common(b->curve, form, out_kind) || !out || (n && !scalars) || n > b->n || (w_xy && !blind)) return H2_ERR_ARGS;
     int rc = ensure_device();
     if (rc != H2_OK) return rc;
-    MsmContext &cx = msm_ctx();
-    const size_t out_bytes = out_kind == H2_OUT_AFFINE ? 64 : 96;
-    std::lock_guard<std::mutex> lk(cx.mu);
-    if ((rc = cx.stage_s.reserve(n * 32 + 32)) != H2_OK) return rc;
-    if ((rc = cx.small.reserve(64 + 32)) != H2_OK) return rc;
-    if ((rc = cx.out.reserve(128)) != H2_OK) return rc;
-    if (n) H2_HIP(hipMemcpyAsync(cx.stage_s.ptr, scalars, n * 32, hipMemcpyHostToDevice, 0));
-    const void *d_bl = nullptr;
-    if (w_xy) {
-        H2_HIP(hipMemcpyAsync(cx.small.ptr, w_xy, 64, hipMemcpyHostToDevice, 0));
-        H2_HIP(hipMemcpyAsync((char *)cx.small.ptr + 64, blind, 32, hipMemcpyHostToDevice, 0));
-        if (form == H2_FORM_CANONICAL) to_mont_async(b->curve, cx.small.as<u32>(), 2, 0);
-        d_bl = (char *)cx.small.ptr + 64;
-        if ((rc = ensure_blind_base(*b, cx.small.ptr, 0, 0, w_xy, form)) != H2_OK) return rc;
+    if (blind) {   // w_xy: compared by content with the handle's blind base, installed if it differs; NULL: the handle's own
+        if (w_xy) {
+            if ((rc = set_blind_base_host(*b, w_xy, form)) != H2_OK) return rc;
+        } else {
+            std::lock_guard<std::mutex> bl(b->mu);
+            if (!b->blind_set) {
+                set_last_error_msg("h2_commit with a blind but the handle has no blind base: call h2_bases_set_blind_base, or pass w_xy");
+                return H2_ERR_ARGS;
+            }
+        }
     }
-    MsmArgs a{cx.stage_s.ptr, d_bl, b->d_table, nullptr, n, true, b->c, b->stride, (u32)b->n, form, out_kind, cx.out.ptr};
-    if ((rc = msm_dispatch(cx, b->curve, a, 0)) != H2_OK) return rc;
-    H2_HIP(hipMemcpyAsync(out, cx.out.ptr, out_bytes, hipMemcpyDeviceToHost, 0));
-    H2_HIP(hipStreamSynchronize(0));
-    return H2_OK;
+    return commit_host_pipelined(*b, scalars, n, blind, form, out_kind, out);
 }
 
 // device-resident partials (the landing buffer of an all-gather) -> their sum, on `stream`

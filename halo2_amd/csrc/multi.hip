@@ -100,8 +100,8 @@ extern "C" int h2_commit_batch_multi(const h2_bases_t *handles, const int *devic
         std::lock_guard<std::mutex> lk(L.mu);
         if ((r = L.prepare(devices[d], std::max<size_t>(n, 1) * 32)) != H2_OK) return r;
         char *small = (char *)L.d_small;
-        if (w_xy) H2_HIP(hipMemcpyAsync(small, w_xy, 64, hipMemcpyHostToDevice, L.st[0]));
-        H2_HIP(hipStreamSynchronize(L.st[0]));
+        // the blind base belongs to the handle and is compared by CONTENT: a call with another w installs it on this device first
+        if (w_xy && (r = h2_bases_set_blind_base(handles[d], w_xy, form)) != H2_OK) return r;
         size_t k = 0;
         for (size_t i = (size_t)d; i < count; i += (size_t)ndev, ++k) {
             const int s = (int)(k % kStreamsPerDevice);
@@ -110,7 +110,7 @@ extern "C" int h2_commit_batch_multi(const h2_bases_t *handles, const int *devic
             // the stream's staging slot is free again once its previous commit's result has been copied out (same stream: ordered)
             if (n) H2_HIP(hipMemcpyAsync(L.d_scalars[s], scalars[i], n * 32, hipMemcpyHostToDevice, st));
             if (w_xy) H2_HIP(hipMemcpyAsync(bl, blinds[i], 32, hipMemcpyHostToDevice, st));
-            r = h2_commit_device(handles[d], L.d_scalars[s], n, w_xy ? small : nullptr, w_xy ? bl : nullptr, form, out_kind, out, st);
+            r = h2_commit_device(handles[d], L.d_scalars[s], n, nullptr, w_xy ? bl : nullptr, form, out_kind, out, st);
             if (r != H2_OK) return r;
             H2_HIP(hipMemcpyAsync(outs[i], out, out_bytes, hipMemcpyDeviceToHost, st));
         }

@@ -244,7 +244,9 @@ extern "C" int h2_transcript_bytes(h2_transcript_t t, uint8_t *out, size_t cap, 
     if (!len || (cap && !out)) return H2_ERR_ARGS;
     std::lock_guard<std::mutex> lk(T->mu);
     *len = T->written.size();
-    if (cap >= T->written.size() && !T->written.empty()) memcpy(out, T->written.data(), T->written.size());
+    if (cap == 0) return H2_OK;                                      // size query
+    if (cap < T->written.size()) return H2_ERR_ARGS;                 // too small a buffer: *len says how much is needed, nothing is copied
+    if (!T->written.empty()) memcpy(out, T->written.data(), T->written.size());
     return H2_OK;
 }
 

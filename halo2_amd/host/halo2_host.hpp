@@ -268,6 +268,9 @@ template <int CURVE> class Params {
         const int wb = h2_commit_column_window_bits(n);        // tables of column commits: 17-bit windows from 2^19 points on
         check(h2_bases_register_ex(CURVE, g[0].data(), n, H2_FORM_MONTGOMERY, wb, &h_g), "h2_bases_register_ex");
         check(h2_bases_register_ex(CURVE, g_lagrange[0].data(), n, H2_FORM_MONTGOMERY, wb, &h_gl), "h2_bases_register_ex");
+        // `w` is a field of Params (commitment.rs:26-33): installed once per table; a commit then passes only its blind scalar
+        check(h2_bases_set_blind_base(h_g, w.data(), H2_FORM_MONTGOMERY), "h2_bases_set_blind_base");
+        check(h2_bases_set_blind_base(h_gl, w.data(), H2_FORM_MONTGOMERY), "h2_bases_set_blind_base");
     }
     ~Params() { for (h2_bases_t h : {h_g, h_gl, h_open}) if (h) h2_bases_free(h); }
     // Params::new (commitment.rs:38-114): g_i = hasher({0, i as LE u32}), g_lagrange by the point iFFT, w = hasher({1}), u = hasher({2});
@@ -345,7 +348,7 @@ template <int CURVE> class Params {
     Jacobian run(h2_bases_t h, const std::vector<Fe> &poly, const Blind<CURVE> &r) const {
         if (poly.size() != n) throw std::invalid_argument("commit: poly.len() != n");
         Jacobian out{};
-        check(h2_commit(h, poly[0].data(), n, w.data(), r.value.data(), H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, out.data()), "h2_commit");
+        check(h2_commit(h, poly[0].data(), n, nullptr, r.value.data(), H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, out.data()), "h2_commit");
         return out;
     }
 };

@@ -105,6 +105,10 @@ class _FingerprintCells:
     def instance(self, col: int, rot: int = 0):
         return self._pt("instance", col, rot)
 
+    def __getattr__(self, name):
+        # an expression input this fingerprint does not know would silently stay out of the key's hash
+        raise AttributeError(f"derive_vk_repr: lowered expressions may only query cells.fixed / advice / instance, not cells.{name}")
+
 
 def derive_vk_repr(params: Params, cs: ConstraintSystem, domain, fixed_commitments, permutation_commitments) -> int:
     """Default `VerifyingKey::transcript_repr` (plonk.rs:75-98): Blake2b-512, personal "Halo2-Verify-Key", over a canonical
@@ -140,8 +144,11 @@ def derive_vk_repr(params: Params, cs: ConstraintSystem, domain, fixed_commitmen
 def keygen_pk(params: Params, cs: ConstraintSystem, fixed_columns, mapping, vk_repr: int | None = None, device=None) -> ProvingKey:
     """keygen.rs:296-380 after `synthesize`.  fixed_columns: integer lists of n rows; mapping[c][r] = (c', r') the cell that
     follows (c, r) in its copy-constraint cycle (permutation/keygen.rs:24-107), identity where unconstrained.
-    vk_repr=None (the default) derives the key's transcript representation from the key itself (`derive_vk_repr`), as the
-    reference's `VerifyingKey::from_parts` does; an explicit value is for interop with a reference-produced key."""
+    vk_repr=None (the default) derives the key's transcript representation from the key itself (`derive_vk_repr`): the same
+    role as `VerifyingKey::from_parts` (plonk.rs:75-98), but NOT the same bytes -- the reference hashes the Debug text of its
+    `PinnedVerificationKey`, this default hashes a JSON serialisation with expression fingerprints.  Proofs made with the default
+    are therefore NOT byte-interoperable with a reference verifier: for interop pass the reference's own `transcript_repr`
+    (tests/test_reference_goldens.py computes it from the pinned key's Debug text)."""
     import torch
     from .domain import EvaluationDomain
     dev = torch.device(device) if device else fields.current_device()

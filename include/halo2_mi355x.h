@@ -76,7 +76,8 @@ int h2_commit_window_bits(size_t n);
 /* 1 if h2_commit_pair_device accepts a registered basis of n points (n >= 8192 and the sort geometry fits), else 0. */
 int h2_commit_pair_supported(size_t n);
 /* Tuning knobs (never change results).  "msm_lane_fraction" in (0.05, 1]: share of the resident wave slots
- * one bucket-accumulation launch claims; < 1 lets commits issued on other streams overlap it (default 1). */
+ * one bucket-accumulation launch claims; < 1 lets commits issued on other streams overlap it (default 1).
+ * "host_commit_chunk": scalars per range of h2_commit's pipelined transfer (0 = default 2^17). */
 int h2_set_option(const char *key, double value);
 
 /* ---- MSM: replaces best_multiexp (halo2_proofs/src/arithmetic.rs:143-180) -------------------- */
@@ -95,13 +96,21 @@ int h2_bases_register_device(int curve, const void *d_bases_xy, size_t n, int fo
  * 15 digits instead of 16 -- which h2_commit_pair_device and h2_ipa_collapsed_generators_device do not take. */
 int h2_bases_register_ex(int curve, const uint64_t *bases_xy, size_t n, int form, int window_bits, h2_bases_t *handle);
 int h2_commit_column_window_bits(size_t n);
+/* `Params::w` (poly/commitment.rs:26-33): installs the multiples of the affine point w_xy as the blind column of the handle's
+ * table.  Compared by content with what the handle holds: the same point is a no-op, a different one waits for the device to
+ * drain (commits with the old w may be in flight), installs it and returns when the column is complete.  Host pointer, blocking. */
+int h2_bases_set_blind_base(h2_bases_t handle, const uint64_t *w_xy, int form);
+/* What a handle holds: the number of registered points, the window width of its table, its curve (any pointer may be NULL). */
+int h2_bases_info(h2_bases_t handle, size_t *n, int *window_bits, int *curve);
 int h2_bases_free(h2_bases_t handle);
 
 /* replaces Params::commit / commit_lagrange (halo2_proofs/src/poly/commitment.rs:119-150):
  * out = sum_{i<n} scalars[i]*g[i] + blind*w.  The reference copies poly+blind and g+w into fresh
  * (n+1)-vectors per call; here g stays on the device and (w, blind) ride along.  `w_xy` / `blind`
  * may both be NULL for a plain MSM over the first n registered bases (IPA rounds,
- * poly/commitment/prover.rs:107-108). */
+ * poly/commitment/prover.rs:107-108); `blind` alone uses the handle's blind base (h2_bases_set_blind_base); a `w_xy` is compared
+ * by content with it and installed first when it differs.  The column crosses PCIe in ranges that are committed as they land
+ * (copy stream + two compute streams), so the transfer runs beside the bucket arithmetic. */
 int h2_commit(h2_bases_t g, const uint64_t *scalars, size_t n, const uint64_t *w_xy,
               const uint64_t *blind, int form, int out_kind, uint64_t *out);
 
@@ -140,11 +149,12 @@ int h2_divide_by_vanishing_poly(int field, uint64_t *a, unsigned ext_k, const ui
  * memory.  Used by batched provers and by bench.py (inputs resident in HBM before timing starts). */
 int h2_msm_device(int curve, const void *d_scalars, const void *d_bases_xy, size_t n, int form,
                   int out_kind, void *d_out, void *stream);
-/* Blind base: `Params::w` is fixed for the life of a `Params` (poly/commitment.rs:26-33) and the handle keeps its multiples as
- * one more column of the registered table.  The handle remembers which w that column holds -- by content for the host-pointer
- * entry points, by device ADDRESS for the device-pointer ones: keep passing the same d_w_xy, and do not change the 64 bytes
- * behind it while commits are in flight.  A different address (or content) rebuilds the column on `stream`; commits that use the
- * old w must have been synchronised by then. */
+/* Blind base: `Params::w` is a field of `Params`, fixed for its life (poly/commitment.rs:26-33, :102-103), and here a property of
+ * the HANDLE: h2_bases_set_blind_base installs its multiples as one more column of the registered table.  A commit that passes
+ * `d_blind` and NO `d_w_xy` uses that column (H2_ERR_ARGS if none was ever installed).  A commit may still present a `d_w_xy`:
+ * its 64 BYTES -- never its address -- are compared with the installed point by one small kernel on `stream`, and only a
+ * different point rebuilds the column (and becomes the handle's blind base); commits that use the old w on other streams
+ * must have completed by then.  d_w_xy without d_blind: H2_ERR_ARGS.  Both NULL: no blind term. */
 int h2_commit_device(h2_bases_t g, const void *d_scalars, size_t n, const void *d_w_xy,
                      const void *d_blind, int form, int out_kind, void *d_out, void *stream);
 /* TWO commits from one column over a registered basis of n points: column i < n - 4 feeds output (i >> pair_shift) & 1, the last
@@ -157,7 +167,8 @@ int h2_commit_pair_device(h2_bases_t g, const void *d_scalars, size_t n, unsigne
 /* `count` independent commits over one registered basis -- the column commits of a prover phase
  * (plonk/prover.rs:93-101, 301-313; vanishing/prover.rs:96-108).  d_scalars[i] / d_blinds[i] / d_outs[i] are
  * device pointers held in HOST arrays; the commits are spread over internal streams (one column's latency-bound
- * sort/reduce kernels overlap another's accumulate) and joined on `stream`.  d_w_xy NULL: no blind term. */
+ * sort/reduce kernels overlap another's accumulate) and joined on `stream`.  d_blinds NULL: no blind term; d_blinds without
+ * d_w_xy: the handle's blind base; a d_w_xy is content-checked once, on `stream`, as for h2_commit_device. */
 int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars, size_t count, size_t n,
                            const void *d_w_xy, const void *const *d_blinds, int form, int out_kind,
                            void *const *d_outs, void *stream);

@@ -1,0 +1,186 @@
+"""The configuration the headline is measured on, under test: column tables with 17-bit windows (`h2_bases_register_ex`,
+what `Params` registers `g` / `g_lagrange` with from 2^19 points on: 2^16 buckets, row / column fold) at 2^19 and 2^20 points
+on both curves, against the C restatement of `Params::commit` / `best_multiexp` (poly/commitment.rs:119-150,
+arithmetic.rs:143-180) -- dense and skewed columns, blinds, prefix lengths, the batch entry point -- and the blind base as a
+property of the handle (`Params::w`, commitment.rs:26-33): content-checked, never keyed by an address.  Also the pipelined
+host-pointer commit (column ranges committed as they cross PCIe)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import halo2_amd as h
+from halo2_amd import fields
+from halo2_amd.arithmetic import _p
+from oracle import c_oracle as co
+from oracle import pasta as o
+
+pytestmark = pytest.mark.gpu
+
+
+def affine_of(curve, out):
+    out = np.ascontiguousarray(out, dtype=np.uint64)
+    return co.jac_to_affine_ints(curve, out) if out.shape[0] == 12 else co.affine_to_ints(curve, out)
+
+
+def _points(curve, ks):
+    bm, _ = o.CURVES[curve]
+    return co.points_to_mont(curve, [o.ec_mul(k, (bm - 1, 2), bm) for k in ks])
+
+
+def _skewed_columns(sf, sm, n):
+    dense = co.random_field(sf, 4100 + n % 97, n)
+    zeros90 = dense.copy()
+    zeros90[np.arange(n) % 10 != 0] = 0
+    small = fields.to_limbs([((i * 2654435761) & 0xFFFF) for i in range(1 << 12)], sf)
+    top = co.to_mont(sf, co.ints_to_limbs([sm - 1 - i for i in range(1 << 12)]))
+    return {
+        "dense": dense,
+        "zeros90": zeros90,
+        "all_equal": np.ascontiguousarray(np.tile(fields.scalar_limbs(0xDEADBEEFCAFE0123456789, sf), (n, 1))),
+        "below_2^16": np.ascontiguousarray(np.tile(small, (n >> 12, 1))),
+        "q-1-i": np.ascontiguousarray(np.tile(top, (n >> 12, 1))),          # maximal digits, every window negative after the recode
+    }
+
+
+@pytest.mark.parametrize("curve,k", [(h.PALLAS, 19), (h.PALLAS, 20), (h.VESTA, 19), (h.VESTA, 20)])
+def test_17_bit_column_tables_match_oracle(curve, k):
+    import torch
+    lib = h.lib()
+    n = 1 << k
+    _, sm = o.CURVES[curve]
+    sf = co.field_of_curve(curve, "scalar")
+    assert lib.h2_commit_column_window_bits(n) == 17                      # what Params and bench.py register with
+    g = co.generate_bases(curve, 0x1700 + k + curve, n)
+    hd = C.c_uint64(0)
+    assert lib.h2_bases_register_ex(curve, _p(g), n, h.FORM_MONTGOMERY, 17, C.byref(hd)) == 0
+    w1, w2 = _points(curve, [0x77, 0x1234567])
+    cols = _skewed_columns(sf, sm, n)
+    blinds = co.random_field(sf, 0xB11D, 4)
+    out = np.zeros(12, np.uint64)
+    dev = torch.device("cuda", 0)
+    d_out = torch.zeros(12, dtype=torch.int64, device=dev)
+
+    def dev_commit(d_col, n_used, d_w, d_bl):
+        rc = lib.h2_commit_device(hd, d_col.data_ptr(), n_used, d_w.data_ptr() if d_w is not None else None,
+                                  d_bl.data_ptr() if d_bl is not None else None, h.FORM_MONTGOMERY, 0, d_out.data_ptr(), None)
+        assert rc == 0, lib.h2_last_error()
+        torch.cuda.synchronize()
+        return affine_of(curve, d_out.cpu().numpy().view(np.uint64))
+
+    # a blind scalar before any blind base was installed: refused, not a commitment to garbage
+    d_dense = torch.from_numpy(cols["dense"].view(np.int64)).to(dev)
+    d_bl = torch.from_numpy(blinds.view(np.int64)).to(dev)
+    assert lib.h2_commit_device(hd, d_dense.data_ptr(), n, None, d_bl[0].data_ptr(), h.FORM_MONTGOMERY, 0, d_out.data_ptr(), None) == 1
+    assert lib.h2_bases_set_blind_base(hd, _p(w1), h.FORM_MONTGOMERY) == 0
+
+    # every column shape, with the handle's blind base, device path; the dense one also through the host path
+    want_w1 = {}
+    for name, col in cols.items():
+        want_w1[name] = co.jac_to_affine_ints(curve, co.commit(curve, g, w1, col, blinds[0]))
+        d_col = d_dense if name == "dense" else torch.from_numpy(col.view(np.int64)).to(dev)
+        assert dev_commit(d_col, n, None, d_bl[0]) == want_w1[name], name
+    assert lib.h2_commit(hd, _p(cols["dense"]), n, None, _p(blinds[0]), h.FORM_MONTGOMERY, 0, _p(out)) == 0     # pipelined ranges
+    assert affine_of(curve, out) == want_w1["dense"]
+
+    # two different w in sequence, by content: host pointers ...
+    want_w2 = co.jac_to_affine_ints(curve, co.commit(curve, g, w2, cols["dense"], blinds[1]))
+    for w, bl, want in ((w2, blinds[1], want_w2), (w1, blinds[0], want_w1["dense"]), (w2, blinds[1], want_w2)):
+        assert lib.h2_commit(hd, _p(cols["dense"]), n, _p(w), _p(bl), h.FORM_MONTGOMERY, 0, _p(out)) == 0
+        assert affine_of(curve, out) == want
+    # ... and ONE device pointer whose 64 bytes are rewritten between commits (the address-keyed cache of round 2 returned the
+    # commitment to the old w here)
+    d_w = torch.from_numpy(w1.view(np.int64)).to(dev)
+    assert dev_commit(d_dense, n, d_w, d_bl[0]) == want_w1["dense"]
+    d_w.copy_(torch.from_numpy(w2.view(np.int64)))
+    assert dev_commit(d_dense, n, d_w, d_bl[1]) == want_w2
+    assert dev_commit(d_dense, n, None, d_bl[1]) == want_w2                   # the presented w became the handle's
+    d_w.copy_(torch.from_numpy(w1.view(np.int64)))
+    assert dev_commit(d_dense, n, d_w, d_bl[0]) == want_w1["dense"]
+    # the canonical form of the same point is the same point
+    w1_canon = np.ascontiguousarray(co.from_mont(co.field_of_curve(curve, "base"), w1.reshape(2, 4)).reshape(8))
+    assert lib.h2_bases_set_blind_base(hd, _p(w1_canon), h.FORM_CANONICAL) == 0
+    assert dev_commit(d_dense, n, None, d_bl[0]) == want_w1["dense"]
+
+    # prefix lengths (IPA rounds commit over the first n' bases, poly/commitment/prover.rs:107-108), with and without blind
+    for n_used in (0, 1, 17, n - 1):
+        want = co.jac_to_affine_ints(curve, co.best_multiexp(curve, cols["dense"][:n_used], g[:n_used]))
+        assert dev_commit(d_dense, n_used, None, None) == want, n_used
+        assert lib.h2_commit(hd, _p(cols["dense"]), n_used, None, None, h.FORM_MONTGOMERY, 0, _p(out)) == 0
+        assert affine_of(curve, out) == want, n_used
+        want_b = co.jac_to_affine_ints(curve, co.commit(curve, np.ascontiguousarray(g[:n_used]), w1, np.ascontiguousarray(cols["dense"][:n_used]), blinds[2]))
+        assert dev_commit(d_dense, n_used, None, d_bl[2]) == want_b, n_used
+
+    # the batch entry point (plonk/prover.rs:305-313) over four different columns with their blinds
+    names = ["dense", "zeros90", "q-1-i", "below_2^16"]
+    d_cols = [torch.from_numpy(cols[nm].view(np.int64)).to(dev) for nm in names]
+    d_outs = torch.zeros((4, 8), dtype=torch.int64, device=dev)
+    arr = C.c_void_p * 4
+    rc = lib.h2_commit_batch_device(hd, arr(*[c_.data_ptr() for c_ in d_cols]), 4, n, None, arr(*[d_bl[i].data_ptr() for i in range(4)]),
+                                    h.FORM_MONTGOMERY, 1, arr(*[d_outs[i].data_ptr() for i in range(4)]), None)
+    assert rc == 0, lib.h2_last_error()
+    torch.cuda.synchronize()
+    got = d_outs.cpu().numpy().view(np.uint64)
+    for i, nm in enumerate(names):
+        want = want_w1[nm] if i == 0 else co.jac_to_affine_ints(curve, co.commit(curve, g, w1, cols[nm], blinds[i]))
+        assert affine_of(curve, got[i]) == want, nm
+    assert lib.h2_bases_free(hd) == 0
+
+
+@pytest.mark.parametrize("n,chunk", [(3000, 1000), (3000, 4096), (20000, 8192), (70001, 16384)])
+def test_pipelined_host_commit_ranges(n, chunk):
+    """h2_commit cuts a host column into table-column ranges that are committed as they land (MsmArgs::col0) and summed:
+    ragged last range, one-pass and two-pass sorts, blind on the last range, prefix lengths that end inside a range."""
+    curve = h.VESTA
+    lib = h.lib()
+    sf = co.field_of_curve(curve, "scalar")
+    g = co.generate_bases(curve, 0x9000 + n, n)
+    col = co.random_field(sf, n, n)
+    w, = _points(curve, [0xABCDEF])
+    blind = fields.scalar_limbs(0x1234567890ABCDEF, sf)
+    hd = C.c_uint64(0)
+    assert lib.h2_bases_register(curve, _p(g), n, h.FORM_MONTGOMERY, C.byref(hd)) == 0
+    assert lib.h2_set_option(b"host_commit_chunk", float(chunk)) == 0
+    out = np.zeros(12, np.uint64)
+    try:
+        for n_used in (n, n - 1, 2 * chunk, 2 * chunk + 1, 1, 0):
+            if n_used > n:
+                continue
+            assert lib.h2_commit(hd, _p(col), n_used, _p(w), _p(blind), h.FORM_MONTGOMERY, 0, _p(out)) == 0, lib.h2_last_error()
+            want = co.jac_to_affine_ints(curve, co.commit(curve, np.ascontiguousarray(g[:n_used]), w, np.ascontiguousarray(col[:n_used]), blind))
+            assert affine_of(curve, out) == want, n_used
+            assert lib.h2_commit(hd, _p(col), n_used, None, None, h.FORM_MONTGOMERY, 1, _p(out)) == 0
+            assert affine_of(curve, out[:8]) == co.jac_to_affine_ints(curve, co.best_multiexp(curve, col[:n_used], g[:n_used])), n_used
+        # canonical scalars through the same ranges
+        canon = np.ascontiguousarray(co.from_mont(sf, col))
+        assert lib.h2_commit(hd, _p(canon), n, None, None, h.FORM_CANONICAL, 0, _p(out)) == 0
+        got = co.jac_to_affine_ints(curve, co.to_mont(co.field_of_curve(curve, "base"), out.reshape(3, 4)).reshape(12))
+        assert got == co.jac_to_affine_ints(curve, co.best_multiexp(curve, col, g))
+    finally:
+        assert lib.h2_set_option(b"host_commit_chunk", 0.0) == 0
+        assert lib.h2_bases_free(hd) == 0
+
+
+def test_commit_batch_multi_two_blind_bases_one_handle():
+    """h2_commit_batch_multi with the same handles and two different w in sequence (the staging slot's fixed address
+    made the second call reuse the first w's multiples)."""
+    curve = h.PALLAS
+    lib = h.lib()
+    sf = co.field_of_curve(curve, "scalar")
+    n = 5000
+    g = co.generate_bases(curve, 0x4444, n)
+    hd = C.c_uint64(0)
+    assert lib.h2_bases_register(curve, _p(g), n, h.FORM_MONTGOMERY, C.byref(hd)) == 0
+    cols = [co.random_field(sf, 70 + i, n) for i in range(3)]
+    blinds = co.random_field(sf, 71, 3)
+    outs = [np.zeros(12, np.uint64) for _ in range(3)]
+    vp3 = C.c_void_p * 3
+    for wk in (0x55, 0x66, 0x55):
+        w, = _points(curve, [wk])
+        rc = lib.h2_commit_batch_multi((C.c_uint64 * 1)(hd.value), (C.c_int * 1)(0), 1, vp3(*[c_.ctypes.data for c_ in cols]), 3, n,
+                                       C.c_void_p(w.ctypes.data), vp3(*[blinds[i].ctypes.data for i in range(3)]), h.FORM_MONTGOMERY, 0,
+                                       vp3(*[o_.ctypes.data for o_ in outs]))
+        assert rc == 0, lib.h2_last_error()
+        for i in range(3):
+            assert affine_of(curve, outs[i]) == co.jac_to_affine_ints(curve, co.commit(curve, g, w, cols[i], blinds[i])), (wk, i)
+    assert lib.h2_bases_free(hd) == 0
