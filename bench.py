@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--no-create-proof", action="store_true", help="skip the configs[3] leg (create_proof simple-example k = 20)")
     ap.add_argument("--minimal", action="store_true",
                     help="only the timed commits and the NTT leg (the workload of the PMC passes: no generic / skewed / Vesta / host-pointer legs)")
+    ap.add_argument("--config5", action="store_true", help="run the configs[4] leg (64 column commits + the split commit) at N = 1 too")
     ap.add_argument("--columns", type=int, default=4, help="distinct scalar columns resident in HBM")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("H2_BENCH_STREAMS", "3")),
                     help="HIP streams the independent column commits are spread over (per GPU)")
@@ -276,6 +277,111 @@ def main():
         th.start()
         th.join(timeout=90)
         split_rccl_c = box.get("ok", "timeout after 90 s")
+
+    # ---- BASELINE configs[4], TIMED: 64 independent 2^20 column commits over the node (64 / world per GPU, one batched call per
+    # rank, no collective) and ONE commit over the registered bases split by table-column range over the ranks, its 96-byte
+    # partials exchanged by a single all-gather and summed locally.  Runs for N > 1 (and at N = 1 with --config5, where the
+    # "exchange" is a gather of one).  Every figure is the max over ranks of a barrier-bracketed region.
+    config5 = None
+    if (world > 1 or args.config5) and not args.minimal:
+        def _maxr(x):
+            if world == 1:
+                return float(x)
+            t_ = torch.tensor([x], dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item())
+        per_rank = max(1, 64 // world)
+        arr = C.c_void_p * per_rank
+        d_bl64 = d_blinds[[i % len(d_cols) for i in range(per_rank)]].contiguous()
+        d_out64 = torch.zeros((per_rank, 12), dtype=torch.int64, device=dev)
+        sc64 = arr(*[d_cols[i % len(d_cols)].data_ptr() for i in range(per_rank)])
+        bl64 = arr(*[d_bl64[i].data_ptr() for i in range(per_rank)])
+        o64 = arr(*[d_out64[i].data_ptr() for i in range(per_rank)])
+        col_ms = []
+        for rep_ in range(3):
+            sync_all()
+            t5 = time.perf_counter()
+            check(lib.h2_commit_batch_device(params_g, sc64, per_rank, n, None, bl64, h.FORM_MONTGOMERY, 0, o64, None), "h2_commit_batch_device")
+            sync_all()
+            col_ms.append(_maxr((time.perf_counter() - t5) * 1e3))
+        cols_ms = min(col_ms[1:])                                         # the first repetition allocates the batch streams' workspaces
+        cols_ok = bool(co.jac_to_affine_ints(curve, d_out64[0].cpu().numpy().view(np.uint64)) == co.jac_to_affine_ints(curve, first))
+        # per-rank PCIe: one 32 MiB column from pageable host memory (what every fresh witness column costs before it is resident)
+        sync_all()
+        t5 = time.perf_counter()
+        d_tmp = torch.from_numpy(cols[0].view(np.int64)).to(dev)
+        torch.cuda.synchronize()
+        h2d_ms = _maxr((time.perf_counter() - t5) * 1e3)
+        del d_tmp
+        # the split commit: same column + blind on every rank
+        shared_c = co.random_field(sf, 4343, n)
+        d_shared = torch.from_numpy(shared_c.view(np.int64)).to(dev)
+        d_shbl = torch.from_numpy(co.random_field(sf, 4344, 1).view(np.int64)).to(dev)[0].contiguous()      # the same blind on every rank
+        reps5 = 12
+        total5 = parallel.split_commit(params_g, d_shared, rank, world, d_shbl)      # untimed: communicator warm-up
+        sync_all()
+        t5 = time.perf_counter()
+        for _ in range(reps5):
+            total5 = parallel.split_commit(params_g, d_shared, rank, world, d_shbl)
+        sync_all()
+        split_ms = _maxr((time.perf_counter() - t5) / reps5 * 1e3)
+        # the exchange step alone: 96 bytes per rank
+        ag_us = None
+        if world > 1 and backend == "nccl":
+            src = torch.zeros(12, dtype=torch.int64, device=dev)
+            dst = torch.zeros((world, 12), dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(dst, src)
+            sync_all()
+            t5 = time.perf_counter()
+            for _ in range(50):
+                dist.all_gather_into_tensor(dst, src)
+            torch.cuda.synchronize()
+            ag_us = _maxr((time.perf_counter() - t5) / 50 * 1e6)
+        whole5 = torch.zeros(12, dtype=torch.int64, device=dev)
+        check(lib.h2_commit_device(params_g, d_shared.data_ptr(), n, None, d_shbl.data_ptr(), h.FORM_MONTGOMERY, 0, whole5.data_ptr(), None), "h2_commit_device")
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        for _ in range(reps5):
+            check(lib.h2_commit_device(params_g, d_shared.data_ptr(), n, None, d_shbl.data_ptr(), h.FORM_MONTGOMERY, 0, whole5.data_ptr(), None), "h2_commit_device")
+        torch.cuda.synchronize()
+        whole_ms = (time.perf_counter() - t5) / reps5 * 1e3
+        split_ok5 = bool(co.jac_to_affine_ints(curve, total5.cpu().numpy().view(np.uint64)) == co.jac_to_affine_ints(curve, whole5.cpu().numpy().view(np.uint64)))
+        # the same split with the exchange inside the library (its own RCCL communicator); watchdog as above
+        lib_ms, lib_ok = None, None
+        if backend == "nccl" and os.environ.get("H2_BENCH_RCCL_C", "1") != "0":
+            import threading
+            box5 = {}
+
+            def _rccl_commit_leg():
+                try:
+                    torch.cuda.set_device(local_rank)
+                    parallel.rccl_init(rank, world)
+                    o_ = parallel.split_commit_rccl(params_g, d_shared, d_shbl)
+                    torch.cuda.synchronize()
+                    t_ = time.perf_counter()
+                    for _ in range(reps5):
+                        o_ = parallel.split_commit_rccl(params_g, d_shared, d_shbl)
+                    torch.cuda.synchronize()
+                    box5["ms"] = (time.perf_counter() - t_) / reps5 * 1e3
+                    box5["ok"] = bool(co.jac_to_affine_ints(curve, o_.cpu().numpy().view(np.uint64)) == co.jac_to_affine_ints(curve, whole5.cpu().numpy().view(np.uint64)))
+                    parallel.rccl_finalize()
+                except Exception as exc:
+                    box5["ok"] = f"error: {exc}"
+            th5 = threading.Thread(target=_rccl_commit_leg, daemon=True)
+            th5.start()
+            th5.join(timeout=90)
+            lib_ok = box5.get("ok", "timeout after 90 s")
+            lib_ms = box5.get("ms")
+        config5 = {"what": "BASELINE configs[4]: 64 independent 2^20-point column commits (with blinds) spread over the ranks, then one commit "
+                           "split by table-column range over the ranks + one 96-byte all-gather + local sum",
+                   "columns_total": per_rank * world, "columns_per_gpu": per_rank, "columns_ms": round(cols_ms, 3),
+                   "columns_Mscalar_mults_per_s": round(per_rank * world * n / cols_ms / 1e3, 1), "columns_first_equals_timed_step": cols_ok,
+                   "h2d_ms_per_32MiB_column_max_over_ranks": round(h2d_ms, 3),
+                   "split_commit_ms": round(split_ms, 4), "whole_commit_one_gpu_ms": round(whole_ms, 4), "split_equals_whole": split_ok5,
+                   "allgather_96B_us": None if ag_us is None else round(ag_us, 1),
+                   "split_commit_rccl_in_library_ms": None if lib_ms is None else round(lib_ms, 4), "split_commit_rccl_in_library_ok": lib_ok,
+                   "exchange_backend": backend}
+        del d_shared
 
     # ---- NTT leg (reported beside the headline value; Fp, k = 20 and 2^22 round trip) ----
     ntt = {}
@@ -511,6 +617,7 @@ def main():
             "kernel_ms_isolated": iso,
             "generic_best_multiexp": generic, "extra": extra, "skewed_columns": skew, "ntt": ntt, "cpu_baseline": cpu,
             "checks": {"split_sum_identity": None if split_ok is None else bool(split_ok), "split_msm_allgather": split_msm_ok, "split_msm_rccl_in_library": split_rccl_c},
+            "config5": config5,
             "input_gen_s": round(gen_s, 2),
         }
         print(json.dumps(out))

@@ -113,6 +113,8 @@ SIGNATURES = {
     "h2_rccl_unique_id": ([C.c_void_p], C.c_int),
     "h2_rccl_init": ([C.c_void_p, C.c_int, C.c_int], C.c_int),
     "h2_rccl_finalize": ([], C.c_int),
+    "h2_commit_split_rccl_device": ([C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p], C.c_int),
+    "h2_commit_range_device": ([C.c_uint64, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p], C.c_int),
     "h2_msm_split_rccl_device": ([C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p], C.c_int),
     "h2_hash_to_curve": ([C.c_int, C.c_char_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p], C.c_int),
     "h2_hash_to_curve_device": ([C.c_int, C.c_char_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p], C.c_int),

@@ -2219,6 +2219,31 @@ static int commit_device_impl(h2_bases_t g, const void *d_scalars, size_t n, con
     return msm_dispatch(cx, b->curve, a, st);
 }
 
+// the commit restricted to table columns [first, first + n): d_scalars[i] multiplies registered base first + i.  One range of a
+// commit that is split over GPUs (h2_commit_split_rccl_device) or over the chunks of a host transfer; the blind term (the
+// handle's blind base) rides with whichever range passes d_blind.
+extern "C" int h2_commit_range_device(h2_bases_t g, const void *d_scalars, size_t first, size_t n, const void *d_blind, int form,
+                                      int out_kind, void *d_out, void *stream) {
+    auto b = find_bases(g);
+    if (!b) return H2_ERR_HANDLE;
+    if (bad_common(b->curve, form, out_kind) || !d_out || (n && !d_scalars) || first > b->n || n > b->n - first) return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    if (d_blind) {
+        std::lock_guard<std::mutex> bl(b->mu);
+        if (!b->blind_set) {
+            set_last_error_msg("range commit with a blind but the handle has no blind base: call h2_bases_set_blind_base");
+            return H2_ERR_ARGS;
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    MsmContext &cx = msm_ctx(st);
+    std::lock_guard<std::mutex> lk(cx.mu);
+    MsmArgs a{d_scalars, d_blind, b->d_table, nullptr, n, true, b->c, b->stride, (u32)b->n, form, out_kind, d_out};
+    a.col0 = (u32)first;
+    return msm_dispatch(cx, b->curve, a, st);
+}
+
 extern "C" int h2_bases_set_blind_base(h2_bases_t g, const uint64_t *w_xy, int form) {
     auto b = find_bases(g);
     if (!b) return H2_ERR_HANDLE;

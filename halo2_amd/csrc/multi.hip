@@ -263,3 +263,28 @@ extern "C" int h2_msm_split_rccl_device(int curve, const void *d_scalars, const 
     if (e) return g_rccl.fail(e, "ncclAllGather");
     return h2_points_sum_device(curve, buf, (size_t)world, form, out_kind, d_out, st);
 }
+
+// The same exchange for a commit over REGISTERED bases (Params::commit, an opening-argument round): every rank holds the table
+// (h2_bases_register on its GPU) and the column; rank r commits table columns [n r / world, n (r + 1) / world) -- no doubling
+// chain, no per-call base traffic -- the last rank carries the blind term, then ONE 96-byte all-gather and the local sum.
+extern "C" int h2_commit_split_rccl_device(h2_bases_t g, const void *d_scalars, size_t n, const void *d_blind, int form, int out_kind,
+                                           void *d_out, void *stream) {
+    if (!d_out || (n && !d_scalars)) return H2_ERR_ARGS;
+    size_t have = 0;
+    int curve = 0;
+    int rc = h2_bases_info(g, &have, nullptr, &curve);
+    if (rc != H2_OK) return rc;
+    if (n > have) return H2_ERR_ARGS;
+    std::lock_guard<std::mutex> lk(g_rccl.mu);
+    if (!g_rccl.comm) return H2_ERR_HANDLE;
+    hipStream_t st = (hipStream_t)stream;
+    const int world = g_rccl.world, rank = g_rccl.rank;
+    const size_t lo = n * (size_t)rank / (size_t)world, hi = n * (size_t)(rank + 1) / (size_t)world;
+    char *buf = (char *)g_rccl.d_buf, *mine = buf + (size_t)world * 96;
+    rc = h2_commit_range_device(g, (const char *)d_scalars + 32 * lo, lo, hi - lo, rank == world - 1 ? d_blind : nullptr, form, H2_OUT_JACOBIAN,
+                                mine, st);
+    if (rc != H2_OK) return rc;
+    int e = g_rccl.AllGather(mine, buf, 96, /*ncclChar*/ 0, g_rccl.comm, st);
+    if (e) return g_rccl.fail(e, "ncclAllGather");
+    return h2_points_sum_device(curve, buf, (size_t)world, form, out_kind, d_out, st);
+}

@@ -138,3 +138,51 @@ def split_msm_rccl(d_scalars, d_bases, curve: int, affine: bool = False):
     check(lib().h2_msm_split_rccl_device(curve, d_scalars.data_ptr(), d_bases.data_ptr(), d_scalars.shape[0], FORM_MONTGOMERY,
                                          OUT_AFFINE if affine else OUT_JACOBIAN, out.data_ptr(), _stream_ptr()), "h2_msm_split_rccl_device")
     return out
+
+
+def split_commit_rccl(handle, d_scalars, d_blind=None, affine: bool = False):
+    """h2_commit_split_rccl_device: one commit over REGISTERED bases (every rank holds the table and the column) split by table
+    column range, the last rank carrying the blind term; one 96-byte all-gather over xGMI, local sum.  `handle`: an h2_bases_t."""
+    import torch
+    from ._lib import FORM_MONTGOMERY, OUT_AFFINE, OUT_JACOBIAN, check, lib
+    from .arithmetic import _stream_ptr
+    out = torch.empty(8 if affine else 12, dtype=torch.int64, device=d_scalars.device)
+    check(lib().h2_commit_split_rccl_device(int(getattr(handle, "value", handle)), d_scalars.data_ptr(), d_scalars.shape[0],
+                                            d_blind.data_ptr() if d_blind is not None else None, FORM_MONTGOMERY,
+                                            OUT_AFFINE if affine else OUT_JACOBIAN, out.data_ptr(), _stream_ptr()), "h2_commit_split_rccl_device")
+    return out
+
+
+def split_commit(handle, d_scalars, rank: int, world: int, d_blind=None):
+    """The same split with the exchange step carried by torch.distributed (backend nccl = RCCL; gloo goes through the host):
+    rank r commits table columns shard_range(n, r, world) with h2_commit_range_device, the 96-byte Jacobian partials are
+    all-gathered, every rank adds them with h2_points_sum_device.  Returns a (12,) CUDA tensor."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from ._lib import FORM_MONTGOMERY, OUT_JACOBIAN, check, lib
+    from .arithmetic import _stream_ptr
+    n = d_scalars.shape[0]
+    lo, hi = shard_range(n, rank, world)
+    dev = d_scalars.device
+    mine = torch.empty(12, dtype=torch.int64, device=dev)
+    hv = int(getattr(handle, "value", handle))
+    check(lib().h2_commit_range_device(hv, d_scalars[lo:].data_ptr() if hi > lo else None, lo, hi - lo,
+                                       d_blind.data_ptr() if (d_blind is not None and rank == world - 1) else None, FORM_MONTGOMERY,
+                                       OUT_JACOBIAN, mine.data_ptr(), _stream_ptr()), "h2_commit_range_device")
+    gathered = torch.empty((world, 12), dtype=torch.int64, device=dev)
+    if world > 1:
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(gathered, mine)
+        else:
+            parts = [torch.empty(12, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(parts, mine.cpu())
+            gathered.copy_(torch.stack(parts))
+    else:
+        gathered[0].copy_(mine)
+    out = torch.empty(12, dtype=torch.int64, device=dev)
+    curve = C.c_int(0)
+    check(lib().h2_bases_info(hv, None, None, C.byref(curve)), "h2_bases_info")
+    check(lib().h2_points_sum_device(curve.value, gathered.data_ptr(), world, FORM_MONTGOMERY, OUT_JACOBIAN, out.data_ptr(), _stream_ptr()),
+          "h2_points_sum_device")
+    return out

@@ -157,6 +157,10 @@ int h2_msm_device(int curve, const void *d_scalars, const void *d_bases_xy, size
  * must have completed by then.  d_w_xy without d_blind: H2_ERR_ARGS.  Both NULL: no blind term. */
 int h2_commit_device(h2_bases_t g, const void *d_scalars, size_t n, const void *d_w_xy,
                      const void *d_blind, int form, int out_kind, void *d_out, void *stream);
+/* The commit restricted to registered bases [first, first + n): d_scalars[i] multiplies base first + i; d_blind (optional) adds
+ * blind * (the handle's blind base).  One range of a commit split over GPUs or over the chunks of a host transfer. */
+int h2_commit_range_device(h2_bases_t g, const void *d_scalars, size_t first, size_t n, const void *d_blind, int form,
+                           int out_kind, void *d_out, void *stream);
 /* TWO commits from one column over a registered basis of n points: column i < n - 4 feeds output (i >> pair_shift) & 1, the last
  * four columns feed outputs 0, 1, 0, 1.  This is one round of the opening argument written over the original generators
  * (poly/commitment/prover.rs:107-114): L_j and R_j have disjoint supports in g, so they share the scalar column produced by
@@ -226,6 +230,12 @@ int h2_rccl_init(const uint8_t id[128], int rank, int world);
 int h2_rccl_finalize(void);
 int h2_msm_split_rccl_device(int curve, const void *d_scalars, const void *d_bases_xy, size_t n, int form,
                              int out_kind, void *d_out, void *stream);
+/* The same exchange for a commit over REGISTERED bases (Params::commit, an opening-argument round; BASELINE configs[4]'s
+ * "RCCL-summed final commit"): every rank holds the table and the column, rank r commits table columns
+ * [n r / world, n (r + 1) / world), the last rank carries the blind term (the handle's blind base), ONE 96-byte ncclAllGather,
+ * every rank writes the total to d_out. */
+int h2_commit_split_rccl_device(h2_bases_t g, const void *d_scalars, size_t n, const void *d_blind, int form, int out_kind,
+                                void *d_out, void *stream);
 
 /* ---- IPA round kernels (next to the MSMs inside commitment::create_proof) ----------------------- */
 /* replaces parallel_generator_collapse (halo2_proofs/src/poly/commitment/prover.rs:154-166):

@@ -60,3 +60,7 @@ def test_bench_two_ranks_gloo():
     assert d["n_gpus"] == 2 and d["checks"]["split_msm_allgather"] is True and d["checks"]["split_sum_identity"] is True
     # whole-job aggregate: both ranks' scalar-mults over the max-over-ranks time
     assert abs(d["ms_per_step"] * 1e-3 * d["value"] * 1e6 - 2 * (1 << 20)) / (2 << 20) < 0.02
+    # BASELINE configs[4] is timed on the N > 1 path: 64 column commits over the ranks + the range-split commit and its exchange
+    c5 = d["config5"]
+    assert c5["columns_total"] == 64 and c5["columns_per_gpu"] == 32 and c5["columns_ms"] > 0 and c5["columns_first_equals_timed_step"] is True
+    assert c5["split_equals_whole"] is True and c5["split_commit_ms"] > 0 and c5["h2d_ms_per_32MiB_column_max_over_ranks"] > 0

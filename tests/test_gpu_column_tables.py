@@ -161,6 +161,41 @@ def test_pipelined_host_commit_ranges(n, chunk):
         assert lib.h2_bases_free(hd) == 0
 
 
+def test_commit_range_device_partials_sum_to_the_commit():
+    """h2_commit_range_device: the commit restricted to table columns [first, first + n) -- what one rank of a commit split over
+    GPUs computes (h2_commit_split_rccl_device, parallel.split_commit); ragged ranges, blind on the last one, both sort paths."""
+    import torch
+    curve = h.PALLAS
+    lib = h.lib()
+    sf = co.field_of_curve(curve, "scalar")
+    dev = torch.device("cuda", 0)
+    for n, cuts in ((3000, [0, 1, 1000, 2999, 3000]), (40000, [0, 13000, 13001, 40000])):
+        g = co.generate_bases(curve, 0x5150 + n, n)
+        col = co.random_field(sf, 0x5151 + n, n)
+        w, = _points(curve, [0x99])
+        blind = co.random_field(sf, 0x5152, 1)
+        hd = C.c_uint64(0)
+        assert lib.h2_bases_register(curve, _p(g), n, h.FORM_MONTGOMERY, C.byref(hd)) == 0
+        assert lib.h2_bases_set_blind_base(hd, _p(w), h.FORM_MONTGOMERY) == 0
+        d_col = torch.from_numpy(col.view(np.int64)).to(dev)
+        d_bl = torch.from_numpy(blind.view(np.int64)).to(dev)
+        parts = torch.zeros((len(cuts) - 1, 12), dtype=torch.int64, device=dev)
+        for r in range(len(cuts) - 1):
+            lo, hi = cuts[r], cuts[r + 1]
+            last = r == len(cuts) - 2
+            rc = lib.h2_commit_range_device(hd, d_col[lo:].data_ptr() if hi > lo else None, lo, hi - lo, d_bl.data_ptr() if last else None,
+                                            h.FORM_MONTGOMERY, 0, parts[r].data_ptr(), None)
+            assert rc == 0, lib.h2_last_error()
+            torch.cuda.synchronize()
+            want = (co.commit(curve, np.ascontiguousarray(g[lo:hi]), w, np.ascontiguousarray(col[lo:hi]), blind[0]) if last
+                    else co.best_multiexp(curve, col[lo:hi], g[lo:hi]))
+            assert affine_of(curve, parts[r].cpu().numpy().view(np.uint64)) == co.jac_to_affine_ints(curve, want), (n, r)
+        total = h.points_sum(parts.cpu().numpy().view(np.uint64), curve)
+        assert affine_of(curve, total) == co.jac_to_affine_ints(curve, co.commit(curve, g, w, col, blind[0]))
+        assert lib.h2_commit_range_device(hd, d_col.data_ptr(), 1, n, None, h.FORM_MONTGOMERY, 0, parts[0].data_ptr(), None) == 1   # past the table
+        assert lib.h2_bases_free(hd) == 0
+
+
 def test_commit_batch_multi_two_blind_bases_one_handle():
     """h2_commit_batch_multi with the same handles and two different w in sequence (the staging slot's fixed address
     made the second call reuse the first w's multiples)."""
