@@ -1036,6 +1036,19 @@ __global__ void __launch_bounds__(64) msm_finish_heavy2(const u32 *__restrict__ 
     }
 }
 
+// total[b] += part[b] over one bucket slice (the ranges of a commit assembled from chunks share one fold): one quad per bucket
+template <int FB>
+__global__ void __launch_bounds__(256) msm_bucket_add(u32 *__restrict__ total, const u32 *__restrict__ part, u32 nb) {
+    H2_LATENCY_STAGE();
+    const u32 b = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+    if (b >= nb) return;
+    const xyzz<FB> p = xyzz_load<FB>(part + 32 * (size_t)b);
+    if (fe_is_zero(p.zz)) return;                              // an empty bucket of this range
+    xyzz<FB> acc = xyzz_load<FB>(total + 32 * (size_t)b);
+    xyzz_add_wide<FB>(acc, p);
+    if ((threadIdx.x & (kGroup - 1)) == 0) xyzz_store<FB>(total + 32 * (size_t)b, acc);
+}
+
 // The three tail kernels below run each logical lane as a quad of 4 hardware lanes (curve_wide.cuh): the chip
 // is nearly idle here, so lanes are free and the dependent-multiply depth per point operation drops 3x.
 
@@ -1469,12 +1482,19 @@ struct MsmArgs {
     int pair_shift = -1;         // >= 0 (registered only): two outputs from one column, see Sort2::pair_shift; d_out holds both
     u32 pair_n = 0;
     u32 col0 = 0;                // registered only: the scalars are table columns [col0, col0 + n_used)
+    // A commit assembled from RANGES (the chunks of a pipelined host transfer): each range runs sort + accumulate + finish and
+    // adds its finished buckets into `add_into` (XYZZ, reference Montgomery form, [NB]) instead of folding them; one fold-only
+    // call (`fold_from`) then reduces the summed buckets: the ranges share ONE fold instead of paying one each.
+    u32 *add_into = nullptr;
+    const u32 *fold_from = nullptr;
 };
 
 template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a, hipStream_t st) {
     size_t m = a.n_used + (a.d_extra_scalar ? 1 : 0);
     int rc;
-    if (m == 0) {
+    const bool fold_only = a.fold_from != nullptr;
+    if (m == 0 && a.add_into) return H2_OK;          // an empty range adds nothing
+    if (m == 0 && !fold_only) {
         if ((rc = cx.ssums.reserve(128)) != H2_OK) return rc;
         H2_HIP(hipMemsetAsync(cx.ssums.ptr, 0, 128, st));
         hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, cx.ssums.as<u32>(), 1, 0, (u32 *)a.d_out, a.out_kind,
@@ -1487,6 +1507,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     const bool glv = !a.table && !a.d_extra_scalar && glv_applies(a.n_used);
     const size_t scalars_n = m;
     if (glv) m *= 2;
+    if (fold_only && m < 1) m = 1;                   // only the bucket geometry (c) matters to the fold
     MsmShape sh = make_shape(m, a.c, a.table, glv);
     const bool pair = a.table && a.pair_shift >= 0;
     if (pair) {                       // one bucket slice per output
@@ -1627,6 +1648,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     const u32 m32 = (u32)m;
     u32 *grand = cx.bsums.as<u32>() + nblocks;
     const u32 tl_id = (u32)(((uintptr_t)st >> 4) & 0xFFFF) << 8;
+    if (!fold_only) {
     TL_STAMP(tl_id | 1);
     prof_begin(PROF_MSM_SORT, st);
     const u32 extra_col = a.d_extra_scalar ? (a.table ? a.extra_col : (u32)a.n_used) : 0xFFFFFFFFu;
@@ -1756,15 +1778,24 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                        cx.heads.as<u32>(), cx.starts.as<u32>(), cx.hscratch.as<u32>(), cx.heavy.as<u32>(), tb, T, lane_div);
     hipLaunchKernelGGL((msm_finish_heavy2<FB>), dim3(max_heavy), dim3(64), 0, st, cx.hscratch.as<u32>(), cx.buckets.as<u32>(),
                        cx.heavy.as<u32>());
+    if (a.add_into) {
+        hipLaunchKernelGGL((msm_bucket_add<FB>), dim3((tb * kGroup + 255) / 256), dim3(256), 0, st, a.add_into, cx.buckets.as<u32>(), tb);
+        prof_end(PROF_MSM_REDUCE, st);
+        H2_HIP(hipGetLastError());
+        return H2_OK;
+    }
+    } else {
+        prof_begin(PROF_MSM_REDUCE, st);
+    }
     {
         // what the fold runs over: the bucket slices themselves, or (wide slices) the row / column sums as two slices
-        const u32 *fold_src = cx.buckets.as<u32>();
+        const u32 *fold_src = fold_only ? a.fold_from : cx.buckets.as<u32>();
         u32 fold_nb = sh.NB, fold_slices = sh.slices;
         int fold_c = sh.c;
         if (wide_reduce) {
             u32 *wide = cx.partial.as<u32>() + 32 * (size_t)(2 * wideNR / kSeg);     // after the fold's own partials
             H2_HIP(hipMemsetAsync(wide, 0, (size_t)2 * wideNR * 128, st));
-            hipLaunchKernelGGL((msm_rowcol_sums<FB>), dim3(wideS + wideNR - 1), dim3(256), (256 / kGroup) * 128, st, cx.buckets.as<u32>(),
+            hipLaunchKernelGGL((msm_rowcol_sums<FB>), dim3(wideS + wideNR - 1), dim3(256), (256 / kGroup) * 128, st, fold_src,
                                wide, wideS, wideNR);
             fold_src = wide;
             fold_nb = wideNR;
@@ -2378,10 +2409,13 @@ extern "C" int h2_msm_batch_device(int curve, const void *const *d_scalars, cons
 // poly/commitment.rs:119-130).  The column is cut into ranges of the registered table's columns; range r is copied on a copy
 // stream and, as soon as it has landed, committed on one of two compute streams as a multiexp of its own over table columns
 // [lo, hi) (MsmArgs::col0) -- so PCIe runs beside the bucket arithmetic of the ranges before it, and only the first range's
-// copy and the last range's fold stay exposed.  The partial points are added by k_points_sum (a group element: any order).
+// copy and ONE fold stay exposed: a range stops after its buckets are finished and adds them into a running bucket slice
+// (MsmArgs::add_into, one per compute stream); the summed slice is folded once (MsmArgs::fold_from).
 namespace {
 constexpr int kPipeMaxChunks = 16;
-constexpr size_t kPipeChunk = (size_t)1 << 17;      // 4 MiB of scalars: ~0.08 ms of PCIe, 0.13 ms of bucket additions
+constexpr size_t kPipeChunk = (size_t)1 << 18;      // 8 MiB of scalars: 0.15 ms of PCIe, 0.26 ms of bucket additions.  Measured at 2^20 (bench/tools/
+                                                    // host_commit_sweep.py): ranges of 2^20 / 2^19 / 2^18 / 2^17 / 2^16 -> 2.25 / 1.88 / 1.80 / 2.20 / 3.10 ms
+                                                    // (every range pays its own sort chain and bucket finish); resident commit 1.52, raw copy 0.59
 struct HostPipe {
     std::mutex mu;
     bool ready = false;
@@ -2416,9 +2450,14 @@ static int commit_host_pipelined(Bases &b, const uint64_t *scalars, size_t n, co
     if (n < 2 * chunk) chunk = std::max<size_t>(n, 1);                       // small columns: one range, nothing to overlap
     chunk = std::max(chunk, (n + kPipeMaxChunks - 1) / kPipeMaxChunks);
     const int chunks = (int)std::max<size_t>(1, (n + chunk - 1) / chunk);
+    const size_t nb = (size_t)1 << (b.c - 1);
     if ((rc = hp.stage.reserve(n * 32 + 64)) != H2_OK) return rc;
-    if ((rc = hp.parts.reserve((size_t)(chunks + 1) * 96)) != H2_OK) return rc;
-    char *d_s = hp.stage.as<char>(), *d_blind = d_s + n * 32, *d_parts = hp.parts.as<char>();
+    if ((rc = hp.parts.reserve(2 * nb * 128 + 128)) != H2_OK) return rc;
+    char *d_s = hp.stage.as<char>(), *d_blind = d_s + n * 32;
+    u32 *total[2] = {hp.parts.as<u32>(), hp.parts.as<u32>() + 32 * nb};
+    char *d_res = (char *)(total[1] + 32 * nb);
+    const int used = chunks > 1 ? 2 : 1;                                     // compute streams in play
+    for (int j = 0; j < used; ++j) H2_HIP(hipMemsetAsync(total[j], 0, nb * 128, hp.comp[j]));
     if (blind) H2_HIP(hipMemcpyAsync(d_blind, blind, 32, hipMemcpyHostToDevice, hp.copy));
     for (int i = 0; i < chunks; ++i) {
         const size_t lo = (size_t)i * chunk, len = std::min(chunk, n - lo);
@@ -2430,25 +2469,31 @@ static int commit_host_pipelined(Bases &b, const uint64_t *scalars, size_t n, co
         std::lock_guard<std::mutex> cl(cx.mu);
         // the blind rides with the last range (its base is column n of the table whatever the range)
         MsmArgs a{d_s + lo * 32, (blind && i == chunks - 1) ? d_blind : nullptr, b.d_table, nullptr, len, true, b.c, b.stride, (u32)b.n, form,
-                  H2_OUT_JACOBIAN, d_parts + (size_t)i * 96};
+                  H2_OUT_JACOBIAN, nullptr};
         a.col0 = (u32)lo;
+        a.add_into = total[i & 1];
         if ((rc = msm_dispatch(cx, b.curve, a, st)) != H2_OK) break;
     }
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < used; ++j) {
         H2_HIP(hipEventRecord(hp.done[j], hp.comp[j]));
         H2_HIP(hipStreamWaitEvent(hp.copy, hp.done[j], 0));
+    }
+    if (rc == H2_OK) {
+        if (used == 2) {
+            const dim3 grid((unsigned)((nb * kGroup + 255) / 256)), blk(256);
+            if (b.curve == H2_PALLAS) hipLaunchKernelGGL((msm_bucket_add<FP>), grid, blk, 0, hp.copy, total[0], (const u32 *)total[1], (u32)nb);
+            else hipLaunchKernelGGL((msm_bucket_add<FQ>), grid, blk, 0, hp.copy, total[0], (const u32 *)total[1], (u32)nb);
+        }
+        MsmContext &cx = msm_ctx(hp.copy);
+        std::lock_guard<std::mutex> cl(cx.mu);
+        MsmArgs a{nullptr, nullptr, b.d_table, nullptr, 0, true, b.c, b.stride, (u32)b.n, form, out_kind, d_res};
+        a.fold_from = total[0];
+        rc = msm_dispatch(cx, b.curve, a, hp.copy);
     }
     if (rc != H2_OK) {
         (void)hipStreamSynchronize(hp.copy);
         return rc;
     }
-    const bool mont = form == H2_FORM_MONTGOMERY;
-    char *d_res = d_parts + (size_t)chunks * 96;
-    if (b.curve == H2_PALLAS)
-        hipLaunchKernelGGL((k_points_sum<FP>), dim3(1), dim3(64), 0, hp.copy, (const u32 *)d_parts, (u32)chunks, (u32 *)d_res, mont, out_kind, mont);
-    else
-        hipLaunchKernelGGL((k_points_sum<FQ>), dim3(1), dim3(64), 0, hp.copy, (const u32 *)d_parts, (u32)chunks, (u32 *)d_res, mont, out_kind, mont);
-    H2_HIP(hipGetLastError());
     H2_HIP(hipMemcpyAsync(out, d_res, out_kind == H2_OUT_AFFINE ? 64 : 96, hipMemcpyDeviceToHost, hp.copy));
     H2_HIP(hipStreamSynchronize(hp.copy));
     return H2_OK;
