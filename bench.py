@@ -531,8 +531,29 @@ def main():
                                 _p(out_h)), "h2_commit")
             e2e.append(time.perf_counter() - t8)
         e2e_ms = sorted(e2e[1:])[len(e2e[1:]) // 2] * 1e3
-        extra["host_pointer_commit"] = {"what": "h2_commit: pageable host scalars -> PCIe -> commit -> 96 B back, one call at a time (SURVEY 8d 'end-to-end including H2D')",
+        extra["host_pointer_commit"] = {"what": "h2_commit: pageable host scalars -> PCIe in 8 MiB ranges, each committed as it lands -> one fold -> 96 B back; one call at a time (SURVEY 8d 'end-to-end including H2D')",
                                         "ms": round(e2e_ms, 4), "Mscalar_mults_per_s": round(n / e2e_ms / 1e3, 1)}
+        # (2b) the literal seam of INTEGRATION.md section 2 at the headline size: best_multiexp -> h2_msm and best_fft -> h2_ntt with HOST
+        # pointers, both PCIe directions inside the call (pageable memory, one call at a time, median of 5)
+        def _med(f, reps=5):
+            f()
+            ts = []
+            for _ in range(reps):
+                t_ = time.perf_counter()
+                f()
+                ts.append(time.perf_counter() - t_)
+            return sorted(ts)[len(ts) // 2] * 1e3
+        msm_h = _med(lambda: check(lib.h2_msm(curve, _p(cols[0]), _p(bases), n, h.FORM_MONTGOMERY, 0, _p(out_h)), "h2_msm"))
+        from oracle import pasta as _pasta
+        host_ntt = {}
+        for log_n in (20, 22):
+            a_h = co.random_field(h.FP, 70 + log_n, 1 << log_n)
+            om = fields.scalar_limbs(_pasta.omega_for(_pasta.P, log_n), h.FP)
+            host_ntt[f"2^{log_n}"] = round(_med(lambda: check(lib.h2_ntt(h.FP, _p(a_h), log_n, _p(om), h.FORM_MONTGOMERY), "h2_ntt")), 4)
+        extra["host_pointer_seam"] = {"what": "the free functions as the Rust shim calls them: host slices in, host results out (SURVEY 8b); thresholds and the "
+                                              "crossover table: INTEGRATION.md section 2, profiles/r03_crossover.json",
+                                      "h2_msm_2^20_ms": round(msm_h, 4), "h2_msm_2^20_Mscalar_mults_per_s": round(n / msm_h / 1e3, 1),
+                                      "h2_ntt_ms": host_ntt, "h2_commit_2^20_ms": round(e2e_ms, 4)}
         # (3) BASELINE configs[3]: create_proof of the reference's simple-example circuit at k = 20 (examples/simple_example.py:
         # product prover + product verifier; columns, quotient FFTs, multi-point opening and the opening argument all on this GPU)
         if args.log_n == 20 and not args.no_create_proof:
@@ -549,11 +570,14 @@ def main():
             prm.close()
             extra["create_proof_simple_example_k20"] = {
                 "accepted_and_wrong_instance_rejected": res["ok"], "create_proof_s": round(res["create_proof_s"], 4),
+                "create_proof_from_host_columns_s": round(res["create_proof_from_host_columns_s"], 4),
+                "host_advice_columns": res["advice_columns"],
                 "create_proof_first_call_s": round(res["create_proof_first_s"], 4), "keygen_s": round(res["keygen_s"], 4),
                 "verify_proof_s": round(res["verify_proof_s"], 4), "proof_bytes": res["proof_bytes"],
                 "params_from_generators_s": round(params_s, 3),
                 "what": "examples/simple_example.py: the reference's simple-example circuit (examples/simple-example.rs) at k = 20 on Vesta, "
-                        "columns already assigned; instance / advice commits, permutation, vanishing argument (quotient FFTs at 2^21), "
+                        "columns already assigned (create_proof_s: resident in HBM; create_proof_from_host_columns_s: the advice columns start in pageable host memory, "
+                        "as after the reference's CPU synthesis, plonk/prover.rs:284-313, and their upload is inside the timed region); instance / advice commits, permutation, vanishing argument (quotient FFTs at 2^21), "
                         "multi-point opening and opening argument on this GPU; create_proof_s = second proof of the process"}
 
     if rank == 0:
