@@ -61,18 +61,27 @@ static constexpr size_t kLdsCap = 160 * 1024 - 512;
 
 // Two-pass sort geometry for a table of `stride` columns and window width c: the low `lowb` bucket bits ride in the
 // entry above the table index (`lb` bits); the remaining bucket_bits - lowb bits select the pass-1 bin.
-static bool sort2_geometry(u32 stride, int c, int *lowb_out, int *lb_out) {
+static bool sort2_geometry(u32 stride, int c, int *lowb_out, int *lb_out, int *side_out = nullptr) {
     const int W = 255 / c + 1, bucket_bits = c - 1;
     const uint64_t top = (uint64_t)W * stride - 1;
     if (top >= ((uint64_t)1 << 31)) return false;
     int lb = 0;
     while ((top >> lb) != 0) ++lb;
-    const int lowb = std::min(31 - lb, bucket_bits - 9);
+    // 512 pass-1 bins whenever the low bucket bits have somewhere to ride: in the entry's spare bits above the table index, or
+    // -- windows of 18 bits and more at 2^20 points, where those are too few -- in a 16-bit SIDE array next to the tagged list
+    // (pass 1 writes 6 bytes per entry instead of 4; without it c = 20 meant 4096 bins and 6-entry runs)
+    int lowb = std::min(31 - lb, bucket_bits - 9), side = 0;
+    static const bool side_ok = [] { const char *e = getenv("H2_SORT_SIDE"); return !(e && atoi(e) == 0); }();      // A/B switch
+    if (side_ok && bucket_bits - 9 > lowb && bucket_bits - 9 <= 14 && W <= 64) {
+        lowb = bucket_bits - 9;
+        side = 1;
+    }
     if (lowb < 1 || bucket_bits - lowb > 12) return false;
     const size_t nh = (size_t)1 << (bucket_bits - lowb);
     if ((nh * 3 + 1 + (size_t)kS1Scalars * W) * 4 > kLdsCap) return false;   // pass-1 stage in LDS
     *lowb_out = lowb;
     *lb_out = lb;
+    if (side_out) *side_out = side;
     return true;
 }
 // The paired commit (h2_commit_pair_device): two bucket slices, key = side * NB + bucket.  Pass 1 stages s1 scalars' digits per
@@ -341,7 +350,10 @@ __global__ void __launch_bounds__(kScanBlock) msm_scan_apply(const u32 *__restri
     u32 tot;
     u32 a = block_excl_scan(g < total ? counts[g] : 0, sh, tot) + bsums[blockIdx.x];
     if (g < total) starts[g] = a;
-    if (g == 0) starts[total] = *grand;
+    if (g == 0) {
+        starts[total] = *grand;
+        starts[total + 1] = 0xFFFFFFFFu;      // sentinel: msm_accumulate reads the boundary after next without a bounds check
+    }
 }
 
 // ---- scatter: bucket-sorted entry list ----------------------------------------------------------
@@ -394,6 +406,7 @@ struct Sort2 {
     u32 lds_window;   // widest pass-2 window (buckets) whose counters fit LDS; wider ones count in HBM
     u32 s1_scalars;   // scalars per pass-1 workgroup (a multiple of 1024)
     u32 nb;           // buckets per slice; generic path: sort key = window * nb + bucket, entry = digit column
+    int side;         // 1: the low bucket bits of a tagged entry live in the 16-bit side array, not in the entry
     u32 col0;         // registered path: scalar i sits in table column col0 + i (a column RANGE of the table: the chunks of a pipelined host commit)
     int pair_shift;   // >= 0: registered PAIR commit -- column i < pair_n feeds output (i >> pair_shift) & 1, a tail column
     u32 pair_n;       //       i >= pair_n feeds output (i - pair_n) & 1; sort key = side * nb + bucket (two bucket slices)
@@ -444,7 +457,7 @@ __device__ __forceinline__ void emit_entries(const fe &s, u32 i, const Sort2 &P,
         u32 side_key = 0;
         if (P.pair_shift >= 0) side_key = (i < P.pair_n ? (i >> P.pair_shift) & 1u : (i - P.pair_n) & 1u) * P.nb;
         for_each_digit(s, P.c, P.W, [&](int w, u32 code) {
-            if (code != kZero32) f(side_key + (code & 0x7FFFFFFFu), (u32)w * P.stride + col, code & 0x80000000u);
+            if (code != kZero32) f(side_key + (code & 0x7FFFFFFFu), (u32)w * P.stride + col, code & 0x80000000u, (u32)w);
         });
         return;
     }
@@ -467,7 +480,7 @@ __device__ __forceinline__ void emit_entries(const fe &s, u32 i, const Sort2 &P,
             const bool up = neg[part] ? raw >= half : raw > half;      // same digit set as msm_recode_glv
             carry = up;
             const u32 digit_mag = up ? (1u << c) - raw : raw;
-            if (digit_mag) f((u32)w * P.nb + digit_mag - 1, (u32)part * P.m + i, (((up ? 1u : 0u) ^ neg[part]) << 31));
+            if (digit_mag) f((u32)w * P.nb + digit_mag - 1, (u32)part * P.m + i, (((up ? 1u : 0u) ^ neg[part]) << 31), (u32)w);
         }
     }
 }
@@ -486,7 +499,7 @@ __global__ void __launch_bounds__(1024) msm_s1_count(const u32 *__restrict__ sca
         if (i >= P.m) break;
         fe s = (extra_scalar && i == P.m - 1) ? fe_load(extra_scalar) : fe_load(scalars + 8 * (size_t)i);
         if (P.mont) s = fe_from_mont<FS>(s);
-        emit_entries<FS, GLV>(s, i, P, [&](u32 key, u32, u32) { atomicAdd(&sh[key >> P.lowb], 1u); });
+        emit_entries<FS, GLV>(s, i, P, [&](u32 key, u32, u32, u32) { atomicAdd(&sh[key >> P.lowb], 1u); });
     }
     __syncthreads();
     for (u32 h = threadIdx.x; h < nh; h += blockDim.x) hist1[(size_t)blk * nh + h] = sh[h];
@@ -517,7 +530,7 @@ __device__ __forceinline__ u32 wave0_excl_scan(u32 *v, u32 n) {
 template <int FS, bool GLV>
 __global__ void __launch_bounds__(1024) msm_s1_scatter(const u32 *__restrict__ scalars, const u32 *__restrict__ extra_scalar, Sort2 P,
                                                        const u32 *__restrict__ hist1, const u32 *__restrict__ bin_count,
-                                                       u32 *__restrict__ bin_start, u32 *__restrict__ tagged) {
+                                                       u32 *__restrict__ bin_start, u32 *__restrict__ tagged, uint16_t *__restrict__ tagged_low) {
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
     const u32 nh = P.nh, blk = blockIdx.x, B1 = gridDim.x;
@@ -550,18 +563,42 @@ __global__ void __launch_bounds__(1024) msm_s1_scatter(const u32 *__restrict__ s
     __syncthreads();
     const u32 lowmask = (1u << P.lowb) - 1;
     for (u32 k = 0; k < P.s1_scalars / 1024; ++k) {
-        const u32 i = blk * P.s1_scalars + k * 1024 + threadIdx.x;
+        const u32 loc = k * 1024 + threadIdx.x, i = blk * P.s1_scalars + loc;
         if (i >= P.m) break;
         fe s = (extra_scalar && i == P.m - 1) ? fe_load(extra_scalar) : fe_load(scalars + 8 * (size_t)i);
         if (P.mont) s = fe_from_mont<FS>(s);
-        emit_entries<FS, GLV>(s, i, P, [&](u32 key, u32 base, u32 sign) {
-            const u32 pos = atomicAdd(&cursor[key >> P.lowb], 1u);
-            stage[pos] = base | ((key & lowmask) << P.lb) | sign;
-        });
+        if (!GLV && P.side) {
+            // the stage word keeps what the copy-out needs to rebuild the entry: scalar (11 bits, s1_scalars <= 2048), window
+            // (6 bits) and the low bucket bits (<= 14), so entry and low bits leave as two contiguous runs per bin
+            emit_entries<FS, GLV>(s, i, P, [&](u32 key, u32, u32 sign, u32 w) {
+                const u32 pos = atomicAdd(&cursor[key >> P.lowb], 1u);
+                stage[pos] = loc | (w << 11) | ((key & lowmask) << 17) | sign;
+            });
+        } else {
+            emit_entries<FS, GLV>(s, i, P, [&](u32 key, u32 base, u32 sign, u32) {
+                const u32 pos = atomicAdd(&cursor[key >> P.lowb], 1u);
+                stage[pos] = base | ((key & lowmask) << P.lb) | sign;
+            });
+        }
     }
     __syncthreads();
     // one wave per bin at a time: contiguous LDS run -> contiguous global run
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    if (!GLV && P.side) {
+        for (u32 h = wave; h < nh; h += nwaves) {
+            const u32 l0 = lstart[h], l1 = lstart[h + 1];
+            u32 *dst = tagged + gstart[h];
+            uint16_t *dlo = tagged_low + gstart[h];
+            for (u32 q = l0 + lane; q < l1; q += 64) {
+                const u32 word = stage[q], i = blk * P.s1_scalars + (word & 2047u), w = (word >> 11) & 63u;
+                u32 col = P.col0 + i;
+                if (i == P.m - 1 && P.extra_col != 0xFFFFFFFFu) col = P.extra_col;
+                dst[q - l0] = (w * P.stride + col) | (word & 0x80000000u);
+                dlo[q - l0] = (uint16_t)((word >> 17) & 0x3FFFu);
+            }
+        }
+        return;
+    }
     for (u32 h = wave; h < nh; h += nwaves) {
         const u32 l0 = lstart[h], l1 = lstart[h + 1];
         u32 *dst = tagged + gstart[h];
@@ -642,9 +679,14 @@ __device__ __forceinline__ u32 rel_bin(const u32 *bounds, u32 nbins, u32 p) {
     return hi;
 }
 
+// low bucket bits of tagged entry p: in the entry's spare bits, or in the side array
+__device__ __forceinline__ u32 s2_low(const Sort2 &P, const uint16_t *__restrict__ low, u32 p, u32 e, u32 lowmask) {
+    return P.side ? (u32)low[p] : (e >> P.lb) & lowmask;
+}
+
 // pass 2, COUNT over one chunk of the tagged list: hist2[woff[c] + (bucket - window base)]
-__global__ void __launch_bounds__(1024) msm_s2_count(const u32 *__restrict__ tagged, const u32 *__restrict__ bin_start, const u32 *__restrict__ hlo,
-                                                     const u32 *__restrict__ woff, Sort2 P, u32 *__restrict__ hist2) {
+__global__ void __launch_bounds__(1024) msm_s2_count(const u32 *__restrict__ tagged, const uint16_t *__restrict__ tagged_low, const u32 *__restrict__ bin_start,
+                                                     const u32 *__restrict__ hlo, const u32 *__restrict__ woff, Sort2 P, u32 *__restrict__ hist2) {
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [window] counters, then the window's bin boundaries
     const u32 cidx = blockIdx.x, M = bin_start[P.nh];
@@ -659,7 +701,7 @@ __global__ void __launch_bounds__(1024) msm_s2_count(const u32 *__restrict__ tag
         const u32 *gb = bin_start + h0 + 1;
         for (u32 p = (u32)p0 + threadIdx.x; p < p1; p += blockDim.x) {
             const u32 e = tagged[p];
-            atomicAdd(&hist2[wo + ((rel_bin(gb, nbins, p) << P.lowb) | ((e >> P.lb) & lowmask))], 1u);
+            atomicAdd(&hist2[wo + ((rel_bin(gb, nbins, p) << P.lowb) | s2_low(P, tagged_low, p, e, lowmask))], 1u);
         }
         return;
     }
@@ -669,7 +711,7 @@ __global__ void __launch_bounds__(1024) msm_s2_count(const u32 *__restrict__ tag
     __syncthreads();
     for (u32 p = (u32)p0 + threadIdx.x; p < p1; p += blockDim.x) {
         const u32 e = tagged[p];
-        atomicAdd(&sh[(rel_bin(bounds, nbins, p) << P.lowb) | ((e >> P.lb) & lowmask)], 1u);
+        atomicAdd(&sh[(rel_bin(bounds, nbins, p) << P.lowb) | s2_low(P, tagged_low, p, e, lowmask)], 1u);
     }
     __syncthreads();
     for (u32 k = threadIdx.x; k < wsize; k += blockDim.x) hist2[wo + k] = sh[k];
@@ -680,7 +722,7 @@ __global__ void __launch_bounds__(1024) msm_s2_count(const u32 *__restrict__ tag
 // column -- group the chunk by bucket in LDS first and copy each bucket's run out contiguously; wider windows write
 // straight from the counters.
 static constexpr u32 kS2StageWindow = 3072;
-__global__ void __launch_bounds__(1024) msm_s2_scatter(const u32 *__restrict__ tagged, const u32 *__restrict__ bin_start,
+__global__ void __launch_bounds__(1024) msm_s2_scatter(const u32 *__restrict__ tagged, const uint16_t *__restrict__ tagged_low, const u32 *__restrict__ bin_start,
                                                        const u32 *__restrict__ hlo, const u32 *__restrict__ woff, Sort2 P,
                                                        u32 *__restrict__ hist2, const u32 *__restrict__ starts, u32 *__restrict__ entries) {
     H2_LATENCY_STAGE();
@@ -690,12 +732,12 @@ __global__ void __launch_bounds__(1024) msm_s2_scatter(const u32 *__restrict__ t
     if (p0 >= M) return;
     const u32 p1 = (u32)min((size_t)M, p0 + P.K2);
     const u32 h0 = hlo[cidx], wo = woff[cidx], wsize = woff[cidx + 1] - wo, nbins = wsize >> P.lowb;
-    const u32 lowmask = (1u << P.lowb) - 1, strip = ~(lowmask << P.lb);
+    const u32 lowmask = (1u << P.lowb) - 1, strip = P.side ? ~0u : ~(lowmask << P.lb);
     if (wsize > P.lds_window) {             // very sparse column: hist2 (exclusive offsets by now) doubles as the cursor
         const u32 *gb = bin_start + h0 + 1;
         for (u32 p = (u32)p0 + threadIdx.x; p < p1; p += blockDim.x) {
             const u32 e = tagged[p];
-            const u32 k = (rel_bin(gb, nbins, p) << P.lowb) | ((e >> P.lb) & lowmask);
+            const u32 k = (rel_bin(gb, nbins, p) << P.lowb) | s2_low(P, tagged_low, p, e, lowmask);
             entries[starts[(h0 << P.lowb) + k] + atomicAdd(&hist2[wo + k], 1u)] = e & strip;
         }
         return;
@@ -707,7 +749,7 @@ __global__ void __launch_bounds__(1024) msm_s2_scatter(const u32 *__restrict__ t
         __syncthreads();
         for (u32 p = (u32)p0 + threadIdx.x; p < p1; p += blockDim.x) {
             const u32 e = tagged[p];
-            const u32 pos = atomicAdd(&sh[(rel_bin(bounds, nbins, p) << P.lowb) | ((e >> P.lb) & lowmask)], 1u);
+            const u32 pos = atomicAdd(&sh[(rel_bin(bounds, nbins, p) << P.lowb) | s2_low(P, tagged_low, p, e, lowmask)], 1u);
             entries[pos] = e & strip;
         }
         return;
@@ -726,7 +768,7 @@ __global__ void __launch_bounds__(1024) msm_s2_scatter(const u32 *__restrict__ t
     __syncthreads();
     for (u32 p = (u32)p0 + threadIdx.x; p < p1; p += blockDim.x) {
         const u32 e = tagged[p];
-        atomicAdd(&lstart[(rel_bin(bounds, nbins, p) << P.lowb) | ((e >> P.lb) & lowmask)], 1u);
+        atomicAdd(&lstart[(rel_bin(bounds, nbins, p) << P.lowb) | s2_low(P, tagged_low, p, e, lowmask)], 1u);
     }
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -738,7 +780,7 @@ __global__ void __launch_bounds__(1024) msm_s2_scatter(const u32 *__restrict__ t
     __syncthreads();
     for (u32 p = (u32)p0 + threadIdx.x; p < p1; p += blockDim.x) {
         const u32 e = tagged[p];                                 // second read of the chunk comes from L2
-        const u32 k = (rel_bin(bounds, nbins, p) << P.lowb) | ((e >> P.lb) & lowmask);
+        const u32 k = (rel_bin(bounds, nbins, p) << P.lowb) | s2_low(P, tagged_low, p, e, lowmask);
         const u32 pos = atomicAdd(&cursor[k], 1u);
         stage[pos] = e & strip;
         kid[pos] = (uint16_t)k;
@@ -822,6 +864,15 @@ __global__ void __launch_bounds__(256) msm_bases_to_m9_glv(const u32 *__restrict
 // carry-free 9 x 29-bit field layer (curve9.cuh, 17.7-18.0 G mixed adds/s against 13.9-15.0 for the 8 x 32 layer,
 // profiles/r02_ubench_fe9.txt) and a flushed segment is converted back to the reference's Montgomery form, canonical, so
 // everything downstream (finish, fold, combine) is unchanged.
+// A 4-byte global load WITH its wait, as one statement the compiler cannot look into: used on the rare path of msm_accumulate
+// only.  A load the compiler tracks, issued under a condition and used after the join, makes it wait for EVERYTHING outstanding
+// at that join on every path (vmcnt counts in order) -- on the common path that would be the gathers issued a moment before.
+__device__ __forceinline__ u32 load_u32_waited(const u32 *p) {
+    u32 v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 template <int FB, bool GLV, bool M9 = false>
 __global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
                                                       u32 extra_index, const u32 *__restrict__ entries,
@@ -838,30 +889,63 @@ __global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(
         if (lo < hi) {
             u32 b = upper_bucket(starts, total_buckets, lo);
             u32 bend = starts[b + 1];
-            bool first = true;
-            u32 e0 = entries[lo], e1 = lo + 1 < hi ? entries[lo + 1] : 0;
+            // Memory operations and the wave's wait counter.  vmcnt counts loads AND stores in issue order, and at a point that
+            // some lanes' control flow reaches with conditional operations in flight the compiler has to wait for ALL of them
+            // (vmcnt(0)).  The loop is therefore arranged so that nothing young is ever outstanding where a wait falls:
+            //   * the gather of the next point and the read of entry i + 2 are UNCONDITIONAL (clamped at the tail), issued
+            //     right after the point gathered one addition ago has been consumed (the asm pin below is that point);
+            //   * the flush of a bucket boundary -- nine stores and the read of the boundary after next -- is DEFERRED to the
+            //     top of the following iteration, behind the gathers, so that a whole mixed addition (~4 us) passes before the
+            //     next wait.  At 17-bit windows a wave crosses a boundary in a quarter of its iterations (240 entries per
+            //     bucket, 64 lanes); issued at the bottom of the loop, each one stalled the wave for a memory round trip.
+            //   * the END of the bucket after the open one is read at the top of EVERY iteration (one dword, a cache hit) and used
+            //     by a flush one iteration later at the earliest: unconditional, so the compiler's wait for it is exact.
+            u32 t2_last = starts[b + 2];                 // starts[total_buckets + 1] is a sentinel (msm_scan_apply)
+            bool first = true, pending = false, t2_ok = true;
+            u32 e0 = entries[lo], e1 = entries[min(lo + 1, hi - 1)];
             affine<FB> nxt = aff_load<FB>(bases + 16 * (size_t)(e0 & 0x7FFFFFFFu));
             for (u32 i = lo; i < hi; ++i) {
-                const affine<FB> p = nxt;
+                // everything issued during the previous iteration -- the gather of this point, entry i + 1, the boundary read, a
+                // flush's stores -- has had a whole mixed addition to complete: this wait is free
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                affine<FB> p = nxt;
+                asm volatile("" : "+v"(p.x.v[0]), "+v"(p.x.v[1]), "+v"(p.x.v[2]), "+v"(p.x.v[3]), "+v"(p.x.v[4]), "+v"(p.x.v[5]), "+v"(p.x.v[6]),
+                             "+v"(p.x.v[7]), "+v"(p.y.v[0]), "+v"(p.y.v[1]), "+v"(p.y.v[2]), "+v"(p.y.v[3]), "+v"(p.y.v[4]), "+v"(p.y.v[5]),
+                             "+v"(p.y.v[6]), "+v"(p.y.v[7])
+                             :
+                             : "memory");
                 const u32 neg = e0 >> 31;
-                const u32 e2 = i + 2 < hi ? entries[i + 2] : 0;
-                if (i + 1 < hi) nxt = aff_load<FB>(bases + 16 * (size_t)(e1 & 0x7FFFFFFFu));
+                const u32 e2 = entries[min(i + 2, hi - 1)];
+                nxt = aff_load<FB>(bases + 16 * (size_t)(e1 & 0x7FFFFFFFu));      // at the tail: a stale, valid entry
+                const u32 t2_cur = starts[b + 2];
                 e0 = e1;
                 e1 = e2;
-                if (!aff_is_identity(p)) {
-                    aff9<FB> q = aff9_unpack<FB>(p);
-                    if (neg) q.y = fe9_sub(fe9_zero(), q.y);          // signed limbs: negation is nine subtractions
-                    xyzz9_madd<FB>(acc, q);
-                }
-                if (i + 1 == bend && i + 1 < hi) {
+                bool flushed = false;
+                if (pending) {
                     // parked as raw limbs (a few stores): the conversion back to the reference's Montgomery form costs most of a
                     // mixed addition and would be paid by the whole wave each time one of its lanes crosses a bucket boundary;
                     // msm_segments_to_r256 does it for all segments at once
                     xyzz9_store_raw<FB>(first ? heads + 36 * (size_t)t : buckets + 36 * (size_t)b, acc);
                     first = false;
                     acc = xyzz9_identity<FB>();
-                    do { ++b; bend = starts[b + 1]; } while (bend <= i + 1);
+                    ++b;
+                    if (t2_ok && t2_last > i) {
+                        bend = t2_last;                                              // = starts[b + 1], read an iteration ago
+                    } else {
+                        // rare: empty buckets follow (sparse columns), or the bucket just closed held a single entry
+                        b = upper_bucket(starts, total_buckets, i);
+                        bend = load_u32_waited(starts + b + 1);
+                    }
+                    flushed = true;
                 }
+                if (!aff_is_identity(p)) {
+                    aff9<FB> q = aff9_unpack<FB>(p);
+                    if (neg) q.y = fe9_sub(fe9_zero(), q.y);          // signed limbs: negation is nine subtractions
+                    xyzz9_madd<FB>(acc, q);
+                }
+                pending = i + 1 == bend && i + 1 < hi;
+                t2_ok = !flushed;            // the read at the top of an iteration that flushed was made for the bucket it closed
+                t2_last = t2_cur;
             }
             xyzz9_store_raw<FB>(first ? heads + 36 * (size_t)t : buckets + 36 * (size_t)b, acc);
             return;
@@ -1433,10 +1517,10 @@ static bool timeline_on() {
 struct MsmContext {
     std::mutex mu;
     DevBuf digits, hist, counts, starts, bsums, entries, heads, heavy, hscratch, buckets, partial, ssums, stage_s, stage_b,
-        out, small, tagged, plan, seg9, bases9, collapse, collapse_list;
+        out, small, tagged, tagged_low, plan, seg9, bases9, collapse, collapse_list;
     void release_all() {
         for (DevBuf *b : {&digits, &hist, &counts, &starts, &bsums, &entries, &heads, &heavy, &hscratch, &buckets, &partial, &ssums,
-                          &stage_s, &stage_b, &out, &small, &tagged, &plan, &seg9, &bases9, &collapse, &collapse_list})
+                          &stage_s, &stage_b, &out, &small, &tagged, &tagged_low, &plan, &seg9, &bases9, &collapse, &collapse_list})
             b->release();
     }
     bool attr_set = false, attr2_set = false;
@@ -1535,6 +1619,11 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         else if (glv) H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB, true>, 256, 0));
         else if (false) H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB, false, true>, 256, 0));
         else H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB, false>, 256, 0));
+        // the M9 accumulate is sized for H2_ACC9_WAVES workgroups per CU even where its register count would let a third one in:
+        // the wave slots and registers left over are what the sort / fold kernels of commits on OTHER streams run in
+        // (H2_ACC_WAVES: sweeps only)
+        static const int acc_waves = [] { const char *e = getenv("H2_ACC_WAVES"); int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? v : H2_ACC9_WAVES; }();
+        if (m9) per_cu = std::min(per_cu, acc_waves);
         lanes = (u32)cus * (u32)std::max(per_cu, 1) * 256u;
     }
     // one round of resident lanes; small problems use fewer lanes so a range keeps >= 16 entries
@@ -1572,12 +1661,13 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         S2.pair_n = a.pair_n;
     } else if (a.table && (sh.c > kMaxC || (sh.NB >= 4096 && m >= 8192))) {
         static const int force_old = [] { const char *e = getenv("H2_MSM_SORT"); return e && atoi(e) == 1 ? 1 : 0; }();
-        int lowb = 0, lb = 0;
-        if (sort2_geometry(a.stride, sh.c, &lowb, &lb) && (sh.c > kMaxC || !force_old)) {
+        int lowb = 0, lb = 0, side = 0;
+        if (sort2_geometry(a.stride, sh.c, &lowb, &lb, &side) && (sh.c > kMaxC || !force_old)) {
             use_sort2 = true;
             S2.m = (u32)m; S2.c = sh.c; S2.W = sh.W; S2.mont = a.form == H2_FORM_MONTGOMERY;
             S2.stride = a.stride; S2.extra_col = a.d_extra_scalar ? a.extra_col : 0xFFFFFFFFu;
             S2.lowb = lowb; S2.lb = lb; S2.nh = sh.NB >> lowb;
+            S2.side = side;
             S2.s1_scalars = kS1Scalars;
             S2.nb = sh.NB;
             S2.B1 = (u32)((m + kS1Scalars - 1) / kS1Scalars);
@@ -1629,6 +1719,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         }
         if ((rc = cx.hist.reserve((size_t)S2.B1 * S2.nh * 4)) != H2_OK) return rc;
         if ((rc = cx.tagged.reserve(all_items * 4)) != H2_OK) return rc;
+        if (S2.side && (rc = cx.tagged_low.reserve(all_items * 2)) != H2_OK) return rc;
         const size_t plan_words = (size_t)S2.nh * 2 + 1 + (size_t)S2.B2 * 2 + 1 + (((size_t)S2.nh + S2.B2 + 1) << S2.lowb);
         if ((rc = cx.plan.reserve(plan_words * 4)) != H2_OK) return rc;
     } else {
@@ -1636,7 +1727,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         if ((rc = cx.hist.reserve((size_t)sh.slices * sh.B * sh.NB * 4)) != H2_OK) return rc;
     }
     if ((rc = cx.counts.reserve((size_t)tb * 4)) != H2_OK) return rc;
-    if ((rc = cx.starts.reserve((size_t)(tb + 1) * 4)) != H2_OK) return rc;
+    if ((rc = cx.starts.reserve((size_t)(tb + 2) * 4)) != H2_OK) return rc;
     if ((rc = cx.bsums.reserve((size_t)(nblocks + 4) * 4)) != H2_OK) return rc;
     if ((rc = cx.entries.reserve(all_items * 4)) != H2_OK) return rc;
     if ((rc = cx.heads.reserve((size_t)std::max<size_t>(T, (size_t)sh.slices * 32) * 128)) != H2_OK) return rc;
@@ -1661,19 +1752,19 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                                (const u32 *)nullptr, S2, hist1);
             hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh);
             hipLaunchKernelGGL((msm_s1_scatter<FS, true>), dim3(S2.B1), dim3(1024), lds1, st, (const u32 *)a.d_scalars,
-                               (const u32 *)nullptr, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>());
+                               (const u32 *)nullptr, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>(), (uint16_t *)nullptr);
         } else {
             hipLaunchKernelGGL((msm_s1_count<FS, false>), dim3(S2.B1), dim3(1024), S2.nh * 4, st, (const u32 *)a.d_scalars,
                                (const u32 *)a.d_extra_scalar, S2, hist1);
             hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh);
             hipLaunchKernelGGL((msm_s1_scatter<FS, false>), dim3(S2.B1), dim3(1024), lds1, st, (const u32 *)a.d_scalars,
-                               (const u32 *)a.d_extra_scalar, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>());
+                               (const u32 *)a.d_extra_scalar, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>(), cx.tagged_low.as<uint16_t>());
         }
         hipLaunchKernelGGL(msm_s2_plan, dim3(1), dim3(kScanBlock), 0, st, bin_start, S2, hlo, woff);
         const size_t hist2_words = ((size_t)S2.nh + S2.B2 + 1) << S2.lowb;
         if (tb > S2.lds_window) H2_HIP(hipMemsetAsync(hist2, 0, hist2_words * 4, st));   // the HBM-counted windows start from zero
         const size_t lds2 = ((size_t)S2.lds_window + S2.nh + 1) * 4;
-        hipLaunchKernelGGL(msm_s2_count, dim3(S2.B2), dim3(1024), lds2, st, cx.tagged.as<u32>(), bin_start, hlo, woff, S2, hist2);
+        hipLaunchKernelGGL(msm_s2_count, dim3(S2.B2), dim3(1024), lds2, st, cx.tagged.as<u32>(), (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, hlo, woff, S2, hist2);
         hipLaunchKernelGGL(msm_s2_prefix, dim3((tb + 255) / 256), dim3(256), 0, st, hist2, bin_start, hlo, woff, S2, cx.counts.as<u32>(),
                            tb);
         hipLaunchKernelGGL(msm_scan_blocksums, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), tb);
@@ -1681,7 +1772,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         hipLaunchKernelGGL(msm_scan_apply, dim3(nblocks), dim3(kScanBlock), 0, st, cx.counts.as<u32>(), cx.bsums.as<u32>(), grand,
                            cx.starts.as<u32>(), tb);
         const size_t lds2s = std::max<size_t>(lds2, ((size_t)kS2StageWindow * 3 + 1 + S2.nh + kS2Chunk) * 4 + (size_t)kS2Chunk * 2);
-        hipLaunchKernelGGL(msm_s2_scatter, dim3(S2.B2), dim3(1024), lds2s, st, cx.tagged.as<u32>(), bin_start, hlo, woff, S2, hist2,
+        hipLaunchKernelGGL(msm_s2_scatter, dim3(S2.B2), dim3(1024), lds2s, st, cx.tagged.as<u32>(), (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, hlo, woff, S2, hist2,
                            cx.starts.as<u32>(), cx.entries.as<u32>());
     } else {
         if (glv)
@@ -2098,6 +2189,10 @@ extern "C" int h2_bases_register(int curve, const uint64_t *bases_xy, size_t n, 
 extern "C" int h2_commit_column_window_bits(size_t n) {
     const int c = choose_c(n ? n : 1, true);
     int lowb, lb;
+    if (const char *e = getenv("H2_COLUMN_C")) {          // sweeps only (bench.py, bench/tools): the width column tables are built with
+        const int v = atoi(e);
+        if (v >= 4 && v <= kMaxCShared && (v <= kMaxC || (n + 1 < ((size_t)1 << 31) && sort2_geometry((u32)n + 1, v, &lowb, &lb)))) return v;
+    }
     return c == 16 && n >= ((size_t)1 << 19) && n + 1 < ((size_t)1 << 31) && sort2_geometry((u32)n + 1, 17, &lowb, &lb) ? 17 : c;
 }
 
