@@ -131,4 +131,43 @@ template <int F> __device__ __forceinline__ void xyzz9_madd(xyzz9<F> &acc, const
     acc.zzz = fe9_mul<F>(acc.zzz, ppp);
 }
 
+// ---- full XYZZ + XYZZ addition on the same layer (add-2008-s: 12M + 2S): the throughput form of the bucket fold --------------
+// rare: p = U2 - U1 passed the cheap filter.  By value, as xyzz9_madd_rare (see there).
+template <int F> __device__ __noinline__ bool xyzz9_add_rare(fe9 p, fe9 r, xyzz9<F> a, xyzz9<F> *out) {
+    if (!fe_is_zero(fe9_canonical<F>(p))) return false;
+    if (!fe_is_zero(fe9_canonical<F>(r))) {
+        *out = xyzz9_identity<F>();
+        return true;
+    }
+    *out = xyzz9_from_r256<F>(xyzz_dbl<F>(xyzz9_to_r256<F>(a)));      // the two operands are the same point
+    return true;
+}
+// acc += q; complete.  Both normalised on entry, acc normalised on exit (same bounds discipline as xyzz9_madd).
+template <int F> __device__ __forceinline__ void xyzz9_add(xyzz9<F> &acc, const xyzz9<F> &q) {
+    if (xyzz9_is_identity(q)) return;
+    if (xyzz9_is_identity(acc)) {
+        acc = q;
+        return;
+    }
+    const fe9 u1 = fe9_mul<F>(acc.x, q.zz), u2 = fe9_mul<F>(q.x, acc.zz);
+    const fe9 s1 = fe9_mul<F>(acc.y, q.zzz), s2 = fe9_mul<F>(q.y, acc.zzz);
+    const fe9 p = fe9_sub(u2, u1), r = fe9_sub(s2, s1);
+    if (fe9_maybe_zero_mod_p(p)) {
+        xyzz9<F> special;
+        if (xyzz9_add_rare<F>(p, r, acc, &special)) {
+            acc = special;
+            return;
+        }
+    }
+    const fe9 pp = fe9_sqr<F>(p);
+    const fe9 ppp = fe9_mul<F>(p, pp);
+    const fe9 qq = fe9_mul<F>(u1, pp);
+    const fe9 x3 = fe9_norm(fe9_sub(fe9_sub(fe9_sqr<F>(r), ppp), fe9_dbl(qq)));
+    const fe9 y3 = fe9_norm(fe9_sub(fe9_mul<F>(r, fe9_sub(qq, x3)), fe9_mul<F>(s1, ppp)));
+    acc.x = x3;
+    acc.y = y3;
+    acc.zz = fe9_mul<F>(fe9_mul<F>(acc.zz, q.zz), pp);
+    acc.zzz = fe9_mul<F>(fe9_mul<F>(acc.zzz, q.zzz), ppp);
+}
+
 }  // namespace h2

@@ -432,8 +432,14 @@ template <int C, typename Fn> __device__ __forceinline__ void for_each_digit_sta
     }
 }
 template <typename Fn> __device__ __forceinline__ void for_each_digit(const fe &s, int c, int W, Fn f) {
+    // compile-time widths: the limb picks become plain register selects (the generic loop below indexes the limbs dynamically: at
+    // c = 17 the pass-1 kernels took 29 + 78 us against 16 + 53 us for the unrolled c = 20)
     if (c == 16) { for_each_digit_static<16>(s, f); return; }
+    if (c == 17) { for_each_digit_static<17>(s, f); return; }
+    if (c == 18) { for_each_digit_static<18>(s, f); return; }
+    if (c == 19) { for_each_digit_static<19>(s, f); return; }
     if (c == 20) { for_each_digit_static<20>(s, f); return; }
+    if (c == 13) { for_each_digit_static<13>(s, f); return; }
     u32 carry = 0;
     const u32 mask = (1u << c) - 1, half = 1u << (c - 1), full = 1u << c;
     for (int w = 0; w < W; ++w) {
@@ -494,8 +500,8 @@ __global__ void __launch_bounds__(1024) msm_s1_count(const u32 *__restrict__ sca
     const u32 nh = P.nh, blk = blockIdx.x;
     for (u32 h = threadIdx.x; h < nh; h += blockDim.x) sh[h] = 0;
     __syncthreads();
-    for (u32 k = 0; k < P.s1_scalars / 1024; ++k) {
-        const u32 i = blk * P.s1_scalars + k * 1024 + threadIdx.x;
+    for (u32 loc = threadIdx.x; loc < P.s1_scalars; loc += blockDim.x) {
+        const u32 i = blk * P.s1_scalars + loc;
         if (i >= P.m) break;
         fe s = (extra_scalar && i == P.m - 1) ? fe_load(extra_scalar) : fe_load(scalars + 8 * (size_t)i);
         if (P.mont) s = fe_from_mont<FS>(s);
@@ -562,8 +568,8 @@ __global__ void __launch_bounds__(1024) msm_s1_scatter(const u32 *__restrict__ s
     }
     __syncthreads();
     const u32 lowmask = (1u << P.lowb) - 1;
-    for (u32 k = 0; k < P.s1_scalars / 1024; ++k) {
-        const u32 loc = k * 1024 + threadIdx.x, i = blk * P.s1_scalars + loc;
+    for (u32 loc = threadIdx.x; loc < P.s1_scalars; loc += blockDim.x) {
+        const u32 i = blk * P.s1_scalars + loc;
         if (i >= P.m) break;
         fe s = (extra_scalar && i == P.m - 1) ? fe_load(extra_scalar) : fe_load(scalars + 8 * (size_t)i);
         if (P.mont) s = fe_from_mont<FS>(s);
@@ -1133,6 +1139,92 @@ __global__ void __launch_bounds__(256) msm_bucket_add(u32 *__restrict__ total, c
     if ((threadIdx.x & (kGroup - 1)) == 0) xyzz_store<FB>(total + 32 * (size_t)b, acc);
 }
 
+// ---- the first levels of the fold of a WIDE bucket slice (registered tables from 2^16 buckets), throughput form ----------------
+// The quad-lane kernels below spend four lanes on a point operation to cut its latency; on the two stages that touch EVERY
+// bucket -- finishing (bucket += heads) and the row / column sums -- that is 2.4x the VALU work of a one-lane addition on the
+// carry-free layer, at 4096 waves, right when another stream's msm_accumulate wants the SIMDs.  These two stages therefore run
+// one lane per point on the raw M9 segments msm_accumulate parks (no msm_segments_to_r256 pass), and only the S + NR row /
+// column sums are converted for the latency-bound tail (msm_reduce_segments on a few hundred points).
+template <int FB>
+__global__ void __launch_bounds__(256) fold9_finish(const u32 *__restrict__ heads9, const u32 *__restrict__ starts, u32 *__restrict__ buckets9,
+                                                    u32 *__restrict__ heavy, u32 total_buckets, u32 T, u32 div) {
+    H2_LATENCY_STAGE();
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= total_buckets) return;
+    const u32 M = starts[total_buckets];
+    T = eff_lanes(M, T, div);
+    const u32 chunk = max(1u, (M + T - 1) / T);
+    const u32 h0 = (starts[b] + chunk - 1) / chunk, h1 = (starts[b + 1] + chunk - 1) / chunk;
+    if (h1 <= h0) return;
+    if (h1 - h0 > kHeavy) {
+        const u32 slot = atomicAdd(&heavy[1], 1u);
+        if (slot < kMaxHeavy) {
+            heavy[2 + slot] = b;
+            atomicAdd(&heavy[0], 1u);
+            return;
+        }
+    }
+    xyzz9<FB> acc = xyzz9_load_raw<FB>(buckets9 + 36 * (size_t)b);
+    for (u32 t = h0; t < h1; ++t) xyzz9_add<FB>(acc, xyzz9_load_raw<FB>(heads9 + 36 * (size_t)t));
+    xyzz9_store_raw<FB>(buckets9 + 36 * (size_t)b, acc);
+}
+// sum of 256 raw points held one per thread -> thread 0 (LDS tree, 36 words per point)
+template <int FB> __device__ __forceinline__ xyzz9<FB> fold9_block_sum(xyzz9<FB> acc, u32 *sh) {
+    const u32 t = threadIdx.x;
+    for (u32 off = 128; off > 0; off >>= 1) {
+        if (t >= off && t < 2 * off) xyzz9_store_raw<FB>(sh + 36 * (size_t)(t - off), acc);
+        __syncthreads();
+        if (t < off) xyzz9_add<FB>(acc, xyzz9_load_raw<FB>(sh + 36 * (size_t)t));
+        __syncthreads();
+    }
+    return acc;
+}
+// heavy buckets (more than kHeavy heads): kHeavyBlocks workgroups share the heads, fold9_finish_heavy2 adds their sums to the bucket
+template <int FB>
+__global__ void __launch_bounds__(256) fold9_finish_heavy(const u32 *__restrict__ heads9, const u32 *__restrict__ starts, u32 *__restrict__ scratch9,
+                                                          const u32 *__restrict__ heavy, u32 total_buckets, u32 T, u32 div) {
+    H2_LATENCY_STAGE();
+    __shared__ __attribute__((aligned(16))) u32 sh[128 * 36];
+    if (blockIdx.y >= min(heavy[1], kMaxHeavy)) return;
+    const u32 b = heavy[2 + blockIdx.y];
+    const u32 M = starts[total_buckets];
+    T = eff_lanes(M, T, div);
+    const u32 chunk = max(1u, (M + T - 1) / T);
+    const u32 h0 = (starts[b] + chunk - 1) / chunk, h1 = (starts[b + 1] + chunk - 1) / chunk;
+    const u32 share = (h1 - h0 + kHeavyBlocks - 1) / kHeavyBlocks;
+    const u32 lo = h0 + blockIdx.x * share, hi = min(h1, lo + share);
+    xyzz9<FB> acc = xyzz9_identity<FB>();
+    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) xyzz9_add<FB>(acc, xyzz9_load_raw<FB>(heads9 + 36 * (size_t)i));
+    acc = fold9_block_sum<FB>(acc, sh);
+    if (threadIdx.x == 0) xyzz9_store_raw<FB>(scratch9 + 36 * ((size_t)blockIdx.y * kHeavyBlocks + blockIdx.x), acc);
+}
+template <int FB>
+__global__ void __launch_bounds__(64) fold9_finish_heavy2(const u32 *__restrict__ scratch9, u32 *__restrict__ buckets9, const u32 *__restrict__ heavy) {
+    H2_LATENCY_STAGE();
+    if (blockIdx.x >= min(heavy[1], kMaxHeavy) || threadIdx.x != 0) return;
+    const u32 b = heavy[2 + blockIdx.x];
+    xyzz9<FB> acc = xyzz9_load_raw<FB>(buckets9 + 36 * (size_t)b);
+    for (u32 i = 0; i < kHeavyBlocks; ++i) xyzz9_add<FB>(acc, xyzz9_load_raw<FB>(scratch9 + 36 * ((size_t)blockIdx.x * kHeavyBlocks + i)));
+    xyzz9_store_raw<FB>(buckets9 + 36 * (size_t)b, acc);
+}
+// row / column sums of the NR x S bucket matrix (see msm_rowcol_sums for the algebra and the output layout): one workgroup per
+// sum, every thread adds its share of the line sequentially, then an LDS tree; thread 0 converts the one result to the
+// reference's Montgomery form for the tail kernels
+template <int FB>
+__global__ void __launch_bounds__(256) fold9_rowcol(const u32 *__restrict__ buckets9, u32 *__restrict__ wide, u32 S, u32 NR) {
+    H2_LATENCY_STAGE();
+    __shared__ __attribute__((aligned(16))) u32 sh[128 * 36];
+    const bool is_col = blockIdx.x < S;
+    const u32 id = is_col ? blockIdx.x : blockIdx.x - S + 1;          // column lo, or row hi (row 0 carries weight 0)
+    const u32 cnt = is_col ? NR : S;
+    const size_t base = is_col ? id : (size_t)id * S, step = is_col ? S : 1;
+    xyzz9<FB> acc = xyzz9_identity<FB>();
+    for (u32 i = threadIdx.x; i < cnt; i += blockDim.x) xyzz9_add<FB>(acc, xyzz9_load_raw<FB>(buckets9 + 36 * (base + (size_t)i * step)));
+    acc = fold9_block_sum<FB>(acc, sh);
+    if (threadIdx.x == 0)
+        xyzz_store<FB>(wide + 32 * (is_col ? (size_t)id : (size_t)NR + id - 1), xyzz9_is_identity(acc) ? xyzz_identity<FB>() : xyzz9_to_r256<FB>(acc));
+}
+
 // The three tail kernels below run each logical lane as a quad of 4 hardware lanes (curve_wide.cuh): the chip
 // is nearly idle here, so lanes are free and the dependent-multiply depth per point operation drops 3x.
 
@@ -1396,13 +1488,14 @@ __global__ void __launch_bounds__(256, H2_ACC9_WAVES) ipa_collapse_buckets(const
     const u32 lo = list_start[lb], hi = list_start[lb + 1];
     xyzz9<FB> acc = xyzz9_identity<FB>();
     if (lo < hi) {
-        u32 e0 = list[lo], e1 = lo + 1 < hi ? list[lo + 1] : 0;
+        // loads unconditional (clamped at the tail), as in msm_accumulate: a conditional load makes hipcc wait for everything in flight
+        u32 e0 = list[lo], e1 = list[min(lo + 1, hi - 1)];
         affine<FB> nxt = aff_load<FB>(table + 16 * ((size_t)(e0 & 0x7FFFFFFFu) + i));
         for (u32 t = lo; t < hi; ++t) {
             const affine<FB> p = nxt;
             const u32 neg = e0 >> 31;
-            const u32 e2 = t + 2 < hi ? list[t + 2] : 0;
-            if (t + 1 < hi) nxt = aff_load<FB>(table + 16 * ((size_t)(e1 & 0x7FFFFFFFu) + i));
+            const u32 e2 = list[min(t + 2, hi - 1)];
+            nxt = aff_load<FB>(table + 16 * ((size_t)(e1 & 0x7FFFFFFFu) + i));
             e0 = e1;
             e1 = e2;
             if (!aff_is_identity(p)) {
@@ -1701,6 +1794,10 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     }
     if (sh.c > kMaxC && !use_sort2) return H2_ERR_ARGS;   // choose_c only picks wide windows the two-pass sort can take
     const bool wide_reduce = sh.NB > 32768u;              // implies the registered path (one slice)
+    static const bool fold9_on = [] { const char *e = getenv("H2_FOLD9"); return !(e && atoi(e) == 0); }();     // A/B switch
+    // first fold levels in throughput form on the raw M9 segments (fold9_* kernels); a range of a chunked commit hands
+    // finished buckets on in the reference's form (add_into), so it keeps the quad-lane finisher
+    const bool fold9 = fold9_on && wide_reduce && a.table && !glv && !pair && !a.add_into && !fold_only;
     u32 wideS = 0, wideNR = 0;
     if (wide_reduce) {
         const int bb = sh.c - 1;
@@ -1732,7 +1829,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     if ((rc = cx.entries.reserve(all_items * 4)) != H2_OK) return rc;
     if ((rc = cx.heads.reserve((size_t)std::max<size_t>(T, (size_t)sh.slices * 32) * 128)) != H2_OK) return rc;
     if ((rc = cx.heavy.reserve((size_t)(max_heavy + 2) * 4)) != H2_OK) return rc;
-    if ((rc = cx.hscratch.reserve((size_t)max_heavy * kHeavyBlocks * 128)) != H2_OK) return rc;
+    if ((rc = cx.hscratch.reserve((size_t)max_heavy * kHeavyBlocks * 144)) != H2_OK) return rc;
     if ((rc = cx.buckets.reserve((size_t)tb * 128)) != H2_OK) return rc;
     if ((rc = cx.partial.reserve(wide_reduce ? ((size_t)2 * wideNR / kSeg + 2 * wideNR) * 128 : (size_t)segs * 128)) != H2_OK) return rc;
     if ((rc = cx.ssums.reserve((size_t)std::max<u32>(sh.slices, 2) * 128)) != H2_OK) return rc;
@@ -1747,17 +1844,22 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         u32 *hist1 = cx.hist.as<u32>(), *bin_count = cx.plan.as<u32>(), *bin_start = bin_count + S2.nh, *hlo = bin_start + S2.nh + 1,
             *woff = hlo + S2.B2, *hist2 = woff + S2.B2 + 1;
         const size_t lds1 = ((size_t)S2.nh * 3 + 1 + (size_t)S2.s1_scalars * (glv ? 2 : 1) * sh.W) * 4;
+        // 512 lanes per pass-1 workgroup: msm_s1_scatter takes 72 registers a lane, and 16 waves of it do not fit beside the two
+        // msm_accumulate waves a SIMD already holds (2 x 168 of 512 registers) -- with 1024 lanes the sort of the NEXT commit on
+        // another stream sat out the whole accumulate (416 us on average in a 3-stream trace against 57 us alone); LDS is free
+        // there, the accumulate uses none.  H2_S1_THREADS: sweeps only.
+        static const u32 s1_threads = [] { const char *e = getenv("H2_S1_THREADS"); int v = e ? atoi(e) : 0; return (u32)(v == 256 || v == 512 || v == 1024 ? v : 512); }();
         if (glv) {
-            hipLaunchKernelGGL((msm_s1_count<FS, true>), dim3(S2.B1), dim3(1024), S2.nh * 4, st, (const u32 *)a.d_scalars,
+            hipLaunchKernelGGL((msm_s1_count<FS, true>), dim3(S2.B1), dim3(s1_threads), S2.nh * 4, st, (const u32 *)a.d_scalars,
                                (const u32 *)nullptr, S2, hist1);
             hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh);
-            hipLaunchKernelGGL((msm_s1_scatter<FS, true>), dim3(S2.B1), dim3(1024), lds1, st, (const u32 *)a.d_scalars,
+            hipLaunchKernelGGL((msm_s1_scatter<FS, true>), dim3(S2.B1), dim3(s1_threads), lds1, st, (const u32 *)a.d_scalars,
                                (const u32 *)nullptr, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>(), (uint16_t *)nullptr);
         } else {
-            hipLaunchKernelGGL((msm_s1_count<FS, false>), dim3(S2.B1), dim3(1024), S2.nh * 4, st, (const u32 *)a.d_scalars,
+            hipLaunchKernelGGL((msm_s1_count<FS, false>), dim3(S2.B1), dim3(s1_threads), S2.nh * 4, st, (const u32 *)a.d_scalars,
                                (const u32 *)a.d_extra_scalar, S2, hist1);
             hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh);
-            hipLaunchKernelGGL((msm_s1_scatter<FS, false>), dim3(S2.B1), dim3(1024), lds1, st, (const u32 *)a.d_scalars,
+            hipLaunchKernelGGL((msm_s1_scatter<FS, false>), dim3(S2.B1), dim3(s1_threads), lds1, st, (const u32 *)a.d_scalars,
                                (const u32 *)a.d_extra_scalar, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>(), cx.tagged_low.as<uint16_t>());
         }
         hipLaunchKernelGGL(msm_s2_plan, dim3(1), dim3(kScanBlock), 0, st, bin_start, S2, hlo, woff);
@@ -1853,8 +1955,9 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         hipLaunchKernelGGL((msm_accumulate<FB, false, true>), dim3(T / 256), dim3(256), 0, st, pts,
                            (const u32 *)nullptr, 0xFFFFFFFFu, cx.entries.as<u32>(), cx.starts.as<u32>(), cx.seg9.as<u32>(),
                            cx.seg9.as<u32>() + 36 * (size_t)T, tb, T, lane_div);
-        hipLaunchKernelGGL((msm_segments_to_r256<FB>), dim3((T + tb + 255) / 256), dim3(256), 0, st, cx.seg9.as<u32>(),
-                           cx.heads.as<u32>(), cx.buckets.as<u32>(), T, tb);
+        if (!fold9)
+            hipLaunchKernelGGL((msm_segments_to_r256<FB>), dim3((T + tb + 255) / 256), dim3(256), 0, st, cx.seg9.as<u32>(),
+                               cx.heads.as<u32>(), cx.buckets.as<u32>(), T, tb);
     }
     else
         hipLaunchKernelGGL((msm_accumulate<FB, false>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases,
@@ -1863,12 +1966,22 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     prof_end(PROF_MSM_ACCUMULATE, st);
     TL_STAMP(tl_id | 3);
     prof_begin(PROF_MSM_REDUCE, st);
+    if (fold9) {
+        // wide slice: finish on the raw M9 segments, one lane per bucket (fold9_* above); the buckets stay in cx.seg9
+        u32 *heads9 = cx.seg9.as<u32>(), *buckets9 = cx.seg9.as<u32>() + 36 * (size_t)T;
+        hipLaunchKernelGGL((fold9_finish<FB>), dim3((tb + 255) / 256), dim3(256), 0, st, (const u32 *)heads9, cx.starts.as<u32>(), buckets9,
+                           cx.heavy.as<u32>(), tb, T, lane_div);
+        hipLaunchKernelGGL((fold9_finish_heavy<FB>), dim3(kHeavyBlocks, max_heavy), dim3(256), 0, st, (const u32 *)heads9, cx.starts.as<u32>(),
+                           cx.hscratch.as<u32>(), cx.heavy.as<u32>(), tb, T, lane_div);
+        hipLaunchKernelGGL((fold9_finish_heavy2<FB>), dim3(max_heavy), dim3(64), 0, st, cx.hscratch.as<u32>(), buckets9, cx.heavy.as<u32>());
+    } else {
     hipLaunchKernelGGL((msm_finish_buckets<FB>), dim3((tb * kGroup + 255) / 256), dim3(256), 0, st, cx.heads.as<u32>(),
                        cx.starts.as<u32>(), cx.buckets.as<u32>(), cx.heavy.as<u32>(), tb, T, lane_div);
     hipLaunchKernelGGL((msm_finish_heavy<FB>), dim3(kHeavyBlocks, max_heavy), dim3(256), (256 / kGroup) * 128, st,
                        cx.heads.as<u32>(), cx.starts.as<u32>(), cx.hscratch.as<u32>(), cx.heavy.as<u32>(), tb, T, lane_div);
     hipLaunchKernelGGL((msm_finish_heavy2<FB>), dim3(max_heavy), dim3(64), 0, st, cx.hscratch.as<u32>(), cx.buckets.as<u32>(),
                        cx.heavy.as<u32>());
+    }
     if (a.add_into) {
         hipLaunchKernelGGL((msm_bucket_add<FB>), dim3((tb * kGroup + 255) / 256), dim3(256), 0, st, a.add_into, cx.buckets.as<u32>(), tb);
         prof_end(PROF_MSM_REDUCE, st);
@@ -1886,8 +1999,12 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         if (wide_reduce) {
             u32 *wide = cx.partial.as<u32>() + 32 * (size_t)(2 * wideNR / kSeg);     // after the fold's own partials
             H2_HIP(hipMemsetAsync(wide, 0, (size_t)2 * wideNR * 128, st));
-            hipLaunchKernelGGL((msm_rowcol_sums<FB>), dim3(wideS + wideNR - 1), dim3(256), (256 / kGroup) * 128, st, fold_src,
-                               wide, wideS, wideNR);
+            if (fold9)
+                hipLaunchKernelGGL((fold9_rowcol<FB>), dim3(wideS + wideNR - 1), dim3(256), 0, st, (const u32 *)(cx.seg9.as<u32>() + 36 * (size_t)T),
+                                   wide, wideS, wideNR);
+            else
+                hipLaunchKernelGGL((msm_rowcol_sums<FB>), dim3(wideS + wideNR - 1), dim3(256), (256 / kGroup) * 128, st, fold_src,
+                                   wide, wideS, wideNR);
             fold_src = wide;
             fold_nb = wideNR;
             fold_slices = 2;
