@@ -585,7 +585,7 @@ def main():
         # collected separately, corrected as MI355X_MICROARCH.md prescribes); null when the workload differs
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
             if args.log_n == 20:
                 t_ = pmc["msm_accumulate_2^20"]
                 traffic = int(t_["fetch_bytes_reported_max"] + t_["write_bytes_max"])

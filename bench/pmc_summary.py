@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Turns the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- collected in separate runs, no trace domains) into
-profiles/r02_pmc_traffic.json, the per-launch HBM byte counts bench.py quotes as `roofline.traffic`.
+profiles/r03_pmc_traffic.json (r02_... last round), the per-launch HBM byte counts bench.py quotes as `roofline.traffic`.
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_f -o f --output-format csv -- python bench.py --steps 3 --warmup 1 --prewarm-ms 0 --minimal --no-cpu-baseline --streams 1
     rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_w -o w --output-format csv -- python bench.py --steps 3 --warmup 1 --prewarm-ms 0 --minimal --no-cpu-baseline --streams 1
-    python bench/pmc_summary.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv > profiles/r02_pmc_traffic.json
+    python bench/pmc_summary.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv > profiles/r03_pmc_traffic.json
 
 Counter values are KiB per dispatch.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide coalesced streaming
 reads by exactly 2x (calibrated for 16 B/lane streams); the x2 is applied to the streaming kernels named in STREAMING and

@@ -1,0 +1,18 @@
+#!/bin/bash
+# The rocprofv3 runs behind profiles/r03_*: `gpurun -- bash bench/tools/collect_profiles_r03.sh`; outputs land under gpurun_out/ and
+# are summarised into profiles/ by the python steps at the bottom (run those where the repo is).  PMC counters are collected in their
+# own passes (no trace domains), as MI355X_MICROARCH.md prescribes.
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+# 1. kernel durations of the bench command itself (3 streams, the driver's --steps 20 --warmup 5) and of the single-stream variant
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03_stats -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-create-proof > $R/gpurun_out/r03_stats_bench.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03_stats1 -o bench1 -- python $R/bench.py --streams 1 --steps 40 --no-cpu-baseline --no-create-proof > $R/gpurun_out/r03_stats1_bench.json 2>/dev/null
+# 2. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes over the minimal workload (timed commits + NTT leg)
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/r03_pmc_f -o f --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --prewarm-ms 0 --minimal --no-cpu-baseline --streams 1 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/r03_pmc_w -o w --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --prewarm-ms 0 --minimal --no-cpu-baseline --streams 1 > /dev/null 2>&1
+ls $R/gpurun_out/r03_stats $R/gpurun_out/r03_pmc_f | head
+# afterwards, in the repo:
+#   python bench/pmc_summary.py gpurun_out/r03_pmc_f/f_counter_collection.csv gpurun_out/r03_pmc_w/w_counter_collection.csv > profiles/r03_pmc_traffic.json
+#   python bench/tools/trace_union.py gpurun_out/r03_stats/bench_kernel_trace.csv  > profiles/r03_accumulate_union_3streams.json
+#   python bench/tools/trace_union.py gpurun_out/r03_stats1/bench1_kernel_trace.csv > profiles/r03_accumulate_union_1stream.json
+#   cp gpurun_out/r03_stats/bench_kernel_stats.csv profiles/r03_kernel_stats_3streams.csv   (and the 1-stream one)
