@@ -1221,7 +1221,9 @@ __global__ void __launch_bounds__(64) fold9_finish_heavy2(const u32 *__restrict_
 }
 // row / column sums of the NR x S bucket matrix (see msm_rowcol_sums for the algebra and the output layout): one workgroup per
 // sum, every thread adds its share of the line sequentially, then an LDS tree; thread 0 converts the one result to the
-// reference's Montgomery form for the tail kernels
+// reference's Montgomery form for the tail kernels.  (Fewer lanes per line were measured: 32 lanes x 8 points is half the
+// VALU work and +1.2 % sustained commit throughput, but 12 dependent additions behind un-prefetched strided loads instead of 8:
+// +40 us on a lone commit, which a 20-commit run and every prover phase feel; 64 lanes x 4 points: no gain either way.)
 template <int FB>
 __global__ void __launch_bounds__(256) fold9_rowcol(const u32 *__restrict__ buckets9, u32 *__restrict__ wide, u32 S, u32 NR) {
     H2_LATENCY_STAGE();
