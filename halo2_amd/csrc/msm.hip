@@ -801,6 +801,68 @@ __global__ void __launch_bounds__(1024) msm_s2_scatter(const u32 *__restrict__ t
     }
 }
 
+// ---- pass 2 in ONE launch: a workgroup per pass-1 bin ----------------------------------------------------------------------
+// The chunked pass 2 above cuts the tagged list into 16 K-entry chunks that may straddle bins, so it needs a plan, a count
+// pass, a per-bucket prefix over the chunks, a three-kernel scan of all bucket totals and then the scatter: seven launches,
+// the tagged list read twice from HBM.  But pass 1 already knows where every bin begins (bin_start), a bin is one contiguous
+// run of the tagged list, and for anything but a pathological column it fits in LDS (2^20 scalars, 17-bit windows: 1024 bins
+// of ~15 K entries).  So: one workgroup per bin counts its 2^lowb buckets in LDS, scans them -- starts[bucket] = bin_start +
+// local prefix, no global scan -- groups the bin by bucket in LDS and writes it out as ONE contiguous copy.  The tagged list is
+// read once from HBM (the second read of a bin hits L2), `entries` is written in full lines.  A bin that does not fit (tens of
+// thousands of equal scalars) is scattered straight to memory by the same workgroup.
+// Counters are bumped with a wave-aggregated form: when every active lane of a wave holds the same key (a column of equal
+// scalars) one lane adds the population count instead of 64 lanes serialising on one LDS address.
+__device__ __forceinline__ u32 lds_ticket(u32 *ctr, u32 k) {
+    const u32 k0 = (u32)__builtin_amdgcn_readfirstlane((int)k);
+    const unsigned long long act = __ballot(1), same = __ballot(k == k0);
+    if (same == act) {
+        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(act >> 32), __builtin_amdgcn_mbcnt_lo((u32)act, 0u));
+        u32 base = 0;
+        if (rank == 0) base = atomicAdd(&ctr[k0], (u32)__popcll(act));
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+        return base + rank;
+    }
+    return atomicAdd(&ctr[k], 1u);
+}
+__global__ void __launch_bounds__(1024) msm_s2_bins(const u32 *__restrict__ tagged, const uint16_t *__restrict__ tagged_low, const u32 *__restrict__ bin_start,
+                                                    Sort2 P, u32 total_buckets, u32 cap, u32 *__restrict__ starts, u32 *__restrict__ entries) {
+    H2_LATENCY_STAGE();
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    const u32 nbk = 1u << P.lowb, h = blockIdx.x;
+    u32 *cnt = sh, *cursor = sh + nbk, *stage = cursor + nbk;          // [nbk] | [nbk] | [cap]
+    const u32 p0 = bin_start[h], p1 = bin_start[h + 1], E = p1 - p0;
+    const u32 lowmask = nbk - 1, strip = P.side ? ~0u : ~(lowmask << P.lb);
+    for (u32 k = threadIdx.x; k < nbk; k += blockDim.x) cnt[k] = 0;
+    __syncthreads();
+    for (u32 p = p0 + threadIdx.x; p < p1; p += blockDim.x) (void)lds_ticket(cnt, s2_low(P, tagged_low, p, tagged[p], lowmask));
+    __syncthreads();
+    if (threadIdx.x < 64) (void)wave0_excl_scan(cnt, nbk);              // cnt[k] = entries of the bin before bucket k
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < nbk; k += blockDim.x) {
+        const u32 b = (h << P.lowb) + k;
+        cursor[k] = cnt[k];
+        if (b < total_buckets) starts[b] = p0 + cnt[k];
+    }
+    if (h == gridDim.x - 1 && threadIdx.x == 0) {
+        starts[total_buckets] = bin_start[gridDim.x];                 // M
+        starts[total_buckets + 1] = 0xFFFFFFFFu;                      // the sentinel msm_accumulate reads past the last boundary
+    }
+    __syncthreads();
+    if (E <= cap) {
+        for (u32 p = p0 + threadIdx.x; p < p1; p += blockDim.x) {       // second read of the bin: L2
+            const u32 e = tagged[p];
+            stage[lds_ticket(cursor, s2_low(P, tagged_low, p, e, lowmask))] = e & strip;
+        }
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < E; i += blockDim.x) entries[p0 + i] = stage[i];
+    } else {
+        for (u32 p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+            const u32 e = tagged[p];
+            entries[p0 + lds_ticket(cursor, s2_low(P, tagged_low, p, e, lowmask))] = e & strip;
+        }
+    }
+}
+
 // per-bucket totals; each chunk's count becomes the bucket-relative offset of that chunk
 __global__ void __launch_bounds__(256) msm_s2_prefix(u32 *__restrict__ hist2, const u32 *__restrict__ bin_start, const u32 *__restrict__ hlo,
                                                      const u32 *__restrict__ woff, Sort2 P, u32 *__restrict__ counts, u32 NB) {
@@ -1646,7 +1708,9 @@ static MsmContext &msm_ctx(hipStream_t st = nullptr) {
     return *slot;
 }
 // h2_trim: the per-(device, stream) scratch of this device goes back to the allocator (the device is idle by then)
+void msm_release_host_pipe();
 void msm_release_workspaces() {
+    msm_release_host_pipe();
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -1876,6 +1940,21 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
             hipLaunchKernelGGL((msm_s1_scatter<FS, false>), dim3(S2.B1), dim3(s1_threads), lds1, st, (const u32 *)a.d_scalars,
                                (const u32 *)a.d_extra_scalar, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>(), cx.tagged_low.as<uint16_t>());
         }
+        // pass 2: one launch, a workgroup per bin, when an average bin fits LDS with room to spare (registered tables; the 9-slice
+        // generic sort has bins of ~64 K entries and keeps the chunked form); H2_S2_BINS=0: the chunked form (A/B)
+        static const bool bins_on = [] { const char *e = getenv("H2_S2_BINS"); return !(e && atoi(e) == 0); }();
+        const size_t nbk = (size_t)1 << S2.lowb;
+        const size_t cap_entries = nbk * 8 + 64 < kLdsCap ? (kLdsCap - nbk * 8) / 4 : 0;
+        const size_t nbins = ((size_t)tb + nbk - 1) >> S2.lowb;
+        if (bins_on && a.table && !glv && S2.lowb <= 12 && nbins == S2.nh && cap_entries && all_items / S2.nh <= cap_entries * 9 / 10) {
+            static bool attr_bins = false;
+            if (!attr_bins) {
+                H2_HIP(hipFuncSetAttribute((const void *)msm_s2_bins, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+                attr_bins = true;
+            }
+            hipLaunchKernelGGL(msm_s2_bins, dim3(S2.nh), dim3(1024), (nbk * 2 + cap_entries) * 4, st, cx.tagged.as<u32>(),
+                               (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, tb, (u32)cap_entries, cx.starts.as<u32>(), cx.entries.as<u32>());
+        } else {
         hipLaunchKernelGGL(msm_s2_plan, dim3(1), dim3(kScanBlock), 0, st, bin_start, S2, hlo, woff);
         const size_t hist2_words = ((size_t)S2.nh + S2.B2 + 1) << S2.lowb;
         if (tb > S2.lds_window) H2_HIP(hipMemsetAsync(hist2, 0, hist2_words * 4, st));   // the HBM-counted windows start from zero
@@ -1890,6 +1969,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         const size_t lds2s = std::max<size_t>(lds2, ((size_t)kS2StageWindow * 3 + 1 + S2.nh + kS2Chunk) * 4 + (size_t)kS2Chunk * 2);
         hipLaunchKernelGGL(msm_s2_scatter, dim3(S2.B2), dim3(1024), lds2s, st, cx.tagged.as<u32>(), (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, hlo, woff, S2, hist2,
                            cx.starts.as<u32>(), cx.entries.as<u32>());
+        }
     } else {
         if (glv)
             hipLaunchKernelGGL((msm_recode_glv<FS>), dim3(((u32)scalars_n + 255) / 256), dim3(256), 0, st, (const u32 *)a.d_scalars,
@@ -2666,6 +2746,15 @@ HostPipe &host_pipe() {
 }
 }  // namespace
 
+
+namespace h2 {
+void msm_release_host_pipe() {            // h2_trim: the staging column and the running bucket slices of h2_commit (the device is idle)
+    HostPipe &hp = host_pipe();
+    std::lock_guard<std::mutex> lk(hp.mu);
+    hp.stage.release();
+    hp.parts.release();
+}
+}  // namespace h2
 
 static int commit_host_pipelined(Bases &b, const uint64_t *scalars, size_t n, const uint64_t *blind, int form, int out_kind, uint64_t *out) {
     HostPipe &hp = host_pipe();

@@ -83,6 +83,44 @@ def test_split_msm_rccl_world_of_one():
         parallel.rccl_finalize()
 
 
+def test_split_commit_over_registered_bases_world_of_one():
+    """The split of a commit over REGISTERED bases (h2_commit_range_device per rank, blind on the last one, 96-byte exchange,
+    local sum) through the library's RCCL communicator and through parallel.split_commit, each with a world of one; and
+    h2_bases_info."""
+    import ctypes as C
+    import torch
+    from halo2_amd._lib import lib
+    from halo2_amd.arithmetic import _p
+    curve, n = h.VESTA, 20000
+    sf = co.field_of_curve(curve, "scalar")
+    g, col = co.generate_bases(curve, 93, n), co.random_field(sf, 94, n)
+    w, blind = co.generate_bases(curve, 95, 1)[0], co.random_field(sf, 96, 1)
+    hd = C.c_uint64(0)
+    assert lib().h2_bases_register(curve, _p(g), n, h.FORM_MONTGOMERY, C.byref(hd)) == 0
+    assert lib().h2_bases_set_blind_base(hd, _p(np.ascontiguousarray(w)), h.FORM_MONTGOMERY) == 0
+    nn, cc, cv = C.c_size_t(0), C.c_int(0), C.c_int(-1)
+    assert lib().h2_bases_info(hd, C.byref(nn), C.byref(cc), C.byref(cv)) == 0
+    assert (nn.value, cc.value, cv.value) == (n, 16, curve)
+    assert lib().h2_bases_info(C.c_uint64(987654), None, None, None) != 0
+    d_col = torch.from_numpy(col.view(np.int64)).cuda()
+    d_bl = torch.from_numpy(blind.view(np.int64)).cuda()[0].contiguous()
+    want = aff(curve, co.commit(curve, g, w, col, blind[0]))
+    out = parallel.split_commit(hd, d_col, 0, 1, d_bl)
+    torch.cuda.synchronize()
+    assert aff(curve, out.cpu().numpy().view(np.uint64)) == want
+    parallel.rccl_init(0, 1)
+    try:
+        out = parallel.split_commit_rccl(hd, d_col, d_bl, affine=True)
+        torch.cuda.synchronize()
+        assert aff(curve, out.cpu().numpy().view(np.uint64)) == want
+        out = parallel.split_commit_rccl(hd, d_col[:12345])                                   # a prefix, no blind
+        torch.cuda.synchronize()
+        assert aff(curve, out.cpu().numpy().view(np.uint64)) == aff(curve, co.best_multiexp(curve, col[:12345], g[:12345]))
+    finally:
+        parallel.rccl_finalize()
+    assert lib().h2_bases_free(hd) == 0
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
