@@ -330,6 +330,45 @@ template <int F> __device__ __forceinline__ fe fe_to_mont(const fe &a) { return 
 template <int F> __device__ __forceinline__ fe fe_from_mont(const fe &a) {
     return fe_mulx<F>(a, fe{{1, 0, 0, 0, 0, 0, 0, 0}});
 }
+// The same value by the reduction half alone (REDC of a 256-bit number): eight steps t <- (t + m p) / 2^32 with m = -t_0
+// (-p^-1 = -1 mod 2^32) and p = [1, P1, P2, P3, 0, 0, 0, 2^30]: three multiply-adds and a carry ripple per step, ~120
+// instructions and a dozen registers against the 248-instruction multiplier.  For the sort kernels, which turn every scalar
+// into its canonical form before cutting digits and should stay small enough to share a SIMD with msm_accumulate.
+template <int F> __device__ __forceinline__ fe fe_redc(const fe &a) {
+    u32 t[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = a.v[i];
+#pragma unroll
+    for (int step = 0; step < 8; step++) {
+        const u32 m = 0u - t[0];
+        u64 acc = (u64)(t[0] != 0);                                            // t_0 + m = 0 or 2^32
+        acc += (u64)t[1] + (u64)m * Mod<F>::P1;
+        t[0] = (u32)acc;
+        acc >>= 32;
+        acc += (u64)t[2] + (u64)m * Mod<F>::P2;
+        t[1] = (u32)acc;
+        acc >>= 32;
+        acc += (u64)t[3] + (u64)m * Mod<F>::P3;
+        t[2] = (u32)acc;
+        acc >>= 32;
+        acc += (u64)t[4];
+        t[3] = (u32)acc;
+        acc >>= 32;
+        acc += (u64)t[5];
+        t[4] = (u32)acc;
+        acc >>= 32;
+        acc += (u64)t[6];
+        t[5] = (u32)acc;
+        acc >>= 32;
+        acc += (u64)t[7] + ((u64)m << 30);                                     // m * 2^30
+        t[6] = (u32)acc;
+        t[7] = (u32)(acc >> 32);
+    }
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    return fe_reduce_once<F>(r);                                               // (a + (R - 1) p) / R < p + 1
+}
 
 // a^(p-2); used only for the handful of Jacobian -> affine conversions
 template <int F> __device__ fe fe_inv(const fe &a) {

@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(1024) msm_s1_count(const u32 *__restrict__ sca
         const u32 i = blk * P.s1_scalars + loc;
         if (i >= P.m) break;
         fe s = (extra_scalar && i == P.m - 1) ? fe_load(extra_scalar) : fe_load(scalars + 8 * (size_t)i);
-        if (P.mont) s = fe_from_mont<FS>(s);
+        if (P.mont) s = fe_redc<FS>(s);
         emit_entries<FS, GLV>(s, i, P, [&](u32 key, u32, u32, u32) { atomicAdd(&sh[key >> P.lowb], 1u); });
     }
     __syncthreads();
@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(1024) msm_s1_scatter(const u32 *__restrict__ s
         const u32 i = blk * P.s1_scalars + loc;
         if (i >= P.m) break;
         fe s = (extra_scalar && i == P.m - 1) ? fe_load(extra_scalar) : fe_load(scalars + 8 * (size_t)i);
-        if (P.mont) s = fe_from_mont<FS>(s);
+        if (P.mont) s = fe_redc<FS>(s);
         if (!GLV && P.side) {
             // the stage word keeps what the copy-out needs to rebuild the entry: scalar (11 bits, s1_scalars <= 2048), window
             // (6 bits) and the low bucket bits (<= 14), so entry and low bits leave as two contiguous runs per bin
@@ -1944,7 +1944,11 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         // generic sort has bins of ~64 K entries and keeps the chunked form); H2_S2_BINS=0: the chunked form (A/B)
         static const bool bins_on = [] { const char *e = getenv("H2_S2_BINS"); return !(e && atoi(e) == 0); }();
         const size_t nbk = (size_t)1 << S2.lowb;
-        const size_t cap_entries = nbk * 8 + 64 < kLdsCap ? (kLdsCap - nbk * 8) / 4 : 0;
+        // LDS stage: the average bin + 25 % (two workgroups per CU where that fits: 2^20 scalars at 17 bits, 15 K-entry bins), at
+        // most what one workgroup can have; a bin beyond its stage takes the direct-scatter branch.  H2_S2_CAP: sweeps only.
+        const size_t cap_max = nbk * 8 + 64 < kLdsCap ? (kLdsCap - nbk * 8) / 4 : 0;
+        static const size_t cap_env = [] { const char *e = getenv("H2_S2_CAP"); return e ? (size_t)atol(e) : (size_t)0; }();
+        const size_t cap_entries = std::min(cap_max, cap_env ? cap_env : std::max<size_t>(4096, all_items / S2.nh * 5 / 4 + 1024));
         const size_t nbins = ((size_t)tb + nbk - 1) >> S2.lowb;
         if (bins_on && a.table && !glv && S2.lowb <= 12 && nbins == S2.nh && cap_entries && all_items / S2.nh <= cap_entries * 9 / 10) {
             static bool attr_bins = false;

@@ -16,6 +16,7 @@ void orc_f_add(int field, uint64_t *r, const uint64_t *a, const uint64_t *b);
 void orc_f_sub(int field, uint64_t *r, const uint64_t *a, const uint64_t *b);
 void orc_f_inv(int field, uint64_t *r, const uint64_t *a);
 void orc_random_field(int field, uint64_t seed, uint64_t *out, size_t n);
+void orc_from_mont(int field, uint64_t *a, size_t n);
 }
 using namespace h2;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -102,6 +103,7 @@ template <int F> __global__ void k_ops9(const u32 *a, const u32 *b, u32 *out, in
         case 3: r = fe9_to_r256<F>(fe9_norm(fe9_sub(x9, y9))); break;
         case 4: r = fe9_to_r256<F>(x9); break;
         case 5: r = fe9_to_r256<F>(fe9_mul_c<F>(x9, y9)); break;
+        case 7: r = fe_redc<F>(x); break;                                  // = fe_from_mont: the sort kernels' canonicalisation
         default: {
             affine<F> pt{x, x};
             const aff9<F> q = aff9_unpack<F>(aff_to_m9<F>(pt));
@@ -112,9 +114,9 @@ template <int F> __global__ void k_ops9(const u32 *a, const u32 *b, u32 *out, in
 }
 template <int F> int run_field9(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b, const u32 *da, const u32 *db, u32 *dout, int n) {
     std::vector<uint64_t> got(4 * (size_t)n);
-    const char *names[] = {"fe9 mul", "fe9 sqr", "fe9 signed chain", "fe9 sub+norm", "fe9 bridge", "fe9 mul_c", "fe9 table form"};
+    const char *names[] = {"fe9 mul", "fe9 sqr", "fe9 signed chain", "fe9 sub+norm", "fe9 bridge", "fe9 mul_c", "fe9 table form", "fe_redc"};
     int fails = 0;
-    for (int op = 0; op < 7; ++op) {
+    for (int op = 0; op < 8; ++op) {
         hipLaunchKernelGGL((k_ops9<F>), dim3((n + 255) / 256), dim3(256), 0, 0, da, db, dout, n, op);
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(got.data(), dout, 32 * (size_t)n, hipMemcpyDeviceToHost));
@@ -129,6 +131,7 @@ template <int F> int run_field9(const std::vector<uint64_t> &a, const std::vecto
                 orc_f_add(F, u, x, y); orc_f_sub(F, u, u, x); orc_f_sub(F, u, u, x); orc_f_sub(F, u, u, x);
                 orc_f_mul(F, w, t, u);
             } else if (op == 3) orc_f_sub(F, w, x, y);
+            else if (op == 7) { memcpy(w, x, 32); orc_from_mont(F, w, 1); }
             else memcpy(w, x, 32);
             if (memcmp(w, &got[4 * i], 32)) { if (!bad) printf("  first mismatch %s idx %d\n", names[op], i); bad++; }
         }
