@@ -635,12 +635,14 @@ def main():
                          "note": "VALU integer-multiply bound, not HBM bound (DESIGN.md section 3): the HBM fraction is reported as the contract "
                                  "asks, the VALU figures are what track kernel quality; traffic = PMC bytes of the registered-bases path, which "
                                  "gathers 16 precomputed multiples per point from a 1 GiB table by design"},
-            # the HBM-bound part of the path (north star: "bucket-scan kernel"): the two-pass bucket sort streams 320 B per
-            # scalar (32 B read twice; 16 entries x 4 B written once, read twice, written once more); time = the sort stage alone
+            # the HBM-bound part of the path (north star: "bucket-scan kernel"): the two-pass bucket sort streams 244 B per scalar
+            # (32 B read twice by pass 1; 15 entries x 4 B written by pass 1, read once and written once by the one-launch pass 2);
+            # time = the sort stage alone on one stream
             "roofline_bucket_sort": (lambda ms_, tr_: {
-                "bound": "hbm", "kernels": "msm_s1_count/_prefix/_scatter, msm_s2_plan/_count/_prefix/_scatter, msm_scan_*",
-                "achieved": round(320.0 * n / (ms_ * 1e-3) / 1e9, 1) if ms_ else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(320.0 * n / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_ else None,
+                "bound": "hbm", "kernels": "msm_s1_count / _prefix / _scatter, msm_s2_bins",
+                "algorithmic_bytes_per_scalar": 244,
+                "achieved": round(244.0 * n / (ms_ * 1e-3) / 1e9, 1) if ms_ else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(244.0 * n / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_ else None,
                 "traffic": tr_, "stage_ms_isolated": ms_})(
                 iso.get("msm_sort"), (pmc or {}).get("msm_bucket_sort_2^20", {}).get("total_hbm_bytes_corrected") if args.log_n == 20 else None),
             "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()},

@@ -17,7 +17,7 @@ import csv
 import json
 import sys
 
-STREAMING = ("ntt_pass", "ntt_pass9", "msm_s1_count", "msm_s1_scatter", "msm_s2_count", "msm_s2_scatter")
+STREAMING = ("ntt_pass", "ntt_pass9", "msm_s1_count", "msm_s1_scatter", "msm_s2_count", "msm_s2_scatter", "msm_s2_bins")
 
 
 def collect(path, counter):
@@ -64,9 +64,10 @@ def main():
             sort[k] = {"read_bytes_corrected": int(v["FETCH_SIZE_KiB_max"] * 1024 * mult), "write_bytes": int((v["WRITE_SIZE_KiB_max"] or 0) * 1024)}
     if sort:
         out["msm_bucket_sort_2^20"] = {"kernels": sort, "total_hbm_bytes_corrected": sum(v["read_bytes_corrected"] + v["write_bytes"] for v in sort.values()),
-                                       "algorithmic_bytes_model": 320 << 20,
-                                       "model": "per scalar: 32 B read twice (count, scatter passes recompute the digits) + 16 entries x 4 B "
-                                                "written by pass 1, read twice and written once by pass 2 = 320 B"}
+                                       "algorithmic_bytes_model": 244 << 20,
+                                       "model": "per scalar: 32 B read twice (the count and scatter passes of pass 1 recompute the digits) + 15 entries x 4 B "
+                                                "written by pass 1, read once and written once by the one-launch pass 2 (msm_s2_bins) = 244 B "
+                                                "(round 2, chunked pass 2 and 16 digits: 320 B)"}
     ntt = {}
     for k, v in kernels.items():
         if "ntt_pass9<0, 10" in k and v["FETCH_SIZE_KiB_max"] is not None:
