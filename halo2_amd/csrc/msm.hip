@@ -590,14 +590,16 @@ __global__ void __launch_bounds__(1024) msm_s1_scatter(const u32 *__restrict__ s
         }
     }
     __syncthreads();
-    // one wave per bin at a time: contiguous LDS run -> contiguous global run
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    // one HALF-wave per bin at a time: contiguous LDS run -> contiguous global run (a workgroup's run of a bin is ~30 entries at
+    // 2048 scalars x 15 digits over 1024 bins: a whole wave per run left half its lanes idle and made the loop twice as long)
+    const u32 wave = threadIdx.x >> 5, lane = threadIdx.x & 31, nwaves = blockDim.x >> 5;
+    constexpr u32 kRunLanes = 32;
     if (!GLV && P.side) {
         for (u32 h = wave; h < nh; h += nwaves) {
             const u32 l0 = lstart[h], l1 = lstart[h + 1];
             u32 *dst = tagged + gstart[h];
             uint16_t *dlo = tagged_low + gstart[h];
-            for (u32 q = l0 + lane; q < l1; q += 64) {
+            for (u32 q = l0 + lane; q < l1; q += kRunLanes) {
                 const u32 word = stage[q], i = blk * P.s1_scalars + (word & 2047u), w = (word >> 11) & 63u;
                 u32 col = P.col0 + i;
                 if (i == P.m - 1 && P.extra_col != 0xFFFFFFFFu) col = P.extra_col;
@@ -610,7 +612,7 @@ __global__ void __launch_bounds__(1024) msm_s1_scatter(const u32 *__restrict__ s
     for (u32 h = wave; h < nh; h += nwaves) {
         const u32 l0 = lstart[h], l1 = lstart[h + 1];
         u32 *dst = tagged + gstart[h];
-        for (u32 q = l0 + lane; q < l1; q += 64) dst[q - l0] = stage[q];
+        for (u32 q = l0 + lane; q < l1; q += kRunLanes) dst[q - l0] = stage[q];
     }
 }
 
