@@ -79,6 +79,17 @@ def main():
         step(i, sps[0])
     torch.cuda.synchronize()
     res["lone_commit_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
+    # a degenerate column: every scalar equal (15 buckets take everything): the one-workgroup-per-bin pass 2 scatters such bins directly
+    from halo2_amd import fields
+    eq = np.ascontiguousarray(np.tile(fields.scalar_limbs(0xDEADBEEFCAFE0123456789, sf), (n, 1)))
+    d_eq = torch.from_numpy(eq.view(np.int64)).to(dev)
+    for rep in range(4):
+        if rep == 1:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        assert lib.h2_commit_device(hd, d_eq.data_ptr(), n, None, None, h.FORM_MONTGOMERY, 0, d_out[0].data_ptr(), sps[0]) == 0
+    torch.cuda.synchronize()
+    res["all_equal_column_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 4)
     print(json.dumps(res))
 
 

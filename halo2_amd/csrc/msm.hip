@@ -826,17 +826,66 @@ __device__ __forceinline__ u32 lds_ticket(u32 *ctr, u32 k) {
     }
     return atomicAdd(&ctr[k], 1u);
 }
+// the same for four keys per lane: when all four are valid and every active lane's four keys are ONE key, a single atomic takes
+// 4 x population; else four tickets.  pos[j] is only written for j < nvalid.
+static constexpr u32 kMaxBig = 32, kBigChunks = 64;      // big bins sorted by the chunked kernels below; workgroups per big bin
+__device__ __forceinline__ void lds_ticket4(u32 *ctr, const u32 k[4], u32 nvalid, u32 pos[4]) {
+    const u32 k0 = (u32)__builtin_amdgcn_readfirstlane((int)k[0]);
+    const bool mine = nvalid == 4 && k[0] == k0 && k[1] == k0 && k[2] == k0 && k[3] == k0;
+    const unsigned long long act = __ballot(1), same = __ballot(mine);
+    if (same == act) {
+        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(act >> 32), __builtin_amdgcn_mbcnt_lo((u32)act, 0u));
+        u32 base = 0;
+        if (rank == 0) base = atomicAdd(&ctr[k0], 4u * (u32)__popcll(act));
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base) + 4u * rank;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pos[j] = base + j;
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if ((u32)j < nvalid) pos[j] = lds_ticket(ctr, k[j]);
+}
 __global__ void __launch_bounds__(1024) msm_s2_bins(const u32 *__restrict__ tagged, const uint16_t *__restrict__ tagged_low, const u32 *__restrict__ bin_start,
-                                                    Sort2 P, u32 total_buckets, u32 cap, u32 *__restrict__ starts, u32 *__restrict__ entries) {
+                                                    Sort2 P, u32 total_buckets, u32 cap, u32 *__restrict__ starts, u32 *__restrict__ entries,
+                                                    u32 *__restrict__ big) {
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
     const u32 nbk = 1u << P.lowb, h = blockIdx.x;
     u32 *cnt = sh, *cursor = sh + nbk, *stage = cursor + nbk;          // [nbk] | [nbk] | [cap]
     const u32 p0 = bin_start[h], p1 = bin_start[h + 1], E = p1 - p0;
     const u32 lowmask = nbk - 1, strip = P.side ? ~0u : ~(lowmask << P.lb);
+    if (h == gridDim.x - 1 && threadIdx.x == 0) {
+        starts[total_buckets] = bin_start[gridDim.x];                 // M
+        starts[total_buckets + 1] = 0xFFFFFFFFu;                      // the sentinel msm_accumulate reads past the last boundary
+    }
+    if (E > cap) {
+        // a bin that does not fit the stage (a degenerate column: every scalar equal, half of them 1 ...) goes on the list of big
+        // bins, which msm_s2_big_* sort with kBigChunks workgroups each; only past kMaxBig such bins does this workgroup do it alone
+        if (threadIdx.x == 0) {
+            const u32 slot = atomicAdd(&big[0], 1u);
+            if (slot < kMaxBig) big[1 + slot] = h;
+            cnt[0] = slot;
+        }
+        __syncthreads();
+        const u32 slot = cnt[0];
+        __syncthreads();
+        if (slot < kMaxBig) return;
+    }
     for (u32 k = threadIdx.x; k < nbk; k += blockDim.x) cnt[k] = 0;
     __syncthreads();
-    for (u32 p = p0 + threadIdx.x; p < p1; p += blockDim.x) (void)lds_ticket(cnt, s2_low(P, tagged_low, p, tagged[p], lowmask));
+    // four consecutive entries per lane and trip: four loads in flight per lane instead of one (a bin of a degenerate column --
+    // every scalar equal, or half of them 1 -- holds up to 2^20 entries and is streamed by this one workgroup, twice)
+    const u32 step = blockDim.x * 4;
+    for (u32 base = p0 + threadIdx.x * 4; base < p1; base += step) {
+        u32 e[4], k[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = base + j < p1 ? tagged[base + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k[j] = base + j < p1 ? s2_low(P, tagged_low, base + j, e[j], lowmask) : 0u;
+        u32 pos[4];
+        lds_ticket4(cnt, k, min(4u, p1 - base), pos);
+    }
     __syncthreads();
     if (threadIdx.x < 64) (void)wave0_excl_scan(cnt, nbk);              // cnt[k] = entries of the bin before bucket k
     __syncthreads();
@@ -845,23 +894,104 @@ __global__ void __launch_bounds__(1024) msm_s2_bins(const u32 *__restrict__ tagg
         cursor[k] = cnt[k];
         if (b < total_buckets) starts[b] = p0 + cnt[k];
     }
-    if (h == gridDim.x - 1 && threadIdx.x == 0) {
-        starts[total_buckets] = bin_start[gridDim.x];                 // M
-        starts[total_buckets + 1] = 0xFFFFFFFFu;                      // the sentinel msm_accumulate reads past the last boundary
+    __syncthreads();
+    const bool fits = E <= cap;
+    for (u32 base = p0 + threadIdx.x * 4; base < p1; base += step) {    // second read of the bin: L2 (a bin beyond the stage that found no
+                                                                        // slot on the big-bin list: scattered by this workgroup alone)
+        u32 e[4], k[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = base + j < p1 ? tagged[base + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k[j] = base + j < p1 ? s2_low(P, tagged_low, base + j, e[j], lowmask) : 0u;
+        u32 pos[4];
+        lds_ticket4(cursor, k, min(4u, p1 - base), pos);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (base + j < p1) {
+                if (fits) stage[pos[j]] = e[j] & strip;
+                else entries[p0 + pos[j]] = e[j] & strip;               // a bin beyond the stage: scattered straight to memory
+            }
+    }
+    if (!fits) return;
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < E; i += blockDim.x) entries[p0 + i] = stage[i];
+}
+
+// ---- big bins (listed by msm_s2_bins): kBigChunks workgroups per bin -- count, prefix, scatter.  Three small launches that
+// return at once when the list is empty (the common case: ~14 us), so that a degenerate column costs what it cost with the
+// chunked pass 2 instead of being streamed by one workgroup per bin (every scalar equal: 1.68 ms against 0.88).
+__global__ void __launch_bounds__(1024) msm_s2_big_count(const u32 *__restrict__ tagged, const uint16_t *__restrict__ tagged_low, const u32 *__restrict__ bin_start,
+                                                         Sort2 P, const u32 *__restrict__ big, u32 *__restrict__ gcnt) {
+    H2_LATENCY_STAGE();
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    const u32 s = blockIdx.y, c = blockIdx.x;
+    if (s >= min(big[0], kMaxBig)) return;
+    const u32 nbk = 1u << P.lowb, lowmask = nbk - 1, h = big[1 + s];
+    const u32 p0 = bin_start[h], p1 = bin_start[h + 1], csize = (p1 - p0 + kBigChunks - 1) / kBigChunks;
+    const u32 a = min(p1, p0 + c * csize), b = min(p1, a + csize);
+    for (u32 k = threadIdx.x; k < nbk; k += blockDim.x) sh[k] = 0;
+    __syncthreads();
+    for (u32 base = a + threadIdx.x * 4; base < b; base += blockDim.x * 4) {
+        u32 e[4], k[4], pos[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = base + j < b ? tagged[base + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k[j] = base + j < b ? s2_low(P, tagged_low, base + j, e[j], lowmask) : 0u;
+        lds_ticket4(sh, k, min(4u, b - base), pos);
     }
     __syncthreads();
-    if (E <= cap) {
-        for (u32 p = p0 + threadIdx.x; p < p1; p += blockDim.x) {       // second read of the bin: L2
-            const u32 e = tagged[p];
-            stage[lds_ticket(cursor, s2_low(P, tagged_low, p, e, lowmask))] = e & strip;
+    u32 *dst = gcnt + ((size_t)s * kBigChunks + c) * nbk;
+    for (u32 k = threadIdx.x; k < nbk; k += blockDim.x) dst[k] = sh[k];
+}
+__global__ void __launch_bounds__(1024) msm_s2_big_prefix(const u32 *__restrict__ bin_start, Sort2 P, u32 total_buckets, const u32 *__restrict__ big,
+                                                          u32 *__restrict__ gcnt, u32 *__restrict__ starts) {
+    H2_LATENCY_STAGE();
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];      // [nbk] bucket totals -> exclusive prefix
+    const u32 s = blockIdx.x;
+    if (s >= min(big[0], kMaxBig)) return;
+    const u32 nbk = 1u << P.lowb, h = big[1 + s], p0 = bin_start[h];
+    for (u32 k = threadIdx.x; k < nbk; k += blockDim.x) {
+        u32 run = 0;
+        for (u32 c = 0; c < kBigChunks; ++c) {
+            u32 *q = gcnt + ((size_t)s * kBigChunks + c) * nbk + k;
+            const u32 t = *q;
+            *q = run;                                               // this chunk's offset inside bucket k
+            run += t;
         }
-        __syncthreads();
-        for (u32 i = threadIdx.x; i < E; i += blockDim.x) entries[p0 + i] = stage[i];
-    } else {
-        for (u32 p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
-            const u32 e = tagged[p];
-            entries[p0 + lds_ticket(cursor, s2_low(P, tagged_low, p, e, lowmask))] = e & strip;
-        }
+        sh[k] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) (void)wave0_excl_scan(sh, nbk);
+    __syncthreads();
+    u32 *base = gcnt + (size_t)kMaxBig * kBigChunks * nbk + (size_t)s * nbk;       // bucket offsets inside the bin, for the scatter
+    for (u32 k = threadIdx.x; k < nbk; k += blockDim.x) {
+        const u32 b = (h << P.lowb) + k;
+        base[k] = sh[k];
+        if (b < total_buckets) starts[b] = p0 + sh[k];
+    }
+}
+__global__ void __launch_bounds__(1024) msm_s2_big_scatter(const u32 *__restrict__ tagged, const uint16_t *__restrict__ tagged_low, const u32 *__restrict__ bin_start,
+                                                           Sort2 P, const u32 *__restrict__ big, const u32 *__restrict__ gcnt, u32 *__restrict__ entries) {
+    H2_LATENCY_STAGE();
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    const u32 s = blockIdx.y, c = blockIdx.x;
+    if (s >= min(big[0], kMaxBig)) return;
+    const u32 nbk = 1u << P.lowb, lowmask = nbk - 1, strip = P.side ? ~0u : ~(lowmask << P.lb), h = big[1 + s];
+    const u32 p0 = bin_start[h], p1 = bin_start[h + 1], csize = (p1 - p0 + kBigChunks - 1) / kBigChunks;
+    const u32 a = min(p1, p0 + c * csize), b = min(p1, a + csize);
+    const u32 *off = gcnt + ((size_t)s * kBigChunks + c) * nbk, *base_k = gcnt + (size_t)kMaxBig * kBigChunks * nbk + (size_t)s * nbk;
+    for (u32 k = threadIdx.x; k < nbk; k += blockDim.x) sh[k] = base_k[k] + off[k];
+    __syncthreads();
+    for (u32 base = a + threadIdx.x * 4; base < b; base += blockDim.x * 4) {
+        u32 e[4], k[4], pos[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = base + j < b ? tagged[base + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k[j] = base + j < b ? s2_low(P, tagged_low, base + j, e[j], lowmask) : 0u;
+        lds_ticket4(sh, k, min(4u, b - base), pos);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (base + j < b) entries[p0 + pos[j]] = e[j] & strip;
     }
 }
 
@@ -1855,7 +1985,13 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         int lb = 0, kb = 0;
         while (((u64)(m - 1) >> lb) != 0) ++lb;
         while (((u64)(tb - 1) >> kb) != 0) ++kb;
-        const int lowb = std::min(31 - lb, std::max(1, kb - 9));
+        // bins of ~16 K entries (kb - 11 bucket bits per bin: 1152 bins for 9 slices of 2^15 buckets), so that pass 2 is the
+        // one-launch form with a bin per workgroup in LDS; H2_GLV_BIN_BITS: sweeps only (9 = the chunked pass 2 of round 2)
+        // Up to 2^19 scalars only: the carry slice of the split (the window above the top of a 128-bit half) puts ~n / 2 entries
+        // into ONE bucket, and a bin that large is scattered by a single workgroup (2^19: sort 0.28 -> 0.16 ms; 2^20: 0.30 -> 0.61)
+        static const int glv_bin_bits = [] { const char *e = getenv("H2_GLV_BIN_BITS"); int v = e ? atoi(e) : 0; return v >= 8 && v <= 12 ? v : 0; }();
+        const int bin_bits = glv_bin_bits ? glv_bin_bits : (scalars_n <= ((size_t)1 << 19) ? 11 : 9);
+        const int lowb = std::min(31 - lb, std::max(1, kb - bin_bits));
         const u32 nh = (tb + (1u << lowb) - 1) >> lowb;
         const u32 s1 = 1024;
         const bool fits = ((size_t)nh * 3 + 1 + (size_t)s1 * 2 * sh.W) * 4 <= kLdsCap;
@@ -1897,7 +2033,8 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         if ((rc = cx.hist.reserve((size_t)S2.B1 * S2.nh * 4)) != H2_OK) return rc;
         if ((rc = cx.tagged.reserve(all_items * 4)) != H2_OK) return rc;
         if (S2.side && (rc = cx.tagged_low.reserve(all_items * 2)) != H2_OK) return rc;
-        const size_t plan_words = (size_t)S2.nh * 2 + 1 + (size_t)S2.B2 * 2 + 1 + (((size_t)S2.nh + S2.B2 + 1) << S2.lowb);
+        const size_t plan_words = (size_t)S2.nh * 2 + 1 + (size_t)S2.B2 * 2 + 1 +
+                                  std::max<size_t>(((size_t)S2.nh + S2.B2 + 1) << S2.lowb, 64 + (((size_t)kMaxBig * (kBigChunks + 1)) << S2.lowb));
         if ((rc = cx.plan.reserve(plan_words * 4)) != H2_OK) return rc;
     } else {
         if ((rc = cx.digits.reserve(all_items * 2)) != H2_OK) return rc;
@@ -1952,14 +2089,21 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         static const size_t cap_env = [] { const char *e = getenv("H2_S2_CAP"); return e ? (size_t)atol(e) : (size_t)0; }();
         const size_t cap_entries = std::min(cap_max, cap_env ? cap_env : std::max<size_t>(4096, all_items / S2.nh * 5 / 4 + 1024));
         const size_t nbins = ((size_t)tb + nbk - 1) >> S2.lowb;
-        if (bins_on && a.table && !glv && S2.lowb <= 12 && nbins == S2.nh && cap_entries && all_items / S2.nh <= cap_entries * 9 / 10) {
+        if (bins_on && S2.lowb <= 12 && nbins == S2.nh && cap_entries && all_items / S2.nh <= cap_entries * 9 / 10) {
             static bool attr_bins = false;
             if (!attr_bins) {
                 H2_HIP(hipFuncSetAttribute((const void *)msm_s2_bins, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
                 attr_bins = true;
             }
+            u32 *big = hist2, *gcnt = hist2 + 64;                                      // the chunked form's histogram area is free here
+            H2_HIP(hipMemsetAsync(big, 0, 4, st));
             hipLaunchKernelGGL(msm_s2_bins, dim3(S2.nh), dim3(1024), (nbk * 2 + cap_entries) * 4, st, cx.tagged.as<u32>(),
-                               (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, tb, (u32)cap_entries, cx.starts.as<u32>(), cx.entries.as<u32>());
+                               (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, tb, (u32)cap_entries, cx.starts.as<u32>(), cx.entries.as<u32>(), big);
+            hipLaunchKernelGGL(msm_s2_big_count, dim3(kBigChunks, kMaxBig), dim3(1024), nbk * 4, st, cx.tagged.as<u32>(),
+                               (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, (const u32 *)big, gcnt);
+            hipLaunchKernelGGL(msm_s2_big_prefix, dim3(kMaxBig), dim3(1024), nbk * 4, st, bin_start, S2, tb, (const u32 *)big, gcnt, cx.starts.as<u32>());
+            hipLaunchKernelGGL(msm_s2_big_scatter, dim3(kBigChunks, kMaxBig), dim3(1024), nbk * 4, st, cx.tagged.as<u32>(),
+                               (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, (const u32 *)big, (const u32 *)gcnt, cx.entries.as<u32>());
         } else {
         hipLaunchKernelGGL(msm_s2_plan, dim3(1), dim3(kScanBlock), 0, st, bin_start, S2, hlo, woff);
         const size_t hist2_words = ((size_t)S2.nh + S2.B2 + 1) << S2.lowb;
