@@ -44,6 +44,7 @@
 #include "common.h"
 #include "curve_wide.cuh"
 #include "curve9.cuh"
+#include "curve9_wide.cuh"
 #include "glv.cuh"
 #include "host_field.h"
 
@@ -1539,13 +1540,16 @@ __global__ void __launch_bounds__(64) msm_combine(const u32 *__restrict__ slice_
         out += (out_kind == H2_OUT_AFFINE ? 16 : 24) * (size_t)blockIdx.x;
         slices = 1;
     }
-    xyzz<FB> r = xyzz_identity<FB>();
+    // the chain runs on the carry-free layer (curve9_wide.cuh): ~850 instructions per doubling against ~1300, and the 128-130
+    // doublings of a generic multiexp's Horner step ARE this kernel (355 us of a 0.6-0.7 ms small multiexp before)
+    xyzz9<FB> r9 = xyzz9_identity<FB>();
     for (int w = slices - 1; w >= 0; --w) {
         if (w != slices - 1)
-            for (int k = 0; k < c; ++k) r = xyzz_dbl_wide<FB>(r);
-        xyzz<FB> s = xyzz_load<FB>(slice_sums + 32 * (size_t)w);
-        xyzz_add_wide<FB>(r, s);
+            for (int k = 0; k < c; ++k) r9 = xyzz9_dbl_wide<FB>(r9);
+        const xyzz9<FB> s9 = xyzz9_from_r256_wide<FB>(xyzz_load<FB>(slice_sums + 32 * (size_t)w));
+        xyzz9_add_wide<FB>(r9, s9);
     }
+    const xyzz<FB> r = xyzz9_to_r256_wide<FB>(r9);
     if (threadIdx.x != 0) return;
     if (out_kind == H2_OUT_AFFINE) {
         affine<FB> a = xyzz_to_affine<FB>(r);
