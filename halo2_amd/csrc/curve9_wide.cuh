@@ -43,7 +43,7 @@ template <int F> __device__ __forceinline__ xyzz9<F> xyzz9_dbl_wide(const xyzz9<
     const fe9 o1 = g9_sel(l, p.y, p.x, p.y, p.y);                                   // not against itself: V = U^2 is formed as 4 Y^2
     const fe9 r1 = fe9_mul<F>(o1, o1);                                              // lane 0: YY = Y^2, lane 1: XX = X^2
     const fe9 yy = g9_bcast<0>(r1), xx = g9_bcast<1>(r1);
-    const fe9 v = fe9_norm(fe9_dbl(fe9_dbl(yy)));
+    const fe9 v = fe9_quadruple_norm(yy);                                           // (a product's limb 0 may be 2^29: see there)
     const fe9 m = fe9_norm(fe9_add(fe9_dbl(xx), xx));                               // 3 XX
     const fe9 r2 = fe9_mul<F>(g9_sel(l, u, p.x, m, v), g9_sel(l, v, v, m, p.zz));   // W = U V, S = X V, MM = M^2, ZZ3 = V ZZ
     const fe9 w = g9_bcast<0>(r2), s = g9_bcast<1>(r2), mm = g9_bcast<2>(r2);

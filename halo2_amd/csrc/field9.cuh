@@ -72,6 +72,21 @@ __device__ __forceinline__ fe9 fe9_norm(const fe9 &a) {
     return r;
 }
 
+// 4 a, normalised, for a PRODUCT a (limbs 0..7 in [0, 2^29], limb 0 may equal 2^29: 4 * 2^29 does not fit an i32, so the low
+// limbs are shifted and carried as unsigned words; limb 8 is small and signed)
+__device__ __forceinline__ fe9 fe9_quadruple_norm(const fe9 &a) {
+    fe9 r;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u32 t = ((u32)a.v[i] << 2) + c;
+        r.v[i] = (i32)(t & M29);
+        c = t >> 29;
+    }
+    r.v[8] = a.v[8] * 4 + (i32)c;
+    return r;
+}
+
 // opaque constants: keep hipcc from turning "* 1" / "* 2^22" into 64-bit shift-and-add sequences (3 carry-linked
 // instructions instead of one multiply-add)
 __device__ __forceinline__ i32 opaque(i32 x) {

@@ -1591,9 +1591,11 @@ __global__ void __launch_bounds__(256) msm_table_chain_wide(const u32 *__restric
     const affine<FB> p = aff_load<FB>(row0 + 16 * (size_t)(first + i));
     xyzz<FB> r = xyzz_identity<FB>();
     xyzz_madd<FB>(r, p);
+    xyzz9<FB> r9 = xyzz9_from_r256_wide<FB>(r);              // the chain itself on the carry-free layer (curve9_wide.cuh)
     for (int w = 1; w < W; ++w) {
-        for (int k = 0; k < c; ++k) r = xyzz_dbl_wide<FB>(r);
-        if ((threadIdx.x & (kGroup - 1)) == 0) xyzz_store<FB>(tmp + 32 * ((size_t)(w - 1) * count + i), r);
+        for (int k = 0; k < c; ++k) r9 = xyzz9_dbl_wide<FB>(r9);
+        const xyzz<FB> out = xyzz9_to_r256_wide<FB>(r9);
+        if ((threadIdx.x & (kGroup - 1)) == 0) xyzz_store<FB>(tmp + 32 * ((size_t)(w - 1) * count + i), out);
     }
 }
 // blind base: column `col` of the table must hold the multiples of `w` (Params::w, poly/commitment.rs:26-33).  ONE workgroup of

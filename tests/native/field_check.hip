@@ -9,6 +9,7 @@
 #define H2_FIELD_EXPERIMENTS 1
 #include "../../halo2_amd/csrc/field.cuh"
 #include "../../halo2_amd/csrc/curve9.cuh"
+#include "../../halo2_amd/csrc/curve9_wide.cuh"
 
 extern "C" {
 void orc_f_mul(int field, uint64_t *r, const uint64_t *a, const uint64_t *b);
@@ -112,6 +113,76 @@ template <int F> __global__ void k_ops9(const u32 *a, const u32 *b, u32 *out, in
     }
     fe_store(out + 8 * i, r);
 }
+// ---- quad-lane point doubling on the carry-free layer (curve9_wide.cuh) against the 8 x 32 one (curve_wide.cuh) ---------------
+// mode 0: a chain of `reps` doublings from the affine point (a[i], b[i]) (the formulas are polynomial identities: the point need
+// not lie on the curve).  mode 1: ONE doubling from a raw M9 state -- the recorded state whose Y^2 leaves the multiplier with
+// limb 0 equal to 2^29 (the only limb value 4 * limb does not fit an i32 for; fe9_quadruple_norm).
+template <int F> __global__ void k_dbl9_wide(const u32 *a, const u32 *b, const u32 *raw, u32 *out, int n, int reps, int mode) {
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+    if (i >= n) return;
+    xyzz<F> r;
+    xyzz9<F> r9;
+    if (mode == 0) {
+        const affine<F> p{fe_load(a + 8 * i), fe_load(b + 8 * i)};
+        r = xyzz_identity<F>();
+        xyzz_madd<F>(r, p);
+        r9 = xyzz9_from_r256_wide<F>(r);
+    } else {
+        r9 = xyzz9_load_raw<F>(raw);
+        r = xyzz9_to_r256_wide<F>(r9);
+    }
+    for (int k = 0; k < reps; ++k) {
+        r = xyzz_dbl_wide<F>(r);
+        r9 = xyzz9_dbl_wide<F>(r9);
+    }
+    const xyzz<F> o = xyzz9_to_r256_wide<F>(r9);
+    bool same = true;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        same = same && o.x.v[j] == r.x.v[j] && o.y.v[j] == r.y.v[j] && o.zz.v[j] == r.zz.v[j] && o.zzz.v[j] == r.zzz.v[j];
+    if ((threadIdx.x & (kGroup - 1)) == 0) out[i] = same ? 0u : 1u;
+}
+__global__ void k_quadruple_norm(u32 *out) {
+    fe9 a = fe9_zero();
+    a.v[0] = 1 << 29;                                      // what a product may leave in limb 0
+    for (int i = 1; i < 8; i++) a.v[i] = (i32)M29 - i;
+    a.v[8] = -5;
+    const fe9 got = fe9_quadruple_norm(a), want = fe9_norm(fe9_dbl(fe9_norm(fe9_dbl(fe9_norm(a)))));
+    u32 bad = 0;
+    for (int i = 0; i < 9; i++) bad |= (u32)(got.v[i] != want.v[i]);
+    out[0] = bad;
+}
+template <int F> int run_wide9(const u32 *da, const u32 *db, int n) {
+    static const u32 kState[36] = {     // Fq, M9 limbs of (X, Y, ZZ, ZZZ): doubling 221 of a 16-bit table chain, found on the device
+        0x038d27b2, 0x05039a9d, 0x12356f7c, 0x15b60e05, 0x0faf35a4, 0x07a6a677, 0x08780ea0, 0x03734c88, 0x00079790,
+        0x01198606, 0x150a0983, 0x15963169, 0x0228e707, 0x076b97cb, 0x15217f1f, 0x0be3beab, 0x1454604c, 0xffe0f2ac,
+        0x0413c791, 0x16925096, 0x1558a0c2, 0x09ab6c99, 0x1f698236, 0x043fa20f, 0x1804ede6, 0x0404f056, 0x00394ee7,
+        0x00ae9230, 0x090ab3d3, 0x0c3cf140, 0x1de44147, 0x0ac239cf, 0x12ae76e2, 0x0bd3b3ec, 0x1aa2ffd3, 0x00369c3d};
+    u32 *draw, *dflag;
+    CK(hipMalloc(&draw, sizeof(kState)));
+    CK(hipMalloc(&dflag, 4 * (size_t)n));
+    CK(hipMemcpy(draw, kState, sizeof(kState), hipMemcpyHostToDevice));
+    std::vector<u32> flag(n);
+    int fails = 0;
+    for (int mode = 0; mode < (F == FQ ? 2 : 1); ++mode) {
+        const int cnt = mode ? 1 : n, reps = mode ? 1 : 48;
+        hipLaunchKernelGGL((k_dbl9_wide<F>), dim3((cnt * kGroup + 255) / 256), dim3(256), 0, 0, da, db, draw, dflag, cnt, reps, mode);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(flag.data(), dflag, 4 * (size_t)cnt, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int i = 0; i < cnt; ++i) bad += flag[i] != 0;
+        printf("field %d %-16s: %d/%d mismatches\n", F, mode ? "dbl9 wide 2^29" : "dbl9 wide chain", bad, cnt);
+        fails += bad != 0;
+    }
+    hipLaunchKernelGGL(k_quadruple_norm, dim3(1), dim3(1), 0, 0, dflag);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(flag.data(), dflag, 4, hipMemcpyDeviceToHost));
+    printf("field %d %-16s: %d/1 mismatches\n", F, "quadruple norm", (int)flag[0]);
+    fails += flag[0] != 0;
+    (void)hipFree(draw);
+    (void)hipFree(dflag);
+    return fails;
+}
 template <int F> int run_field9(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b, const u32 *da, const u32 *db, u32 *dout, int n) {
     std::vector<uint64_t> got(4 * (size_t)n);
     const char *names[] = {"fe9 mul", "fe9 sqr", "fe9 signed chain", "fe9 sub+norm", "fe9 bridge", "fe9 mul_c", "fe9 table form", "fe_redc"};
@@ -198,6 +269,7 @@ template <int F> int run_field() {
             }
     printf("field %d lazy mul / sub / zero-test / 300-step chain over 9 representative pairs: done\n", F);
     fails += run_field9<F>(a, b, da, db, dout, n);
+    fails += run_wide9<F>(da, db, n);
     CK(hipFree(da)); CK(hipFree(db)); CK(hipFree(dout));
     return fails;
 }

@@ -219,3 +219,31 @@ def test_commit_batch_multi_two_blind_bases_one_handle():
         for i in range(3):
             assert affine_of(curve, outs[i]) == co.jac_to_affine_ints(curve, co.commit(curve, g, w, cols[i], blinds[i])), (wk, i)
     assert lib.h2_bases_free(hd) == 0
+
+
+@pytest.mark.parametrize("curve", [h.PALLAS, h.VESTA])
+def test_small_registered_tables_quad_lane_chain(curve):
+    """Tables of up to 2^16 points are filled by the quad-lane doubling chain on the carry-free layer (msm_table_chain_wide,
+    curve9_wide.cuh); registered from host and from device memory, 16-bit windows (240 doublings per point), commits against
+    `best_multiexp` (arithmetic.rs:143-180).  The Vesta table of 2^14 points from seed 0x219 holds the point whose chain meets a
+    product with low limb 2^29 (field_check's recorded state)."""
+    import torch
+    lib = h.lib()
+    sf = co.field_of_curve(curve, "scalar")
+    for n in (16384, 32772, 65536):
+        g = co.generate_bases(curve, 0x99 + n % 1000, n)
+        col = co.random_field(sf, 5 + n, n)
+        d_col = torch.from_numpy(col.view(np.int64)).cuda()
+        want = co.jac_to_affine_ints(curve, co.best_multiexp(curve, col, g))
+        for on_device in (False, True):
+            hd = C.c_uint64(0)
+            if on_device:
+                dg = torch.from_numpy(g.view(np.int64)).cuda()
+                assert lib.h2_bases_register_device(curve, dg.data_ptr(), n, h.FORM_MONTGOMERY, C.byref(hd)) == 0
+            else:
+                assert lib.h2_bases_register(curve, _p(g), n, h.FORM_MONTGOMERY, C.byref(hd)) == 0
+            out = torch.empty(12, dtype=torch.int64, device="cuda:0")
+            assert lib.h2_commit_device(hd, d_col.data_ptr(), n, None, None, h.FORM_MONTGOMERY, 0, out.data_ptr(), None) == 0
+            torch.cuda.synchronize()
+            assert affine_of(curve, out.cpu().numpy().view(np.uint64)) == want, (n, on_device)
+            lib.h2_bases_free(hd)
