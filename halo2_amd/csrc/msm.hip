@@ -618,9 +618,16 @@ __global__ void __launch_bounds__(1024) msm_s1_scatter(const u32 *__restrict__ s
 }
 
 // column-wise exclusive scan of hist1[B1][nh]; bin_count[h] = column total.  16 columns per workgroup, 64 row groups.
-__global__ void __launch_bounds__(1024) msm_s1_prefix(u32 *__restrict__ hist1, u32 *__restrict__ bin_count, u32 B1, u32 nh) {
+// (It also zeroes the two small counter areas later kernels of the same multiexp count into -- `z2`: the two words of the
+// heavy-bucket list, `z1`: the oversized-bin counter of pass 2 -- which saves two 5 us memset nodes on the stream.)
+__global__ void __launch_bounds__(1024) msm_s1_prefix(u32 *__restrict__ hist1, u32 *__restrict__ bin_count, u32 B1, u32 nh, u32 *__restrict__ z2,
+                                                      u32 *__restrict__ z1) {
     H2_LATENCY_STAGE();
     __shared__ u32 part[64][17];
+    if (blockIdx.x == 0 && threadIdx.x < 3) {
+        if (threadIdx.x < 2) z2[threadIdx.x] = 0;
+        else if (z1) z1[0] = 0;
+    }
     const u32 r = threadIdx.x >> 4, cl = threadIdx.x & 15, col = blockIdx.x * 16 + cl;
     const u32 rg = (B1 + 63) / 64, r0 = min(B1, r * rg), r1 = min(B1, r0 + rg);
     u32 sum = 0;
@@ -1365,23 +1372,64 @@ __global__ void __launch_bounds__(256) fold9_finish(const u32 *__restrict__ head
     for (u32 t = h0; t < h1; ++t) xyzz9_add<FB>(acc, xyzz9_load_raw<FB>(heads9 + 36 * (size_t)t));
     xyzz9_store_raw<FB>(buckets9 + 36 * (size_t)b, acc);
 }
-// sum of 256 raw points held one per thread -> thread 0 (LDS tree, 36 words per point)
-template <int FB> __device__ __forceinline__ xyzz9<FB> fold9_block_sum(xyzz9<FB> acc, u32 *sh) {
-    const u32 t = threadIdx.x;
-    for (u32 off = 128; off > 0; off >>= 1) {
-        if (t >= off && t < 2 * off) xyzz9_store_raw<FB>(sh + 36 * (size_t)(t - off), acc);
+// ---- the levels after that: trees, on quads of lanes ---------------------------------------------------------------------------
+// Past the per-bucket stage every sum is a TREE (a line of the bucket matrix, the heads of a heavy bucket, a bit plane of the
+// line sums): its depth in dependent point additions is the latency, and most lanes idle anyway.  A point addition on a quad
+// of lanes (curve9_wide.cuh: 4 product levels of ~165 instructions) takes a wave ~850 instructions for 16 additions where
+// the one-lane form takes ~2700 for up to 64 -- less wave time from the third tree level up, and a third of the latency at
+// every level (a line of 256 buckets: 72 -> ~25 us).
+//
+#ifndef H2_FOLD_D
+#define H2_FOLD_D 2
+#endif
+// quad q of the workgroup sums the raw points src[36 * index(k)], k = q, q + nq, ... < count.  D points are in flight: each
+// lane fetches ONE coordinate (9 words) of each and the quad exchanges them by DPP when the point's turn comes -- the strided
+// loads of a line overlap instead of each waiting behind the previous addition.  These kernels run while other streams'
+// msm_accumulate holds two waves a SIMD (2 x 168 of 512 registers): they are bounded to the 168 that still fit beside them
+// (__launch_bounds__(.., 3)), which two points in flight meet without spilling the addition's own temporaries.
+template <int FB, int D = 4, class Index> __device__ __forceinline__ xyzz9<FB> fold9_quad_gather(const u32 *__restrict__ src, u32 count, Index index) {
+    const u32 q = threadIdx.x / kGroup, l = threadIdx.x & (kGroup - 1), nq = blockDim.x / kGroup;
+    xyzz9<FB> acc = xyzz9_identity<FB>();
+    for (u32 k0 = q; k0 < count; k0 += D * nq) {
+        fe9 co[D];
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            const u32 k = k0 + j * nq;
+            co[j] = fe9_zero();                                  // (an all-zero point is the identity: skipped by the addition)
+            if (k < count) {
+                const u32 *w = src + 36 * (size_t)index(k) + 9 * l;
+#pragma unroll
+                for (int i = 0; i < 9; i++) co[j].v[i] = (i32)w[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < D; j++)
+            xyzz9_add_wide<FB>(acc, xyzz9<FB>{g9_bcast<0>(co[j]), g9_bcast<1>(co[j]), g9_bcast<2>(co[j]), g9_bcast<3>(co[j])});
+    }
+    return acc;
+}
+// the sum of the nq points the quads of a workgroup hold -> quad 0 (every lane of it); sh: nq / 2 raw points.  (Rotating the
+// tree by a wave per workgroup index, so that the workgroups sharing a CU do not all finish on their wave 0, was measured: the
+// line sums got 5 us SLOWER.)
+__device__ __forceinline__ u32 fold9_vquad() { return threadIdx.x / kGroup; }
+__device__ __forceinline__ bool fold9_root() { return threadIdx.x < kGroup; }
+template <int FB> __device__ __forceinline__ xyzz9<FB> fold9_quads_sum(xyzz9<FB> acc, u32 *sh) {
+    const u32 q = fold9_vquad(), nq = blockDim.x / kGroup;
+    const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
+    for (u32 off = nq / 2; off > 0; off >>= 1) {
+        if (q >= off && q < 2 * off && lead) xyzz9_store_raw<FB>(sh + 36 * (size_t)(q - off), acc);
         __syncthreads();
-        if (t < off) xyzz9_add<FB>(acc, xyzz9_load_raw<FB>(sh + 36 * (size_t)t));
+        if (q < off) xyzz9_add_wide<FB>(acc, xyzz9_load_raw<FB>(sh + 36 * (size_t)q));
         __syncthreads();
     }
     return acc;
 }
 // heavy buckets (more than kHeavy heads): kHeavyBlocks workgroups share the heads, fold9_finish_heavy2 adds their sums to the bucket
 template <int FB>
-__global__ void __launch_bounds__(256) fold9_finish_heavy(const u32 *__restrict__ heads9, const u32 *__restrict__ starts, u32 *__restrict__ scratch9,
+__global__ void __launch_bounds__(256, 3) fold9_finish_heavy(const u32 *__restrict__ heads9, const u32 *__restrict__ starts, u32 *__restrict__ scratch9,
                                                           const u32 *__restrict__ heavy, u32 total_buckets, u32 T, u32 div) {
     H2_LATENCY_STAGE();
-    __shared__ __attribute__((aligned(16))) u32 sh[128 * 36];
+    __shared__ __attribute__((aligned(16))) u32 sh[32 * 36];
     if (blockIdx.y >= min(heavy[1], kMaxHeavy)) return;
     const u32 b = heavy[2 + blockIdx.y];
     const u32 M = starts[total_buckets];
@@ -1390,48 +1438,109 @@ __global__ void __launch_bounds__(256) fold9_finish_heavy(const u32 *__restrict_
     const u32 h0 = (starts[b] + chunk - 1) / chunk, h1 = (starts[b + 1] + chunk - 1) / chunk;
     const u32 share = (h1 - h0 + kHeavyBlocks - 1) / kHeavyBlocks;
     const u32 lo = h0 + blockIdx.x * share, hi = min(h1, lo + share);
-    xyzz9<FB> acc = xyzz9_identity<FB>();
-    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) xyzz9_add<FB>(acc, xyzz9_load_raw<FB>(heads9 + 36 * (size_t)i));
-    acc = fold9_block_sum<FB>(acc, sh);
-    if (threadIdx.x == 0) xyzz9_store_raw<FB>(scratch9 + 36 * ((size_t)blockIdx.y * kHeavyBlocks + blockIdx.x), acc);
+    xyzz9<FB> acc = fold9_quad_gather<FB, H2_FOLD_D>(heads9, hi > lo ? hi - lo : 0u, [lo](u32 k) { return lo + k; });
+    acc = fold9_quads_sum<FB>(acc, sh);
+    if (fold9_root() && (threadIdx.x & (kGroup - 1)) == 0) xyzz9_store_raw<FB>(scratch9 + 36 * ((size_t)blockIdx.y * kHeavyBlocks + blockIdx.x), acc);
 }
 template <int FB>
-__global__ void __launch_bounds__(64) fold9_finish_heavy2(const u32 *__restrict__ scratch9, u32 *__restrict__ buckets9, const u32 *__restrict__ heavy) {
+__global__ void __launch_bounds__(64, 3) fold9_finish_heavy2(const u32 *__restrict__ scratch9, u32 *__restrict__ buckets9, const u32 *__restrict__ heavy) {
     H2_LATENCY_STAGE();
-    __shared__ __attribute__((aligned(16))) u32 sh[16 * 36];
+    __shared__ __attribute__((aligned(16))) u32 sh[8 * 36];
     if (blockIdx.x >= min(heavy[1], kMaxHeavy)) return;
-    // lanes 0..31 hold one partial each; a 5-level LDS tree (6 dependent additions instead of kHeavyBlocks)
-    const u32 b = heavy[2 + blockIdx.x], t = threadIdx.x;
-    xyzz9<FB> acc = t < kHeavyBlocks ? xyzz9_load_raw<FB>(scratch9 + 36 * ((size_t)blockIdx.x * kHeavyBlocks + t)) : xyzz9_identity<FB>();
-    for (u32 off = 16; off > 0; off >>= 1) {
-        if (t >= off && t < 2 * off) xyzz9_store_raw<FB>(sh + 36 * (size_t)(t - off), acc);
-        __syncthreads();
-        if (t < off) xyzz9_add<FB>(acc, xyzz9_load_raw<FB>(sh + 36 * (size_t)t));
-        __syncthreads();
-    }
-    if (t == 0) {
-        xyzz9_add<FB>(acc, xyzz9_load_raw<FB>(buckets9 + 36 * (size_t)b));
-        xyzz9_store_raw<FB>(buckets9 + 36 * (size_t)b, acc);
+    // 16 quads: two partials each, a 4-level tree, then the bucket's own segment (6 dependent additions)
+    const u32 b = heavy[2 + blockIdx.x];
+    const u32 *src = scratch9 + 36 * ((size_t)blockIdx.x * kHeavyBlocks);
+    xyzz9<FB> acc = fold9_quad_gather<FB, H2_FOLD_D>(src, kHeavyBlocks, [](u32 k) { return k; });
+    acc = fold9_quads_sum<FB>(acc, sh);
+    if (fold9_root()) {
+        xyzz9_add_wide<FB>(acc, xyzz9_load_raw<FB>(buckets9 + 36 * (size_t)b));
+        if ((threadIdx.x & (kGroup - 1)) == 0) xyzz9_store_raw<FB>(buckets9 + 36 * (size_t)b, acc);
     }
 }
-// row / column sums of the NR x S bucket matrix (see msm_rowcol_sums for the algebra and the output layout): one workgroup per
-// sum, every thread adds its share of the line sequentially, then an LDS tree; thread 0 converts the one result to the
-// reference's Montgomery form for the tail kernels.  (Fewer lanes per line were measured: 32 lanes x 8 points is half the
-// VALU work and +1.2 % sustained commit throughput, but 12 dependent additions behind un-prefetched strided loads instead of 8:
-// +40 us on a lone commit, which a 20-commit run and every prover phase feel; 64 lanes x 4 points: no gain either way.)
+// row / column sums of the NR x S bucket matrix (see msm_rowcol_sums for the algebra): one workgroup of 64 quads per line,
+// lines9[lo] = C_lo (lo < S), lines9[S + hi] = R_hi (1 <= hi < NR; row 0 carries weight 0 and is never formed), raw M9.
 template <int FB>
-__global__ void __launch_bounds__(256) fold9_rowcol(const u32 *__restrict__ buckets9, u32 *__restrict__ wide, u32 S, u32 NR) {
+__global__ void __launch_bounds__(256, 3) fold9_rowcol(const u32 *__restrict__ buckets9, u32 *__restrict__ lines9, u32 S, u32 NR) {
     H2_LATENCY_STAGE();
-    __shared__ __attribute__((aligned(16))) u32 sh[128 * 36];
+    __shared__ __attribute__((aligned(16))) u32 sh[32 * 36];
     const bool is_col = blockIdx.x < S;
-    const u32 id = is_col ? blockIdx.x : blockIdx.x - S + 1;          // column lo, or row hi (row 0 carries weight 0)
+    const u32 id = is_col ? blockIdx.x : blockIdx.x - S + 1;          // column lo, or row hi
     const u32 cnt = is_col ? NR : S;
-    const size_t base = is_col ? id : (size_t)id * S, step = is_col ? S : 1;
-    xyzz9<FB> acc = xyzz9_identity<FB>();
-    for (u32 i = threadIdx.x; i < cnt; i += blockDim.x) xyzz9_add<FB>(acc, xyzz9_load_raw<FB>(buckets9 + 36 * (base + (size_t)i * step)));
-    acc = fold9_block_sum<FB>(acc, sh);
-    if (threadIdx.x == 0)
-        xyzz_store<FB>(wide + 32 * (is_col ? (size_t)id : (size_t)NR + id - 1), xyzz9_is_identity(acc) ? xyzz_identity<FB>() : xyzz9_to_r256<FB>(acc));
+    const u32 base = is_col ? id : id * S, step = is_col ? S : 1;
+    xyzz9<FB> acc = fold9_quad_gather<FB, H2_FOLD_D>(buckets9, cnt, [base, step](u32 k) { return base + k * step; });
+    acc = fold9_quads_sum<FB>(acc, sh);
+    if (fold9_root() && (threadIdx.x & (kGroup - 1)) == 0) xyzz9_store_raw<FB>(lines9 + 36 * (size_t)(is_col ? id : S + id), acc);
+}
+// The rest of the fold of a wide slice in ONE launch.  sum_j (j + 1) B_j = sum_lo (lo + 1) C_lo + S sum_hi hi R_hi is a sum of
+// `planes` = log2 S + log2 NR bit planes: plane t (weight 2^t) holds the columns with bit t of lo + 1 set (t < log2 S; plane
+// log2 S holds C_{S-1} alone) and the rows with bit t - log2 S of hi set.  Workgroup t sums plane t -- a tree over at most
+// S / 2 + NR / 2 lines, no doubling anywhere -- and the workgroup that finishes LAST (a counter behind a fence; it leaves
+// the counter at zero for the next launch) combines the planes pairwise: T[2 k s] += 2^s T[(2 k + 1) s] for s = 1, 2, 4, ...:
+// 19 dependent quad-lane operations for 16 planes, against the ~60 of a running sum over segments, a slice tree and a Horner
+// step in three launches (reduce_segments + sum_slice + combine: 126 us of a 1.28 ms commit; this kernel: see DESIGN.md).
+template <int FB>
+__global__ void __launch_bounds__(256, 3) fold9_planes(const u32 *__restrict__ lines9, u32 *__restrict__ planes9, u32 *__restrict__ counter, u32 S, u32 NR,
+                                                    int cb, u32 *__restrict__ out, int out_kind, int out_mont) {
+    H2_LATENCY_STAGE();
+    __shared__ __attribute__((aligned(16))) u32 sh[32 * 36];
+    __shared__ u32 s_last;
+    const u32 t = blockIdx.x, planes = gridDim.x, q = threadIdx.x / kGroup;
+    const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
+    const u32 ncol = (int)t < cb ? S / 2 : (int)t == cb ? 1u : 0u, nrow = (int)t >= cb ? NR / 2 : 0u;
+    const u32 jc = t, jr = t - (u32)cb;
+    xyzz9<FB> acc = fold9_quad_gather<FB, H2_FOLD_D>(lines9, ncol + nrow, [=](u32 k) {
+        if (k < ncol) {
+            if ((int)jc == cb) return S - 1;                                                         // lo + 1 = S
+            return ((((k >> jc) << (jc + 1)) | (1u << jc) | (k & ((1u << jc) - 1u))) - 1u);         // k-th value of lo + 1 with bit jc set
+        }
+        const u32 r = k - ncol;
+        return S + (((r >> jr) << (jr + 1)) | (1u << jr) | (r & ((1u << jr) - 1u)));                // k-th hi with bit jr set
+    });
+    acc = fold9_quads_sum<FB>(acc, sh);
+    if (fold9_root() && lead) {
+        xyzz9_store_raw<FB>(planes9 + 36 * (size_t)t, acc);
+        __threadfence();
+        s_last = atomicAdd(counter, 1u) == planes - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // pairwise combination of the planes (slots beyond `planes` are identities: their doublings return at once)
+    if (q < 32 && lead) xyzz9_store_raw<FB>(sh + 36 * (size_t)q, q < planes ? xyzz9_load_raw<FB>(planes9 + 36 * (size_t)q) : xyzz9_identity<FB>());
+    __syncthreads();
+    u32 np2 = 1;
+    while (np2 < planes) np2 <<= 1;
+    for (u32 s = 1; s < np2; s <<= 1) {
+        const u32 lo = 2 * q * s, hi = lo + s;
+        const bool mine = hi < planes;
+        xyzz9<FB> a = xyzz9_identity<FB>();
+        if (mine) {
+            xyzz9<FB> b9 = xyzz9_load_raw<FB>(sh + 36 * (size_t)hi);
+            for (u32 k = 0; k < s; ++k) b9 = xyzz9_dbl_wide<FB>(b9);
+            a = xyzz9_load_raw<FB>(sh + 36 * (size_t)lo);
+            xyzz9_add_wide<FB>(a, b9);
+        }
+        __syncthreads();
+        if (mine && lead) xyzz9_store_raw<FB>(sh + 36 * (size_t)lo, a);
+        __syncthreads();
+    }
+    if (threadIdx.x >= kGroup) return;
+    const xyzz<FB> r = xyzz9_to_r256_wide<FB>(xyzz9_load_raw<FB>(sh));
+    if (threadIdx.x != 0) return;
+    *counter = 0;
+    if (out_kind == H2_OUT_AFFINE) {
+        affine<FB> o = xyzz_to_affine<FB>(r);
+        if (!out_mont) { o.x = fe_from_mont<FB>(o.x); o.y = fe_from_mont<FB>(o.y); }
+        fe_store(out, o.x);
+        fe_store(out + 8, o.y);
+    } else {
+        fe X, Y, Z;
+        xyzz_to_jacobian<FB>(r, X, Y, Z);
+        if (!out_mont) { X = fe_from_mont<FB>(X); Y = fe_from_mont<FB>(Y); Z = fe_from_mont<FB>(Z); }
+        fe_store(out, X);
+        fe_store(out + 8, Y);
+        fe_store(out + 16, Z);
+    }
 }
 
 // The three tail kernels below run each logical lane as a quad of 4 hardware lanes (curve_wide.cuh): the chip
@@ -1824,10 +1933,10 @@ static bool timeline_on() {
 struct MsmContext {
     std::mutex mu;
     DevBuf digits, hist, counts, starts, bsums, entries, heads, heavy, hscratch, buckets, partial, ssums, stage_s, stage_b,
-        out, small, tagged, tagged_low, plan, seg9, bases9, collapse, collapse_list;
+        out, small, tagged, tagged_low, plan, seg9, bases9, collapse, collapse_list, fold_ctr;
     void release_all() {
         for (DevBuf *b : {&digits, &hist, &counts, &starts, &bsums, &entries, &heads, &heavy, &hscratch, &buckets, &partial, &ssums,
-                          &stage_s, &stage_b, &out, &small, &tagged, &tagged_low, &plan, &seg9, &bases9, &collapse, &collapse_list})
+                          &stage_s, &stage_b, &out, &small, &tagged, &tagged_low, &plan, &seg9, &bases9, &collapse, &collapse_list, &fold_ctr})
             b->release();
     }
     bool attr_set = false, attr2_set = false;
@@ -2054,7 +2163,12 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     if ((rc = cx.heavy.reserve((size_t)(max_heavy + 2) * 4)) != H2_OK) return rc;
     if ((rc = cx.hscratch.reserve((size_t)max_heavy * kHeavyBlocks * 144)) != H2_OK) return rc;
     if ((rc = cx.buckets.reserve((size_t)tb * 128)) != H2_OK) return rc;
-    if ((rc = cx.partial.reserve(wide_reduce ? ((size_t)2 * wideNR / kSeg + 2 * wideNR) * 128 : (size_t)segs * 128)) != H2_OK) return rc;
+    if ((rc = cx.partial.reserve(wide_reduce ? std::max(((size_t)2 * wideNR / kSeg + 2 * wideNR) * 128, ((size_t)wideS + wideNR + 32) * 144)
+                                             : (size_t)segs * 128)) != H2_OK) return rc;
+    if (fold9 && !cx.fold_ctr.ptr) {                      // fold9_planes' arrival counter: zero once, every launch leaves it at zero
+        if ((rc = cx.fold_ctr.reserve(64)) != H2_OK) return rc;
+        H2_HIP(hipMemsetAsync(cx.fold_ctr.ptr, 0, 64, st));
+    }
     if ((rc = cx.ssums.reserve((size_t)std::max<u32>(sh.slices, 2) * 128)) != H2_OK) return rc;
     const u32 m32 = (u32)m;
     u32 *grand = cx.bsums.as<u32>() + nblocks;
@@ -2075,13 +2189,13 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         if (glv) {
             hipLaunchKernelGGL((msm_s1_count<FS, true>), dim3(S2.B1), dim3(s1_threads), S2.nh * 4, st, (const u32 *)a.d_scalars,
                                (const u32 *)nullptr, S2, hist1);
-            hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh);
+            hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh, cx.heavy.as<u32>(), hist2);
             hipLaunchKernelGGL((msm_s1_scatter<FS, true>), dim3(S2.B1), dim3(s1_threads), lds1, st, (const u32 *)a.d_scalars,
                                (const u32 *)nullptr, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>(), (uint16_t *)nullptr);
         } else {
             hipLaunchKernelGGL((msm_s1_count<FS, false>), dim3(S2.B1), dim3(s1_threads), S2.nh * 4, st, (const u32 *)a.d_scalars,
                                (const u32 *)a.d_extra_scalar, S2, hist1);
-            hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh);
+            hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh, cx.heavy.as<u32>(), hist2);
             hipLaunchKernelGGL((msm_s1_scatter<FS, false>), dim3(S2.B1), dim3(s1_threads), lds1, st, (const u32 *)a.d_scalars,
                                (const u32 *)a.d_extra_scalar, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>(), cx.tagged_low.as<uint16_t>());
         }
@@ -2101,8 +2215,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                 H2_HIP(hipFuncSetAttribute((const void *)msm_s2_bins, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
                 attr_bins = true;
             }
-            u32 *big = hist2, *gcnt = hist2 + 64;                                      // the chunked form's histogram area is free here
-            H2_HIP(hipMemsetAsync(big, 0, 4, st));
+            u32 *big = hist2, *gcnt = hist2 + 64;                 // the chunked form's histogram area is free here; msm_s1_prefix zeroed *big
             hipLaunchKernelGGL(msm_s2_bins, dim3(S2.nh), dim3(1024), (nbk * 2 + cap_entries) * 4, st, cx.tagged.as<u32>(),
                                (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, tb, (u32)cap_entries, cx.starts.as<u32>(), cx.entries.as<u32>(), big);
             hipLaunchKernelGGL(msm_s2_big_count, dim3(kBigChunks, kMaxBig), dim3(1024), nbk * 4, st, cx.tagged.as<u32>(),
@@ -2188,7 +2301,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     } else {
         H2_HIP(hipMemsetAsync(cx.buckets.ptr, 0, (size_t)tb * 128, st));
     }
-    H2_HIP(hipMemsetAsync(cx.heavy.ptr, 0, 8, st));
+    if (!use_sort2) H2_HIP(hipMemsetAsync(cx.heavy.ptr, 0, 8, st));          // (the two-pass sort's msm_s1_prefix zeroed it)
     prof_end(PROF_MSM_SORT, st);
     TL_STAMP(tl_id | 2);
     prof_begin(PROF_MSM_ACCUMULATE, st);
@@ -2246,15 +2359,25 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         const u32 *fold_src = fold_only ? a.fold_from : cx.buckets.as<u32>();
         u32 fold_nb = sh.NB, fold_slices = sh.slices;
         int fold_c = sh.c;
+        if (fold9) {
+            // line sums, then the bit planes of the line weights and their combination in one launch (fold9_planes)
+            u32 *lines9 = cx.partial.as<u32>(), *planes9 = lines9 + 36 * (size_t)(wideS + wideNR);
+            int cb = 0;
+            while ((1u << cb) < wideS) ++cb;
+            hipLaunchKernelGGL((fold9_rowcol<FB>), dim3(wideS + wideNR - 1), dim3(256), 0, st, (const u32 *)(cx.seg9.as<u32>() + 36 * (size_t)T),
+                               lines9, wideS, wideNR);
+            hipLaunchKernelGGL((fold9_planes<FB>), dim3(sh.c - 1), dim3(256), 0, st, (const u32 *)lines9, planes9, cx.fold_ctr.as<u32>(), wideS, wideNR,
+                               cb, (u32 *)a.d_out, a.out_kind, a.form == H2_FORM_MONTGOMERY);
+            prof_end(PROF_MSM_REDUCE, st);
+            TL_STAMP(tl_id | 4);
+            H2_HIP(hipGetLastError());
+            return H2_OK;
+        }
         if (wide_reduce) {
             u32 *wide = cx.partial.as<u32>() + 32 * (size_t)(2 * wideNR / kSeg);     // after the fold's own partials
             H2_HIP(hipMemsetAsync(wide, 0, (size_t)2 * wideNR * 128, st));
-            if (fold9)
-                hipLaunchKernelGGL((fold9_rowcol<FB>), dim3(wideS + wideNR - 1), dim3(256), 0, st, (const u32 *)(cx.seg9.as<u32>() + 36 * (size_t)T),
-                                   wide, wideS, wideNR);
-            else
-                hipLaunchKernelGGL((msm_rowcol_sums<FB>), dim3(wideS + wideNR - 1), dim3(256), (256 / kGroup) * 128, st, fold_src,
-                                   wide, wideS, wideNR);
+            hipLaunchKernelGGL((msm_rowcol_sums<FB>), dim3(wideS + wideNR - 1), dim3(256), (256 / kGroup) * 128, st, fold_src,
+                               wide, wideS, wideNR);
             fold_src = wide;
             fold_nb = wideNR;
             fold_slices = 2;
