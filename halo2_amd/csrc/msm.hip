@@ -1466,10 +1466,11 @@ __global__ void __launch_bounds__(256, 3) fold9_rowcol(const u32 *__restrict__ b
     const bool is_col = blockIdx.x < S;
     const u32 id = is_col ? blockIdx.x : blockIdx.x - S + 1;          // column lo, or row hi
     const u32 cnt = is_col ? NR : S;
-    const u32 base = is_col ? id : id * S, step = is_col ? S : 1;
+    const u32 base = blockIdx.y * S * NR + (is_col ? id : id * S), step = is_col ? S : 1;      // blockIdx.y: the bucket slice (paired commits: 2)
     xyzz9<FB> acc = fold9_quad_gather<FB, H2_FOLD_D>(buckets9, cnt, [base, step](u32 k) { return base + k * step; });
     acc = fold9_quads_sum<FB>(acc, sh);
-    if (fold9_root() && (threadIdx.x & (kGroup - 1)) == 0) xyzz9_store_raw<FB>(lines9 + 36 * (size_t)(is_col ? id : S + id), acc);
+    if (fold9_root() && (threadIdx.x & (kGroup - 1)) == 0)
+        xyzz9_store_raw<FB>(lines9 + 36 * ((size_t)blockIdx.y * (S + NR) + (is_col ? id : S + id)), acc);
 }
 // The rest of the fold of a wide slice in ONE launch.  sum_j (j + 1) B_j = sum_lo (lo + 1) C_lo + S sum_hi hi R_hi is a sum of
 // `planes` = log2 S + log2 NR bit planes: plane t (weight 2^t) holds the columns with bit t of lo + 1 set (t < log2 S; plane
@@ -1486,6 +1487,10 @@ __global__ void __launch_bounds__(256, 3) fold9_planes(const u32 *__restrict__ l
     __shared__ u32 s_last;
     const u32 t = blockIdx.x, planes = gridDim.x, q = threadIdx.x / kGroup;
     const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
+    lines9 += 36 * (size_t)blockIdx.y * (S + NR);                     // blockIdx.y: the bucket slice = the output (paired commits: 2)
+    planes9 += 36 * (size_t)blockIdx.y * 32;
+    counter += blockIdx.y;
+    out += (out_kind == H2_OUT_AFFINE ? 16 : 24) * (size_t)blockIdx.y;
     const u32 ncol = (int)t < cb ? S / 2 : (int)t == cb ? 1u : 0u, nrow = (int)t >= cb ? NR / 2 : 0u;
     const u32 jc = t, jr = t - (u32)cb;
     xyzz9<FB> acc = fold9_quad_gather<FB, H2_FOLD_D>(lines9, ncol + nrow, [=](u32 k) {
@@ -2128,9 +2133,9 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     static const bool fold9_on = [] { const char *e = getenv("H2_FOLD9"); return !(e && atoi(e) == 0); }();     // A/B switch
     // first fold levels in throughput form on the raw M9 segments (fold9_* kernels); a range of a chunked commit hands
     // finished buckets on in the reference's form (add_into), so it keeps the quad-lane finisher
-    const bool fold9 = fold9_on && wide_reduce && a.table && !glv && !pair && !a.add_into && !fold_only;
+    const bool fold9 = fold9_on && sh.NB >= 32768u && a.table && !glv && !a.add_into && !fold_only;
     u32 wideS = 0, wideNR = 0;
-    if (wide_reduce) {
+    if (wide_reduce || fold9) {
         const int bb = sh.c - 1;
         wideS = 1u << (bb / 2);
         wideNR = sh.NB / wideS;
@@ -2163,8 +2168,8 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     if ((rc = cx.heavy.reserve((size_t)(max_heavy + 2) * 4)) != H2_OK) return rc;
     if ((rc = cx.hscratch.reserve((size_t)max_heavy * kHeavyBlocks * 144)) != H2_OK) return rc;
     if ((rc = cx.buckets.reserve((size_t)tb * 128)) != H2_OK) return rc;
-    if ((rc = cx.partial.reserve(wide_reduce ? std::max(((size_t)2 * wideNR / kSeg + 2 * wideNR) * 128, ((size_t)wideS + wideNR + 32) * 144)
-                                             : (size_t)segs * 128)) != H2_OK) return rc;
+    if ((rc = cx.partial.reserve(std::max(wide_reduce ? ((size_t)2 * wideNR / kSeg + 2 * wideNR) * 128 : (size_t)segs * 128,
+                                          fold9 ? (size_t)sh.slices * (wideS + wideNR + 32) * 144 : (size_t)0))) != H2_OK) return rc;
     if (fold9 && !cx.fold_ctr.ptr) {                      // fold9_planes' arrival counter: zero once, every launch leaves it at zero
         if ((rc = cx.fold_ctr.reserve(64)) != H2_OK) return rc;
         H2_HIP(hipMemsetAsync(cx.fold_ctr.ptr, 0, 64, st));
@@ -2361,13 +2366,13 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         int fold_c = sh.c;
         if (fold9) {
             // line sums, then the bit planes of the line weights and their combination in one launch (fold9_planes)
-            u32 *lines9 = cx.partial.as<u32>(), *planes9 = lines9 + 36 * (size_t)(wideS + wideNR);
+            u32 *lines9 = cx.partial.as<u32>(), *planes9 = lines9 + 36 * (size_t)sh.slices * (wideS + wideNR);
             int cb = 0;
             while ((1u << cb) < wideS) ++cb;
-            hipLaunchKernelGGL((fold9_rowcol<FB>), dim3(wideS + wideNR - 1), dim3(256), 0, st, (const u32 *)(cx.seg9.as<u32>() + 36 * (size_t)T),
-                               lines9, wideS, wideNR);
-            hipLaunchKernelGGL((fold9_planes<FB>), dim3(sh.c - 1), dim3(256), 0, st, (const u32 *)lines9, planes9, cx.fold_ctr.as<u32>(), wideS, wideNR,
-                               cb, (u32 *)a.d_out, a.out_kind, a.form == H2_FORM_MONTGOMERY);
+            hipLaunchKernelGGL((fold9_rowcol<FB>), dim3(wideS + wideNR - 1, sh.slices), dim3(256), 0, st,
+                               (const u32 *)(cx.seg9.as<u32>() + 36 * (size_t)T), lines9, wideS, wideNR);
+            hipLaunchKernelGGL((fold9_planes<FB>), dim3(sh.c - 1, sh.slices), dim3(256), 0, st, (const u32 *)lines9, planes9, cx.fold_ctr.as<u32>(),
+                               wideS, wideNR, cb, (u32 *)a.d_out, a.out_kind, a.form == H2_FORM_MONTGOMERY);
             prof_end(PROF_MSM_REDUCE, st);
             TL_STAMP(tl_id | 4);
             H2_HIP(hipGetLastError());
