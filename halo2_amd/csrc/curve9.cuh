@@ -5,9 +5,10 @@
 // Limb / value bounds through one addition (N = normalised: limbs 0..7 in [0, 2^29), |value| < 2^256):
 //   u2, s2, pp, ppp, qq, zz', zzz'   products                       -> N
 //   p = u2 - X1, r = s2 - Y1         N - N: |limbs| < 2^29, |value| < 2^257                  (squared / multiplied by N: fine)
-//   x3 = r^2 - ppp - 2 qq            |limbs| < 3 * 2^29, |value| < 2^258  -> carry pass -> N  (it is multiplied by r below)
-//   y3 = r (qq - x3) - Y1 ppp        N - N                                -> carry pass -> N  (it meets s2 in the next r)
-// so two carry passes (24 plain VALU ops each) per addition, and no other reduction of any kind.
+//   x3 = r^2 - ppp - 2 qq            fe9_sqr_minus: limbs normalised, |value| < 2^258            (it is multiplied by r below)
+//   y3 = r (qq - x3) - Y1 ppp        fe9_dot2 (one reduction for both products): |r (qq - x3)| < 2^257 * 1.25 * 2^258 and
+//                                    |Y1 ppp| < 2^512, sum < 2^516 -> N                         (it meets s2 in the next r)
+// so no carry pass at all: the two results that used to need one leave the multiplier normalised.
 #pragma once
 #include "curve.cuh"
 #include "field9.cuh"
@@ -123,8 +124,11 @@ template <int F> __device__ __forceinline__ void xyzz9_madd(xyzz9<F> &acc, const
     const fe9 pp = fe9_sqr<F>(p);
     const fe9 ppp = fe9_mul<F>(p, pp);
     const fe9 qq = fe9_mul<F>(acc.x, pp);
-    const fe9 x3 = fe9_norm(fe9_sub(fe9_sub(fe9_sqr<F>(r), ppp), fe9_dbl(qq)));
-    const fe9 y3 = fe9_norm(fe9_sub(fe9_mul<F>(r, fe9_sub(qq, x3)), fe9_mul<F>(acc.y, ppp)));
+    // X3 = R^2 - PPP - 2 Q and Y3 = R (Q - X3) - Y1 PPP in the fused forms (field9.cuh): the subtrahend of X3 rides in the
+    // square's upper columns, the two products of Y3 share one reduction -- 138 instructions fewer than two products, a square,
+    // three subtractions and two carry passes, and both results leave normalised
+    const fe9 x3 = fe9_sqr_minus<F>(r, fe9_add(fe9_dbl(qq), ppp));
+    const fe9 y3 = fe9_dot2<F>(r, fe9_sub(qq, x3), fe9_sub(fe9_zero(), acc.y), ppp);
     acc.x = x3;
     acc.y = y3;
     acc.zz = fe9_mul<F>(acc.zz, pp);
@@ -162,8 +166,8 @@ template <int F> __device__ __forceinline__ void xyzz9_add(xyzz9<F> &acc, const 
     const fe9 pp = fe9_sqr<F>(p);
     const fe9 ppp = fe9_mul<F>(p, pp);
     const fe9 qq = fe9_mul<F>(u1, pp);
-    const fe9 x3 = fe9_norm(fe9_sub(fe9_sub(fe9_sqr<F>(r), ppp), fe9_dbl(qq)));
-    const fe9 y3 = fe9_norm(fe9_sub(fe9_mul<F>(r, fe9_sub(qq, x3)), fe9_mul<F>(s1, ppp)));
+    const fe9 x3 = fe9_sqr_minus<F>(r, fe9_add(fe9_dbl(qq), ppp));
+    const fe9 y3 = fe9_dot2<F>(r, fe9_sub(qq, x3), fe9_sub(fe9_zero(), s1), ppp);
     acc.x = x3;
     acc.y = y3;
     acc.zz = fe9_mul<F>(fe9_mul<F>(acc.zz, q.zz), pp);

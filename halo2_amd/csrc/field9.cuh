@@ -163,6 +163,29 @@ template <int F> __device__ __forceinline__ fe9 fe9_sqr(const fe9 &a) {
 #endif
 }
 
+// ---- fused forms for the point formulas (generated, gen_field9_mul.py) ----------------------------------------------------------
+// fe9_dot2(a, b, c, d) = (a b + c d) 2^-261: both products share one pass over the columns and ONE Montgomery reduction (207
+// multiply-adds against 2 x 126, and the difference of two products needs no subtraction / carry pass afterwards).  A column holds
+// at most 18 + 5 terms below 2^58: limbs of all four operands in [-2^29, 2^29], |a b + c d| < 2^516 for a normalised result.
+// fe9_sqr_minus(a, s) = a^2 2^-261 - s for a signed limb vector s (limbs below 2^31 in magnitude): s_i enters column 9 + i with
+// weight -1, the result leaves normalised like any product (value: that of the square, in (-2^255, 2^255 + p), minus s).
+template <int F> __device__ __forceinline__ fe9 fe9_dot2(const fe9 &a, const fe9 &b, const fe9 &c, const fe9 &d) {
+#if H2_FE9_IMPL == 0
+    return fe9_norm(fe9_add(fe9_mul_c<F>(a, b), fe9_mul_c<F>(c, d)));
+#else
+#include "field9_dot2.inc"
+    return r;
+#endif
+}
+template <int F> __device__ __forceinline__ fe9 fe9_sqr_minus(const fe9 &a, const fe9 &s) {
+#if H2_FE9_IMPL == 0
+    return fe9_norm(fe9_sub(fe9_sqr_c<F>(a), s));
+#else
+#include "field9_sqr_minus.inc"
+    return r;
+#endif
+}
+
 // ---- 8 x 32 <-> 9 x 29 repacking (values, not Montgomery forms) -------------------------------------------------------
 __device__ __forceinline__ fe9 fe9_unpack(const fe &a) {
     fe9 r;

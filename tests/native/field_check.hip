@@ -91,6 +91,7 @@ template <int F, int IMPL> __global__ void __launch_bounds__(256) k_chain(const 
 // ---- the carry-free 9 x 29 layer (field9.cuh) against the C oracle.  Inputs / outputs cross in the reference's Montgomery form.
 // op 0: mul   1: sqr   2: (a - b)^2 (a + b - 3a) on signed un-normalised limbs   3: a - b after a carry pass
 // op 4: bridge round trip r256 -> M9 -> r256   5: plain-C multiplier (fe9_mul_c)   6: M9 table form (aff_to_m9 + unpack) times b
+// op 8: fe9_dot2 (two products, one reduction)   9: fe9_sqr_minus (subtrahend in the upper columns of the square)
 template <int F> __global__ void k_ops9(const u32 *a, const u32 *b, u32 *out, int n, int op) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -105,6 +106,8 @@ template <int F> __global__ void k_ops9(const u32 *a, const u32 *b, u32 *out, in
         case 4: r = fe9_to_r256<F>(x9); break;
         case 5: r = fe9_to_r256<F>(fe9_mul_c<F>(x9, y9)); break;
         case 7: r = fe_redc<F>(x); break;                                  // = fe_from_mont: the sort kernels' canonicalisation
+        case 8: r = fe9_to_r256<F>(fe9_dot2<F>(x9, y9, fe9_sub(x9, y9), fe9_sub(fe9_zero(), fe9_add(x9, y9)))); break;   // a b - (a - b)(a + b), signed limbs
+        case 9: r = fe9_to_r256<F>(fe9_sqr_minus<F>(fe9_sub(x9, y9), fe9_add(fe9_dbl(x9), y9))); break;                   // (a - b)^2 - (2 a + b)
         default: {
             affine<F> pt{x, x};
             const aff9<F> q = aff9_unpack<F>(aff_to_m9<F>(pt));
@@ -185,9 +188,9 @@ template <int F> int run_wide9(const u32 *da, const u32 *db, int n) {
 }
 template <int F> int run_field9(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b, const u32 *da, const u32 *db, u32 *dout, int n) {
     std::vector<uint64_t> got(4 * (size_t)n);
-    const char *names[] = {"fe9 mul", "fe9 sqr", "fe9 signed chain", "fe9 sub+norm", "fe9 bridge", "fe9 mul_c", "fe9 table form", "fe_redc"};
+    const char *names[] = {"fe9 mul", "fe9 sqr", "fe9 signed chain", "fe9 sub+norm", "fe9 bridge", "fe9 mul_c", "fe9 table form", "fe_redc", "fe9 dot2", "fe9 sqr_minus"};
     int fails = 0;
-    for (int op = 0; op < 8; ++op) {
+    for (int op = 0; op < 10; ++op) {
         hipLaunchKernelGGL((k_ops9<F>), dim3((n + 255) / 256), dim3(256), 0, 0, da, db, dout, n, op);
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(got.data(), dout, 32 * (size_t)n, hipMemcpyDeviceToHost));
@@ -203,7 +206,11 @@ template <int F> int run_field9(const std::vector<uint64_t> &a, const std::vecto
                 orc_f_mul(F, w, t, u);
             } else if (op == 3) orc_f_sub(F, w, x, y);
             else if (op == 7) { memcpy(w, x, 32); orc_from_mont(F, w, 1); }
-            else memcpy(w, x, 32);
+            else if (op == 8) {
+                orc_f_mul(F, w, x, y); orc_f_sub(F, t, x, y); orc_f_add(F, u, x, y); orc_f_mul(F, t, t, u); orc_f_sub(F, w, w, t);
+            } else if (op == 9) {
+                orc_f_sub(F, t, x, y); orc_f_mul(F, t, t, t); orc_f_add(F, u, x, x); orc_f_add(F, u, u, y); orc_f_sub(F, w, t, u);
+            } else memcpy(w, x, 32);
             if (memcmp(w, &got[4 * i], 32)) { if (!bad) printf("  first mismatch %s idx %d\n", names[op], i); bad++; }
         }
         printf("field %d %-16s: %d/%d mismatches\n", F, names[op], bad, n);
