@@ -106,8 +106,8 @@ template <int F> __device__ __forceinline__ void xyzz9_madd(xyzz9<F> &acc, const
     if (xyzz9_is_identity(acc)) {
         acc.x = q.x;
         acc.y = q.y;
-        acc.zz = fe9_one<F>();
-        acc.zzz = fe9_one<F>();
+        acc.zz = fe9_one_here<F>();      // (as plain constants hipcc hoists their 12 v_mov to the top of the accumulation loop: every
+        acc.zzz = acc.zz;                //  iteration paid for what the first entry of a bucket needs)
         return;
     }
     const fe9 u2 = fe9_mul<F>(q.x, acc.zz);
