@@ -158,7 +158,10 @@ template <int F> __device__ __forceinline__ void xyzz9_add(xyzz9<F> &acc, const 
     const fe9 p = fe9_sub(u2, u1), r = fe9_sub(s2, s1);
     if (fe9_maybe_zero_mod_p(p)) {
         xyzz9<F> special;
-        if (xyzz9_add_rare<F>(p, r, acc, &special)) {
+        // the OTHER operand goes to the out-of-line function (when it matters the two are the same point): handing over the
+        // loop-carried accumulator made hipcc keep it in scratch memory through every caller's loop (36 words stored and
+        // reloaded per addition -- 78 MB of scratch writes per launch of the line-sum kernel)
+        if (xyzz9_add_rare<F>(p, r, q, &special)) {
             acc = special;
             return;
         }

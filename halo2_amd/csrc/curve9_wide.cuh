@@ -69,7 +69,7 @@ template <int F> __device__ __forceinline__ void xyzz9_add_wide(xyzz9<F> &acc, c
     const fe9 p = fe9_sub(u2, u1), rr = fe9_sub(s2, s1);
     if (fe9_maybe_zero_mod_p(p)) {                       // rare; every lane of the quad takes the same one-lane path
         xyzz9<F> special;
-        if (xyzz9_add_rare<F>(p, rr, acc, &special)) {
+        if (xyzz9_add_rare<F>(p, rr, q, &special)) {          // q, not acc: see xyzz9_add
             acc = special;
             return;
         }
