@@ -1475,17 +1475,18 @@ __global__ void __launch_bounds__(256, 3) fold9_rowcol(const u32 *__restrict__ b
 // The rest of the fold of a wide slice in ONE launch.  sum_j (j + 1) B_j = sum_lo (lo + 1) C_lo + S sum_hi hi R_hi is a sum of
 // `planes` = log2 S + log2 NR bit planes: plane t (weight 2^t) holds the columns with bit t of lo + 1 set (t < log2 S; plane
 // log2 S holds C_{S-1} alone) and the rows with bit t - log2 S of hi set.  Workgroup t sums plane t -- a tree over at most
-// S / 2 + NR / 2 lines, no doubling anywhere -- and the workgroup that finishes LAST (a counter behind a fence; it leaves
-// the counter at zero for the next launch) combines the planes pairwise: T[2 k s] += 2^s T[(2 k + 1) s] for s = 1, 2, 4, ...:
-// 19 dependent quad-lane operations for 16 planes, against the ~60 of a running sum over segments, a slice tree and a Horner
-// step in three launches (reduce_segments + sum_slice + combine: 126 us of a 1.28 ms commit; this kernel: see DESIGN.md).
+// S / 2 + NR / 2 lines --, doubles the sum t times (the planes do that side by side: the top plane's t doublings are the chain
+// nothing shortens, everything else hides behind it), and the workgroup that finishes LAST (a counter behind a fence; it leaves
+// the counter at zero for the next launch) adds the 16 weighted planes with one more tree: ~8 + 15 + 5 dependent quad-lane
+// operations, against the ~60 of a running sum over segments, a slice tree and a Horner step in three launches
+// (reduce_segments + sum_slice + combine: 126 us of a 1.28 ms commit; this kernel: ~70).
 template <int FB>
 __global__ void __launch_bounds__(256, 3) fold9_planes(const u32 *__restrict__ lines9, u32 *__restrict__ planes9, u32 *__restrict__ counter, u32 S, u32 NR,
                                                     int cb, u32 *__restrict__ out, int out_kind, int out_mont) {
     H2_LATENCY_STAGE();
     __shared__ __attribute__((aligned(16))) u32 sh[32 * 36];
     __shared__ u32 s_last;
-    const u32 t = blockIdx.x, planes = gridDim.x, q = threadIdx.x / kGroup;
+    const u32 t = blockIdx.x, planes = gridDim.x;
     const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
     lines9 += 36 * (size_t)blockIdx.y * (S + NR);                     // blockIdx.y: the bucket slice = the output (paired commits: 2)
     planes9 += 36 * (size_t)blockIdx.y * 32;
@@ -1502,36 +1503,23 @@ __global__ void __launch_bounds__(256, 3) fold9_planes(const u32 *__restrict__ l
         return S + (((r >> jr) << (jr + 1)) | (1u << jr) | (r & ((1u << jr) - 1u)));                // k-th hi with bit jr set
     });
     acc = fold9_quads_sum<FB>(acc, sh);
-    if (fold9_root() && lead) {
-        xyzz9_store_raw<FB>(planes9 + 36 * (size_t)t, acc);
-        __threadfence();
-        s_last = atomicAdd(counter, 1u) == planes - 1 ? 1u : 0u;
+    if (fold9_root()) {
+        for (u32 k = 0; k < t; ++k) acc = xyzz9_dbl_wide<FB>(acc);         // the plane's weight, applied here: the planes double side by side
+        if (lead) {
+            xyzz9_store_raw<FB>(planes9 + 36 * (size_t)t, acc);
+            __threadfence();
+            s_last = atomicAdd(counter, 1u) == planes - 1 ? 1u : 0u;
+        }
     }
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    // pairwise combination of the planes (slots beyond `planes` are identities: their doublings return at once)
-    if (q < 32 && lead) xyzz9_store_raw<FB>(sh + 36 * (size_t)q, q < planes ? xyzz9_load_raw<FB>(planes9 + 36 * (size_t)q) : xyzz9_identity<FB>());
-    __syncthreads();
-    u32 np2 = 1;
-    while (np2 < planes) np2 <<= 1;
-    for (u32 s = 1; s < np2; s <<= 1) {
-        const u32 lo = 2 * q * s, hi = lo + s;
-        const bool mine = hi < planes;
-        xyzz9<FB> a = xyzz9_identity<FB>();
-        if (mine) {
-            xyzz9<FB> b9 = xyzz9_load_raw<FB>(sh + 36 * (size_t)hi);
-            for (u32 k = 0; k < s; ++k) b9 = xyzz9_dbl_wide<FB>(b9);
-            a = xyzz9_load_raw<FB>(sh + 36 * (size_t)lo);
-            xyzz9_add_wide<FB>(a, b9);
-        }
-        __syncthreads();
-        if (mine && lead) xyzz9_store_raw<FB>(sh + 36 * (size_t)lo, a);
-        __syncthreads();
-    }
-    if (threadIdx.x >= kGroup) return;
-    const xyzz<FB> r = xyzz9_to_r256_wide<FB>(xyzz9_load_raw<FB>(sh));
-    if (threadIdx.x != 0) return;
+    // the workgroup that arrived last adds the weighted planes (a tree again)
+    acc = fold9_quad_gather<FB, H2_FOLD_D>(planes9, planes, [](u32 k) { return k; });
+    acc = fold9_quads_sum<FB>(acc, sh);
+    if (!fold9_root()) return;
+    const xyzz<FB> r = xyzz9_to_r256_wide<FB>(acc);
+    if (!lead) return;
     *counter = 0;
     if (out_kind == H2_OUT_AFFINE) {
         affine<FB> o = xyzz_to_affine<FB>(r);
