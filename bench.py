@@ -540,7 +540,7 @@ def main():
         extra["host_pointer_commit"] = {"what": "h2_commit: pageable host scalars -> PCIe in 8 MiB ranges, each committed as it lands -> one fold -> 96 B back; one call at a time (SURVEY 8d 'end-to-end including H2D')",
                                         "ms": round(e2e_ms, 4), "Mscalar_mults_per_s": round(n / e2e_ms / 1e3, 1)}
         # (2b) the literal seam of INTEGRATION.md section 2 at the headline size: best_multiexp -> h2_msm and best_fft -> h2_ntt with HOST
-        # pointers, both PCIe directions inside the call (pageable memory, one call at a time, median of 5)
+        # pointers, both PCIe directions inside the call (pageable memory, one call at a time, median of 5 after one warm-up call)
         def _med(f, reps=5):
             f()
             ts = []
@@ -627,11 +627,12 @@ def main():
                                   "top window of a scalar below q < 2^254 + 2^126 never exceeds 2^16, so the recode carries nothing out of it)",
                                   "achieved_Gmadd_per_s": round(madds / (avg_ms * 1e-3) / 1e9, 2) if acc_cnt else None,
                                   "isolated_Gmadd_per_s": round(madds / (iso["msm_accumulate"] * 1e-3) / 1e9, 2) if iso.get("msm_accumulate") else None,
-                                  "modmul_per_madd": 10, "v_mad_i64_i32_per_madd": 1188, "instructions_per_madd": 2000,
-                                  "issue_bound_Gmadd_per_s": 26.5,
-                                  "issue_bound_source": "1188 v_mad_i64_i32 per mixed add at the measured 4.8 cycles per wave-instruction per SIMD "
-                                                        "(profiles/r01_ubench_valu.txt): 1024 SIMDs x 2.4 GHz x 64 lanes / (1188 x 4.8) - the bound if nothing but the "
-                                                        "multiply-adds issued; the whole add is ~2000 instructions (DESIGN.md section 3.1; profiles/r02_ubench_fe9.txt: 17.7-18.0 G madd/s for the addition loop alone, which the kernel now reaches)"},
+                                  "modmul_per_madd": 10, "montgomery_reductions_per_madd": 9, "v_mad_i64_i32_per_madd": 1151, "instructions_per_madd": 1800,
+                                  "issue_bound_Gmadd_per_s": 21.8,
+                                  "issue_bound_source": "the mixed addition is ~1800 instructions on its common path (hipcc -S: 1151 v_mad_i64_i32 -- 8 products, 2 squares, "
+                                                        "Y3's two products under ONE reduction -- + ~290 shifts / bit ops inside the multipliers + ~360 of unpacking, sign, "
+                                                        "subtractions and loop control); one wave-instruction per 4 cycles per SIMD: 1024 SIMDs x 2.4 GHz x 64 lanes / "
+                                                        "(1800 x 4) -- the bound of THIS instruction stream; isolated_Gmadd_per_s is the kernel alone on the chip (DESIGN.md section 3.3)"},
                          "note": "VALU integer-multiply bound, not HBM bound (DESIGN.md section 3): the HBM fraction is reported as the contract "
                                  "asks, the VALU figures are what track kernel quality; traffic = PMC bytes of the registered-bases path, which "
                                  "gathers 16 precomputed multiples per point from a 1 GiB table by design"},
