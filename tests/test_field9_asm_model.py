@@ -1,0 +1,160 @@
+"""The generated carry-free multipliers (halo2_amd/csrc/field9_*.inc, written by gen_field9_mul.py), checked on the CPU: the
+asm text of each statement is interpreted instruction by instruction (the nine instruction forms the generator emits, with
+their gfx950 semantics on 32- / 64-bit registers) and the result compared with big-integer arithmetic -- value congruent to
+a b 2^-261 (resp. a^2, a b + c d, a^2 - s 2^261) mod p, limbs normalised as field9.cuh promises, the 64-bit column accumulator
+never overflowing.  Signed and un-normalised operands at the bounds the point formulas use (curve9.cuh), both Pasta moduli,
+and the limb value 2^29 a product may leave in limb 0.  The device runs the same statements against the C oracle in
+tests/native/field_check.hip; this test needs no GPU."""
+import os
+import random
+import re
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "halo2_amd", "csrc")
+P = {0: 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001,
+     1: 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001}
+M29 = (1 << 29) - 1
+
+
+def _s32(x):
+    x &= 0xFFFFFFFF
+    return x - (1 << 32) if x >> 31 else x
+
+
+def _s64(x):
+    x &= (1 << 64) - 1
+    return x - (1 << 64) if x >> 63 else x
+
+
+def _statement(name):
+    text = open(os.path.join(CSRC, name)).read()
+    asm = re.search(r'asm\("(.*?)"\n\s*:', text, re.S).group(1)
+    return asm.split("\\n\\t")
+
+
+def _run(ins, operands, field):
+    """Interprets one generated statement.  operands: {'a': [9 ints], ...}; returns the nine result limbs (signed 32-bit)."""
+    p = P[field]
+    limbs = [(p >> (29 * i)) & M29 for i in range(9)]
+    reg = {}                                   # 32-bit registers by name, values as unsigned 32-bit
+    for k, v in operands.items():
+        for i, x in enumerate(v):
+            assert -(1 << 31) <= x < (1 << 31)
+            reg[f"%[{k}{i}]"] = x & 0xFFFFFFFF
+    reg["%[k1]"], reg["%[k2]"], reg["%[k3]"] = limbs[1], limbs[2], limbs[3]
+    peak = 0
+
+    def rd32(tok):
+        if tok in reg:
+            return reg[tok]
+        return int(tok, 0) & 0xFFFFFFFF       # inline constant / literal
+
+    def rd64(tok):
+        if tok.startswith("v["):
+            lo, hi = re.match(r"v\[(\d+):(\d+)\]", tok).groups()
+            return reg[f"v{lo}"] | (reg[f"v{hi}"] << 32)
+        return int(tok, 0) & ((1 << 64) - 1)  # -1 / 0 as a 64-bit inline constant
+
+    def wr64(tok, val):
+        lo, hi = re.match(r"v\[(\d+):(\d+)\]", tok).groups()
+        reg[f"v{lo}"], reg[f"v{hi}"] = val & 0xFFFFFFFF, (val >> 32) & 0xFFFFFFFF
+
+    for line in ins:
+        op, rest = line.split(None, 1)
+        a = [t.strip() for t in rest.split(",")]
+        if op in ("s_movk_i32", "s_mov_b32", "v_mov_b32"):
+            reg[a[0]] = rd32(a[1])
+        elif op == "v_mad_i64_i32":            # D = S0 * S1 + S2, signed, 64-bit; a[1] is the (unused) carry-out
+            val = _s32(rd32(a[2])) * _s32(rd32(a[3])) + _s64(rd64(a[4]))
+            assert -(1 << 63) <= val < (1 << 63), "column accumulator overflow"
+            peak = max(peak, abs(val))
+            wr64(a[0], val & ((1 << 64) - 1))
+        elif op == "v_lshl_add_u64":           # D = (S0 << S1) + S2
+            val = (_s64(rd64(a[1])) << int(a[2])) + _s64(rd64(a[3]))
+            assert -(1 << 63) <= val < (1 << 63), "column accumulator overflow"
+            wr64(a[0], val & ((1 << 64) - 1))
+        elif op == "v_ashrrev_i64":            # D = S1 >> S0 (arithmetic)
+            wr64(a[0], (_s64(rd64(a[2])) >> int(a[1])) & ((1 << 64) - 1))
+        elif op == "v_bfi_b32":                # D = (S0 & S1) | (~S0 & S2)
+            s0, s1, s2 = rd32(a[1]), rd32(a[2]), rd32(a[3])
+            reg[a[0]] = ((s0 & s1) | (~s0 & s2)) & 0xFFFFFFFF
+        elif op == "v_and_b32":
+            reg[a[0]] = rd32(a[1]) & rd32(a[2])
+        elif op == "v_add_u32":
+            reg[a[0]] = (rd32(a[1]) + rd32(a[2])) & 0xFFFFFFFF
+        elif op == "v_sub_u32":
+            reg[a[0]] = (rd32(a[1]) - rd32(a[2])) & 0xFFFFFFFF
+        else:
+            raise AssertionError(f"instruction form the model does not know: {line}")
+    return [_s32(reg[f"%[r{i}]"]) for i in range(9)], peak
+
+
+def _value(limbs):
+    return sum(x << (29 * i) for i, x in enumerate(limbs))
+
+
+def _limbs_of(value, rng, spread):
+    """A signed 9-limb representation of `value` (limbs 0..7 within +-2^spread around their canonical digits)."""
+    out, carry = [], 0
+    for i in range(8):
+        digit = ((value >> (29 * i)) & M29) + carry
+        wobble = rng.randrange(-(1 << spread) // (1 << 29), (1 << spread) // (1 << 29) + 1) if spread > 29 else 0
+        out.append(digit - (wobble << 29))
+        carry = wobble
+    out.append((value >> 232) + carry)
+    assert _value(out) == value
+    return out
+
+
+def _operand(rng, p, kind):
+    if kind == "normalised":                   # what a product leaves: value in (-2^255, 2^255 + p), limbs 0..7 in [0, 2^29)
+        return _limbs_of(rng.randrange(-(1 << 255), (1 << 255) + p), rng, 29)
+    if kind == "difference":                   # normalised - normalised: limbs in (-2^29, 2^29), |value| < 2^257
+        a, b = _operand(rng, p, "normalised"), _operand(rng, p, "normalised")
+        return [x - y for x, y in zip(a, b)]
+    if kind == "wide":                         # limbs up to 2^30 in magnitude, |value| < 2^258
+        return _limbs_of(rng.randrange(-(1 << 258) + 1, 1 << 258), rng, 30)
+    raise ValueError(kind)
+
+
+def _check_result(r, want_mod_p, p, value_bound):
+    assert all(0 <= x < (1 << 29) for x in r[1:8]) and 1 <= r[0] <= (1 << 29), r       # limb 0: the pending +1 lands here
+    v = _value(r)
+    assert v % p == want_mod_p % p
+    assert abs(v) < value_bound
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_generated_multipliers_against_big_integers(field):
+    p = P[field]
+    rinv = pow(1 << 261, -1, p)
+    rng = random.Random(0x9E37 + field)
+    mul, sqr = _statement("field9_mul.inc"), _statement("field9_sqr.inc")
+    dot2, sqr_minus = _statement("field9_dot2.inc"), _statement("field9_sqr_minus.inc")
+    assert sum(i.startswith("v_mad") for i in mul) == 126 and sum(i.startswith("v_mad") for i in dot2) == 207
+    for trial in range(60):
+        kinds = ("normalised", "difference", "wide") if trial % 3 else ("normalised", "normalised", "normalised")
+        a, b = _operand(rng, p, kinds[trial % 2]), _operand(rng, p, "normalised")
+        if trial == 7:
+            a[0] = 1 << 29                      # the limb value only a product's limb 0 takes
+        r, _ = _run(mul, {"a": a, "b": b}, field)
+        _check_result(r, _value(a) * _value(b) * rinv, p, (1 << 255) + p + 1)
+        d = _operand(rng, p, "difference")
+        r, _ = _run(sqr, {"a": d}, field)
+        _check_result(r, _value(d) ** 2 * rinv, p, (1 << 255) + p + 1)
+        # Y3 = R (Q - X3) + (-Y1) PPP: difference x difference + normalised x normalised (curve9.cuh)
+        c, e = _operand(rng, p, "difference"), _operand(rng, p, "normalised")
+        f = [-x for x in _operand(rng, p, "normalised")]
+        r, peak = _run(dot2, {"a": d, "b": c, "c": f, "d": e}, field)
+        _check_result(r, (_value(d) * _value(c) + _value(f) * _value(e)) * rinv, p, 1 << 256)
+        assert peak < 1 << 63
+        # X3 = R^2 - (PPP + 2 Q): the subtrahend's limbs reach 3 * 2^29
+        s = [x + 2 * y for x, y in zip(_operand(rng, p, "normalised"), _operand(rng, p, "normalised"))]
+        r, _ = _run(sqr_minus, {"a": d, "s": s}, field)
+        _check_result(r, _value(d) ** 2 * rinv - _value(s), p, 1 << 258)
+    # extreme limbs: every limb of every operand at +-2^29 (the column bound of fe9_dot2: 18 + 5 terms below 2^58)
+    top = [(1 << 29)] * 8 + [1 << 24]
+    neg = [-x for x in top]
+    r, peak = _run(dot2, {"a": top, "b": top, "c": neg, "d": neg}, field)
+    assert peak < 1 << 63 and _value(r) % p == (2 * _value(top) ** 2 * rinv) % p
