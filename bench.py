@@ -628,11 +628,11 @@ def main():
                                   "achieved_Gmadd_per_s": round(madds / (avg_ms * 1e-3) / 1e9, 2) if acc_cnt else None,
                                   "isolated_Gmadd_per_s": round(madds / (iso["msm_accumulate"] * 1e-3) / 1e9, 2) if iso.get("msm_accumulate") else None,
                                   "modmul_per_madd": 10, "montgomery_reductions_per_madd": 9, "v_mad_i64_i32_per_madd": 1151, "instructions_per_madd": 1800,
-                                  "issue_bound_Gmadd_per_s": 21.8,
-                                  "issue_bound_source": "the mixed addition is ~1800 instructions on its common path (hipcc -S: 1151 v_mad_i64_i32 -- 8 products, 2 squares, "
-                                                        "Y3's two products under ONE reduction -- + ~290 shifts / bit ops inside the multipliers + ~360 of unpacking, sign, "
-                                                        "subtractions and loop control); one wave-instruction per 4 cycles per SIMD: 1024 SIMDs x 2.4 GHz x 64 lanes / "
-                                                        "(1800 x 4) -- the bound of THIS instruction stream; isolated_Gmadd_per_s is the kernel alone on the chip (DESIGN.md section 3.3)"},
+                                  "issue_bound_Gmadd_per_s": 23.5,
+                                  "issue_bound_source": "the mixed addition is ~1800 instructions on its common path (hipcc -S), 1151 of them v_mad_i64_i32 (8 products, 2 squares, "
+                                                        "Y3's two products under ONE reduction); a SIMD retires one v_mad_i64_i32 per 5.8 cycles with the kernel's two waves "
+                                                        "resident (bench/ubench_madlat.hip, profiles/r03_ubench_madlat.txt): 1024 SIMDs x 2.4 GHz x 64 lanes / (1151 x 5.8) -- the "
+                                                        "bound if nothing but the multiply-adds took time; isolated_Gmadd_per_s is the kernel alone on the chip (DESIGN.md section 3.3)"},
                          "note": "VALU integer-multiply bound, not HBM bound (DESIGN.md section 3): the HBM fraction is reported as the contract "
                                  "asks, the VALU figures are what track kernel quality; traffic = PMC bytes of the registered-bases path, which "
                                  "gathers 16 precomputed multiples per point from a 1 GiB table by design"},
