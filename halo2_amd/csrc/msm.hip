@@ -1379,6 +1379,7 @@ __global__ void __launch_bounds__(256) fold9_finish(const u32 *__restrict__ head
 // the one-lane form takes ~2700 for up to 64 -- less wave time from the third tree level up, and a third of the latency at
 // every level (a line of 256 buckets: 72 -> ~25 us).
 //
+static constexpr int kOutSliceSum = 100;      // fold9_planes: the slice's sum as XYZZ (32 words) instead of a finished commitment
 #ifndef H2_FOLD_D
 #define H2_FOLD_D 2
 #endif
@@ -1491,7 +1492,7 @@ __global__ void __launch_bounds__(256, 3) fold9_planes(const u32 *__restrict__ l
     lines9 += 36 * (size_t)blockIdx.y * (S + NR);                     // blockIdx.y: the bucket slice = the output (paired commits: 2)
     planes9 += 36 * (size_t)blockIdx.y * 32;
     counter += blockIdx.y;
-    out += (out_kind == H2_OUT_AFFINE ? 16 : 24) * (size_t)blockIdx.y;
+    out += (out_kind == kOutSliceSum ? 32 : out_kind == H2_OUT_AFFINE ? 16 : 24) * (size_t)blockIdx.y;
     const u32 ncol = (int)t < cb ? S / 2 : (int)t == cb ? 1u : 0u, nrow = (int)t >= cb ? NR / 2 : 0u;
     const u32 jc = t, jr = t - (u32)cb;
     xyzz9<FB> acc = fold9_quad_gather<FB, H2_FOLD_D>(lines9, ncol + nrow, [=](u32 k) {
@@ -1521,6 +1522,10 @@ __global__ void __launch_bounds__(256, 3) fold9_planes(const u32 *__restrict__ l
     const xyzz<FB> r = xyzz9_to_r256_wide<FB>(acc);
     if (!lead) return;
     *counter = 0;
+    if (out_kind == kOutSliceSum) {              // a window slice of a generic multiexp: XYZZ in the reference's form, for msm_combine
+        xyzz_store<FB>(out, r);
+        return;
+    }
     if (out_kind == H2_OUT_AFFINE) {
         affine<FB> o = xyzz_to_affine<FB>(r);
         if (!out_mont) { o.x = fe_from_mont<FB>(o.x); o.y = fe_from_mont<FB>(o.y); }
@@ -2096,9 +2101,11 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         // bins of ~16 K entries (kb - 11 bucket bits per bin: 1152 bins for 9 slices of 2^15 buckets), so that pass 2 is the
         // one-launch form with a bin per workgroup in LDS; H2_GLV_BIN_BITS: sweeps only (9 = the chunked pass 2 of round 2)
         // Up to 2^19 scalars only: the carry slice of the split (the window above the top of a 128-bit half) puts ~n / 2 entries
-        // into ONE bucket, and a bin that large is scattered by a single workgroup (2^19: sort 0.28 -> 0.16 ms; 2^20: 0.30 -> 0.61)
+        // into ONE bucket, and a bin that large was scattered by a single workgroup (2^19: sort 0.28 -> 0.16 ms; 2^20: 0.30 -> 0.61).
+        // With the oversized-bin kernels (msm_s2_big_*) that bin is chunked over 64 workgroups: 2^20 takes the one-launch form with
+        // 10 bits (1.83 -> 1.71 ms on one box; 11 bits 1.80, 12 bits 1.83); from 2^21 the forms are equal within 1 %.
         static const int glv_bin_bits = [] { const char *e = getenv("H2_GLV_BIN_BITS"); int v = e ? atoi(e) : 0; return v >= 8 && v <= 12 ? v : 0; }();
-        const int bin_bits = glv_bin_bits ? glv_bin_bits : (scalars_n <= ((size_t)1 << 19) ? 11 : 9);
+        const int bin_bits = glv_bin_bits ? glv_bin_bits : (scalars_n <= ((size_t)1 << 19) ? 11 : scalars_n <= ((size_t)1 << 20) ? 10 : 9);
         const int lowb = std::min(31 - lb, std::max(1, kb - bin_bits));
         const u32 nh = (tb + (1u << lowb) - 1) >> lowb;
         const u32 s1 = 1024;
@@ -2119,9 +2126,10 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     if (sh.c > kMaxC && !use_sort2) return H2_ERR_ARGS;   // choose_c only picks wide windows the two-pass sort can take
     const bool wide_reduce = sh.NB > 32768u;              // implies the registered path (one slice)
     static const bool fold9_on = [] { const char *e = getenv("H2_FOLD9"); return !(e && atoi(e) == 0); }();     // A/B switch
-    // first fold levels in throughput form on the raw M9 segments (fold9_* kernels); a range of a chunked commit hands
-    // finished buckets on in the reference's form (add_into), so it keeps the quad-lane finisher
-    const bool fold9 = fold9_on && sh.NB >= 32768u && a.table && !glv && !a.add_into && !fold_only;
+    // the fold on the carry-free layer (fold9_* kernels: registered tables from 16-bit windows, paired commits, and the window
+    // slices of a large generic multiexp); a range of a chunked commit hands finished buckets on in the reference's form
+    // (add_into), so it keeps the 8 x 32 finisher
+    const bool fold9 = fold9_on && sh.NB >= 32768u && m9 && !a.add_into && !fold_only;
     u32 wideS = 0, wideNR = 0;
     if (wide_reduce || fold9) {
         const int bb = sh.c - 1;
@@ -2359,8 +2367,13 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
             while ((1u << cb) < wideS) ++cb;
             hipLaunchKernelGGL((fold9_rowcol<FB>), dim3(wideS + wideNR - 1, sh.slices), dim3(256), 0, st,
                                (const u32 *)(cx.seg9.as<u32>() + 36 * (size_t)T), lines9, wideS, wideNR);
+            const bool windows = glv;                // the slices are window slices: their sums meet in msm_combine's Horner step
             hipLaunchKernelGGL((fold9_planes<FB>), dim3(sh.c - 1, sh.slices), dim3(256), 0, st, (const u32 *)lines9, planes9, cx.fold_ctr.as<u32>(),
-                               wideS, wideNR, cb, (u32 *)a.d_out, a.out_kind, a.form == H2_FORM_MONTGOMERY);
+                               wideS, wideNR, cb, windows ? cx.ssums.as<u32>() : (u32 *)a.d_out, windows ? kOutSliceSum : a.out_kind,
+                               a.form == H2_FORM_MONTGOMERY);
+            if (windows)
+                hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, cx.ssums.as<u32>(), (int)sh.slices, sh.c, (u32 *)a.d_out, a.out_kind,
+                                   a.form == H2_FORM_MONTGOMERY);
             prof_end(PROF_MSM_REDUCE, st);
             TL_STAMP(tl_id | 4);
             H2_HIP(hipGetLastError());
