@@ -2129,7 +2129,8 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     // the fold on the carry-free layer (fold9_* kernels: registered tables from 16-bit windows, paired commits, and the window
     // slices of a large generic multiexp); a range of a chunked commit hands finished buckets on in the reference's form
     // (add_into), so it keeps the 8 x 32 finisher
-    const bool fold9 = fold9_on && sh.NB >= 32768u && m9 && !a.add_into && !fold_only;
+    static const u32 fold9_min_nb = [] { const char *e = getenv("H2_FOLD9_MIN_NB"); int v = e ? atoi(e) : 0; return (u32)(v >= 64 ? v : 128); }();
+    const bool fold9 = fold9_on && sh.NB >= fold9_min_nb && m9 && !a.add_into && !fold_only;
     u32 wideS = 0, wideNR = 0;
     if (wide_reduce || fold9) {
         const int bb = sh.c - 1;
