@@ -408,6 +408,7 @@ struct Sort2 {
     u32 K2, B2;       // pass-2 chunk size and worst-case chunk count
     u32 lds_window;   // widest pass-2 window (buckets) whose counters fit LDS; wider ones count in HBM
     u32 s1_scalars;   // scalars per pass-1 workgroup (a multiple of 1024)
+    u32 run_lanes;    // lanes that copy one bin's run out of the pass-1 stage (a power of two <= 64)
     u32 nb;           // buckets per slice; generic path: sort key = window * nb + bucket, entry = digit column
     int side;         // 1: the low bucket bits of a tagged entry live in the 16-bit side array, not in the entry
     u32 col0;         // registered path: scalar i sits in table column col0 + i (a column RANGE of the table: the chunks of a pipelined host commit)
@@ -591,10 +592,10 @@ __global__ void __launch_bounds__(1024) msm_s1_scatter(const u32 *__restrict__ s
         }
     }
     __syncthreads();
-    // one HALF-wave per bin at a time: contiguous LDS run -> contiguous global run (a workgroup's run of a bin is ~30 entries at
-    // 2048 scalars x 15 digits over 1024 bins: a whole wave per run left half its lanes idle and made the loop twice as long)
-    const u32 wave = threadIdx.x >> 5, lane = threadIdx.x & 31, nwaves = blockDim.x >> 5;
-    constexpr u32 kRunLanes = 32;
+    // P.run_lanes (16) lanes per bin at a time: contiguous LDS run -> contiguous global run.  A workgroup's run of a bin is ~30
+    // entries at 2048 scalars x 15 digits over 1024 bins and a bin costs its group three dependent LDS reads before the first
+    // store, whatever the run's length: the loop is as long as the bins a group walks (whole waves: 2x; half waves -> 16 lanes: -10 us)
+    const u32 kRunLanes = P.run_lanes, wave = threadIdx.x / kRunLanes, lane = threadIdx.x & (kRunLanes - 1), nwaves = blockDim.x / kRunLanes;
     if (!GLV && P.side) {
         for (u32 h = wave; h < nh; h += nwaves) {
             const u32 l0 = lstart[h], l1 = lstart[h + 1];
@@ -2057,6 +2058,8 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     Sort2 S2;
     memset(&S2, 0, sizeof S2);
     S2.pair_shift = -1;
+    static const u32 run_lanes_env = [] { const char *e = getenv("H2_S1_RUN_LANES"); int v = e ? atoi(e) : 0; return (u32)(v == 8 || v == 16 || v == 32 || v == 64 ? v : 16); }();
+    S2.run_lanes = run_lanes_env;
     bool use_sort2 = false;
     if (pair) {
         // key = side * NB + bucket over both slices (the generic path's multi-slice geometry), entry = table index
