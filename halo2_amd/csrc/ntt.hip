@@ -314,6 +314,20 @@ __device__ __forceinline__ fe9 ntt_fold9(const fe9 &v, const i32 *qp) {
     r.v[8] = v.v[8] - z;
     return fe9_norm(r);
 }
+// canonical packed value of a FOLDED element: |value| < 2^253 + 2^132 (ntt_fold9), so value + p lies in (0, 2p) and ONE conditional
+// subtraction is exact (fe9_canonical_small covers (-p, 2p) with two)
+template <int F> __device__ __forceinline__ fe ntt_canonical_folded9(const fe9 &v) {
+    const fe9 pk = fe9_p_shl<F>(0);
+    fe9 t, d;
+#pragma unroll
+    for (int i = 0; i < 9; i++) t.v[i] = v.v[i] + pk.v[i];
+    t = fe9_norm(t);
+#pragma unroll
+    for (int i = 0; i < 9; i++) d.v[i] = t.v[i] - pk.v[i];
+    d = fe9_norm(d);
+    if (d.v[8] >= 0) t = d;
+    return fe9_pack(t);
+}
 // packed, non-negative, below 2^256, same residue (what leaves a pass that is not the last)
 template <int F> __device__ __forceinline__ fe ntt_pack_lazy9(const fe9 &v) {       // |value| < 2^254.2
     const fe9 pk = fe9_p_shl<F>(0);
@@ -404,7 +418,7 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
             const u32 m3 = A.store_mode == 2 ? (u32)(x % 3) : 0;
             w = fe9_canonical_small<F>(fe9_mul<F>(v, m3 == 0 ? k0 : m3 == 1 ? k1 : k2));
         } else if (A.last) {
-            w = fe9_canonical_small<F>(v);
+            w = ntt_canonical_folded9<F>(v);
         } else {
             w = ntt_pack_lazy9<F>(v);
         }
