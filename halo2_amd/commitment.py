@@ -80,7 +80,7 @@ class Params:
         self._h_g = C.c_uint64(0)
         self._h_gl = C.c_uint64(0)
         self.device_index = int(lib().h2_current_device())     # the registered tables live on the device current now
-        # tables that only serve column commits take the width that is fastest for independent commits (17 bits from 2^19 on)
+        # tables that only serve column commits take the width that is fastest for independent commits (17 bits from 2^18 on)
         wb = int(lib().h2_commit_column_window_bits(self.n))
         check(lib().h2_bases_register_ex(curve, _p(self.g), self.n, FORM_MONTGOMERY, wb, C.byref(self._h_g)), "h2_bases_register_ex")
         check(lib().h2_bases_register_ex(curve, _p(self.g_lagrange), self.n, FORM_MONTGOMERY, wb, C.byref(self._h_gl)),

@@ -2680,7 +2680,7 @@ extern "C" int h2_bases_register(int curve, const uint64_t *bases_xy, size_t n, 
     return bases_register_impl(curve, bases_xy, false, n, form, handle);
 }
 
-// Window width for a table that only serves independent column commits (Params::g, g_lagrange): from 2^19 points on 17 bits --
+// Window width for a table that only serves independent column commits (Params::g, g_lagrange): from 2^18 points on 17 bits --
 // 255 = 15 x 17, so a scalar leaves 15 digits instead of 16 (the top window of a scalar below q never exceeds 2^16, half the
 // window, so the signed recode carries nothing out of it): the accumulate is ~6 % shorter, the sort and
 // the fold (2^16 buckets) ~0.07 ms longer, which independent commits hide (953-966 against 925-939 M scalar-mults/s, one box,
@@ -2693,7 +2693,7 @@ extern "C" int h2_commit_column_window_bits(size_t n) {
         const int v = atoi(e);
         if (v >= 4 && v <= kMaxCShared && (v <= kMaxC || (n + 1 < ((size_t)1 << 31) && sort2_geometry((u32)n + 1, v, &lowb, &lb)))) return v;
     }
-    return c == 16 && n >= ((size_t)1 << 19) && n + 1 < ((size_t)1 << 31) && sort2_geometry((u32)n + 1, 17, &lowb, &lb) ? 17 : c;
+    return c == 16 && n >= ((size_t)1 << 18) && n + 1 < ((size_t)1 << 31) && sort2_geometry((u32)n + 1, 17, &lowb, &lb) ? 17 : c;
 }
 
 extern "C" int h2_bases_register_ex(int curve, const uint64_t *bases_xy, size_t n, int form, int window_bits, h2_bases_t *handle) {

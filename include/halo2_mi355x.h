@@ -92,7 +92,7 @@ int h2_bases_register(int curve, const uint64_t *bases_xy, size_t n, int form, h
 int h2_bases_register_device(int curve, const void *d_bases_xy, size_t n, int form, h2_bases_t *handle);
 /* the same with the table's window width chosen by the caller (0 = the library's choice, as h2_bases_register; 4 .. 20, wider
  * than 16 only where the two-pass sort fits: H2_ERR_ARGS otherwise).  h2_commit_column_window_bits(n) is the width to ask for
- * when the table only serves independent column commits (Params::g / g_lagrange): 17 bits from 2^19 points on -- a scalar has
+ * when the table only serves independent column commits (Params::g / g_lagrange): 17 bits from 2^18 points on -- a scalar has
  * 15 digits instead of 16 -- which h2_commit_pair_device and h2_ipa_collapsed_generators_device do not take. */
 int h2_bases_register_ex(int curve, const uint64_t *bases_xy, size_t n, int form, int window_bits, h2_bases_t *handle);
 int h2_commit_column_window_bits(size_t n);
