@@ -156,7 +156,9 @@ static int choose_c(size_t n, bool shared_buckets) {
     // whose top window is nearly empty (255 mod c small: 12, 14) send that window through the heavy-bucket path.  Measured, one
     // commit alone (bench/tools/c_sweep_registered.py): 8 bits up to 2^9 points (0.21-0.27 ms), 10 up to 2^10 (0.32), 13 up to
     // 2^13 (0.35-0.39; 12 bits at 2^12: 0.59; a paired commit at 2^13: 0.39 against 0.44 with 16), 16 from 2^14 on (0.41-0.49;
-    // the cost model below picked 13-14 bits there: 2^15 0.48 -> 0.42).
+    // the cost model below picked 13-14 bits there: 2^15 0.48 -> 0.42).  Re-measured in round 3 with the fold on the carry-free
+    // layer (bench/tools/lone_commit_ms.py, H2_MSM_C): 2^14 / 2^15 / 2^16 at 16 bits 0.24 / 0.27 / 0.27 ms, at 14 bits 0.32 / 0.37 /
+    // 0.42, at 13 bits 0.37 / 0.54 / 0.59 -- the table stands.
     if (shared_buckets) return n <= 512 ? 8 : n <= 1536 ? 10 : n <= 12288 ? 13 : 16;
     double best = 1e300;
     int bc = 4;
