@@ -158,8 +158,9 @@ static int choose_c(size_t n, bool shared_buckets) {
     // 2^13 (0.35-0.39; 12 bits at 2^12: 0.59; a paired commit at 2^13: 0.39 against 0.44 with 16), 16 from 2^14 on (0.41-0.49;
     // the cost model below picked 13-14 bits there: 2^15 0.48 -> 0.42).  Re-measured in round 3 with the fold on the carry-free
     // layer (bench/tools/lone_commit_ms.py, H2_MSM_C): 2^14 / 2^15 / 2^16 at 16 bits 0.24 / 0.27 / 0.27 ms, at 14 bits 0.32 / 0.37 /
-    // 0.42, at 13 bits 0.37 / 0.54 / 0.59 -- the table stands.
-    if (shared_buckets) return n <= 512 ? 8 : n <= 1536 ? 10 : n <= 12288 ? 13 : 16;
+    // 0.42, at 13 bits 0.37 / 0.54 / 0.59; 2^13 at 16 / 13 bits 0.244 / 0.294; 2^12 0.254 / 0.236; 2^11 0.263 / 0.222; 2^10 0.248 / 0.200
+    // (10 bits: 0.258); 2^9 0.251 / 0.196 (8 bits: 0.256); 2^8 at 13 / 8 bits 0.204 / 0.196: 8 bits up to 2^8, 13 up to 2^12, 16 beyond.
+    if (shared_buckets) return n <= 384 ? 8 : n <= 6144 ? 13 : 16;
     double best = 1e300;
     int bc = 4;
     for (int c = 4; c <= kMaxC; ++c) {
