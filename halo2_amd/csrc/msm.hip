@@ -151,7 +151,9 @@ static int choose_c(size_t n, bool shared_buckets) {
     // Small multiexps are pure latency (a chain of ~128 doublings plus the per-slice folds); measured over c = 4..14
     // (bench/tools/c_sweep_small.py): 0.67-0.72 ms at c = 10 up to 2^12 points, c = 13 up to 2^19 (2^18: 1.08 against 1.20 ms at
     // c = 16, 2^19: 1.43 against 1.52; 2^20: equal, and the accumulate is shorter with 16), c = 16 beyond.
-    if (glv) return n <= 4096 ? 10 : n <= 524288 ? 13 : 16;
+    // (round 3, with the fold on the carry-free layer, bench/tools/generic_ms.py: 2^12 at 13 / 10 bits 0.461 / 0.474 ms; 2^18 at 16 / 13
+    // bits 0.846 / 0.851; 2^19 1.11 / 1.165: 10 bits up to 2^11, 13 up to 2^18, 16 beyond)
+    if (glv) return n <= 2048 ? 10 : n <= 262144 ? 13 : 16;
     // Registered tables: a commit below ~2^17 points is a chain of latency-bound kernels, not bucket arithmetic, and the widths
     // whose top window is nearly empty (255 mod c small: 12, 14) send that window through the heavy-bucket path.  Measured, one
     // commit alone (bench/tools/c_sweep_registered.py): 8 bits up to 2^9 points (0.21-0.27 ms), 10 up to 2^10 (0.32), 13 up to
