@@ -59,7 +59,7 @@ def test_argument_validation_without_gpu():
     assert lib.h2_ipa_default_switch_rounds(20, 1) == 6 and lib.h2_ipa_default_switch_rounds(16, 1) == 2
     assert lib.h2_ipa_default_switch_rounds(15, 1) == 0 and lib.h2_ipa_default_switch_rounds(20, 0) == 0
     assert lib.h2_commit_pair_supported(8192 + 4) == 1 and lib.h2_commit_pair_supported(4096 + 4) == 0
-    assert [lib.h2_commit_window_bits(1 << k) for k in (4, 10, 12, 13, 14, 20)] == [8, 10, 13, 13, 16, 16]
+    assert [lib.h2_commit_window_bits(1 << k) for k in (4, 10, 12, 13, 14, 20)] == [8, 13, 13, 16, 16, 16]
     hh = C.c_uint64(0)
     assert lib.h2_bases_register_device(9, None, 4, 1, C.byref(hh)) == _lib.H2_ERR_ARGS
     assert lib.h2_ipa_collapsed_generators_device(424242, 16, 2, p(z4), 1, None, None) == _lib.H2_ERR_HANDLE
