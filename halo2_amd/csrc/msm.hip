@@ -2138,7 +2138,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     // slices of a large generic multiexp); a range of a chunked commit hands finished buckets on in the reference's form
     // (add_into), so it keeps the 8 x 32 finisher
     static const u32 fold9_min_nb = [] { const char *e = getenv("H2_FOLD9_MIN_NB"); int v = e ? atoi(e) : 0; return (u32)(v >= 64 ? v : 128); }();
-    const bool fold9 = fold9_on && sh.NB >= fold9_min_nb && m9 && !a.add_into && !fold_only;
+    const bool fold9 = fold9_on && sh.NB >= fold9_min_nb && sh.slices <= 16 && m9 && !a.add_into && !fold_only;      // (16: arrival counters of fold9_planes)
     u32 wideS = 0, wideNR = 0;
     if (wide_reduce || fold9) {
         const int bb = sh.c - 1;
