@@ -77,6 +77,8 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", os.environ.get("MASTER_PORT", "29517"), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
+    if rank != 0:
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)        # only rank 0 speaks on stdout (libraries print banners through C stdio)
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                  f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
@@ -653,11 +655,24 @@ def main():
             "config5": config5,
             "input_gen_s": round(gen_s, 2),
         }
-        print(json.dumps(out))
+        final_line = json.dumps(out)
     lib.h2_bases_free(params_g)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # The JSON line is the LAST thing on stdout: RCCL (torch's communicator, the library's own) prints a version banner through
+        # C stdio, which sits in the C buffer until the process exits -- i.e. it would land AFTER a line printed from Python.  Flush
+        # the C buffers first, print, then point fd 1 at /dev/null so that nothing a library says at teardown can follow the line.
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(final_line)
+        sys.stdout.flush()
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
 
 
 if __name__ == "__main__":
