@@ -10,6 +10,9 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 # 2. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes over the minimal workload (timed commits + NTT leg)
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/r03_pmc_f -o f --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --prewarm-ms 0 --minimal --no-cpu-baseline --streams 1 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/r03_pmc_w -o w --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --prewarm-ms 0 --minimal --no-cpu-baseline --streams 1 > /dev/null 2>&1
+# 3. issue / wait shares of a wave's cycles (SQ counters, one pass): summarise with bench/tools/sq_summary.py > profiles/r03_pmc_sq.json
+C="SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+timeout 300 rocprofv3 --pmc $C -d $R/gpurun_out/r03_sq_msm -o m --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --prewarm-ms 0 --minimal --no-cpu-baseline --streams 1 > /dev/null 2>&1
 ls $R/gpurun_out/r03_stats $R/gpurun_out/r03_pmc_f | head
 # afterwards, in the repo:
 #   python bench/pmc_summary.py gpurun_out/r03_pmc_f/f_counter_collection.csv gpurun_out/r03_pmc_w/w_counter_collection.csv > profiles/r03_pmc_traffic.json

@@ -11,7 +11,7 @@ import sys
 
 def main():
     out = {"source": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS "
-                     "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE (one pass, no trace domains) -- python bench/tools/ntt_only.py 22  /  python bench.py "
+                     "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE (one pass, no trace domains) -- python bench.py "
                      "--steps 3 --warmup 1 --prewarm-ms 0 --minimal --no-cpu-baseline --streams 1; every counter divided by SQ_WAVE_CYCLES of "
                      "the same kernel (share of a wave's cycles)", "kernels": {}}
     for path in sys.argv[1:]:
