@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--columns", type=int, default=4, help="distinct scalar columns resident in HBM")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("H2_BENCH_STREAMS", "3")),
                     help="HIP streams the independent column commits are spread over (per GPU)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("H2_BENCH_BATCH", "5")),
+                    help="column commits per h2_commit_batch_device call (the columns of a prover phase are independent, plonk/prover.rs:301-313): "
+                         "K consecutive steps share one sort / accumulate / fold launch set; 1 = one h2_commit_device call per step")
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed commits issued before the W warm-up steps until this much wall time has passed: the chip's clocks "
                          "take a few hundred ms of sustained load to settle (the first ~20 launches of a cold run are 10-15 %% slower)")
@@ -116,7 +119,13 @@ def main():
     params_g = C.c_uint64(0)
     from halo2_amd.arithmetic import _p
     col_bits = int(lib.h2_commit_column_window_bits(n))       # Params::g as halo2_amd.Params registers it (17-bit windows at 2^20)
+    # per-device setup, timed apart from the steps so that a 1 -> 8 GPU curve can be separated from it: the 64 MiB upload of `g`
+    # from pageable host memory + the table build (15 or 16 rows of 2^(c w) multiples, 1 GiB at k = 20) -- once per Params per GPU
+    torch.cuda.synchronize()
+    t_reg = time.perf_counter()
     check(lib.h2_bases_register_ex(curve, _p(bases), n, h.FORM_MONTGOMERY, col_bits, C.byref(params_g)), "h2_bases_register_ex")
+    torch.cuda.synchronize()
+    register_ms = (time.perf_counter() - t_reg) * 1e3
     d_cols = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]
     # the blind term of Params::commit: w = a further seeded point, r = one seeded scalar per column (commitment.rs:119-130)
     w_host = co.generate_bases(curve, 0x77, 1)[0]
@@ -135,28 +144,44 @@ def main():
                                   0, d_out[i % d_out.shape[0]].data_ptr(), sps[i % len(sps)])
         check(rc, "h2_commit_device")
 
+    # K steps per call: the library's column-batched commit (one launch set for K independent columns, blockIdx.z = column).
+    # A step is still ONE column commit with its blind; the batches go round-robin over the streams.
+    K_B = max(1, min(args.batch, 8))
+    vpK = C.c_void_p * K_B
+
+    def step_batch(i0, k, j):
+        cs_ = [(i0 + q) % len(d_cols) for q in range(k)]
+        rc = lib.h2_commit_batch_device(params_g, (C.c_void_p * k)(*[d_cols[c_].data_ptr() for c_ in cs_]), k, n, None,
+                                        (C.c_void_p * k)(*[d_blinds[c_].data_ptr() for c_ in cs_]), h.FORM_MONTGOMERY, 0,
+                                        (C.c_void_p * k)(*[d_out[(i0 + q) % d_out.shape[0]].data_ptr() for q in range(k)]), sps[j % len(sps)])
+        check(rc, "h2_commit_batch_device")
+
+    def run_steps(count):
+        if K_B <= 1:
+            for i in range(count):
+                step(i)
+            return
+        for j, i0 in enumerate(range(0, count, K_B)):
+            step_batch(i0, min(K_B, count - i0), j)
+
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(len(sps)):     # one untimed commit per stream: each (device, stream) pair owns a workspace that is
-        step(i)                   # allocated on first use (hipMalloc synchronises the device)
-    sync_all()
+    run_steps(len(sps) * K_B)     # one untimed call per stream: each (device, stream) pair owns a workspace that is
+    sync_all()                    # allocated on first use (hipMalloc synchronises the device)
     t_pre = time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:      # clock settling, untimed (not part of W or K)
-        for i in range(2 * len(sps)):
-            step(i)
+        run_steps(2 * len(sps) * K_B)
         torch.cuda.synchronize()
     sync_all()
-    for i in range(args.warmup):
-        step(i)
+    run_steps(args.warmup)
     sync_all()
     lib.h2_profile_enable(1)
     sync_all()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -167,6 +192,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if world > 1:                 # setup: the slowest rank's (8 table builds share nothing but the host's memory bandwidth)
+        t = torch.tensor([register_ms], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        register_ms = float(t.item())
     prof, busy = {}, {}
     for name, slot in (("msm_accumulate", 0), ("msm_sort", 2), ("msm_reduce", 3)):
         ms, bz, cnt = C.c_double(0), C.c_double(0), C.c_uint64(0)
@@ -606,8 +635,9 @@ def main():
         # their durations would count shared time once per launch (r1: 1.82 ms "per launch" inside a 1.33 ms step)
         avg_ms = busy["msm_accumulate"] / max(acc_cnt, 1)
         sum_ms = acc_ms / max(acc_cnt, 1)
-        achieved = ALGO_BYTES_PER_PAIR * (n + 1) / (avg_ms * 1e-3) / 1e9 if acc_cnt else None
-        madds = (255 // col_bits + (1 if 255 % col_bits else 0)) * (n + 1)      # non-zero digits per scalar: 16 at 16 bits, 15 at 17 (255 = 15 x 17)
+        cols_per_launch = args.steps / max(acc_cnt, 1)          # a batched commit accumulates its K columns in ONE launch (blockIdx.z = column)
+        achieved = ALGO_BYTES_PER_PAIR * (n + 1) * cols_per_launch / (avg_ms * 1e-3) / 1e9 if acc_cnt else None
+        madds = (255 // col_bits + (1 if 255 % col_bits else 0)) * (n + 1)      # per COLUMN; non-zero digits per scalar: 16 at 16 bits, 15 at 17 (255 = 15 x 17)
         out = {
             "metric": "Pallas MSM Mscalar-mults/s (+ Fp NTT Gbutterflies/s) at k=20",
             "value": round(value, 3), "unit": "Mscalar-mults/s", "n_gpus": world, "steps": args.steps,
@@ -617,17 +647,20 @@ def main():
             "config": {"workload": f"2^{args.log_n}-point Pallas best_multiexp, uniform random Fq scalars, "
                                    "bases resident (Params::g registered), one column commit WITH its blind term per step per GPU",
                        "window_bits": col_bits, "columns_resident": args.columns, "streams": len(streams),
+                       "columns_per_call": K_B, "columns_per_call_note": "K consecutive steps = K independent columns handed to h2_commit_batch_device in one call "
+                                                                         "(plonk/prover.rs:301-313 commits a phase's columns together); every step is still one full 2^20 commit with its blind",
                        "msm_lane_fraction": lane_fraction,
                        "parallelism": f"{world} GPU(s) x {len(streams)} stream(s) of independent column commits"},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 2) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
-                         "traffic": traffic, "avg_kernel_ms": round(avg_ms, 4), "launches": int(acc_cnt),
+                         "traffic": int(traffic * cols_per_launch) if traffic else traffic, "avg_kernel_ms": round(avg_ms, 4), "launches": int(acc_cnt),
+                         "columns_per_launch": round(cols_per_launch, 3),
                          "avg_kernel_ms_definition": "union of the launch intervals on the device / launches (HIP events on the launching "
                                                      "streams, timed region only); overlapped_launch_ms = plain mean of the launch durations",
                          "overlapped_launch_ms": round(sum_ms, 4), "kernel_ms_isolated": iso.get("msm_accumulate"),
-                         "valu": {"madd_per_launch": madds, "madd_per_launch_definition": "non-zero digits of the column: 16 per scalar at 16-bit windows, 15 at 17 bits (255 = 15 x 17; the "
+                         "valu": {"madd_per_launch": int(madds * cols_per_launch), "madd_per_launch_definition": "columns_per_launch x non-zero digits of the column: 16 per scalar at 16-bit windows, 15 at 17 bits (255 = 15 x 17; the "
                                   "top window of a scalar below q < 2^254 + 2^126 never exceeds 2^16, so the recode carries nothing out of it)",
-                                  "achieved_Gmadd_per_s": round(madds / (avg_ms * 1e-3) / 1e9, 2) if acc_cnt else None,
+                                  "achieved_Gmadd_per_s": round(madds * cols_per_launch / (avg_ms * 1e-3) / 1e9, 2) if acc_cnt else None,
                                   "isolated_Gmadd_per_s": round(madds / (iso["msm_accumulate"] * 1e-3) / 1e9, 2) if iso.get("msm_accumulate") else None,
                                   "modmul_per_madd": 10, "montgomery_reductions_per_madd": 9, "v_mad_i64_i32_per_madd": 1151, "instructions_per_madd": 1800,
                                   "issue_bound_Gmadd_per_s": 23.5,
@@ -653,6 +686,9 @@ def main():
             "generic_best_multiexp": generic, "extra": extra, "skewed_columns": skew, "ntt": ntt, "cpu_baseline": cpu,
             "checks": {"split_sum_identity": None if split_ok is None else bool(split_ok), "split_msm_allgather": split_msm_ok, "split_msm_rccl_in_library": split_rccl_c},
             "config5": config5,
+            "setup": {"bases_register_ms_max_over_ranks": round(register_ms, 1),
+                      "what": "h2_bases_register_ex per GPU, untimed by the steps: 64 MiB of `g` from pageable host memory + the precomputed table "
+                              f"({255 // col_bits + (1 if 255 % col_bits else 0)} rows of {n} + 1 points, 64 B each); once per Params per device"},
             "input_gen_s": round(gen_s, 2),
         }
         final_line = json.dumps(out)

@@ -38,6 +38,7 @@ SIGNATURES = {
     "h2_commit_column_window_bits": ([C.c_size_t], C.c_int),
     "h2_bases_set_blind_base": ([C.c_uint64, u64p, C.c_int], C.c_int),
     "h2_bases_info": ([C.c_uint64, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+    "h2_bases_blind_base_set": ([C.c_uint64], C.c_int),
     "h2_bases_free": ([C.c_uint64], C.c_int),
     "h2_commit": ([C.c_uint64, u64p, C.c_size_t, u64p, u64p, C.c_int, C.c_int, u64p], C.c_int),
     "h2_ntt": ([C.c_int, u64p, C.c_uint, u64p, C.c_int], C.c_int),

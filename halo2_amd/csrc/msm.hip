@@ -421,6 +421,25 @@ struct Sort2 {
     u32 pair_n;       //       i >= pair_n feeds output (i - pair_n) & 1; sort key = side * nb + bucket (two bucket slices)
 };
 
+// ---- column-batched launches ------------------------------------------------------------------------------------------------------
+// The column commits of a prover phase are independent multiexps over ONE registered table (plonk/prover.rs:93-101, 301-313;
+// vanishing/prover.rs:96-108).  A batched commit (h2_commit_batch_device) runs every stage ONCE for K columns: blockIdx.z is the
+// column, the per-column work areas lie a fixed stride apart, the scalar / blind / output pointers ride in the kernel arguments.
+// The sort and fold stages are chains of short latency-bound launches when they serve one column; with K columns per launch they
+// become throughput kernels, and the accumulate's K x 512 workgroups refill the chip as they retire instead of as whole launches.
+static constexpr int kMaxCols = 8;
+struct ColIn {                      // pass 1 of the sort
+    const u32 *scalars[kMaxCols];
+    const u32 *blinds[kMaxCols];    // null entries: no blind term
+};
+struct ColOut {                     // fold9_planes
+    u32 *out[kMaxCols];
+};
+struct ColStride {                  // 32-bit words between the areas of consecutive columns (all zero for a single column)
+    u32 hist, plan, items, starts, heavy, hscratch, heads, buckets, lines, planes, ctr;
+};
+#define H2_COLZ(ptr, stride) ((ptr) + (size_t)blockIdx.z * (stride))
+
 // signed window digits of one scalar (same recoding as msm_recode, 32-bit codes so that windows may exceed 16 bits),
 // handed to f(w, code): code = kZero32 for digit 0, else (|d| - 1) | (d < 0) << 31
 template <int C, typename Fn> __device__ __forceinline__ void for_each_digit_static(const fe &s, Fn f) {
@@ -503,9 +522,14 @@ __device__ __forceinline__ void emit_entries(const fe &s, u32 i, const Sort2 &P,
 // pass 1, COUNT: hist1[blk][h] = this workgroup's entries per bin
 template <int FS, bool GLV>
 __global__ void __launch_bounds__(1024) msm_s1_count(const u32 *__restrict__ scalars, const u32 *__restrict__ extra_scalar, Sort2 P,
-                                                     u32 *__restrict__ hist1) {
+                                                     u32 *__restrict__ hist1, ColIn ci, ColStride cs) {
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [nh] counters
+    if (gridDim.z > 1) {
+        scalars = ci.scalars[blockIdx.z];
+        extra_scalar = ci.blinds[blockIdx.z];
+        hist1 = H2_COLZ(hist1, cs.hist);
+    }
     const u32 nh = P.nh, blk = blockIdx.x;
     for (u32 h = threadIdx.x; h < nh; h += blockDim.x) sh[h] = 0;
     __syncthreads();
@@ -545,9 +569,19 @@ __device__ __forceinline__ u32 wave0_excl_scan(u32 *v, u32 n) {
 template <int FS, bool GLV>
 __global__ void __launch_bounds__(1024) msm_s1_scatter(const u32 *__restrict__ scalars, const u32 *__restrict__ extra_scalar, Sort2 P,
                                                        const u32 *__restrict__ hist1, const u32 *__restrict__ bin_count,
-                                                       u32 *__restrict__ bin_start, u32 *__restrict__ tagged, uint16_t *__restrict__ tagged_low) {
+                                                       u32 *__restrict__ bin_start, u32 *__restrict__ tagged, uint16_t *__restrict__ tagged_low,
+                                                       ColIn ci, ColStride cs) {
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    if (gridDim.z > 1) {
+        scalars = ci.scalars[blockIdx.z];
+        extra_scalar = ci.blinds[blockIdx.z];
+        hist1 = H2_COLZ(hist1, cs.hist);
+        bin_count = H2_COLZ(bin_count, cs.plan);
+        bin_start = H2_COLZ(bin_start, cs.plan);
+        tagged = H2_COLZ(tagged, cs.items);
+        if (tagged_low) tagged_low = H2_COLZ(tagged_low, cs.items);
+    }
     const u32 nh = P.nh, blk = blockIdx.x, B1 = gridDim.x;
     u32 *gstart = sh;                 // [nh] bin_start, then bin_start + this workgroup's offset inside the bin
     u32 *lstart = sh + nh;            // [nh + 1] where the bin's run begins in the stage
@@ -627,12 +661,21 @@ __global__ void __launch_bounds__(1024) msm_s1_scatter(const u32 *__restrict__ s
 // (It also zeroes the two small counter areas later kernels of the same multiexp count into -- `z2`: the two words of the
 // heavy-bucket list, `z1`: the oversized-bin counter of pass 2 -- which saves two 5 us memset nodes on the stream.)
 __global__ void __launch_bounds__(1024) msm_s1_prefix(u32 *__restrict__ hist1, u32 *__restrict__ bin_count, u32 B1, u32 nh, u32 *__restrict__ z2,
-                                                      u32 *__restrict__ z1) {
+                                                      u32 *__restrict__ z1, u32 *__restrict__ sentinel, ColStride cs) {
     H2_LATENCY_STAGE();
     __shared__ u32 part[64][17];
-    if (blockIdx.x == 0 && threadIdx.x < 3) {
+    if (gridDim.z > 1) {
+        hist1 = H2_COLZ(hist1, cs.hist);
+        bin_count = H2_COLZ(bin_count, cs.plan);
+        z2 = H2_COLZ(z2, cs.heavy);
+        if (z1) z1 = H2_COLZ(z1, cs.plan);
+        sentinel = H2_COLZ(sentinel, cs.starts);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 4) {
         if (threadIdx.x < 2) z2[threadIdx.x] = 0;
-        else if (z1) z1[0] = 0;
+        else if (threadIdx.x == 2) { if (z1) z1[0] = 0; }
+        else *sentinel = 0xFFFFFFFFu;       // starts[total_buckets + 1]: what msm_accumulate reads past the last boundary -- written HERE for
+                                            // every form of pass 2 (one-launch bins, oversized bins, chunked); the one-pass sort: msm_scan_apply
     }
     const u32 r = threadIdx.x >> 4, cl = threadIdx.x & 15, col = blockIdx.x * 16 + cl;
     const u32 rg = (B1 + 63) / 64, r0 = min(B1, r * rg), r1 = min(B1, r0 + rg);
@@ -862,17 +905,22 @@ __device__ __forceinline__ void lds_ticket4(u32 *ctr, const u32 k[4], u32 nvalid
 }
 __global__ void __launch_bounds__(1024) msm_s2_bins(const u32 *__restrict__ tagged, const uint16_t *__restrict__ tagged_low, const u32 *__restrict__ bin_start,
                                                     Sort2 P, u32 total_buckets, u32 cap, u32 *__restrict__ starts, u32 *__restrict__ entries,
-                                                    u32 *__restrict__ big) {
+                                                    u32 *__restrict__ big, ColStride cs) {
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    if (gridDim.z > 1) {
+        tagged = H2_COLZ(tagged, cs.items);
+        if (tagged_low) tagged_low = H2_COLZ(tagged_low, cs.items);
+        bin_start = H2_COLZ(bin_start, cs.plan);
+        starts = H2_COLZ(starts, cs.starts);
+        entries = H2_COLZ(entries, cs.items);
+        big = H2_COLZ(big, cs.plan);
+    }
     const u32 nbk = 1u << P.lowb, h = blockIdx.x;
     u32 *cnt = sh, *cursor = sh + nbk, *stage = cursor + nbk;          // [nbk] | [nbk] | [cap]
     const u32 p0 = bin_start[h], p1 = bin_start[h + 1], E = p1 - p0;
     const u32 lowmask = nbk - 1, strip = P.side ? ~0u : ~(lowmask << P.lb);
-    if (h == gridDim.x - 1 && threadIdx.x == 0) {
-        starts[total_buckets] = bin_start[gridDim.x];                 // M
-        starts[total_buckets + 1] = 0xFFFFFFFFu;                      // the sentinel msm_accumulate reads past the last boundary
-    }
+    if (h == gridDim.x - 1 && threadIdx.x == 0) starts[total_buckets] = bin_start[gridDim.x];      // M  (the sentinel behind it: msm_s1_prefix)
     if (E > cap) {
         // a bin that does not fit the stage (a degenerate column: every scalar equal, half of them 1 ...) goes on the list of big
         // bins, which msm_s2_big_* sort with kBigChunks workgroups each; only past kMaxBig such bins does this workgroup do it alone
@@ -935,10 +983,18 @@ __global__ void __launch_bounds__(1024) msm_s2_bins(const u32 *__restrict__ tagg
 // return at once when the list is empty (the common case: ~14 us), so that a degenerate column costs what it cost with the
 // chunked pass 2 instead of being streamed by one workgroup per bin (every scalar equal: 1.68 ms against 0.88).
 __global__ void __launch_bounds__(1024) msm_s2_big_count(const u32 *__restrict__ tagged, const uint16_t *__restrict__ tagged_low, const u32 *__restrict__ bin_start,
-                                                         Sort2 P, const u32 *__restrict__ big, u32 *__restrict__ gcnt) {
+                                                         Sort2 P, const u32 *__restrict__ big, u32 *__restrict__ gcnt, ColStride cs) {
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
     const u32 s = blockIdx.y, c = blockIdx.x;
+    if (gridDim.z > 1) {
+        big = H2_COLZ(big, cs.plan);
+        if (s >= min(big[0], kMaxBig)) return;
+        tagged = H2_COLZ(tagged, cs.items);
+        if (tagged_low) tagged_low = H2_COLZ(tagged_low, cs.items);
+        bin_start = H2_COLZ(bin_start, cs.plan);
+        gcnt = H2_COLZ(gcnt, cs.plan);
+    }
     if (s >= min(big[0], kMaxBig)) return;
     const u32 nbk = 1u << P.lowb, lowmask = nbk - 1, h = big[1 + s];
     const u32 p0 = bin_start[h], p1 = bin_start[h + 1], csize = (p1 - p0 + kBigChunks - 1) / kBigChunks;
@@ -958,10 +1014,16 @@ __global__ void __launch_bounds__(1024) msm_s2_big_count(const u32 *__restrict__
     for (u32 k = threadIdx.x; k < nbk; k += blockDim.x) dst[k] = sh[k];
 }
 __global__ void __launch_bounds__(1024) msm_s2_big_prefix(const u32 *__restrict__ bin_start, Sort2 P, u32 total_buckets, const u32 *__restrict__ big,
-                                                          u32 *__restrict__ gcnt, u32 *__restrict__ starts) {
+                                                          u32 *__restrict__ gcnt, u32 *__restrict__ starts, ColStride cs) {
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];      // [nbk] bucket totals -> exclusive prefix
     const u32 s = blockIdx.x;
+    if (gridDim.z > 1) {
+        big = H2_COLZ(big, cs.plan);
+        bin_start = H2_COLZ(bin_start, cs.plan);
+        gcnt = H2_COLZ(gcnt, cs.plan);
+        starts = H2_COLZ(starts, cs.starts);
+    }
     if (s >= min(big[0], kMaxBig)) return;
     const u32 nbk = 1u << P.lowb, h = big[1 + s], p0 = bin_start[h];
     for (u32 k = threadIdx.x; k < nbk; k += blockDim.x) {
@@ -985,10 +1047,20 @@ __global__ void __launch_bounds__(1024) msm_s2_big_prefix(const u32 *__restrict_
     }
 }
 __global__ void __launch_bounds__(1024) msm_s2_big_scatter(const u32 *__restrict__ tagged, const uint16_t *__restrict__ tagged_low, const u32 *__restrict__ bin_start,
-                                                           Sort2 P, const u32 *__restrict__ big, const u32 *__restrict__ gcnt, u32 *__restrict__ entries) {
+                                                           Sort2 P, const u32 *__restrict__ big, const u32 *__restrict__ gcnt, u32 *__restrict__ entries,
+                                                           ColStride cs) {
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
     const u32 s = blockIdx.y, c = blockIdx.x;
+    if (gridDim.z > 1) {
+        big = H2_COLZ(big, cs.plan);
+        if (s >= min(big[0], kMaxBig)) return;
+        tagged = H2_COLZ(tagged, cs.items);
+        if (tagged_low) tagged_low = H2_COLZ(tagged_low, cs.items);
+        bin_start = H2_COLZ(bin_start, cs.plan);
+        gcnt = H2_COLZ(gcnt, cs.plan);
+        entries = H2_COLZ(entries, cs.items);
+    }
     if (s >= min(big[0], kMaxBig)) return;
     const u32 nbk = 1u << P.lowb, lowmask = nbk - 1, strip = P.side ? ~0u : ~(lowmask << P.lb), h = big[1 + s];
     const u32 p0 = bin_start[h], p1 = bin_start[h + 1], csize = (p1 - p0 + kBigChunks - 1) / kBigChunks;
@@ -1093,8 +1165,14 @@ template <int FB, bool GLV, bool M9 = false>
 __global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
                                                       u32 extra_index, const u32 *__restrict__ entries,
                                                       const u32 *__restrict__ starts, u32 *__restrict__ heads,
-                                                      u32 *__restrict__ buckets, u32 total_buckets, u32 T, u32 div) {
+                                                      u32 *__restrict__ buckets, u32 total_buckets, u32 T, u32 div, ColStride cs) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (M9 && gridDim.z > 1) {           // column-batched commit: blockIdx.z = column (the table is shared)
+        entries = H2_COLZ(entries, cs.items);
+        starts = H2_COLZ(starts, cs.starts);
+        heads = H2_COLZ(heads, cs.heads);
+        buckets = H2_COLZ(buckets, cs.buckets);
+    }
     const u32 M = starts[total_buckets];
     T = eff_lanes(M, T, div);
     if (t >= T) return;
@@ -1357,10 +1435,16 @@ __global__ void __launch_bounds__(256) msm_bucket_add(u32 *__restrict__ total, c
 // column sums are converted for the latency-bound tail (msm_reduce_segments on a few hundred points).
 template <int FB>
 __global__ void __launch_bounds__(256) fold9_finish(const u32 *__restrict__ heads9, const u32 *__restrict__ starts, u32 *__restrict__ buckets9,
-                                                    u32 *__restrict__ heavy, u32 total_buckets, u32 T, u32 div) {
+                                                    u32 *__restrict__ heavy, u32 total_buckets, u32 T, u32 div, ColStride cs) {
     H2_LATENCY_STAGE();
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= total_buckets) return;
+    if (gridDim.z > 1) {
+        heads9 = H2_COLZ(heads9, cs.heads);
+        starts = H2_COLZ(starts, cs.starts);
+        buckets9 = H2_COLZ(buckets9, cs.buckets);
+        heavy = H2_COLZ(heavy, cs.heavy);
+    }
     const u32 M = starts[total_buckets];
     T = eff_lanes(M, T, div);
     const u32 chunk = max(1u, (M + T - 1) / T);
@@ -1434,9 +1518,15 @@ template <int FB> __device__ __forceinline__ xyzz9<FB> fold9_quads_sum(xyzz9<FB>
 // heavy buckets (more than kHeavy heads): kHeavyBlocks workgroups share the heads, fold9_finish_heavy2 adds their sums to the bucket
 template <int FB>
 __global__ void __launch_bounds__(256, 3) fold9_finish_heavy(const u32 *__restrict__ heads9, const u32 *__restrict__ starts, u32 *__restrict__ scratch9,
-                                                          const u32 *__restrict__ heavy, u32 total_buckets, u32 T, u32 div) {
+                                                          const u32 *__restrict__ heavy, u32 total_buckets, u32 T, u32 div, ColStride cs) {
     H2_LATENCY_STAGE();
     __shared__ __attribute__((aligned(16))) u32 sh[32 * 36];
+    if (gridDim.z > 1) {
+        heavy = H2_COLZ(heavy, cs.heavy);
+        heads9 = H2_COLZ(heads9, cs.heads);
+        starts = H2_COLZ(starts, cs.starts);
+        scratch9 = H2_COLZ(scratch9, cs.hscratch);
+    }
     if (blockIdx.y >= min(heavy[1], kMaxHeavy)) return;
     const u32 b = heavy[2 + blockIdx.y];
     const u32 M = starts[total_buckets];
@@ -1450,9 +1540,15 @@ __global__ void __launch_bounds__(256, 3) fold9_finish_heavy(const u32 *__restri
     if (fold9_root() && (threadIdx.x & (kGroup - 1)) == 0) xyzz9_store_raw<FB>(scratch9 + 36 * ((size_t)blockIdx.y * kHeavyBlocks + blockIdx.x), acc);
 }
 template <int FB>
-__global__ void __launch_bounds__(64, 3) fold9_finish_heavy2(const u32 *__restrict__ scratch9, u32 *__restrict__ buckets9, const u32 *__restrict__ heavy) {
+__global__ void __launch_bounds__(64, 3) fold9_finish_heavy2(const u32 *__restrict__ scratch9, u32 *__restrict__ buckets9, const u32 *__restrict__ heavy,
+                                                             ColStride cs) {
     H2_LATENCY_STAGE();
     __shared__ __attribute__((aligned(16))) u32 sh[8 * 36];
+    if (gridDim.z > 1) {
+        heavy = H2_COLZ(heavy, cs.heavy);
+        scratch9 = H2_COLZ(scratch9, cs.hscratch);
+        buckets9 = H2_COLZ(buckets9, cs.buckets);
+    }
     if (blockIdx.x >= min(heavy[1], kMaxHeavy)) return;
     // 16 quads: two partials each, a 4-level tree, then the bucket's own segment (6 dependent additions)
     const u32 b = heavy[2 + blockIdx.x];
@@ -1467,9 +1563,13 @@ __global__ void __launch_bounds__(64, 3) fold9_finish_heavy2(const u32 *__restri
 // row / column sums of the NR x S bucket matrix (see msm_rowcol_sums for the algebra): one workgroup of 64 quads per line,
 // lines9[lo] = C_lo (lo < S), lines9[S + hi] = R_hi (1 <= hi < NR; row 0 carries weight 0 and is never formed), raw M9.
 template <int FB>
-__global__ void __launch_bounds__(256, 3) fold9_rowcol(const u32 *__restrict__ buckets9, u32 *__restrict__ lines9, u32 S, u32 NR) {
+__global__ void __launch_bounds__(256, 3) fold9_rowcol(const u32 *__restrict__ buckets9, u32 *__restrict__ lines9, u32 S, u32 NR, ColStride cs) {
     H2_LATENCY_STAGE();
     __shared__ __attribute__((aligned(16))) u32 sh[32 * 36];
+    if (gridDim.z > 1) {
+        buckets9 = H2_COLZ(buckets9, cs.buckets);
+        lines9 = H2_COLZ(lines9, cs.lines);
+    }
     const bool is_col = blockIdx.x < S;
     const u32 id = is_col ? blockIdx.x : blockIdx.x - S + 1;          // column lo, or row hi
     const u32 cnt = is_col ? NR : S;
@@ -1489,10 +1589,16 @@ __global__ void __launch_bounds__(256, 3) fold9_rowcol(const u32 *__restrict__ b
 // (reduce_segments + sum_slice + combine: 126 us of a 1.28 ms commit; this kernel: ~70).
 template <int FB>
 __global__ void __launch_bounds__(256, 3) fold9_planes(const u32 *__restrict__ lines9, u32 *__restrict__ planes9, u32 *__restrict__ counter, u32 S, u32 NR,
-                                                    int cb, u32 *__restrict__ out, int out_kind, int out_mont) {
+                                                    int cb, u32 *__restrict__ out, int out_kind, int out_mont, ColOut co, ColStride cs) {
     H2_LATENCY_STAGE();
     __shared__ __attribute__((aligned(16))) u32 sh[32 * 36];
     __shared__ u32 s_last;
+    if (gridDim.z > 1) {
+        lines9 = H2_COLZ(lines9, cs.lines);
+        planes9 = H2_COLZ(planes9, cs.planes);
+        counter = H2_COLZ(counter, cs.ctr);
+        out = co.out[blockIdx.z];
+    }
     const u32 t = blockIdx.x, planes = gridDim.x;
     const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
     lines9 += 36 * (size_t)blockIdx.y * (S + NR);                     // blockIdx.y: the bucket slice = the output (paired commits: 2)
@@ -1943,7 +2049,7 @@ struct MsmContext {
                           &stage_s, &stage_b, &out, &small, &tagged, &tagged_low, &plan, &seg9, &bases9, &collapse, &collapse_list, &fold_ctr})
             b->release();
     }
-    bool attr_set = false, attr2_set = false;
+    bool attr_set = false, attr2_set = false, attr_bins_set = false;
     u32 lanes[2][3] = {{0, 0, 0}, {0, 0, 0}};  // resident lanes of msm_accumulate<FP / FQ, plain / GLV> on this device
 };
 
@@ -1993,7 +2099,15 @@ struct MsmArgs {
     // call (`fold_from`) then reduces the summed buckets: the ranges share ONE fold instead of paying one each.
     u32 *add_into = nullptr;
     const u32 *fold_from = nullptr;
+    // Column-batched commit (registered tables, wide windows): ncols independent columns of n_used scalars each run through ONE
+    // launch set, blockIdx.z = column (ColIn / ColOut / ColStride above).  Host arrays of device pointers; col_blinds may be null.
+    // msm_launch answers H2_ERR_BATCH_SHAPE before launching anything when the shape does not take the batched form.
+    int ncols = 1;
+    const void *const *col_scalars = nullptr;
+    const void *const *col_blinds = nullptr;
+    void *const *col_outs = nullptr;
 };
+static constexpr int H2_ERR_BATCH_SHAPE = -1000;     // internal: never leaves this file
 
 template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a, hipStream_t st) {
     size_t m = a.n_used + (a.d_extra_scalar ? 1 : 0);
@@ -2015,6 +2129,9 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     if (glv) m *= 2;
     if (fold_only && m < 1) m = 1;                   // only the bucket geometry (c) matters to the fold
     MsmShape sh = make_shape(m, a.c, a.table, glv);
+    const u32 K = a.ncols > 1 ? (u32)a.ncols : 1u;
+    if (K > 1 && (K > (u32)kMaxCols || !a.table || a.pair_shift >= 0 || a.add_into || fold_only || !a.col_scalars || !a.col_outs || a.n_used == 0))
+        return H2_ERR_BATCH_SHAPE;
     const bool pair = a.table && a.pair_shift >= 0;
     if (pair) {                       // one bucket slice per output
         sh.slices = 2;
@@ -2132,6 +2249,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         }
     }
     if (sh.c > kMaxC && !use_sort2) return H2_ERR_ARGS;   // choose_c only picks wide windows the two-pass sort can take
+    if (K > 1 && !use_sort2) return H2_ERR_BATCH_SHAPE;
     const bool wide_reduce = sh.NB > 32768u;              // implies the registered path (one slice)
     static const bool fold9_on = [] { const char *e = getenv("H2_FOLD9"); return !(e && atoi(e) == 0); }();     // A/B switch
     // the fold on the carry-free layer (fold9_* kernels: registered tables from 16-bit windows, paired commits, and the window
@@ -2139,12 +2257,30 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     // (add_into), so it keeps the 8 x 32 finisher
     static const u32 fold9_min_nb = [] { const char *e = getenv("H2_FOLD9_MIN_NB"); int v = e ? atoi(e) : 0; return (u32)(v >= 64 ? v : 128); }();
     const bool fold9 = fold9_on && sh.NB >= fold9_min_nb && sh.slices <= 16 && m9 && !a.add_into && !fold_only;      // (16: arrival counters of fold9_planes)
+    if (K > 1 && !fold9) return H2_ERR_BATCH_SHAPE;
+    // pass 2 of the two-pass sort in its one-launch form (a workgroup per pass-1 bin)?  Decided here, before anything is launched,
+    // because a column-batched commit exists in that form only.
+    bool s2_bins_form = false;
+    size_t s2_cap_entries = 0;
+    if (use_sort2) {
+        static const bool bins_on = [] { const char *e = getenv("H2_S2_BINS"); return !(e && atoi(e) == 0); }();
+        const size_t nbk = (size_t)1 << S2.lowb;
+        // LDS stage: the average bin + 25 % (two workgroups per CU where that fits: 2^20 scalars at 17 bits, 15 K-entry bins), at
+        // most what one workgroup can have; a bin beyond its stage takes the direct-scatter branch.  H2_S2_CAP: sweeps only.
+        const size_t cap_max = nbk * 8 + 64 < kLdsCap ? (kLdsCap - nbk * 8) / 4 : 0;
+        static const size_t cap_env = [] { const char *e = getenv("H2_S2_CAP"); return e ? (size_t)atol(e) : (size_t)0; }();
+        s2_cap_entries = std::min(cap_max, cap_env ? cap_env : std::max<size_t>(4096, all_items / S2.nh * 5 / 4 + 1024));
+        const size_t nbins = ((size_t)tb + nbk - 1) >> S2.lowb;
+        s2_bins_form = bins_on && S2.lowb <= 12 && nbins == S2.nh && s2_cap_entries && all_items / S2.nh <= s2_cap_entries * 9 / 10;
+    }
+    if (K > 1 && !s2_bins_form) return H2_ERR_BATCH_SHAPE;
     u32 wideS = 0, wideNR = 0;
     if (wide_reduce || fold9) {
         const int bb = sh.c - 1;
         wideS = 1u << (bb / 2);
         wideNR = sh.NB / wideS;
     }
+    size_t plan_words = 0;
     if (use_sort2) {
         if (!cx.attr2_set) {
             H2_HIP(hipFuncSetAttribute((const void *)msm_s2_count, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
@@ -2155,29 +2291,56 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
             H2_HIP(hipFuncSetAttribute((const void *)msm_s1_scatter<FQ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
             cx.attr2_set = true;
         }
-        if ((rc = cx.hist.reserve((size_t)S2.B1 * S2.nh * 4)) != H2_OK) return rc;
-        if ((rc = cx.tagged.reserve(all_items * 4)) != H2_OK) return rc;
-        if (S2.side && (rc = cx.tagged_low.reserve(all_items * 2)) != H2_OK) return rc;
-        const size_t plan_words = (size_t)S2.nh * 2 + 1 + (size_t)S2.B2 * 2 + 1 +
-                                  std::max<size_t>(((size_t)S2.nh + S2.B2 + 1) << S2.lowb, 64 + (((size_t)kMaxBig * (kBigChunks + 1)) << S2.lowb));
-        if ((rc = cx.plan.reserve(plan_words * 4)) != H2_OK) return rc;
+        if ((rc = cx.hist.reserve((size_t)K * S2.B1 * S2.nh * 4)) != H2_OK) return rc;
+        if ((rc = cx.tagged.reserve((size_t)K * all_items * 4)) != H2_OK) return rc;
+        if (S2.side && (rc = cx.tagged_low.reserve((size_t)K * all_items * 2 + 64)) != H2_OK) return rc;
+        plan_words = (size_t)S2.nh * 2 + 1 + (size_t)S2.B2 * 2 + 1 +
+                     std::max<size_t>(((size_t)S2.nh + S2.B2 + 1) << S2.lowb, 64 + (((size_t)kMaxBig * (kBigChunks + 1)) << S2.lowb));
+        plan_words = (plan_words + 3) & ~(size_t)3;
+        if ((rc = cx.plan.reserve((size_t)K * plan_words * 4)) != H2_OK) return rc;
     } else {
         if ((rc = cx.digits.reserve(all_items * 2)) != H2_OK) return rc;
         if ((rc = cx.hist.reserve((size_t)sh.slices * sh.B * sh.NB * 4)) != H2_OK) return rc;
     }
     if ((rc = cx.counts.reserve((size_t)tb * 4)) != H2_OK) return rc;
-    if ((rc = cx.starts.reserve((size_t)(tb + 2) * 4)) != H2_OK) return rc;
+    if ((rc = cx.starts.reserve((size_t)K * (tb + 2) * 4)) != H2_OK) return rc;
     if ((rc = cx.bsums.reserve((size_t)(nblocks + 4) * 4)) != H2_OK) return rc;
-    if ((rc = cx.entries.reserve(all_items * 4)) != H2_OK) return rc;
+    if ((rc = cx.entries.reserve((size_t)K * all_items * 4)) != H2_OK) return rc;
     if ((rc = cx.heads.reserve((size_t)std::max<size_t>(T, (size_t)sh.slices * 32) * 128)) != H2_OK) return rc;
-    if ((rc = cx.heavy.reserve((size_t)(max_heavy + 2) * 4)) != H2_OK) return rc;
-    if ((rc = cx.hscratch.reserve((size_t)max_heavy * kHeavyBlocks * 144)) != H2_OK) return rc;
+    if ((rc = cx.heavy.reserve((size_t)K * (max_heavy + 2) * 4)) != H2_OK) return rc;
+    if ((rc = cx.hscratch.reserve((size_t)K * max_heavy * kHeavyBlocks * 144)) != H2_OK) return rc;
     if ((rc = cx.buckets.reserve((size_t)tb * 128)) != H2_OK) return rc;
     if ((rc = cx.partial.reserve(std::max(wide_reduce ? ((size_t)2 * wideNR / kSeg + 2 * wideNR) * 128 : (size_t)segs * 128,
-                                          fold9 ? (size_t)sh.slices * (wideS + wideNR + 32) * 144 : (size_t)0))) != H2_OK) return rc;
-    if (fold9 && !cx.fold_ctr.ptr) {                      // fold9_planes' arrival counter: zero once, every launch leaves it at zero
-        if ((rc = cx.fold_ctr.reserve(64)) != H2_OK) return rc;
-        H2_HIP(hipMemsetAsync(cx.fold_ctr.ptr, 0, 64, st));
+                                          fold9 ? (size_t)K * sh.slices * (wideS + wideNR + 32) * 144 : (size_t)0))) != H2_OK) return rc;
+    if (fold9 && cx.fold_ctr.cap < (size_t)K * 64) {      // fold9_planes' arrival counters (16 words per column): zero once, every launch leaves them at zero
+        if ((rc = cx.fold_ctr.reserve((size_t)kMaxCols * 64)) != H2_OK) return rc;
+        H2_HIP(hipMemsetAsync(cx.fold_ctr.ptr, 0, (size_t)kMaxCols * 64, st));
+    }
+    // column-batched commit: the per-column pointers and the distances between the per-column work areas (32-bit words)
+    ColIn ci;
+    ColOut co;
+    ColStride cs;
+    memset(&ci, 0, sizeof ci);
+    memset(&co, 0, sizeof co);
+    memset(&cs, 0, sizeof cs);
+    if (K > 1) {
+        for (u32 k = 0; k < K; ++k) {
+            ci.scalars[k] = (const u32 *)a.col_scalars[k];
+            ci.blinds[k] = a.col_blinds ? (const u32 *)a.col_blinds[k] : nullptr;
+            co.out[k] = (u32 *)a.col_outs[k];
+            if (!ci.scalars[k] || !co.out[k] || (a.d_extra_scalar && !ci.blinds[k])) return H2_ERR_ARGS;
+        }
+        cs.hist = (u32)((size_t)S2.B1 * S2.nh);
+        cs.plan = (u32)plan_words;
+        cs.items = (u32)all_items;
+        cs.starts = tb + 2;
+        cs.heavy = max_heavy + 2;
+        cs.hscratch = max_heavy * kHeavyBlocks * 36;
+        cs.heads = T * 36;
+        cs.buckets = tb * 36;
+        cs.lines = sh.slices * (wideS + wideNR) * 36;
+        cs.planes = sh.slices * 32 * 36;
+        cs.ctr = 16;
     }
     if ((rc = cx.ssums.reserve((size_t)std::max<u32>(sh.slices, 2) * 128)) != H2_OK) return rc;
     const u32 m32 = (u32)m;
@@ -2198,41 +2361,38 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         static const u32 s1_threads = [] { const char *e = getenv("H2_S1_THREADS"); int v = e ? atoi(e) : 0; return (u32)(v == 256 || v == 512 || v == 1024 ? v : 512); }();
         if (glv) {
             hipLaunchKernelGGL((msm_s1_count<FS, true>), dim3(S2.B1), dim3(s1_threads), S2.nh * 4, st, (const u32 *)a.d_scalars,
-                               (const u32 *)nullptr, S2, hist1);
-            hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh, cx.heavy.as<u32>(), hist2);
+                               (const u32 *)nullptr, S2, hist1, ci, cs);
+            hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh, cx.heavy.as<u32>(), hist2, cx.starts.as<u32>() + tb + 1, cs);
             hipLaunchKernelGGL((msm_s1_scatter<FS, true>), dim3(S2.B1), dim3(s1_threads), lds1, st, (const u32 *)a.d_scalars,
-                               (const u32 *)nullptr, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>(), (uint16_t *)nullptr);
+                               (const u32 *)nullptr, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>(), (uint16_t *)nullptr, ci, cs);
         } else {
-            hipLaunchKernelGGL((msm_s1_count<FS, false>), dim3(S2.B1), dim3(s1_threads), S2.nh * 4, st, (const u32 *)a.d_scalars,
-                               (const u32 *)a.d_extra_scalar, S2, hist1);
-            hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh, cx.heavy.as<u32>(), hist2);
-            hipLaunchKernelGGL((msm_s1_scatter<FS, false>), dim3(S2.B1), dim3(s1_threads), lds1, st, (const u32 *)a.d_scalars,
-                               (const u32 *)a.d_extra_scalar, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>(), cx.tagged_low.as<uint16_t>());
+            hipLaunchKernelGGL((msm_s1_count<FS, false>), dim3(S2.B1, 1, K), dim3(s1_threads), S2.nh * 4, st, (const u32 *)a.d_scalars,
+                               (const u32 *)a.d_extra_scalar, S2, hist1, ci, cs);
+            hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16, 1, K), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh, cx.heavy.as<u32>(), hist2, cx.starts.as<u32>() + tb + 1, cs);
+            hipLaunchKernelGGL((msm_s1_scatter<FS, false>), dim3(S2.B1, 1, K), dim3(s1_threads), lds1, st, (const u32 *)a.d_scalars,
+                               (const u32 *)a.d_extra_scalar, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>(), cx.tagged_low.as<uint16_t>(), ci, cs);
         }
         // pass 2: one launch, a workgroup per bin, when an average bin fits LDS with room to spare (registered tables; the 9-slice
         // generic sort has bins of ~64 K entries and keeps the chunked form); H2_S2_BINS=0: the chunked form (A/B)
-        static const bool bins_on = [] { const char *e = getenv("H2_S2_BINS"); return !(e && atoi(e) == 0); }();
         const size_t nbk = (size_t)1 << S2.lowb;
-        // LDS stage: the average bin + 25 % (two workgroups per CU where that fits: 2^20 scalars at 17 bits, 15 K-entry bins), at
-        // most what one workgroup can have; a bin beyond its stage takes the direct-scatter branch.  H2_S2_CAP: sweeps only.
-        const size_t cap_max = nbk * 8 + 64 < kLdsCap ? (kLdsCap - nbk * 8) / 4 : 0;
-        static const size_t cap_env = [] { const char *e = getenv("H2_S2_CAP"); return e ? (size_t)atol(e) : (size_t)0; }();
-        const size_t cap_entries = std::min(cap_max, cap_env ? cap_env : std::max<size_t>(4096, all_items / S2.nh * 5 / 4 + 1024));
-        const size_t nbins = ((size_t)tb + nbk - 1) >> S2.lowb;
-        if (bins_on && S2.lowb <= 12 && nbins == S2.nh && cap_entries && all_items / S2.nh <= cap_entries * 9 / 10) {
-            static bool attr_bins = false;
-            if (!attr_bins) {
+        const size_t cap_entries = s2_cap_entries;
+        if (s2_bins_form) {
+            if (!cx.attr_bins_set) {                              // per (device, stream) context: the attribute is per device
                 H2_HIP(hipFuncSetAttribute((const void *)msm_s2_bins, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-                attr_bins = true;
+                cx.attr_bins_set = true;
             }
             u32 *big = hist2, *gcnt = hist2 + 64;                 // the chunked form's histogram area is free here; msm_s1_prefix zeroed *big
-            hipLaunchKernelGGL(msm_s2_bins, dim3(S2.nh), dim3(1024), (nbk * 2 + cap_entries) * 4, st, cx.tagged.as<u32>(),
-                               (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, tb, (u32)cap_entries, cx.starts.as<u32>(), cx.entries.as<u32>(), big);
-            hipLaunchKernelGGL(msm_s2_big_count, dim3(kBigChunks, kMaxBig), dim3(1024), nbk * 4, st, cx.tagged.as<u32>(),
-                               (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, (const u32 *)big, gcnt);
-            hipLaunchKernelGGL(msm_s2_big_prefix, dim3(kMaxBig), dim3(1024), nbk * 4, st, bin_start, S2, tb, (const u32 *)big, gcnt, cx.starts.as<u32>());
-            hipLaunchKernelGGL(msm_s2_big_scatter, dim3(kBigChunks, kMaxBig), dim3(1024), nbk * 4, st, cx.tagged.as<u32>(),
-                               (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, (const u32 *)big, (const u32 *)gcnt, cx.entries.as<u32>());
+            // the oversized-bin kernels return at once when the list is empty (the common case).  256-lane workgroups: a 1024-lane
+            // workgroup of an EMPTY launch still needs four wave slots on every SIMD of one CU, and sat behind other streams'
+            // accumulate for 10-160 us (profiles/r03_kernel_stats_3streams.csv) before it could find out that it had nothing to do
+            static const u32 big_threads = [] { const char *e = getenv("H2_S2_BIG_THREADS"); int v = e ? atoi(e) : 0; return (u32)(v == 256 || v == 512 || v == 1024 ? v : 256); }();
+            hipLaunchKernelGGL(msm_s2_bins, dim3(S2.nh, 1, K), dim3(1024), (nbk * 2 + cap_entries) * 4, st, cx.tagged.as<u32>(),
+                               (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, tb, (u32)cap_entries, cx.starts.as<u32>(), cx.entries.as<u32>(), big, cs);
+            hipLaunchKernelGGL(msm_s2_big_count, dim3(kBigChunks, kMaxBig, K), dim3(big_threads), nbk * 4, st, cx.tagged.as<u32>(),
+                               (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, (const u32 *)big, gcnt, cs);
+            hipLaunchKernelGGL(msm_s2_big_prefix, dim3(kMaxBig, 1, K), dim3(big_threads), nbk * 4, st, bin_start, S2, tb, (const u32 *)big, gcnt, cx.starts.as<u32>(), cs);
+            hipLaunchKernelGGL(msm_s2_big_scatter, dim3(kBigChunks, kMaxBig, K), dim3(big_threads), nbk * 4, st, cx.tagged.as<u32>(),
+                               (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, (const u32 *)big, (const u32 *)gcnt, cx.entries.as<u32>(), cs);
         } else {
         hipLaunchKernelGGL(msm_s2_plan, dim3(1), dim3(kScanBlock), 0, st, bin_start, S2, hlo, woff);
         const size_t hist2_words = ((size_t)S2.nh + S2.B2 + 1) << S2.lowb;
@@ -2306,8 +2466,9 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
 #endif
     if (m9) {
         if (glv && (rc = cx.bases9.reserve((size_t)scalars_n * 128 + 64)) != H2_OK) return rc;
-        if ((rc = cx.seg9.reserve(((size_t)T + tb) * 144)) != H2_OK) return rc;
-        H2_HIP(hipMemsetAsync(cx.seg9.as<u32>() + 36 * (size_t)T, 0, (size_t)tb * 144, st));
+        // raw M9 segments: the heads of the T ranges of every column, then the bucket slots of every column (zeroed in one go)
+        if ((rc = cx.seg9.reserve((size_t)K * ((size_t)T + tb) * 144)) != H2_OK) return rc;
+        H2_HIP(hipMemsetAsync(cx.seg9.as<u32>() + 36 * (size_t)T * K, 0, (size_t)K * tb * 144, st));
     } else {
         H2_HIP(hipMemsetAsync(cx.buckets.ptr, 0, (size_t)tb * 128, st));
     }
@@ -2317,7 +2478,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     prof_begin(PROF_MSM_ACCUMULATE, st);
     if (glv && !m9)
         hipLaunchKernelGGL((msm_accumulate<FB, true>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases, (const u32 *)nullptr,
-                           (u32)scalars_n, cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T, lane_div);
+                           (u32)scalars_n, cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T, lane_div, cs);
     else if (m9) {
         const u32 *pts = (const u32 *)a.d_bases;
         if (glv) {
@@ -2325,9 +2486,9 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                                cx.bases9.as<u32>(), (u32)scalars_n);
             pts = cx.bases9.as<u32>();
         }
-        hipLaunchKernelGGL((msm_accumulate<FB, false, true>), dim3(T / 256), dim3(256), 0, st, pts,
+        hipLaunchKernelGGL((msm_accumulate<FB, false, true>), dim3(T / 256, 1, K), dim3(256), 0, st, pts,
                            (const u32 *)nullptr, 0xFFFFFFFFu, cx.entries.as<u32>(), cx.starts.as<u32>(), cx.seg9.as<u32>(),
-                           cx.seg9.as<u32>() + 36 * (size_t)T, tb, T, lane_div);
+                           cx.seg9.as<u32>() + 36 * (size_t)T * K, tb, T, lane_div, cs);
         if (!fold9)
             hipLaunchKernelGGL((msm_segments_to_r256<FB>), dim3((T + tb + 255) / 256), dim3(256), 0, st, cx.seg9.as<u32>(),
                                cx.heads.as<u32>(), cx.buckets.as<u32>(), T, tb);
@@ -2335,18 +2496,18 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     else
         hipLaunchKernelGGL((msm_accumulate<FB, false>), dim3(T / 256), dim3(256), 0, st, (const u32 *)a.d_bases,
                            (const u32 *)a.d_extra_base, (!a.table && a.d_extra_base) ? (u32)a.n_used : 0xFFFFFFFFu,
-                           cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T, lane_div);
+                           cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T, lane_div, cs);
     prof_end(PROF_MSM_ACCUMULATE, st);
     TL_STAMP(tl_id | 3);
     prof_begin(PROF_MSM_REDUCE, st);
     if (fold9) {
         // wide slice: finish on the raw M9 segments, one lane per bucket (fold9_* above); the buckets stay in cx.seg9
-        u32 *heads9 = cx.seg9.as<u32>(), *buckets9 = cx.seg9.as<u32>() + 36 * (size_t)T;
-        hipLaunchKernelGGL((fold9_finish<FB>), dim3((tb + 255) / 256), dim3(256), 0, st, (const u32 *)heads9, cx.starts.as<u32>(), buckets9,
-                           cx.heavy.as<u32>(), tb, T, lane_div);
-        hipLaunchKernelGGL((fold9_finish_heavy<FB>), dim3(kHeavyBlocks, max_heavy), dim3(256), 0, st, (const u32 *)heads9, cx.starts.as<u32>(),
-                           cx.hscratch.as<u32>(), cx.heavy.as<u32>(), tb, T, lane_div);
-        hipLaunchKernelGGL((fold9_finish_heavy2<FB>), dim3(max_heavy), dim3(64), 0, st, cx.hscratch.as<u32>(), buckets9, cx.heavy.as<u32>());
+        u32 *heads9 = cx.seg9.as<u32>(), *buckets9 = cx.seg9.as<u32>() + 36 * (size_t)T * K;
+        hipLaunchKernelGGL((fold9_finish<FB>), dim3((tb + 255) / 256, 1, K), dim3(256), 0, st, (const u32 *)heads9, cx.starts.as<u32>(), buckets9,
+                           cx.heavy.as<u32>(), tb, T, lane_div, cs);
+        hipLaunchKernelGGL((fold9_finish_heavy<FB>), dim3(kHeavyBlocks, max_heavy, K), dim3(256), 0, st, (const u32 *)heads9, cx.starts.as<u32>(),
+                           cx.hscratch.as<u32>(), cx.heavy.as<u32>(), tb, T, lane_div, cs);
+        hipLaunchKernelGGL((fold9_finish_heavy2<FB>), dim3(max_heavy, 1, K), dim3(64), 0, st, cx.hscratch.as<u32>(), buckets9, cx.heavy.as<u32>(), cs);
     } else {
     hipLaunchKernelGGL((msm_finish_buckets<FB>), dim3((tb * kGroup + 255) / 256), dim3(256), 0, st, cx.heads.as<u32>(),
                        cx.starts.as<u32>(), cx.buckets.as<u32>(), cx.heavy.as<u32>(), tb, T, lane_div);
@@ -2371,15 +2532,15 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         int fold_c = sh.c;
         if (fold9) {
             // line sums, then the bit planes of the line weights and their combination in one launch (fold9_planes)
-            u32 *lines9 = cx.partial.as<u32>(), *planes9 = lines9 + 36 * (size_t)sh.slices * (wideS + wideNR);
+            u32 *lines9 = cx.partial.as<u32>(), *planes9 = lines9 + 36 * (size_t)K * sh.slices * (wideS + wideNR);
             int cb = 0;
             while ((1u << cb) < wideS) ++cb;
-            hipLaunchKernelGGL((fold9_rowcol<FB>), dim3(wideS + wideNR - 1, sh.slices), dim3(256), 0, st,
-                               (const u32 *)(cx.seg9.as<u32>() + 36 * (size_t)T), lines9, wideS, wideNR);
+            hipLaunchKernelGGL((fold9_rowcol<FB>), dim3(wideS + wideNR - 1, sh.slices, K), dim3(256), 0, st,
+                               (const u32 *)(cx.seg9.as<u32>() + 36 * (size_t)T * K), lines9, wideS, wideNR, cs);
             const bool windows = glv;                // the slices are window slices: their sums meet in msm_combine's Horner step
-            hipLaunchKernelGGL((fold9_planes<FB>), dim3(sh.c - 1, sh.slices), dim3(256), 0, st, (const u32 *)lines9, planes9, cx.fold_ctr.as<u32>(),
+            hipLaunchKernelGGL((fold9_planes<FB>), dim3(sh.c - 1, sh.slices, K), dim3(256), 0, st, (const u32 *)lines9, planes9, cx.fold_ctr.as<u32>(),
                                wideS, wideNR, cb, windows ? cx.ssums.as<u32>() : (u32 *)a.d_out, windows ? kOutSliceSum : a.out_kind,
-                               a.form == H2_FORM_MONTGOMERY);
+                               a.form == H2_FORM_MONTGOMERY, co, cs);
             if (windows)
                 hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, cx.ssums.as<u32>(), (int)sh.slices, sh.c, (u32 *)a.d_out, a.out_kind,
                                    a.form == H2_FORM_MONTGOMERY);
@@ -2802,6 +2963,13 @@ extern "C" int h2_bases_info(h2_bases_t handle, size_t *n, int *window_bits, int
     return H2_OK;
 }
 
+extern "C" int h2_bases_blind_base_set(h2_bases_t handle) {
+    auto b = find_bases(handle);
+    if (!b) return -H2_ERR_HANDLE;
+    std::lock_guard<std::mutex> bl(b->mu);
+    return b->blind_set ? 1 : 0;
+}
+
 extern "C" int h2_bases_free(h2_bases_t handle) {
     std::shared_ptr<Bases> b;
     {
@@ -2961,6 +3129,54 @@ extern "C" int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars
             }
         }
     }
+    // The column-batched form (ColIn / ColStride above): groups of up to kMaxCols columns, each group ONE launch set with
+    // blockIdx.z = column.  A single group runs on the caller's stream as it is; several groups alternate over two internal
+    // streams, so that one group's sort and fold run beside the other's accumulate.  Shapes the batched form does not take
+    // (narrow windows, small columns: msm_launch says so before launching anything) fall through to one commit per column
+    // on three streams, as before.  H2_BATCH_COLS: sweeps only (1 = the per-column form).
+    static const size_t batch_cols = [] { const char *e = getenv("H2_BATCH_COLS"); int v = e ? atoi(e) : 0; return (size_t)(v >= 1 && v <= kMaxCols ? v : kMaxCols); }();
+    if (count >= 2 && batch_cols >= 2 && n > 0) {
+        auto b = find_bases(g);
+        if (!b) return H2_ERR_HANDLE;
+        if (bad_common(b->curve, form, out_kind) || n > b->n) return H2_ERR_ARGS;
+        for (size_t i = 0; i < count; ++i)
+            if (!d_scalars[i] || !d_outs[i] || (d_blinds && !d_blinds[i])) return H2_ERR_ARGS;
+        const size_t groups = (count + batch_cols - 1) / batch_cols;
+        const bool forked = groups > 1;
+        if (forked) {
+            H2_HIP(hipEventRecord(bs.fork, user));
+            for (size_t i = 0; i < 2; ++i) H2_HIP(hipStreamWaitEvent(bs.s[i], bs.fork, 0));
+        }
+        bool taken = true;
+        size_t first = 0;
+        for (size_t gidx = 0; gidx < groups && rc == H2_OK; ++gidx) {
+            const size_t gsize = count / groups + (gidx < count % groups ? 1 : 0);      // balanced groups
+            hipStream_t st = forked ? bs.s[gidx & 1] : user;
+            MsmContext &cx = msm_ctx(st);
+            std::lock_guard<std::mutex> cl(cx.mu);
+            MsmArgs a{d_scalars[first], d_blinds ? d_blinds[first] : nullptr, b->d_table, nullptr, n, true, b->c, b->stride, (u32)b->n, form, out_kind, d_outs[first]};
+            a.lane_fraction = fraction;
+            if (gsize > 1) {
+                a.ncols = (int)gsize;
+                a.col_scalars = d_scalars + first;
+                a.col_blinds = d_blinds ? d_blinds + first : nullptr;
+                a.col_outs = d_outs + first;
+            }
+            rc = msm_dispatch(cx, b->curve, a, st);
+            if (rc == H2_ERR_BATCH_SHAPE) {            // nothing was launched
+                rc = H2_OK;
+                taken = false;
+                break;
+            }
+            first += gsize;
+        }
+        if (forked)
+            for (size_t i = 0; i < 2; ++i) {
+                H2_HIP(hipEventRecord(bs.done[i], bs.s[i]));
+                H2_HIP(hipStreamWaitEvent(user, bs.done[i], 0));
+            }
+        if (taken || rc != H2_OK) return rc;
+    }
     H2_HIP(hipEventRecord(bs.fork, user));
     for (size_t i = 0; i < want; ++i) H2_HIP(hipStreamWaitEvent(bs.s[i], bs.fork, 0));
     for (size_t i = 0; i < count && rc == H2_OK; ++i)
@@ -3050,11 +3266,33 @@ void msm_release_host_pipe() {            // h2_trim: the staging column and the
 }
 }  // namespace h2
 
+static int commit_host_pipelined_locked(HostPipe &hp, Bases &b, const uint64_t *scalars, size_t n, const uint64_t *blind, int form, int out_kind,
+                                       uint64_t *out);
+// The pipeline lives on the device that holds the table: the current device is switched to it for the call (the host pipe, its
+// streams and the msm contexts are all keyed by the current device), and ANY early return -- a HIP error half-way through the
+// ranges -- first waits for the copy stream and both compute streams, so that nothing still runs against hp.stage / hp.parts when
+// the next call reserves (hipFree) or zeroes them.
 static int commit_host_pipelined(Bases &b, const uint64_t *scalars, size_t n, const uint64_t *blind, int form, int out_kind, uint64_t *out) {
-    HostPipe &hp = host_pipe();
-    std::lock_guard<std::mutex> lk(hp.mu);
-    int rc = hp.prepare();
-    if (rc != H2_OK) return rc;
+    int cur = 0;
+    H2_HIP(hipGetDevice(&cur));
+    if (cur != b.device) H2_HIP(hipSetDevice(b.device));
+    int rc;
+    {
+        HostPipe &hp = host_pipe();
+        std::lock_guard<std::mutex> lk(hp.mu);
+        rc = hp.prepare();
+        if (rc == H2_OK) rc = commit_host_pipelined_locked(hp, b, scalars, n, blind, form, out_kind, out);
+        if (rc != H2_OK && hp.ready) {
+            (void)hipStreamSynchronize(hp.copy);
+            for (auto &c : hp.comp) (void)hipStreamSynchronize(c);
+        }
+    }
+    if (cur != b.device) (void)hipSetDevice(cur);
+    return rc;
+}
+static int commit_host_pipelined_locked(HostPipe &hp, Bases &b, const uint64_t *scalars, size_t n, const uint64_t *blind, int form, int out_kind,
+                                       uint64_t *out) {
+    int rc = H2_OK;
     size_t chunk = g_pipe_chunk.load() ? g_pipe_chunk.load() : kPipeChunk;
     if (n < 2 * chunk) chunk = std::max<size_t>(n, 1);                       // small columns: one range, nothing to overlap
     chunk = std::max(chunk, (n + kPipeMaxChunks - 1) / kPipeMaxChunks);
@@ -3099,10 +3337,7 @@ static int commit_host_pipelined(Bases &b, const uint64_t *scalars, size_t n, co
         a.fold_from = total[0];
         rc = msm_dispatch(cx, b.curve, a, hp.copy);
     }
-    if (rc != H2_OK) {
-        (void)hipStreamSynchronize(hp.copy);
-        return rc;
-    }
+    if (rc != H2_OK) return rc;                      // (the caller drains the three streams)
     H2_HIP(hipMemcpyAsync(out, d_res, out_kind == H2_OUT_AFFINE ? 64 : 96, hipMemcpyDeviceToHost, hp.copy));
     H2_HIP(hipStreamSynchronize(hp.copy));
     return H2_OK;

@@ -275,6 +275,13 @@ extern "C" int h2_commit_split_rccl_device(h2_bases_t g, const void *d_scalars, 
     int rc = h2_bases_info(g, &have, nullptr, &curve);
     if (rc != H2_OK) return rc;
     if (n > have) return H2_ERR_ARGS;
+    // rank-independent preconditions are checked on EVERY rank before any work: only the last rank hands the blind to its range
+    // commit, and a failure there alone would leave the other ranks waiting in the all-gather
+    if ((form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY) || (out_kind != H2_OUT_JACOBIAN && out_kind != H2_OUT_AFFINE)) return H2_ERR_ARGS;
+    if (d_blind && h2_bases_blind_base_set(g) != 1) {
+        set_last_error_msg("split commit with a blind but the handle has no blind base: call h2_bases_set_blind_base on every rank");
+        return H2_ERR_ARGS;
+    }
     std::lock_guard<std::mutex> lk(g_rccl.mu);
     if (!g_rccl.comm) return H2_ERR_HANDLE;
     hipStream_t st = (hipStream_t)stream;
@@ -283,8 +290,12 @@ extern "C" int h2_commit_split_rccl_device(h2_bases_t g, const void *d_scalars, 
     char *buf = (char *)g_rccl.d_buf, *mine = buf + (size_t)world * 96;
     rc = h2_commit_range_device(g, (const char *)d_scalars + 32 * lo, lo, hi - lo, rank == world - 1 ? d_blind : nullptr, form, H2_OUT_JACOBIAN,
                                 mine, st);
-    if (rc != H2_OK) return rc;
+    // a rank-LOCAL failure (a HIP error, an allocation) still takes part in the exchange, with the identity as its partial (Z = 0),
+    // so that the peers leave the collective; it then reports its own status
+    const int local_rc = rc;
+    if (local_rc != H2_OK) (void)hipMemsetAsync(mine, 0, 96, st);
     int e = g_rccl.AllGather(mine, buf, 96, /*ncclChar*/ 0, g_rccl.comm, st);
+    if (local_rc != H2_OK) return local_rc;
     if (e) return g_rccl.fail(e, "ncclAllGather");
     return h2_points_sum_device(curve, buf, (size_t)world, form, out_kind, d_out, st);
 }

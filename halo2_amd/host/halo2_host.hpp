@@ -265,7 +265,7 @@ template <int CURVE> class Params {
     Params(uint32_t k_, std::vector<Affine> g_, std::vector<Affine> g_lagrange_, const Affine &w_, const Affine &u_)
         : k(k_), n((uint64_t)1 << k_), g(std::move(g_)), g_lagrange(std::move(g_lagrange_)), w(w_), u(u_) {
         if (g.size() != n || g_lagrange.size() != n) throw std::invalid_argument("Params: need 2^k generators");
-        const int wb = h2_commit_column_window_bits(n);        // tables of column commits: 17-bit windows from 2^19 points on
+        const int wb = h2_commit_column_window_bits(n);        // tables of column commits: 17-bit windows from 2^18 points on
         check(h2_bases_register_ex(CURVE, g[0].data(), n, H2_FORM_MONTGOMERY, wb, &h_g), "h2_bases_register_ex");
         check(h2_bases_register_ex(CURVE, g_lagrange[0].data(), n, H2_FORM_MONTGOMERY, wb, &h_gl), "h2_bases_register_ex");
         // `w` is a field of Params (commitment.rs:26-33): installed once per table; a commit then passes only its blind scalar

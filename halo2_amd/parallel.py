@@ -165,11 +165,18 @@ def split_commit(handle, d_scalars, rank: int, world: int, d_blind=None):
     n = d_scalars.shape[0]
     lo, hi = shard_range(n, rank, world)
     dev = d_scalars.device
-    mine = torch.empty(12, dtype=torch.int64, device=dev)
+    mine = torch.zeros(12, dtype=torch.int64, device=dev)          # all-zero limbs = the identity (Z = 0)
     hv = int(getattr(handle, "value", handle))
-    check(lib().h2_commit_range_device(hv, d_scalars[lo:].data_ptr() if hi > lo else None, lo, hi - lo,
-                                       d_blind.data_ptr() if (d_blind is not None and rank == world - 1) else None, FORM_MONTGOMERY,
-                                       OUT_JACOBIAN, mine.data_ptr(), _stream_ptr()), "h2_commit_range_device")
+    # rank-independent preconditions on EVERY rank, before anyone enters the gather: only the last rank passes the blind down, and
+    # its failure alone would leave the others waiting in the collective
+    if d_blind is not None and lib().h2_bases_blind_base_set(hv) != 1:
+        raise ValueError("split_commit: a blind scalar but the handle has no blind base (h2_bases_set_blind_base on every rank)")
+    # a rank-LOCAL failure still takes part in the exchange (with the identity), then raises
+    local_rc = lib().h2_commit_range_device(hv, d_scalars[lo:].data_ptr() if hi > lo else None, lo, hi - lo,
+                                            d_blind.data_ptr() if (d_blind is not None and rank == world - 1) else None, FORM_MONTGOMERY,
+                                            OUT_JACOBIAN, mine.data_ptr(), _stream_ptr())
+    if local_rc != 0:
+        mine.zero_()
     gathered = torch.empty((world, 12), dtype=torch.int64, device=dev)
     if world > 1:
         if dist.get_backend() == "nccl":
@@ -180,6 +187,7 @@ def split_commit(handle, d_scalars, rank: int, world: int, d_blind=None):
             gathered.copy_(torch.stack(parts))
     else:
         gathered[0].copy_(mine)
+    check(local_rc, "h2_commit_range_device")
     out = torch.empty(12, dtype=torch.int64, device=dev)
     curve = C.c_int(0)
     check(lib().h2_bases_info(hv, None, None, C.byref(curve)), "h2_bases_info")

@@ -77,7 +77,7 @@ int h2_commit_window_bits(size_t n);
 int h2_commit_pair_supported(size_t n);
 /* Tuning knobs (never change results).  "msm_lane_fraction" in (0.05, 1]: share of the resident wave slots
  * one bucket-accumulation launch claims; < 1 lets commits issued on other streams overlap it (default 1).
- * "host_commit_chunk": scalars per range of h2_commit's pipelined transfer (0 = default 2^17). */
+ * "host_commit_chunk": scalars per range of h2_commit's pipelined transfer (0 = default 2^18 = 8 MiB). */
 int h2_set_option(const char *key, double value);
 
 /* ---- MSM: replaces best_multiexp (halo2_proofs/src/arithmetic.rs:143-180) -------------------- */
@@ -102,6 +102,10 @@ int h2_commit_column_window_bits(size_t n);
 int h2_bases_set_blind_base(h2_bases_t handle, const uint64_t *w_xy, int form);
 /* What a handle holds: the number of registered points, the window width of its table, its curve (any pointer may be NULL). */
 int h2_bases_info(h2_bases_t handle, size_t *n, int *window_bits, int *curve);
+/* 1 if the handle has a blind base installed (h2_bases_set_blind_base, or a w_xy presented to a commit), 0 if not, a negative
+ * status for a dead handle.  The rank-independent precondition of a blinded commit that is split over GPUs: every rank checks it
+ * BEFORE entering the exchange step, so that either all ranks fail or none waits in a collective for one that never arrives. */
+int h2_bases_blind_base_set(h2_bases_t handle);
 int h2_bases_free(h2_bases_t handle);
 
 /* replaces Params::commit / commit_lagrange (halo2_proofs/src/poly/commitment.rs:119-150):

@@ -64,3 +64,26 @@ def test_bench_two_ranks_gloo():
     c5 = d["config5"]
     assert c5["columns_total"] == 64 and c5["columns_per_gpu"] == 32 and c5["columns_ms"] > 0 and c5["columns_first_equals_timed_step"] is True
     assert c5["split_equals_whole"] is True and c5["split_commit_ms"] > 0 and c5["h2d_ms_per_32MiB_column_max_over_ranks"] > 0
+
+
+def test_bench_eight_ranks_gloo_rehearsal():
+    """The driver's 8-GPU launch line rehearsed as far as one GPU allows (H2_BENCH_BACKEND=gloo maps the 8 ranks onto the devices
+    the box has): eight processes, eight registered tables, per-rank columns, config 5 with 64 / 8 = 8 columns per rank in one
+    batched call, the range-split commit over 8 ranges with its all-gather, ONE JSON line last on stdout."""
+    env = dict(os.environ, H2_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                          "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5",
+                          "--warmup", "1", "--no-cpu-baseline", "--no-create-proof", "--prewarm-ms", "50"],
+                         capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.strip().splitlines()[-1].startswith("{")            # the line is the LAST thing on stdout
+    d = _last_json(out.stdout)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak"
+    assert d["checks"]["split_msm_allgather"] is True and d["checks"]["split_sum_identity"] is True
+    assert abs(d["ms_per_step"] * 1e-3 * d["value"] * 1e6 - 8 * (1 << 20)) / (8 << 20) < 0.02      # whole-job aggregate over 8 ranks
+    c5 = d["config5"]
+    assert c5["columns_total"] == 64 and c5["columns_per_gpu"] == 8 and c5["columns_first_equals_timed_step"] is True
+    assert c5["split_equals_whole"] is True and c5["split_commit_ms"] > 0
+    assert d["setup"]["bases_register_ms_max_over_ranks"] > 0

@@ -247,3 +247,71 @@ def test_small_registered_tables_quad_lane_chain(curve):
             torch.cuda.synchronize()
             assert affine_of(curve, out.cpu().numpy().view(np.uint64)) == want, (n, on_device)
             lib.h2_bases_free(hd)
+
+
+@pytest.mark.parametrize("curve,k,bits", [(h.PALLAS, 18, 17), (h.VESTA, 16, 16), (h.PALLAS, 20, 17)])
+def test_column_batched_commit_matches_oracle(curve, k, bits):
+    """The column-batched form of h2_commit_batch_device (one sort / accumulate / fold launch set for K columns, blockIdx.z =
+    column; csrc/msm.hip ColIn / ColStride): every column shape side by side -- dense, 90 %-zero, all-equal (oversized pass-2 bins
+    and heavy buckets IN ONE column of the batch), < 2^16, q - 1 - i --, with and without blinds, counts that fill one group
+    (2, 5, 8), spill into two (9: groups of 5 + 4 on two internal streams) and a prefix length, each output against the C
+    restatement of Params::commit (poly/commitment.rs:119-130).  2^20 at 17 bits is the configuration bench.py times."""
+    import torch
+    lib = h.lib()
+    n = 1 << k
+    _, sm = o.CURVES[curve]
+    sf = co.field_of_curve(curve, "scalar")
+    g = co.generate_bases(curve, 0x2200 + k + curve, n)
+    hd = C.c_uint64(0)
+    assert lib.h2_bases_register_ex(curve, _p(g), n, h.FORM_MONTGOMERY, bits, C.byref(hd)) == 0
+    (w1,) = _points(curve, [0x4242])
+    assert lib.h2_bases_set_blind_base(hd, _p(w1), h.FORM_MONTGOMERY) == 0
+    cols = _skewed_columns(sf, sm, n)
+    names = list(cols) + ["dense2", "dense3", "dense4", "dense5"]
+    for i in range(2, 6):
+        cols[f"dense{i}"] = co.random_field(sf, 5200 + i, n)
+    blinds = co.random_field(sf, 0xB22D, len(names))
+    dev = torch.device("cuda", 0)
+    d_cols = {nm: torch.from_numpy(cols[nm].view(np.int64)).to(dev) for nm in names}
+    d_bl = torch.from_numpy(blinds.view(np.int64)).to(dev)
+    want_b = {}
+    want_nb = {}
+
+    def want(nm, with_blind, n_used=n):
+        key = (nm, n_used)
+        tab = want_b if with_blind else want_nb
+        if key not in tab:
+            i = names.index(nm)
+            tab[key] = (co.jac_to_affine_ints(curve, co.commit(curve, np.ascontiguousarray(g[:n_used]), w1, np.ascontiguousarray(cols[nm][:n_used]), blinds[i]))
+                        if with_blind else co.jac_to_affine_ints(curve, co.best_multiexp(curve, cols[nm][:n_used], g[:n_used])))
+        return tab[key]
+
+    def batch(sel, with_blind, out_kind, n_used=n):
+        cnt = len(sel)
+        arr = C.c_void_p * cnt
+        d_outs = torch.zeros((cnt, 8 if out_kind else 12), dtype=torch.int64, device=dev)
+        bl = arr(*[d_bl[names.index(nm)].data_ptr() for nm in sel]) if with_blind else None
+        rc = lib.h2_commit_batch_device(hd, arr(*[d_cols[nm].data_ptr() for nm in sel]), cnt, n_used, None, bl, h.FORM_MONTGOMERY, out_kind,
+                                        arr(*[d_outs[i].data_ptr() for i in range(cnt)]), None)
+        assert rc == 0, lib.h2_last_error()
+        torch.cuda.synchronize()
+        got = d_outs.cpu().numpy().view(np.uint64)
+        for i, nm in enumerate(sel):
+            assert affine_of(curve, got[i]) == want(nm, with_blind, n_used), (nm, cnt, with_blind, n_used)
+
+    full = k <= 18
+    batch(names[:5], True, 0)                               # the five shapes in one launch set, Jacobian out
+    batch(["dense", "dense2"], False, 1)                    # two columns, no blind, affine out
+    batch(names[:8], True, 1)                               # a full group
+    if full:
+        batch(names, True, 0)                               # nine: two groups on two internal streams
+        batch(["all_equal", "all_equal", "zeros90"], True, 0)   # the same column twice (shared input, separate work areas)
+        batch(["dense", "q-1-i", "dense3"], True, 0, n_used=n - 5)      # prefix of the table (IPA rounds commit over the first n' bases)
+        batch(["dense", "zeros90"], False, 0, n_used=17)    # tiny prefix: the shape falls back to one commit per column
+    # a repeat on the warm workspaces gives the same points, and a lone commit right after a batch is unaffected
+    batch(names[:5], True, 0)
+    d_one = torch.zeros(12, dtype=torch.int64, device=dev)
+    assert lib.h2_commit_device(hd, d_cols["dense"].data_ptr(), n, None, d_bl[0].data_ptr(), h.FORM_MONTGOMERY, 0, d_one.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert affine_of(curve, d_one.cpu().numpy().view(np.uint64)) == want("dense", True)
+    assert lib.h2_bases_free(hd) == 0
