@@ -278,9 +278,20 @@ __global__ void __launch_bounds__(1024) ntt_pass(const u32 *__restrict__ in, u32
 // three planes, so data keeps the caller's form: (a 2^256)(w 2^261) / 2^261 = a w 2^256.
 // Bounds: only the LIMBS have to stay small between the stages -- a twiddle is below p < 2^255, so a multiplication tolerates
 // |value| < 2^261 on the data side.  A radix-4 round adds two products (each below 2^256.3 in magnitude) to an element, so
-// after the five rounds of a 10-stage pass |value| < 2^256.4 + 5 x 2^257.3 < 2^260; one carry pass per output and round keeps
-// limbs 0..7 in [0, 2^29) and lets limb 8 absorb the growth.  The value is folded once, when the element leaves the pass:
-// q = round(value / 2^254) from the top limb, minus q p read from a 129-entry LDS table -> |value| < 2^253.1.
+// after the five rounds of a 10-stage pass |value| < 2^256.4 + 5 x 2^257.3 < 2^260; limb 8 absorbs the growth.  The value is
+// folded once, when the element leaves the pass: q = round(value / 2^254) from the top limb, minus q p read from a 129-entry
+// LDS table -> |value| < 2^253.1.
+// Carry passes (round 4): the CONSUMER normalises, and only what it adds without multiplying.  A round's outputs are
+//     o = (e0 +- e1 wA) +- (e2 +- e3 wA) wB      with every product's limbs in [0, 2^29]   (field9.cuh)
+// so with e0 normalised (limbs 0..7 in [0, 2^29)) every output limb lies in (-2^30, 3 x 2^29) -- call that RAW.  Next round:
+//   * e1, e3 are multiplied as they are: a column of the multiplier holds at most 9 x (3 x 2^29)(2^29) = 27 x 2^58 of products
+//     plus < 3.01 x 2^58 of reduction terms plus a carry below 2^34 -- under 2^63;
+//   * e2 meets a product before ITS multiplication (e2 +- e3 wA): raw it could reach 4 x 2^29 (36 x 2^58 per column: too much),
+//     so it takes a carry pass first -- then |e2 +- e3 wA| < 2^30;
+//   * e0 is never multiplied: it takes a carry pass so that the outputs are RAW again.
+// Two carry passes per radix-4 group and round instead of four (one per output), none in a pass's first round (its inputs come
+// unpacked from memory) and none after its last (the fold / the store factor's multiplication take RAW limbs): 8 instead of 20
+// per lane in a 10-stage pass, ~290 of ~5600 instructions.
 struct Tw9 {
     const uint4 *a, *b;
     const u32 *c;
@@ -288,6 +299,16 @@ struct Tw9 {
 __device__ __forceinline__ fe9 tw9_load(const Tw9 &t, size_t e) {
     const uint4 x = t.a[e], y = t.b[e];
     return fe9{{(i32)x.x, (i32)x.y, (i32)x.z, (i32)x.w, (i32)y.x, (i32)y.y, (i32)y.z, (i32)y.w, (i32)t.c[e]}};
+}
+// entry `base + xm` with `base` wave-uniform (a stage's first entry) and xm < 2^27 per lane: the lane offset stays a 32-bit byte
+// offset beside a scalar base (global_load ... v_off, s[base:base+1]) instead of three 64-bit address computations per twiddle
+__device__ __forceinline__ fe9 tw9_load32(const Tw9 &t, size_t base, u32 xm) {
+    const char *pa = reinterpret_cast<const char *>(t.a + base), *pb = reinterpret_cast<const char *>(t.b + base),
+               *pc = reinterpret_cast<const char *>(t.c + base);
+    const u32 o16 = xm << 4, o4 = xm << 2;
+    const uint4 x = *reinterpret_cast<const uint4 *>(pa + o16), y = *reinterpret_cast<const uint4 *>(pb + o16);
+    const u32 z = *reinterpret_cast<const u32 *>(pc + o4);
+    return fe9{{(i32)x.x, (i32)x.y, (i32)x.z, (i32)x.w, (i32)y.x, (i32)y.y, (i32)y.z, (i32)y.w, (i32)z}};
 }
 struct Lds9 {
     uint4 *a, *b;
@@ -316,25 +337,26 @@ __device__ __forceinline__ fe9 ntt_fold9(const fe9 &v, const i32 *qp) {
 }
 // canonical packed value of a FOLDED element: |value| < 2^253 + 2^132 (ntt_fold9), so value + p lies in (0, 2p) and ONE conditional
 // subtraction is exact (fe9_canonical_small covers (-p, 2p) with two)
+// v is NORMALISED (ntt_fold9 ends in a carry pass), so its sign is the sign of limb 8 (limbs 0..7 are non-negative and
+// below 2^29, i.e. the low part lies in [0, 2^232)): add p exactly when it is negative -- ONE carry pass, no trial subtraction
+// (round 3 added p, carried, subtracted p again, carried again and selected: 135 instructions per element; this is ~70).
 template <int F> __device__ __forceinline__ fe ntt_canonical_folded9(const fe9 &v) {
     const fe9 pk = fe9_p_shl<F>(0);
-    fe9 t, d;
-#pragma unroll
-    for (int i = 0; i < 9; i++) t.v[i] = v.v[i] + pk.v[i];
-    t = fe9_norm(t);
-#pragma unroll
-    for (int i = 0; i < 9; i++) d.v[i] = t.v[i] - pk.v[i];
-    d = fe9_norm(d);
-    if (d.v[8] >= 0) t = d;
-    return fe9_pack(t);
-}
-// packed, non-negative, below 2^256, same residue (what leaves a pass that is not the last)
-template <int F> __device__ __forceinline__ fe ntt_pack_lazy9(const fe9 &v) {       // |value| < 2^254.2
-    const fe9 pk = fe9_p_shl<F>(0);
+    const i32 neg = v.v[8] >> 31;                 // all ones iff value < 0
     fe9 t;
 #pragma unroll
-    for (int i = 0; i < 9; i++) t.v[i] = v.v[i] + pk.v[i];
-    return fe9_pack(fe9_norm(t));
+    for (int i = 0; i < 9; i++) t.v[i] = v.v[i] + (pk.v[i] & neg);      // (p has six non-zero limbs: the others fold away)
+    return fe9_pack(fe9_norm(t));                 // value in [0, p)
+}
+// What leaves a pass that is not the last: the folded value as a 256-bit TWO'S COMPLEMENT word (|value| < 2^253.1 fits with room
+// to spare; fe9_pack's shifts and ors are already that for a negative limb 8), read back by ntt_unpack_signed9 with an arithmetic
+// shift for limb 8.  The intermediate vector never leaves the transform, and adding p + a second carry pass to make it
+// non-negative is ~30 instructions per element saved.
+__device__ __forceinline__ fe ntt_pack_signed9(const fe9 &v) { return fe9_pack(v); }            // v normalised
+__device__ __forceinline__ fe9 ntt_unpack_signed9(const fe &a) {
+    fe9 r = fe9_unpack(a);
+    r.v[8] = (i32)a.v[7] >> 8;                    // bits 232..255, sign-extended
+    return r;
 }
 
 template <int F, int R, bool FIRST>
@@ -390,7 +412,7 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
             }
             return v;
         }
-        return fe9_unpack(fe_load(in + 8 * ((hi_idx << (s0 + r)) + lo0 + ((size_t)row << s0) + col)));
+        return ntt_unpack_signed9(fe_load(in + 8 * ((hi_idx << (s0 + r)) + lo0 + ((size_t)row << s0) + col)));      // ntt_pack_signed9 wrote it
     };
     auto load_factors = [&](fe9 &lk0, fe9 &lk1) {
         lk0 = lk1 = fe9_zero();
@@ -420,7 +442,7 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
         } else if (A.last) {
             w = ntt_canonical_folded9<F>(v);
         } else {
-            w = ntt_pack_lazy9<F>(v);
+            w = ntt_pack_signed9(v);
         }
         fe_store(out + 8 * x, w);
     };
@@ -442,37 +464,29 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
     };
     // stage-major table: the 2^t twiddles of stage t, omega^(xm 2^(L-t-1)) for xm < 2^t, sit contiguously at 2^t - 1 + xm, so
     // the T lanes of a tile row read T consecutive entries (one 128-byte run per plane) instead of entries 2^(L-t-1) apart
-    auto tw_addr = [&](int u, size_t &eA, size_t &eB0, size_t &eB1) {
+    // the three twiddles of round u: which = 0 (wA, entry 2^t - 1 + xm), 1 (wB0, 2^(t+1) - 1 + xm), 2 (wB1, 2^t further on).  The host
+    // routes transforms beyond 2^28 to the 8 x 32 kernel, so every in-stage index xm is below 2^27 here and stays a 32-bit lane
+    // offset beside the stage's scalar base (tw9_load32).
+    auto tw_get = [&](int u, int which) -> fe9 {
         u32 q, col;
         lane_of(u, q, col);
         const int t = s0 + u;
         const u32 low = q & ((1u << u) - 1);
-        const size_t xm = ((size_t)low << s0) + (FIRST ? 0 : lo0 + col);
-        eA = (((size_t)1 << t) - 1) + xm;
-        eB0 = (((size_t)2 << t) - 1) + xm;
-        eB1 = eB0 + ((size_t)1 << t);
+        const u32 xm = (low << s0) + (FIRST ? 0u : (u32)lo0 + col);
+        const size_t base = which == 0 ? (((size_t)1 << t) - 1) : which == 1 ? (((size_t)2 << t) - 1) : (((size_t)3 << t) - 1);
+        return tw9_load32(tw, base, xm);
     };
     // the first twiddle of a round (needed at once) is fetched one round ahead; the other two are requested at the top of the
     // round and first used two multiplications later
     fe9 wA = fe9_zero();
-    if (R >= 2 && tid < ngrp && !FIRST) {
-        size_t eA, eB0, eB1;
-        tw_addr(0, eA, eB0, eB1);
-        wA = tw9_load(tw, eA);
-    }
+    if (R >= 2 && tid < ngrp && !FIRST) wA = tw_get(0, 0);
     __syncthreads();                                   // the q p table (and, unfused, the tile) is in LDS
 #pragma unroll
     for (int u = 0; u + 1 < R; u += 2) {
         if (tid < ngrp) {
-            size_t eA, eB0, eB1;
-            tw_addr(u, eA, eB0, eB1);
-            const fe9 wB0 = tw9_load(tw, eB0), wB1 = tw9_load(tw, eB1);
+            const fe9 wB0 = tw_get(u, 1), wB1 = tw_get(u, 2);
             fe9 nA = fe9_zero();
-            if (u + 3 < R) {
-                size_t nB0, nB1;
-                tw_addr(u + 2, eA, nB0, nB1);
-                nA = tw9_load(tw, eA);
-            }
+            if (u + 3 < R) nA = tw_get(u + 2, 0);
             u32 q, col;
             lane_of(u, q, col);
             const u32 low = q & ((1u << u) - 1);
@@ -487,7 +501,8 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
                 e2 = load_elem(mid00 + 2, col, lk0, lk1);
                 e3 = load_elem(mid00 + 3, col, lk0, lk1);
             } else {
-                e0 = lds9_get(S, s00), e1 = lds9_get(S, s01), e2 = lds9_get(S, s10), e3 = lds9_get(S, s11);
+                // RAW limbs in LDS (header comment): the two elements that are added before anything multiplies them take the carry pass
+                e0 = fe9_norm(lds9_get(S, s00)), e1 = lds9_get(S, s01), e2 = fe9_norm(lds9_get(S, s10)), e3 = lds9_get(S, s11);
             }
             if (!(FIRST && u == 0)) {
                 e1 = fe9_mul<F>(e1, wA);
@@ -495,8 +510,8 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
             }
             const fe9 a0 = fe9_add(e0, e1), a1 = fe9_sub(e0, e1);
             const fe9 a2 = fe9_mul<F>(fe9_add(e2, e3), wB0), a3 = fe9_mul<F>(fe9_sub(e2, e3), wB1);
-            const fe9 o00 = fe9_norm(fe9_add(a0, a2)), o10 = fe9_norm(fe9_sub(a0, a2));
-            const fe9 o01 = fe9_norm(fe9_add(a1, a3)), o11 = fe9_norm(fe9_sub(a1, a3));
+            const fe9 o00 = fe9_add(a0, a2), o10 = fe9_sub(a0, a2);                   // RAW: limbs in (-2^30, 3 x 2^29)
+            const fe9 o01 = fe9_add(a1, a3), o11 = fe9_sub(a1, a3);
             if (FUSE_STORE && u == R - 2) {
                 fe9 k0, k1, k2;
                 store_factors(k0, k1, k2);
@@ -525,7 +540,7 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
             const u32 s_a = (mid0 << logT) + col, s_b = s_a + (T << u);
             const size_t xm = ((size_t)low << s0) + (FIRST ? 0 : (lo0 + col));
             fe9 a = lds9_get(S, s_a), b = lds9_get(S, s_b);
-            if (!(FIRST && u == 0)) b = fe9_mul<F>(b, tw9_load(tw, (((size_t)1 << t) - 1) + xm));
+            if (!(FIRST && u == 0)) b = fe9_mul<F>(b, tw9_load32(tw, ((size_t)1 << t) - 1, (u32)xm));
             lds9_put(S, s_a, fe9_norm(fe9_add(a, b)));
             lds9_put(S, s_b, fe9_norm(fe9_sub(a, b)));
         }
@@ -694,10 +709,13 @@ static bool ntt_on_fe9() {
     static const bool on = [] { const char *e = getenv("H2_NTT_FE9"); return !(e && atoi(e) == 0); }();
     return on;
 }
+// the carry-free passes keep in-stage twiddle indices in 32-bit lane offsets (tw9_load32): transforms up to 2^28; beyond that
+// (16 GiB vectors and up) the 8 x 32 kernel with its 32-byte table entries takes over
+static bool ntt_use_fe9(int L) { return ntt_on_fe9() && L <= 28; }
 template <int F, int R, bool FIRST>
 static int launch_pass_t(const PassArgs &A, unsigned tiles, u32 threads, size_t lds, hipStream_t st, const u32 *src, u32 *dst,
                          const u32 *tw) {
-    if (ntt_on_fe9()) {
+    if (ntt_use_fe9(A.L)) {
         static bool attr9 = false;
         if (!attr9) {
             H2_HIP(hipFuncSetAttribute((const void *)ntt_pass9<F, R, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -785,7 +803,7 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
         return H2_OK;
     }
     std::shared_ptr<TwEntry> tw;
-    int rc = get_twiddles(cx, J.field, L, J.omega, st, tw, ntt_on_fe9() ? 1 : 0);
+    int rc = get_twiddles(cx, J.field, L, J.omega, st, tw, ntt_use_fe9(L) ? 1 : 0);
     if (rc != H2_OK) return rc;
 
     // pass plan: ceil(L / maxr) passes, stages spread evenly (H2_NTT_MAXR / H2_NTT_LOGT / H2_NTT_LDS: tuning sweeps only).
