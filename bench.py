@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--columns", type=int, default=4, help="distinct scalar columns resident in HBM")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("H2_BENCH_STREAMS", "3")),
                     help="HIP streams the independent column commits are spread over (per GPU)")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("H2_BENCH_BATCH", "5")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("H2_BENCH_BATCH", "1")),
                     help="column commits per h2_commit_batch_device call (the columns of a prover phase are independent, plonk/prover.rs:301-313): "
                          "K consecutive steps share one sort / accumulate / fold launch set; 1 = one h2_commit_device call per step")
     ap.add_argument("--prewarm-ms", type=float, default=400.0,

@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
 #pragma unroll
     for (int u = 0; u + 1 < R; u += 2) {
         if (tid < ngrp) {
-            const fe9 wB0 = tw_get(u, 1), wB1 = tw_get(u, 2);
+            const fe9 wB0 = (FIRST && u == 0) ? fe9_zero() : tw_get(u, 1), wB1 = tw_get(u, 2);
             fe9 nA = fe9_zero();
             if (u + 3 < R) nA = tw_get(u + 2, 0);
             u32 q, col;
@@ -509,7 +509,10 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
                 e3 = fe9_mul<F>(e3, wA);
             }
             const fe9 a0 = fe9_add(e0, e1), a1 = fe9_sub(e0, e1);
-            const fe9 a2 = fe9_mul<F>(fe9_add(e2, e3), wB0), a3 = fe9_mul<F>(fe9_sub(e2, e3), wB1);
+            // the transform's first round: stage 1's twiddle for the pair (e2 + e3) is omega^0 for every group (stage-major entry 1) --
+            // a carry pass stands in for that multiplication by one (limbs back in [0, 2^29): the outputs stay RAW)
+            const fe9 a2 = (FIRST && u == 0) ? fe9_norm(fe9_add(e2, e3)) : fe9_mul<F>(fe9_add(e2, e3), wB0);
+            const fe9 a3 = fe9_mul<F>(fe9_sub(e2, e3), wB1);
             const fe9 o00 = fe9_add(a0, a2), o10 = fe9_sub(a0, a2);                   // RAW: limbs in (-2^30, 3 x 2^29)
             const fe9 o01 = fe9_add(a1, a3), o11 = fe9_sub(a1, a3);
             if (FUSE_STORE && u == R - 2) {
