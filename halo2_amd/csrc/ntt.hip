@@ -69,6 +69,26 @@ __global__ void __launch_bounds__(256) ntt_twiddles(u32 *__restrict__ tw, fepara
 
 __device__ __forceinline__ u32 bitrev(u32 x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
+// Workgroup -> tile map of the passes after the first.  A tile is (hi, lo): elements hi 2^(s0+r) + mid 2^s0 + lo T + col; its
+// in-pass twiddles omega^((low 2^s0 + lo T + col) ...) depend on `lo` alone.  So (1) the tiles of one `lo` -- one per `hi` -- read
+// the SAME table entries, and (2) neighbouring `lo` read NEIGHBOURING entries: T consecutive entries per tile row, i.e. T / 8 of a
+// 128-byte line of the two 16-byte planes and T / 32 of a line of the 4-byte plane.  The dispatcher puts workgroup b on XCD b % 8
+// (observed, MI355X_MICROARCH.md -- a speed assumption only: any placement gives the same results), each XCD with its own L2.
+// With tile = b the 32 / T tiles that share a line sat on as many different XCDs and each fetched the line for itself: the second
+// pass of a 2^20 transform fetched 166 MiB for 68 MiB of data + twiddles (profiles/r04_pmc_traffic.json; FETCH_SIZE calibrated
+// on these very patterns, bench/ubench_fetch.hip).  Here XCD x takes the x-th CONTIGUOUS EIGHTH of the `lo` range, for every
+// `hi`; in dispatch order `lo` runs fastest (the line sharers run side by side), then `hi` (the next tiles re-read what the XCD's
+// L2 already holds): 72 MiB at 2^20.  Measured alternatives: a contiguous eighth of the TILES (right for one `hi`, but at 2^22
+// every XCD then needs every twiddle of the middle pass: 159 -> 266 MiB), groups of the 32 / T line sharers dealt round-robin
+// (2^20: 81 MiB, the last pass of 2^22 319 against 272).
+__device__ __forceinline__ u32 ntt_tile_of_block(u32 b, u32 nblocks, int s0, int logT) {
+    const int lt = s0 - logT;                           // log2 tiles per hi
+    if (lt < 3 || (nblocks & 7u)) return b;             // fewer than eight tiles per hi: dispatch order as it is
+    const u32 xcd = b & 7u, k = b >> 3;                 // k-th workgroup of its XCD
+    const u32 lo_local = k & ((1u << (lt - 3)) - 1u), hi = k >> (lt - 3);
+    return (hi << lt) | (xcd << (lt - 3)) | lo_local;
+}
+
 struct PassArgs {
     int L;        // log2 n
     int s0;       // first stage of this pass (stage t pairs x and x + 2^t)
@@ -389,9 +409,10 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
     if (FIRST) {
         c0 = blockIdx.x << logT;
     } else {
+        const u32 tile_id = ntt_tile_of_block(blockIdx.x, gridDim.x, s0, logT);
         u32 tiles_per_hi = 1u << (s0 - logT);
-        hi_idx = blockIdx.x / tiles_per_hi;
-        lo0 = (size_t)(blockIdx.x % tiles_per_hi) << logT;
+        hi_idx = tile_id / tiles_per_hi;
+        lo0 = (size_t)(tile_id % tiles_per_hi) << logT;
     }
     // With an even number of stages the first radix-4 round takes its four elements straight from global memory and the last
     // one stores straight to it: no load-all / barrier / store-all phases, a wave starts multiplying as soon as ITS loads are
