@@ -62,7 +62,7 @@ static constexpr size_t kLdsCap = 160 * 1024 - 512;
 
 // Two-pass sort geometry for a table of `stride` columns and window width c: the low `lowb` bucket bits ride in the
 // entry above the table index (`lb` bits); the remaining bucket_bits - lowb bits select the pass-1 bin.
-static bool sort2_geometry(u32 stride, int c, int *lowb_out, int *lb_out, int *side_out = nullptr) {
+static bool sort2_geometry(u32 stride, int c, int *lowb_out, int *lb_out, int *side_out = nullptr, u32 *s1_out = nullptr) {
     const int W = 255 / c + 1, bucket_bits = c - 1;
     const uint64_t top = (uint64_t)W * stride - 1;
     if (top >= ((uint64_t)1 << 31)) return false;
@@ -81,7 +81,12 @@ static bool sort2_geometry(u32 stride, int c, int *lowb_out, int *lb_out, int *s
     }
     if (lowb < 1 || bucket_bits - lowb > 12) return false;
     const size_t nh = (size_t)1 << (bucket_bits - lowb);
-    if ((nh * 3 + 1 + (size_t)kS1Scalars * W) * 4 > kLdsCap) return false;   // pass-1 stage in LDS
+    // pass-1 stage in LDS: 2048 scalars' digits per workgroup, 1024 where narrower windows mean more digits per scalar (13-bit tables:
+    // 20 digits) -- only for callers that ask (s1_out); the others keep the fixed 2048 they were measured with
+    u32 s1 = kS1Scalars;
+    if (s1_out && (nh * 3 + 1 + (size_t)s1 * W) * 4 > kLdsCap) s1 = 1024;
+    if ((nh * 3 + 1 + (size_t)s1 * W) * 4 > kLdsCap) return false;
+    if (s1_out) *s1_out = s1;
     *lowb_out = lowb;
     *lb_out = lb;
     if (side_out) *side_out = side;
@@ -2200,18 +2205,21 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         S2.lds_window = std::min<u32>(tb, 32768u);
         S2.pair_shift = a.pair_shift;
         S2.pair_n = a.pair_n;
-    } else if (a.table && (sh.c > kMaxC || (sh.NB >= 4096 && m >= 8192))) {
+    } else if (a.table && (sh.c > kMaxC || (sh.NB >= 4096 && (m >= 8192 || K > 1)))) {
+        // (a column-batched commit exists in the two-pass form only, so it takes it from 13-bit tables on whatever the column length:
+        // eight 2^12-point columns in one launch set are 0.3 ms against 0.9 ms for eight chains of one-pass sorts)
         static const int force_old = [] { const char *e = getenv("H2_MSM_SORT"); return e && atoi(e) == 1 ? 1 : 0; }();
         int lowb = 0, lb = 0, side = 0;
-        if (sort2_geometry(a.stride, sh.c, &lowb, &lb, &side) && (sh.c > kMaxC || !force_old)) {
+        u32 s1 = kS1Scalars;
+        if (sort2_geometry(a.stride, sh.c, &lowb, &lb, &side, &s1) && (sh.c > kMaxC || !force_old)) {
             use_sort2 = true;
             S2.m = (u32)m; S2.c = sh.c; S2.W = sh.W; S2.mont = a.form == H2_FORM_MONTGOMERY;
             S2.stride = a.stride; S2.extra_col = a.d_extra_scalar ? a.extra_col : 0xFFFFFFFFu;
             S2.lowb = lowb; S2.lb = lb; S2.nh = sh.NB >> lowb;
             S2.side = side;
-            S2.s1_scalars = kS1Scalars;
+            S2.s1_scalars = s1;
             S2.nb = sh.NB;
-            S2.B1 = (u32)((m + kS1Scalars - 1) / kS1Scalars);
+            S2.B1 = (u32)((m + s1 - 1) / s1);
             S2.K2 = kS2Chunk;
             S2.B2 = (u32)((all_items + kS2Chunk - 1) / kS2Chunk);
             S2.lds_window = std::min<u32>(sh.NB, 32768u);
@@ -3134,8 +3142,16 @@ extern "C" int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars
     // streams, so that one group's sort and fold run beside the other's accumulate.  Shapes the batched form does not take
     // (narrow windows, small columns: msm_launch says so before launching anything) fall through to one commit per column
     // on three streams, as before.  H2_BATCH_COLS: sweeps only (1 = the per-column form).
-    static const size_t batch_cols = [] { const char *e = getenv("H2_BATCH_COLS"); int v = e ? atoi(e) : 0; return (size_t)(v >= 1 && v <= kMaxCols ? v : kMaxCols); }();
-    if (count >= 2 && batch_cols >= 2 && n > 0) {
+    static const int batch_env = [] { const char *e = getenv("H2_BATCH_COLS"); int v = e ? atoi(e) : 0; return v >= 1 && v <= kMaxCols ? v : 0; }();
+    const size_t batch_cols = batch_env ? (size_t)batch_env : (size_t)kMaxCols;
+    // Which form (measured on one MI355X, bench/tools/batch_vs_fork.py, profiles/r04_batch_vs_fork.txt; ms per column, batched / forked):
+    //   2^13 x 8: 0.059 / 0.116    2^14 x 8: 0.065 / 0.115    2^16 x 8: 0.102 / 0.143    2^18 x 2, 3, 8: 0.353 / 0.386, 0.302 / 0.323, 0.287 / 0.290
+    //   2^20 x 2: 1.105 / 1.177    2^20 x 3: 1.094 / 1.099    2^20 x 8: 1.064 / 1.037
+    // Below ~2^18 points a commit is a chain of short launches and the batched form shares every one of them; at 2^20 the accumulate
+    // is 80 % of a commit, K x 512 workgroups of it do not tile the chip as evenly as one launch per column sized to it, and three
+    // streams of whole commits hide more of the tails: many full-size columns keep the forked form.
+    const bool prefer_fork = !batch_env && n >= ((size_t)1 << 19) && count > 3;
+    if (count >= 2 && batch_cols >= 2 && n > 0 && !prefer_fork) {
         auto b = find_bases(g);
         if (!b) return H2_ERR_HANDLE;
         if (bad_common(b->curve, form, out_kind) || n > b->n) return H2_ERR_ARGS;

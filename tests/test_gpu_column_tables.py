@@ -38,8 +38,8 @@ def _skewed_columns(sf, sm, n):
         "dense": dense,
         "zeros90": zeros90,
         "all_equal": np.ascontiguousarray(np.tile(fields.scalar_limbs(0xDEADBEEFCAFE0123456789, sf), (n, 1))),
-        "below_2^16": np.ascontiguousarray(np.tile(small, (n >> 12, 1))),
-        "q-1-i": np.ascontiguousarray(np.tile(top, (n >> 12, 1))),          # maximal digits, every window negative after the recode
+        "below_2^16": np.ascontiguousarray(np.tile(small, (n >> 12, 1)) if n >= (1 << 12) else small[:n]),
+        "q-1-i": np.ascontiguousarray(np.tile(top, (n >> 12, 1)) if n >= (1 << 12) else top[:n]),          # maximal digits, every window negative after the recode
     }
 
 
@@ -249,7 +249,8 @@ def test_small_registered_tables_quad_lane_chain(curve):
             lib.h2_bases_free(hd)
 
 
-@pytest.mark.parametrize("curve,k,bits", [(h.PALLAS, 18, 17), (h.VESTA, 16, 16), (h.PALLAS, 20, 17)])
+@pytest.mark.parametrize("curve,k,bits", [(h.PALLAS, 18, 17), (h.VESTA, 16, 16), (h.PALLAS, 20, 17), (h.VESTA, 12, 13), (h.PALLAS, 11, 13),
+                                          (h.VESTA, 13, 16)])
 def test_column_batched_commit_matches_oracle(curve, k, bits):
     """The column-batched form of h2_commit_batch_device (one sort / accumulate / fold launch set for K columns, blockIdx.z =
     column; csrc/msm.hip ColIn / ColStride): every column shape side by side -- dense, 90 %-zero, all-equal (oversized pass-2 bins
