@@ -622,10 +622,10 @@ def main():
         # collected separately, corrected as MI355X_MICROARCH.md prescribes); null when the workload differs
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
             if args.log_n == 20:
                 t_ = pmc["msm_accumulate_2^20"]
-                traffic = int(t_["fetch_bytes_reported_max"] + t_["write_bytes_max"])
+                traffic = int(t_.get("fetch_bytes_corrected", t_["fetch_bytes_reported_max"]) + t_["write_bytes_max"])
         except Exception:
             pmc = None
         total_mults = float(n) * args.steps * world
@@ -669,8 +669,9 @@ def main():
                                                         "resident (bench/ubench_madlat.hip, profiles/r03_ubench_madlat.txt): 1024 SIMDs x 2.4 GHz x 64 lanes / (1151 x 5.8) -- the "
                                                         "bound if nothing but the multiply-adds took time; isolated_Gmadd_per_s is the kernel alone on the chip (DESIGN.md section 3.3)"},
                          "note": "VALU integer-multiply bound, not HBM bound (DESIGN.md section 3): the HBM fraction is reported as the contract "
-                                 "asks, the VALU figures are what track kernel quality; traffic = PMC bytes of the registered-bases path, which "
-                                 "gathers 16 precomputed multiples per point from a 1 GiB table by design"},
+                                 "asks, the VALU figures are what track kernel quality; traffic = PMC bytes of the registered-bases path (FETCH_SIZE calibrated on 64-byte random gathers, "
+                                 "profiles/r04_pmc_traffic.json), which gathers 15 precomputed multiples per point from a 1 GiB table by design: a 64-byte point "
+                                 "is half a 128-byte line, and the line is what moves"},
             # the HBM-bound part of the path (north star: "bucket-scan kernel"): the two-pass bucket sort streams 244 B per scalar
             # (32 B read twice by pass 1; 15 entries x 4 B written by pass 1, read once and written once by the one-launch pass 2);
             # time = the sort stage alone on one stream
@@ -681,6 +682,15 @@ def main():
                 "frac": round(244.0 * n / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_ else None,
                 "traffic": tr_, "stage_ms_isolated": ms_})(
                 iso.get("msm_sort"), (pmc or {}).get("msm_bucket_sort_2^20", {}).get("total_hbm_bytes_corrected") if args.log_n == 20 else None),
+            # the second hot kernel of the path (BASELINE configs[2]): the NTT passes, priced the same way -- 64 B per element per
+            # transform over the transform's wall time, against HBM; traffic = PMC bytes of the two passes
+            # (FETCH_SIZE calibrated on the passes' own access patterns, profiles/r04_pmc_traffic.json)
+            "roofline_ntt": (lambda e_: None if not e_ else {
+                "bound": "hbm", "kernel": "ntt_pass9 (two passes of 10 stages at 2^20)", "achieved": e_["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(e_["algorithmic_GBps"] / HBM_PEAK_GBS, 5), "ms_per_transform": e_["ms"], "kernel_ms_per_transform": e_["kernel_ms"],
+                "traffic": (pmc or {}).get("ntt_2^20", {}).get("total_hbm_bytes_corrected"),
+                "note": "VALU-bound like the MSM: 10.5 M modular multiplications per 2^20 transform at ~200 G/s are 0.052 ms before any addition, carry pass "
+                        "or LDS round trip; the passes issue ~4800 instructions per lane and pass (DESIGN.md section 4)"})(ntt.get("2^20")),
             "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()},
             "kernel_ms_isolated": iso,
             "generic_best_multiexp": generic, "extra": extra, "skewed_columns": skew, "ntt": ntt, "cpu_baseline": cpu,

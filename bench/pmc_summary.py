@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Turns the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- collected in separate runs, no trace domains) into
-profiles/r03_pmc_traffic.json (r02_... last round), the per-launch HBM byte counts bench.py quotes as `roofline.traffic`.
+profiles/r04_pmc_traffic.json (r03_... last round), the per-launch HBM byte counts bench.py quotes as `roofline.traffic`.
+Optional third / fourth argument (round 4): the same two counters over bench/ubench_fetch.hip, kernels that move a KNOWN number
+of bytes in the NTT's access patterns -- the calibration behind the read correction (see `calibration` in the output).
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_f -o f --output-format csv -- python bench.py --steps 3 --warmup 1 --prewarm-ms 0 --minimal --no-cpu-baseline --streams 1
@@ -9,7 +11,8 @@ profiles/r03_pmc_traffic.json (r02_... last round), the per-launch HBM byte coun
 
 Counter values are KiB per dispatch.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide coalesced streaming
 reads by exactly 2x (calibrated for 16 B/lane streams); the x2 is applied to the streaming kernels named in STREAMING and
-not to msm_accumulate's 64-byte random gathers (uncalibrated pattern: lower bound)."""
+not to msm_accumulate's 64-byte random gathers (round 4: bench/ubench_fetch.hip calibrates 64-byte and 16-byte gathered runs as
+well -- also exactly half; the accumulate figure is still quoted as reported, i.e. as a lower bound)."""
 from __future__ import annotations
 
 import collections
@@ -44,8 +47,29 @@ def main():
     def pick(prefix):
         return {k: v for k, v in kernels.items() if k.startswith(prefix) and v["FETCH_SIZE_KiB_max"] is not None}
 
+    # calibration (bench/ubench_fetch.hip): reported KiB / true KiB per pattern
+    TRUE_KIB = {"cal_stream16": 32768, "cal_rows128": 32768, "cal_runs16": 16384, "cal_runs4": 4096, "cal_gather64": 262144, "cal_write_stream16": 32768, "cal_write_rows128": 32768}
+    calibration = None
+    if len(sys.argv) > 4:
+        cf, cw = collect(sys.argv[3], "FETCH_SIZE"), collect(sys.argv[4], "WRITE_SIZE")
+        calibration = {"what": "bench/ubench_fetch.hip under the same two counters: every kernel moves a known number of bytes exactly once; "
+                               "ratio = reported / true.  cal_stream16: 16 B per lane streaming (the pattern the guide's x2 was calibrated on); "
+                               "cal_rows128: the NTT's data loads (128-byte rows 32 KiB apart); cal_runs16 / cal_runs4: the stage-major twiddle "
+                               "gathers of a second pass (64-byte / 16-byte runs, 16 KiB / 4 KiB apart); cal_gather64: msm_accumulate's pattern, 2^22 random 64-byte "
+                               "slots of a 1 GiB table (true_KiB = the 256 MiB REQUESTED; a slot is half a 128-byte line); cal_write_*: the stores",
+                       "kernels": {}}
+        for k, true_kib in TRUE_KIB.items():
+            src = cw if "write" in k else cf
+            vals = [v for name, vs in src.items() if name.startswith(k + " ") for v in vs]
+            if vals:
+                calibration["kernels"][k] = {"true_KiB": true_kib, "reported_KiB_avg": round(sum(vals) / len(vals), 1), "ratio": round(sum(vals) / len(vals) / true_kib, 4)}
+        rr = [v["ratio"] for k, v in calibration["kernels"].items() if "write" not in k and "gather" not in k]
+        calibration["read_correction"] = round(1.0 / (sum(rr) / len(rr)), 3) if rr else None
+        calibration["conclusion"] = ("FETCH_SIZE reports half the bytes for EVERY read pattern measured (streaming, 128-byte rows, 64-byte and 16-byte "
+                                     "gathered runs): the x2 applies to the twiddle gathers as well; WRITE_SIZE is exact")
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1 "
                      "--prewarm-ms 0 --minimal --no-cpu-baseline --streams 1, one MI355X; summarised by bench/pmc_summary.py",
+           "calibration": calibration,
            "units": __doc__.split("Counter values")[1].strip().replace("\n", " "),
            "kernels": kernels}
     acc = pick("h2::msm_accumulate<0, false, true>")
@@ -53,6 +77,9 @@ def main():
         k = max(acc, key=lambda k_: acc[k_]["FETCH_SIZE_KiB_max"])
         out["msm_accumulate_2^20"] = {
             "algorithmic_bytes": 96 << 20, "fetch_bytes_reported_max": int(acc[k]["FETCH_SIZE_KiB_max"] * 1024),
+            "fetch_bytes_corrected": int(acc[k]["FETCH_SIZE_KiB_max"] * 1024 * 2),
+            "correction": "x2, as for every other pattern: cal_gather64 (random 64-byte slots of a 1 GiB table) REPORTS exactly the bytes it requests, "
+                          "i.e. half of what moves -- a gathered 64-byte point is half a 128-byte line and the line is what the memory system fetches",
             "write_bytes_max": int((acc[k]["WRITE_SIZE_KiB_max"] or 0) * 1024),
             "note": "the registered-bases path gathers one 64-B point per non-zero digit (15 per scalar with the 17-bit windows of a column table, 16 with 16-bit ones) from the table of precomputed 2^(c w) multiples: ~1 GiB of gathers + 64 MiB of sorted entries by design; bench/ubench_madd "
                     "shows the kernel runs at the same speed when the table is L2-resident, i.e. this traffic is not what bounds it"}
@@ -70,11 +97,24 @@ def main():
                                                 "(round 2, chunked pass 2 and 16 digits: 320 B)"}
     ntt = {}
     for k, v in kernels.items():
-        if "ntt_pass9<0, 10" in k and v["FETCH_SIZE_KiB_max"] is not None:
-            ntt[k] = {"read_bytes_corrected": int(v["FETCH_SIZE_KiB_max"] * 1024 * 2), "write_bytes": int((v["WRITE_SIZE_KiB_max"] or 0) * 1024)}
+        if "ntt_pass9<0, 10" in k and v["FETCH_SIZE_KiB_avg"] is not None:
+            ntt[k] = {"read_bytes_corrected": int(v["FETCH_SIZE_KiB_avg"] * 1024 * 2), "write_bytes": int((v["WRITE_SIZE_KiB_avg"] or 0) * 1024)}
     if ntt:
+        tot = sum(v["read_bytes_corrected"] + v["write_bytes"] for v in ntt.values())
         out["ntt_2^20"] = {"algorithmic_bytes": 64 << 20, "plan": "two passes of 10 stages (ntt_pass9)", "passes": ntt,
-                           "total_hbm_bytes_corrected": sum(v["read_bytes_corrected"] + v["write_bytes"] for v in ntt.values())}
+                           "total_hbm_bytes_corrected": tot, "ratio_to_algorithmic": round(tot / (64 << 20), 3),
+                           "floor_of_this_plan": "two passes move the vector twice (2 x 64 MiB) and the second reads its 2^20 single-use stage-major "
+                                                 "twiddles once (2^20 x 36 B = 36 MiB): 164 MiB = 2.56 x the 64 MiB the metric counts -- a 2-pass transform "
+                                                 "that LOADS its twiddles cannot be below that; computing them instead costs a multiplication per butterfly "
+                                                 "on a VALU-bound pass (DESIGN.md section 4)"}
+    ntt22 = {}
+    for k, v in kernels.items():
+        if ("ntt_pass9<0, 8" in k or "ntt_pass9<0, 6" in k) and "grid=1048576" in k and v["FETCH_SIZE_KiB_avg"] is not None:
+            ntt22[k] = {"read_bytes_corrected": int(v["FETCH_SIZE_KiB_avg"] * 1024 * 2), "write_bytes": int((v["WRITE_SIZE_KiB_avg"] or 0) * 1024)}
+    if ntt22:
+        tot = sum(v["read_bytes_corrected"] + v["write_bytes"] for v in ntt22.values())
+        out["ntt_2^22"] = {"algorithmic_bytes": 256 << 20, "plan": "three passes of 8 + 8 + 6 stages", "passes": ntt22, "total_hbm_bytes_corrected": tot,
+                           "ratio_to_algorithmic": round(tot / (256 << 20), 3)}
     print(json.dumps(out, indent=1))
 
 

@@ -54,6 +54,19 @@ extern "C" __global__ void __launch_bounds__(256) cal_runs4(const u32 *__restric
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
+// one 64-byte point (four 16-byte loads) per lane at a pseudo-random 64-byte slot of a 1 GiB table: msm_accumulate's gathers.  A slot is
+// HALF a 128-byte line and the other half belongs to a point nobody near in time wants: the memory system moves the line.
+extern "C" __global__ void __launch_bounds__(256) cal_gather64(const uint4 *__restrict__ src, u32 *__restrict__ sink, size_t ngather, u32 slot_mask) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 acc = 0;
+    for (; t < ngather; t += (size_t)gridDim.x * blockDim.x) {
+        const u32 slot = ((u32)t * 2654435761u + 0x9e3779b9u) & slot_mask;          // odd multiplier: a permutation of the slots
+        const uint4 *p = src + 4 * (size_t)slot;
+        const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        acc ^= a.x ^ b.y ^ c.z ^ d.w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
 // 32 B per lane written as two 16-byte stores, 4-lane rows `row_stride32` apart (the NTT's second-pass stores); and plain streaming
 extern "C" __global__ void __launch_bounds__(256) cal_write_rows128(uint4 *__restrict__ dst, size_t rows, size_t row_stride32) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -91,6 +104,8 @@ int main() {
         hipLaunchKernelGGL(cal_runs16, grid, blk, 0, 0, (const uint4 *)((char *)buf + ((size_t)128 << 20) + ((size_t)rep << 24)), sink, (size_t)262144, 4u, (size_t)1024);
         // 16-byte runs, 4 KiB apart (plane c: 4 MiB)
         hipLaunchKernelGGL(cal_runs4, grid, blk, 0, 0, (const u32 *)((char *)buf + ((size_t)640 << 20) + ((size_t)rep << 22)), sink, (size_t)262144, 4u, (size_t)1024);
+        // 2^22 gathers of 64 B (256 MiB requested) over the whole 1 GiB buffer, every slot at most once
+        hipLaunchKernelGGL(cal_gather64, grid, blk, 0, 0, (const uint4 *)buf, sink, (size_t)1 << 22, (u32)((1u << 24) - 1));
         hipLaunchKernelGGL(cal_write_stream16, grid, blk, 0, 0, (uint4 *)((char *)buf + ((size_t)768 << 20)), payload / 16);
         hipLaunchKernelGGL(cal_write_rows128, grid, blk, 0, 0, (uint4 *)((char *)buf + ((size_t)832 << 20)), payload / 128, (size_t)1024);
         CK(hipDeviceSynchronize());
