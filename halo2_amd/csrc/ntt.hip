@@ -879,6 +879,12 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
         int colbits = A.first ? (L - A.r) : s0;
         A.logT = std::min(want_logT, colbits);
         while (A.logT > 0 && ((32u << A.r) << A.logT) > lds_cap) A.logT--;
+        // a transform alone on the chip, below 2^20: wide tiles are FEW tiles (2^18 as 10 + 8 stages at four columns = 64 workgroups
+        // on 256 CUs) -- narrow them until there is one per CU.  Measured (profiles/r04_ntt_tile_width.txt): 2^19 0.0615 -> 0.0545 ms,
+        // 2^18 0.0518 -> 0.0375, 2^17 0.0498 -> 0.0288, 2^16 0.0342 -> 0.0243.  Batched column transforms (plan 1) fill the chip
+        // with columns instead and keep their 128-byte rows.
+        if (J.plan == 0)
+            while (A.logT > 0 && (n >> (A.r + A.logT)) < 256) A.logT--;
         // keep >= 256 lanes per workgroup when the pass is narrow
         while (A.logT < colbits && ((1 << A.r) << A.logT) < 1024 && ((32u << A.r) << (A.logT + 1)) <= lds_cap) A.logT++;
         if (A.first) {
