@@ -877,7 +877,8 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
         const bool last = i == P - 1;
         A.last = last;
         int colbits = A.first ? (L - A.r) : s0;
-        A.logT = std::min(want_logT, colbits);
+        static const int first_logT = [] { const char *e = getenv("H2_NTT_LOGT_FIRST"); int v = e ? atoi(e) : -1; return v >= 0 && v <= 5 ? v : -1; }();   // sweeps only
+        A.logT = std::min(A.first && first_logT >= 0 ? first_logT : want_logT, colbits);
         while (A.logT > 0 && ((32u << A.r) << A.logT) > lds_cap) A.logT--;
         // a transform alone on the chip, below 2^20: wide tiles are FEW tiles (2^18 as 10 + 8 stages at four columns = 64 workgroups
         // on 256 CUs) -- narrow them until there is one per CU.  Measured (profiles/r04_ntt_tile_width.txt): 2^19 0.0615 -> 0.0545 ms,
