@@ -101,9 +101,14 @@ template <int F> __device__ __noinline__ bool xyzz9_madd_rare(fe9 p, fe9 r, aff9
 }
 
 // acc += q; complete.  acc normalised on entry and exit.
-template <int F> __device__ __forceinline__ void xyzz9_madd(xyzz9<F> &acc, const aff9<F> &q) {
-    if (aff9_is_identity(q)) return;
-    if (xyzz9_is_identity(acc)) {
+// HOT = the caller's accumulation loop (msm_accumulate): q is known not to be the identity (the caller tested the packed point
+// before unpacking it), and the accumulator is the identity exactly when limb 0 of its ZZ is zero -- every ZZ such a loop ever
+// holds is all-zero (the identity), the constant one (limb 0 = 0x1fffff81) or a PRODUCT, whose limb 0 lies in [1, 2^29]
+// (field9.cuh: the pending + 1 of the multiplier lands there).  Saves the second identity test on 18 limbs and seven of the nine
+// ors of the first, per addition.
+template <int F, bool HOT = false> __device__ __forceinline__ void xyzz9_madd(xyzz9<F> &acc, const aff9<F> &q) {
+    if (!HOT && aff9_is_identity(q)) return;
+    if (HOT ? acc.zz.v[0] == 0 : xyzz9_is_identity(acc)) {
         acc.x = q.x;
         acc.y = q.y;
         acc.zz = fe9_one_here<F>();      // (as plain constants hipcc hoists their 12 v_mov to the top of the accumulation loop: every

@@ -1149,6 +1149,9 @@ __global__ void __launch_bounds__(256) msm_bases_to_m9_glv(const u32 *__restrict
     fe_store(d1 + 8, phi.y);
 }
 
+#ifndef H2_ACC_LOOP
+#define H2_ACC_LOOP 2       // 1: the round-3 loop (gather issued before the point is repacked); 2: point consumed first (round 4) -- A/B builds
+#endif
 #ifndef H2_ACC9_WAVES
 #define H2_ACC9_WAVES 2     // waves per SIMD the M9 accumulate is compiled for: 2, 3 and 4 run the adds equally fast (profiles/r02_ubench_fe9.txt);
                             // at 2 the register file keeps room for the sort / fold kernels of commits on other streams (3 streams: 903 vs 861 M/s)
@@ -1207,12 +1210,26 @@ __global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(
                 // everything issued during the previous iteration -- the gather of this point, entry i + 1, the boundary read, a
                 // flush's stores -- has had a whole mixed addition to complete: this wait is free
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if H2_ACC_LOOP == 2
+                // The gathered point is CONSUMED (identity test, repacking into nine limbs per coordinate) before the next gather is
+                // issued into the same sixteen registers: the packed point's live range ends at the pin below, so there is no
+                // register rotation at the loop's back edge (eleven moves per addition in the form that issued the gather first).
+                // The gather still has a whole addition (~7500 cycles) to land.
+                const bool p_ident = aff_is_identity(nxt);
+                aff9<FB> q = aff9_unpack<FB>(nxt);
+                asm volatile("" : "+v"(q.x.v[0]), "+v"(q.x.v[1]), "+v"(q.x.v[2]), "+v"(q.x.v[3]), "+v"(q.x.v[4]), "+v"(q.x.v[5]), "+v"(q.x.v[6]),
+                             "+v"(q.x.v[7]), "+v"(q.x.v[8]), "+v"(q.y.v[0]), "+v"(q.y.v[1]), "+v"(q.y.v[2]), "+v"(q.y.v[3]), "+v"(q.y.v[4]),
+                             "+v"(q.y.v[5]), "+v"(q.y.v[6]), "+v"(q.y.v[7]), "+v"(q.y.v[8])
+                             :
+                             : "memory");
+#else
                 affine<FB> p = nxt;
                 asm volatile("" : "+v"(p.x.v[0]), "+v"(p.x.v[1]), "+v"(p.x.v[2]), "+v"(p.x.v[3]), "+v"(p.x.v[4]), "+v"(p.x.v[5]), "+v"(p.x.v[6]),
                              "+v"(p.x.v[7]), "+v"(p.y.v[0]), "+v"(p.y.v[1]), "+v"(p.y.v[2]), "+v"(p.y.v[3]), "+v"(p.y.v[4]), "+v"(p.y.v[5]),
                              "+v"(p.y.v[6]), "+v"(p.y.v[7])
                              :
                              : "memory");
+#endif
                 const u32 neg = e0 >> 31;
                 const u32 e2 = entries[min(i + 2, hi - 1)];
                 nxt = aff_load<FB>(bases + 16 * (size_t)(e1 & 0x7FFFFFFFu));      // at the tail: a stale, valid entry
@@ -1237,11 +1254,18 @@ __global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(
                     }
                     flushed = true;
                 }
+#if H2_ACC_LOOP == 2
+                if (!p_ident) {
+                    if (neg) q.y = fe9_sub(fe9_zero(), q.y);          // signed limbs: negation is nine subtractions
+                    xyzz9_madd<FB, true>(acc, q);
+                }
+#else
                 if (!aff_is_identity(p)) {
                     aff9<FB> q = aff9_unpack<FB>(p);
                     if (neg) q.y = fe9_sub(fe9_zero(), q.y);          // signed limbs: negation is nine subtractions
                     xyzz9_madd<FB>(acc, q);
                 }
+#endif
                 pending = i + 1 == bend && i + 1 < hi;
                 t2_ok = !flushed;            // the read at the top of an iteration that flushed was made for the bucket it closed
                 t2_last = t2_cur;
