@@ -2079,6 +2079,8 @@ struct MsmContext {
             b->release();
     }
     bool attr_set = false, attr2_set = false, attr_bins_set = false;
+    hipStream_t copy_stream = nullptr;      // h2_msm: the bases cross PCIe on this one while the sort runs (null-stream context only)
+    hipEvent_t copy_done = nullptr;
     u32 lanes[2][3] = {{0, 0, 0}, {0, 0, 0}};  // resident lanes of msm_accumulate<FP / FQ, plain / GLV> on this device
 };
 
@@ -2131,6 +2133,9 @@ struct MsmArgs {
     // Column-batched commit (registered tables, wide windows): ncols independent columns of n_used scalars each run through ONE
     // launch set, blockIdx.z = column (ColIn / ColOut / ColStride above).  Host arrays of device pointers; col_blinds may be null.
     // msm_launch answers H2_ERR_BATCH_SHAPE before launching anything when the shape does not take the batched form.
+    // phase: 0 the whole multiexp; 1 stop after the sort (nothing has read d_bases yet); 2 resume after it (same arguments, same stream).
+    // h2_msm uses 1 / 2 to run the sort -- which needs the scalars only -- while the bases are still crossing PCIe.
+    int phase = 0;
     int ncols = 1;
     const void *const *col_scalars = nullptr;
     const void *const *col_blinds = nullptr;
@@ -2382,7 +2387,9 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     TL_STAMP(tl_id | 1);
     prof_begin(PROF_MSM_SORT, st);
     const u32 extra_col = a.d_extra_scalar ? (a.table ? a.extra_col : (u32)a.n_used) : 0xFFFFFFFFu;
-    if (use_sort2) {
+    if (a.phase == 2) {
+        // the sort was enqueued by the phase-1 call
+    } else if (use_sort2) {
         u32 *hist1 = cx.hist.as<u32>(), *bin_count = cx.plan.as<u32>(), *bin_start = bin_count + S2.nh, *hlo = bin_start + S2.nh + 1,
             *woff = hlo + S2.B2, *hist2 = woff + S2.B2 + 1;
         const size_t lds1 = ((size_t)S2.nh * 3 + 1 + (size_t)S2.s1_scalars * (glv ? 2 : 1) * sh.W) * 4;
@@ -2496,6 +2503,17 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                 first_s != (size_t)-1 ? sb[first_s] : 0, bad_e, first_e);
     }
 #endif
+    if (a.phase == 1) {
+        // every workspace the rest needs is reserved NOW: a reservation that grows frees and synchronises, which the phase-2 call must
+        // not do under the sort's feet
+        if (m9) {
+            if (glv && (rc = cx.bases9.reserve((size_t)scalars_n * 128 + 64)) != H2_OK) return rc;
+            if ((rc = cx.seg9.reserve((size_t)K * ((size_t)T + tb) * 144)) != H2_OK) return rc;
+        }
+        prof_end(PROF_MSM_SORT, st);
+        H2_HIP(hipGetLastError());
+        return H2_OK;
+    }
     if (m9) {
         if (glv && (rc = cx.bases9.reserve((size_t)scalars_n * 128 + 64)) != H2_OK) return rc;
         // raw M9 segments: the heads of the T ranges of every column, then the bucket slots of every column (zeroed in one go)
@@ -2832,14 +2850,42 @@ extern "C" int h2_msm(int curve, const uint64_t *scalars, const uint64_t *bases_
     if ((rc = cx.stage_s.reserve(n * 32 + 32)) != H2_OK) return rc;
     if ((rc = cx.stage_b.reserve(n * 64 + 64)) != H2_OK) return rc;
     if ((rc = cx.out.reserve(128)) != H2_OK) return rc;
-    if (n) {
-        H2_HIP(hipMemcpyAsync(cx.stage_s.ptr, scalars, n * 32, hipMemcpyHostToDevice, 0));
-        H2_HIP(hipMemcpyAsync(cx.stage_b.ptr, bases_xy, n * 64, hipMemcpyHostToDevice, 0));
-        if (form == H2_FORM_CANONICAL) to_mont_async(curve, cx.stage_b.as<u32>(), n * 2, 0);
-    }
     MsmArgs a{cx.stage_s.ptr, nullptr, cx.stage_b.ptr, nullptr, n, false, choose_c(n ? n : 1, false), 0, 0xFFFFFFFFu, form,
               out_kind, cx.out.ptr};
-    if ((rc = msm_dispatch(cx, curve, a, 0)) != H2_OK) return rc;
+    // Large multiexps: the scalars cross first (a third of the bytes), the sort -- which reads nothing else -- is enqueued, and only
+    // then does the host enter the copy of the bases, on a second stream: the sort runs while the bases are on the bus (2^20 points:
+    // 0.25 ms of a 3.6 ms call).  H2_MSM_HOST_OVERLAP=0: copy, copy, compute (A/B).
+    static const bool overlap_on = [] { const char *e = getenv("H2_MSM_HOST_OVERLAP"); return !(e && atoi(e) == 0); }();
+    if (n >= ((size_t)1 << 16) && overlap_on) {
+        if (!cx.copy_stream) {
+            H2_HIP(hipStreamCreateWithFlags(&cx.copy_stream, hipStreamNonBlocking));
+            H2_HIP(hipEventCreateWithFlags(&cx.copy_done, hipEventDisableTiming));
+        }
+        H2_HIP(hipStreamSynchronize(0));                       // the staging buffers may still be read by an earlier call's kernels
+        H2_HIP(hipMemcpyAsync(cx.stage_s.ptr, scalars, n * 32, hipMemcpyHostToDevice, 0));
+        a.phase = 1;
+        if ((rc = msm_dispatch(cx, curve, a, 0)) != H2_OK) { (void)hipStreamSynchronize(0); return rc; }
+        hipError_t e = hipMemcpyAsync(cx.stage_b.ptr, bases_xy, n * 64, hipMemcpyHostToDevice, cx.copy_stream);
+        if (e == hipSuccess && form == H2_FORM_CANONICAL) to_mont_async(curve, cx.stage_b.as<u32>(), n * 2, cx.copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(cx.copy_done, cx.copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(0, cx.copy_done, 0);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(cx.copy_stream);
+            (void)hipStreamSynchronize(0);
+            set_last_hip_error(e, __FILE__, __LINE__);
+            return H2_ERR_HIP;
+        }
+        a.phase = 2;
+        rc = msm_dispatch(cx, curve, a, 0);
+        if (rc != H2_OK) { (void)hipStreamSynchronize(0); return rc; }
+    } else {
+        if (n) {
+            H2_HIP(hipMemcpyAsync(cx.stage_s.ptr, scalars, n * 32, hipMemcpyHostToDevice, 0));
+            H2_HIP(hipMemcpyAsync(cx.stage_b.ptr, bases_xy, n * 64, hipMemcpyHostToDevice, 0));
+            if (form == H2_FORM_CANONICAL) to_mont_async(curve, cx.stage_b.as<u32>(), n * 2, 0);
+        }
+        if ((rc = msm_dispatch(cx, curve, a, 0)) != H2_OK) return rc;
+    }
     H2_HIP(hipMemcpyAsync(out, cx.out.ptr, out_bytes, hipMemcpyDeviceToHost, 0));
     H2_HIP(hipStreamSynchronize(0));
     return H2_OK;
