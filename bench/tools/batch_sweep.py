@@ -17,7 +17,7 @@ bases = co.generate_bases(curve, 0x48414C4F32, n)
 ncol = 4
 cols = [co.random_field(sf, 1000 + c, n) for c in range(ncol)]
 hd = C.c_uint64(0)
-assert lib.h2_bases_register_ex(curve, _p(bases), n, 1, 17, C.byref(hd)) == 0
+assert lib.h2_bases_register_ex(curve, _p(bases), n, 1, int(os.environ.get("C_BITS", "17")), C.byref(hd)) == 0
 w = co.generate_bases(curve, 0x77, 1)[0]
 assert lib.h2_bases_set_blind_base(hd, _p(w), 1) == 0
 dev = torch.device("cuda", 0)
