@@ -739,11 +739,13 @@ static bool ntt_use_fe9(int L) { return ntt_on_fe9() && L <= 28; }
 template <int F, int R, bool FIRST>
 static int launch_pass_t(const PassArgs &A, unsigned tiles, u32 threads, size_t lds, hipStream_t st, const u32 *src, u32 *dst,
                          const u32 *tw) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     if (ntt_use_fe9(A.L)) {
-        static bool attr9 = false;
-        if (!attr9) {
+        static bool attr9[16] = {false};     // per DEVICE (the attribute is): a process driving several GPUs sets it on each; callers hold cx.mu
+        if (!attr9[dev & 15]) {
             H2_HIP(hipFuncSetAttribute((const void *)ntt_pass9<F, R, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr9 = true;
+            attr9[dev & 15] = true;
         }
         const size_t count = A.L >= 1 ? ((size_t)1 << (A.L - 1)) : 1;
         Tw9 t9;
@@ -754,10 +756,10 @@ static int launch_pass_t(const PassArgs &A, unsigned tiles, u32 threads, size_t 
         hipLaunchKernelGGL((ntt_pass9<F, R, FIRST>), dim3(tiles), dim3(threads), lds9, st, src, dst, t9, A);
         return H2_OK;
     }
-    static bool attr = false;  // raise the dynamic-LDS cap once per instantiation
-    if (!attr) {
+    static bool attr[16] = {false};  // raise the dynamic-LDS cap once per instantiation and device
+    if (!attr[dev & 15]) {
         H2_HIP(hipFuncSetAttribute((const void *)ntt_pass<F, R, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        attr = true;
+        attr[dev & 15] = true;
     }
     hipLaunchKernelGGL((ntt_pass<F, R, FIRST>), dim3(tiles), dim3(threads), lds, st, src, dst, tw, A);
     return H2_OK;

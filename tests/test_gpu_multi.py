@@ -162,3 +162,32 @@ def test_split_msm_two_ranks_hip_path():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def test_split_commit_blind_precondition_is_checked_on_every_rank():
+    """only the LAST rank of a split commit hands the blind to its range commit; if the handle has no blind base
+    that rank alone would fail and leave the others waiting in the all-gather.  h2_bases_blind_base_set is the rank-independent
+    precondition: parallel.split_commit (any rank) and h2_commit_split_rccl_device refuse BEFORE entering the exchange."""
+    import ctypes as C
+    import torch
+    from halo2_amd.arithmetic import _p
+    lib = h.lib()
+    curve, n = h.PALLAS, 1 << 12
+    sf = co.field_of_curve(curve, "scalar")
+    g = co.generate_bases(curve, 0x5151, n)
+    hd = C.c_uint64(0)
+    assert lib.h2_bases_register(curve, _p(g), n, h.FORM_MONTGOMERY, C.byref(hd)) == 0
+    assert lib.h2_bases_blind_base_set(hd) == 0
+    assert lib.h2_bases_blind_base_set(C.c_uint64(0xDEAD0001)) < 0                       # no such handle
+    d_col = torch.from_numpy(co.random_field(sf, 1, n).view(np.int64)).to("cuda:0")
+    d_bl = torch.from_numpy(co.random_field(sf, 2, 1).view(np.int64)).to("cuda:0")[0].contiguous()
+    for rank in (0, 1):                    # rank 0 of a world of two never touches the blind itself -- and still refuses
+        with pytest.raises(ValueError):
+            parallel.split_commit(hd, d_col, rank, 2, d_bl)
+    w = co.generate_bases(curve, 0x77, 1)[0]
+    assert lib.h2_bases_set_blind_base(hd, _p(w), h.FORM_MONTGOMERY) == 0
+    assert lib.h2_bases_blind_base_set(hd) == 1
+    out = parallel.split_commit(hd, d_col, 0, 1, d_bl)
+    want = co.commit(curve, g, w, co.random_field(sf, 1, n), co.random_field(sf, 2, 1)[0])
+    assert co.jac_to_affine_ints(curve, out.cpu().numpy().view(np.uint64)) == co.jac_to_affine_ints(curve, want)
+    assert lib.h2_bases_free(hd) == 0
