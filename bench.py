@@ -178,7 +178,10 @@ def main():
     sync_all()
     run_steps(args.warmup)
     sync_all()
-    lib.h2_profile_enable(1)
+    # HIP events around the three stages inside the timed region.  H2_BENCH_PROF_LEVEL=2 records the dominant kernel only, 0 nothing:
+    # measured on one box, twice each (profiles/r04_bench_event_overhead.txt): 1066-1087 / 1071-1087 / 1087-1096 M/s -- the events cost
+    # less than the run-to-run noise
+    lib.h2_profile_enable(int(os.environ.get("H2_BENCH_PROF_LEVEL", "1")))
     sync_all()
     t0 = time.perf_counter()
     run_steps(args.steps)
@@ -691,7 +694,7 @@ def main():
                 "traffic": (pmc or {}).get("ntt_2^20", {}).get("total_hbm_bytes_corrected"),
                 "note": "VALU-bound like the MSM: 10.5 M modular multiplications per 2^20 transform at ~200 G/s are 0.052 ms before any addition, carry pass "
                         "or LDS round trip; the passes issue ~4800 instructions per lane and pass (DESIGN.md section 4)"})(ntt.get("2^20")),
-            "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()},
+            "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items() if v[1]},
             "kernel_ms_isolated": iso,
             "generic_best_multiexp": generic, "extra": extra, "skewed_columns": skew, "ntt": ntt, "cpu_baseline": cpu,
             "checks": {"split_sum_identity": None if split_ok is None else bool(split_ok), "split_msm_allgather": split_msm_ok, "split_msm_rccl_in_library": split_rccl_c},

@@ -48,6 +48,7 @@ int ensure_device() {
 struct ProfState {
     std::mutex mu;
     bool on = false;
+    unsigned mask = 0xF;        // slots that record (h2_profile_enable(2): the dominant kernels only -- every pair of events costs the stream ~10 us)
     struct Pair { hipEvent_t a, b; };
     std::vector<Pair> pending[PROF_SLOTS];
     hipEvent_t open[PROF_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
@@ -58,7 +59,7 @@ struct ProfState {
 static ProfState g_prof;
 bool prof_enabled() { return g_prof.on; }
 void prof_begin(int slot, hipStream_t st) {
-    if (!g_prof.on) return;
+    if (!g_prof.on || !((g_prof.mask >> slot) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_prof.mu);
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
@@ -66,7 +67,7 @@ void prof_begin(int slot, hipStream_t st) {
     g_prof.open[slot] = e;
 }
 void prof_end(int slot, hipStream_t st) {
-    if (!g_prof.on) return;
+    if (!g_prof.on || !((g_prof.mask >> slot) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (!g_prof.open[slot]) return;
     hipEvent_t e;
@@ -81,6 +82,7 @@ void prof_end(int slot, hipStream_t st) {
 extern "C" int h2_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(h2::g_prof.mu);
     h2::g_prof.on = on != 0;
+    h2::g_prof.mask = on == 2 ? ((1u << h2::PROF_MSM_ACCUMULATE) | (1u << h2::PROF_NTT_PASS)) : 0xFu;
     if (on) {
         for (int s = 0; s < h2::PROF_SLOTS; ++s) {
             h2::g_prof.total_ms[s] = 0;

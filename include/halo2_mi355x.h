@@ -430,6 +430,9 @@ int h2_hash_to_curve_device(int curve, const char *domain_prefix, const void *d_
 #define H2_PROF_NTT_PASS 1
 #define H2_PROF_MSM_SORT 2
 #define H2_PROF_MSM_REDUCE 3
+/* on = 1: every slot records; on = 2: only the dominant kernels (H2_PROF_MSM_ACCUMULATE, H2_PROF_NTT_PASS) -- an event pair costs the
+ * launching stream ~10 us, and bench.py's timed region wants the accumulate's duration without paying for the sort's and the fold's;
+ * on = 0: off. */
 int h2_profile_enable(int on);
 int h2_profile_read(int slot, double *total_ms, uint64_t *launches);
 /* The same, plus `busy_ms`: the length of the union of the launch intervals since h2_profile_enable(1).  With launches
