@@ -207,7 +207,10 @@ __device__ __forceinline__ u32 limb_at(const fe &s, int idx) {
 // The sort and tail stages are short dependent chains; when another stream's msm_accumulate shares the SIMDs they
 // must win issue arbitration or they stretch 3-4x and the stream they belong to feeds the chip late (timeline in
 // DESIGN.md section 5).  msm_accumulate stays at priority 0.
-#define H2_LATENCY_STAGE() __builtin_amdgcn_s_setprio(3)
+#ifndef H2_TAIL_PRIO
+#define H2_TAIL_PRIO 3      // measured again in round 4 under the bench's load (profiles/r04_ab_tail_priority.txt)
+#endif
+#define H2_LATENCY_STAGE() __builtin_amdgcn_s_setprio(H2_TAIL_PRIO)
 
 // ---- recode: scalars -> signed window digits -------------------------------------------------
 // code = 0xFFFF for digit 0, else (|d| - 1) | (d < 0 ? 0x8000 : 0);  digits[w * m + i]
