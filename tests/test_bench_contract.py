@@ -87,3 +87,16 @@ def test_bench_eight_ranks_gloo_rehearsal():
     assert c5["columns_total"] == 64 and c5["columns_per_gpu"] == 8 and c5["columns_first_equals_timed_step"] is True
     assert c5["split_equals_whole"] is True and c5["split_commit_ms"] > 0
     assert d["setup"]["bases_register_ms_max_over_ranks"] > 0
+
+
+def test_bench_batched_steps():
+    """--batch K: K consecutive steps go to h2_commit_batch_device as one column-batched call; a step is still one full commit, the line
+    says so (`config.columns_per_call`, `roofline.columns_per_launch`) and the first output still equals the split-and-sum identity."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--batch", "3",
+                          "--no-cpu-baseline", "--no-create-proof", "--prewarm-ms", "20"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["config"]["columns_per_call"] == 3 and d["steps"] == 6
+    assert abs(d["roofline"]["columns_per_launch"] - 3.0) < 1e-6 and d["roofline"]["launches"] == 2
+    assert abs(d["ms_per_step"] * 1e-3 * d["value"] * 1e6 - (1 << 20)) / (1 << 20) < 0.02
+    assert d["checks"]["split_sum_identity"] is True
