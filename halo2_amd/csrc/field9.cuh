@@ -141,7 +141,7 @@ template <int F, bool SQUARE> __device__ __forceinline__ fe9 fe9_mul_impl(const 
 template <int F> __device__ __forceinline__ fe9 fe9_mul_c(const fe9 &a, const fe9 &b) { return fe9_mul_impl<F, false>(a, b); }
 template <int F> __device__ __forceinline__ fe9 fe9_sqr_c(const fe9 &a) { return fe9_mul_impl<F, true>(a, a); }
 
-// The shipped multiplier / squarer: one asm statement each, generated by gen_field9_mul.py (126 / 90 multiply-adds, 17 shifts,
+// The shipped multiplier / squarer: one asm statement each, generated by gen_field9_mul.py (126 / 90 multiply-adds, 16 shifts + one funnel shift,
 // 17 bit ops; limb 0 of the result lies in [1, 2^29], see the generator's docstring).
 #ifndef H2_FE9_IMPL
 #define H2_FE9_IMPL 1

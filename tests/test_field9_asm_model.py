@@ -79,6 +79,8 @@ def _run(ins, operands, field):
         elif op == "v_bfi_b32":                # D = (S0 & S1) | (~S0 & S2)
             s0, s1, s2 = rd32(a[1]), rd32(a[2]), rd32(a[3])
             reg[a[0]] = ((s0 & s1) | (~s0 & s2)) & 0xFFFFFFFF
+        elif op == "v_alignbit_b32":           # D = ({S0, S1} >> S2[4:0]) & 0xffffffff: the last column's limb 8
+            reg[a[0]] = (((rd32(a[1]) << 32) | rd32(a[2])) >> (int(a[3], 0) & 31)) & 0xFFFFFFFF
         elif op == "v_and_b32":
             reg[a[0]] = rd32(a[1]) & rd32(a[2])
         elif op == "v_add_u32":
