@@ -83,7 +83,8 @@ static bool sort2_geometry(u32 stride, int c, int *lowb_out, int *lb_out, int *s
     const size_t nh = (size_t)1 << (bucket_bits - lowb);
     // pass-1 stage in LDS: 2048 scalars' digits per workgroup, 1024 where narrower windows mean more digits per scalar (13-bit tables:
     // 20 digits) -- only for callers that ask (s1_out); the others keep the fixed 2048 they were measured with
-    u32 s1 = kS1Scalars;
+    static const u32 s1_env = [] { const char *e = getenv("H2_S1_SCALARS"); int v = e ? atoi(e) : 0; return (u32)(v == 512 || v == 1024 || v == 2048 ? v : 0); }();   // sweeps only
+    u32 s1 = s1_out && s1_env ? s1_env : kS1Scalars;
     if (s1_out && (nh * 3 + 1 + (size_t)s1 * W) * 4 > kLdsCap) s1 = 1024;
     if ((nh * 3 + 1 + (size_t)s1 * W) * 4 > kLdsCap) return false;
     if (s1_out) *s1_out = s1;
