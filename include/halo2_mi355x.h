@@ -174,9 +174,12 @@ int h2_commit_pair_device(h2_bases_t g, const void *d_scalars, size_t n, unsigne
                           void *d_out, void *stream);
 /* `count` independent commits over one registered basis -- the column commits of a prover phase
  * (plonk/prover.rs:93-101, 301-313; vanishing/prover.rs:96-108).  d_scalars[i] / d_blinds[i] / d_outs[i] are
- * device pointers held in HOST arrays; the commits are spread over internal streams (one column's latency-bound
- * sort/reduce kernels overlap another's accumulate) and joined on `stream`.  d_blinds NULL: no blind term; d_blinds without
- * d_w_xy: the handle's blind base; a d_w_xy is content-checked once, on `stream`, as for h2_commit_device. */
+ * device pointers held in HOST arrays.  The library picks the faster of two forms by size and count: the COLUMN-BATCHED form --
+ * one sort / accumulate / fold launch set for up to eight columns at a time, the column a grid dimension; a single group runs on
+ * `stream` itself, several alternate over two internal streams -- or one commit per column spread over three internal streams
+ * (many full-size columns: one column's sort / fold beside another's accumulate); either way the work is joined on `stream`.
+ * d_blinds NULL: no blind term; d_blinds without d_w_xy: the handle's blind base; a d_w_xy is content-checked once, on
+ * `stream`, as for h2_commit_device. */
 int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars, size_t count, size_t n,
                            const void *d_w_xy, const void *const *d_blinds, int form, int out_kind,
                            void *const *d_outs, void *stream);
