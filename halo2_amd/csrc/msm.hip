@@ -2207,7 +2207,11 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     // a lane fraction < 1 (h2_set_option) leaves wave slots free so that the latency-bound sort / reduce kernels
     // of a commit running on ANOTHER stream can overlap this kernel (independent column commits)
     const double fraction = a.lane_fraction > 0.0 ? a.lane_fraction : g_lane_fraction.load();
-    const u32 usable = std::max(256u, (u32)(lanes * fraction) / 256u * 256u);
+    // H2_ACC_OVERSUB = k (sweeps only): k times as many, k times shorter lanes than the chip holds at once -- workgroups then enter as
+    // slots free up, which evens out a launch that found some CUs half taken by other streams' sort / fold kernels, at the price of
+    // k times the range heads for the finisher
+    static const u32 oversub = [] { const char *e = getenv("H2_ACC_OVERSUB"); int v = e ? atoi(e) : 0; return (u32)(v >= 1 && v <= 8 ? v : 1); }();
+    const u32 usable = std::max(256u, (u32)(lanes * fraction) / 256u * 256u) * (a.table ? oversub : 1u);
     // entries per lane of the accumulate: 16 for full-size columns; small commits are chains of latency-bound kernels and run
     // shorter with more, shorter lanes (one registered commit at 2^11 .. 2^15 points: 3-7 % faster at 8; H2_MSM_DIV: sweeps only)
     static const u32 env_div = [] { const char *e = getenv("H2_MSM_DIV"); int v = e ? atoi(e) : 0; return (u32)(v >= 1 && v <= 64 ? v : 0); }();
