@@ -41,6 +41,15 @@ def run(count, K, S):
                                         arr(*[d_out[(i0 + q) % 128].data_ptr() for q in range(k)]), sps[j % S])
         assert rc == 0, lib.h2_last_error()
 
+# SWEEP_SECONDS=t: first keep the first (K, S) running for t seconds (clock_watch.sh samples the shader clock meanwhile)
+if os.environ.get("SWEEP_SECONDS"):
+    run(100, Ks[0], Ss[0]); torch.cuda.synchronize()
+    open(os.environ.get("SWEEP_MARK", "/tmp/sweep_started"), "w").write("1")
+    t0 = time.perf_counter(); cnt = 0
+    while time.perf_counter() - t0 < float(os.environ["SWEEP_SECONDS"]):
+        run(100, Ks[0], Ss[0]); torch.cuda.synchronize(); cnt += 100
+    dt = time.perf_counter() - t0
+    print(f"sustained K={Ks[0]} S={Ss[0]}: {cnt} columns in {dt:.2f} s = {dt / cnt * 1e3:.4f} ms/col", flush=True)
 ref = None
 for K in Ks:
     for S in Ss:

@@ -446,8 +446,19 @@ struct ColOut {                     // fold9_planes
 };
 struct ColStride {                  // 32-bit words between the areas of consecutive columns (all zero for a single column)
     u32 hist, plan, items, starts, heavy, hscratch, heads, buckets, lines, planes, ctr;
+    u32 entries;      // sorted entries: `items` apart, or 0 when the columns are JOINED (below)
+    u32 joined;       // != 0: the pass-1 bin count nh.  The columns' sorted entries then form ONE list (column z's behind those of the
+                      // columns before it) with ONE boundary array over K x total_buckets buckets (bucket b of column z at
+                      // z * total_buckets + b), which msm_accumulate and fold9_finish walk as if it were a single commit
 };
 #define H2_COLZ(ptr, stride) ((ptr) + (size_t)blockIdx.z * (stride))
+// joined columns: the entries of the columns before this one (each column's total sits behind its pass-1 bin starts, at [nh])
+__device__ __forceinline__ u32 col_entry_base(const u32 *__restrict__ bin_start_col0, const ColStride &cs) {
+    u32 s = 0;
+    if (cs.joined)
+        for (u32 k = 0; k < blockIdx.z; ++k) s += bin_start_col0[(size_t)k * cs.plan + cs.joined];
+    return s;
+}
 
 // signed window digits of one scalar (same recoding as msm_recode, 32-bit codes so that windows may exceed 16 bits),
 // handed to f(w, code): code = kZero32 for digit 0, else (|d| - 1) | (d < 0) << 31
@@ -917,19 +928,22 @@ __global__ void __launch_bounds__(1024) msm_s2_bins(const u32 *__restrict__ tagg
                                                     u32 *__restrict__ big, ColStride cs) {
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    u32 cb = 0;                                                         // joined columns: where this column's entries begin
     if (gridDim.z > 1) {
+        cb = col_entry_base(bin_start, cs);
         tagged = H2_COLZ(tagged, cs.items);
         if (tagged_low) tagged_low = H2_COLZ(tagged_low, cs.items);
         bin_start = H2_COLZ(bin_start, cs.plan);
         starts = H2_COLZ(starts, cs.starts);
-        entries = H2_COLZ(entries, cs.items);
+        entries = H2_COLZ(entries, cs.entries);
         big = H2_COLZ(big, cs.plan);
     }
     const u32 nbk = 1u << P.lowb, h = blockIdx.x;
     u32 *cnt = sh, *cursor = sh + nbk, *stage = cursor + nbk;          // [nbk] | [nbk] | [cap]
-    const u32 p0 = bin_start[h], p1 = bin_start[h + 1], E = p1 - p0;
+    const u32 p0 = bin_start[h], p1 = bin_start[h + 1], E = p1 - p0, q0 = cb + p0;     // q0: the bin's place in the sorted list
     const u32 lowmask = nbk - 1, strip = P.side ? ~0u : ~(lowmask << P.lb);
-    if (h == gridDim.x - 1 && threadIdx.x == 0) starts[total_buckets] = bin_start[gridDim.x];      // M  (the sentinel behind it: msm_s1_prefix)
+    // M  (the sentinel behind it: msm_s1_prefix).  Joined columns: that slot is bucket 0 of the next column, which writes the same value.
+    if (h == gridDim.x - 1 && threadIdx.x == 0) starts[total_buckets] = cb + bin_start[gridDim.x];
     if (E > cap) {
         // a bin that does not fit the stage (a degenerate column: every scalar equal, half of them 1 ...) goes on the list of big
         // bins, which msm_s2_big_* sort with kBigChunks workgroups each; only past kMaxBig such bins does this workgroup do it alone
@@ -963,7 +977,7 @@ __global__ void __launch_bounds__(1024) msm_s2_bins(const u32 *__restrict__ tagg
     for (u32 k = threadIdx.x; k < nbk; k += blockDim.x) {
         const u32 b = (h << P.lowb) + k;
         cursor[k] = cnt[k];
-        if (b < total_buckets) starts[b] = p0 + cnt[k];
+        if (b < total_buckets) starts[b] = q0 + cnt[k];
     }
     __syncthreads();
     const bool fits = E <= cap;
@@ -980,12 +994,12 @@ __global__ void __launch_bounds__(1024) msm_s2_bins(const u32 *__restrict__ tagg
         for (int j = 0; j < 4; ++j)
             if (base + j < p1) {
                 if (fits) stage[pos[j]] = e[j] & strip;
-                else entries[p0 + pos[j]] = e[j] & strip;               // a bin beyond the stage: scattered straight to memory
+                else entries[q0 + pos[j]] = e[j] & strip;               // a bin beyond the stage: scattered straight to memory
             }
     }
     if (!fits) return;
     __syncthreads();
-    for (u32 i = threadIdx.x; i < E; i += blockDim.x) entries[p0 + i] = stage[i];
+    for (u32 i = threadIdx.x; i < E; i += blockDim.x) entries[q0 + i] = stage[i];
 }
 
 // ---- big bins (listed by msm_s2_bins): kBigChunks workgroups per bin -- count, prefix, scatter.  Three small launches that
@@ -1027,14 +1041,17 @@ __global__ void __launch_bounds__(1024) msm_s2_big_prefix(const u32 *__restrict_
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];      // [nbk] bucket totals -> exclusive prefix
     const u32 s = blockIdx.x;
+    u32 cb = 0;
     if (gridDim.z > 1) {
         big = H2_COLZ(big, cs.plan);
+        if (s >= min(big[0], kMaxBig)) return;
+        cb = col_entry_base(bin_start, cs);
         bin_start = H2_COLZ(bin_start, cs.plan);
         gcnt = H2_COLZ(gcnt, cs.plan);
         starts = H2_COLZ(starts, cs.starts);
     }
     if (s >= min(big[0], kMaxBig)) return;
-    const u32 nbk = 1u << P.lowb, h = big[1 + s], p0 = bin_start[h];
+    const u32 nbk = 1u << P.lowb, h = big[1 + s], p0 = cb + bin_start[h];
     for (u32 k = threadIdx.x; k < nbk; k += blockDim.x) {
         u32 run = 0;
         for (u32 c = 0; c < kBigChunks; ++c) {
@@ -1061,14 +1078,16 @@ __global__ void __launch_bounds__(1024) msm_s2_big_scatter(const u32 *__restrict
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
     const u32 s = blockIdx.y, c = blockIdx.x;
+    u32 cb = 0;
     if (gridDim.z > 1) {
         big = H2_COLZ(big, cs.plan);
         if (s >= min(big[0], kMaxBig)) return;
+        cb = col_entry_base(bin_start, cs);
         tagged = H2_COLZ(tagged, cs.items);
         if (tagged_low) tagged_low = H2_COLZ(tagged_low, cs.items);
         bin_start = H2_COLZ(bin_start, cs.plan);
         gcnt = H2_COLZ(gcnt, cs.plan);
-        entries = H2_COLZ(entries, cs.items);
+        entries = H2_COLZ(entries, cs.entries);
     }
     if (s >= min(big[0], kMaxBig)) return;
     const u32 nbk = 1u << P.lowb, lowmask = nbk - 1, strip = P.side ? ~0u : ~(lowmask << P.lb), h = big[1 + s];
@@ -1086,7 +1105,7 @@ __global__ void __launch_bounds__(1024) msm_s2_big_scatter(const u32 *__restrict
         lds_ticket4(sh, k, min(4u, b - base), pos);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (base + j < b) entries[p0 + pos[j]] = e[j] & strip;
+            if (base + j < b) entries[cb + p0 + pos[j]] = e[j] & strip;
     }
 }
 
@@ -1180,7 +1199,7 @@ __global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(
                                                       u32 *__restrict__ buckets, u32 total_buckets, u32 T, u32 div, ColStride cs) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (M9 && gridDim.z > 1) {           // column-batched commit: blockIdx.z = column (the table is shared)
-        entries = H2_COLZ(entries, cs.items);
+        entries = H2_COLZ(entries, cs.entries);
         starts = H2_COLZ(starts, cs.starts);
         heads = H2_COLZ(heads, cs.heads);
         buckets = H2_COLZ(buckets, cs.buckets);
@@ -2216,7 +2235,14 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     // shorter with more, shorter lanes (one registered commit at 2^11 .. 2^15 points: 3-7 % faster at 8; H2_MSM_DIV: sweeps only)
     static const u32 env_div = [] { const char *e = getenv("H2_MSM_DIV"); int v = e ? atoi(e) : 0; return (u32)(v >= 1 && v <= 64 ? v : 0); }();
     const u32 lane_div = env_div ? env_div : (all_items < ((size_t)1 << 20) ? 8u : 16u);
-    u32 T = (u32)std::min<size_t>(usable, std::max<size_t>(256, (all_items / lane_div + 255) / 256 * 256));
+    // Column-batched commits are JOINED (ColStride::joined) unless H2_BATCH_JOIN=0: the K sorted lists form one, which ONE launch of
+    // msm_accumulate cuts into equal ranges -- the chip is tiled exactly as by a single commit (a launch per column leaves its last
+    // round of workgroups ragged, and K of them next to each other share CUs unevenly), and the finisher meets T range heads per
+    // batch instead of per column.
+    static const bool join_env = [] { const char *e = getenv("H2_BATCH_JOIN"); return !(e && e[0] == '0'); }();
+    const bool joined = K > 1 && join_env;
+    u32 T = (u32)std::min<size_t>(usable, std::max<size_t>(256, ((joined ? K : 1) * all_items / lane_div + 255) / 256 * 256));
+    const size_t head_slots = joined ? (size_t)T : (size_t)T * K;      // range heads parked in cx.seg9, in front of the K x tb bucket slots
     const u32 max_heavy = kMaxHeavy;
     // two-pass sort (registered path): always for windows beyond 16 bits, else for large bucket counts
     Sort2 S2;
@@ -2378,7 +2404,9 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         cs.hist = (u32)((size_t)S2.B1 * S2.nh);
         cs.plan = (u32)plan_words;
         cs.items = (u32)all_items;
-        cs.starts = tb + 2;
+        cs.entries = joined ? 0u : (u32)all_items;
+        cs.joined = joined ? S2.nh : 0u;
+        cs.starts = joined ? tb : tb + 2;
         cs.heavy = max_heavy + 2;
         cs.hscratch = max_heavy * kHeavyBlocks * 36;
         cs.heads = T * 36;
@@ -2415,7 +2443,10 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         } else {
             hipLaunchKernelGGL((msm_s1_count<FS, false>), dim3(S2.B1, 1, K), dim3(s1_threads), S2.nh * 4, st, (const u32 *)a.d_scalars,
                                (const u32 *)a.d_extra_scalar, S2, hist1, ci, cs);
-            hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16, 1, K), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh, cx.heavy.as<u32>(), hist2, cx.starts.as<u32>() + tb + 1, cs);
+            ColStride cs1 = cs;                   // joined columns: one heavy-bucket list and one sentinel, behind the K x tb boundaries
+            if (joined) cs1.heavy = cs1.starts = 0;
+            hipLaunchKernelGGL(msm_s1_prefix, dim3((S2.nh + 15) / 16, 1, K), dim3(1024), 0, st, hist1, bin_count, S2.B1, S2.nh, cx.heavy.as<u32>(), hist2,
+                               cx.starts.as<u32>() + (joined ? (size_t)K * tb : (size_t)tb) + 1, cs1);
             hipLaunchKernelGGL((msm_s1_scatter<FS, false>), dim3(S2.B1, 1, K), dim3(s1_threads), lds1, st, (const u32 *)a.d_scalars,
                                (const u32 *)a.d_extra_scalar, S2, hist1, bin_count, bin_start, cx.tagged.as<u32>(), cx.tagged_low.as<uint16_t>(), ci, cs);
         }
@@ -2516,7 +2547,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         // not do under the sort's feet
         if (m9) {
             if (glv && (rc = cx.bases9.reserve((size_t)scalars_n * 128 + 64)) != H2_OK) return rc;
-            if ((rc = cx.seg9.reserve((size_t)K * ((size_t)T + tb) * 144)) != H2_OK) return rc;
+            if ((rc = cx.seg9.reserve((head_slots + (size_t)K * tb) * 144)) != H2_OK) return rc;
         }
         prof_end(PROF_MSM_SORT, st);
         H2_HIP(hipGetLastError());
@@ -2525,8 +2556,8 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     if (m9) {
         if (glv && (rc = cx.bases9.reserve((size_t)scalars_n * 128 + 64)) != H2_OK) return rc;
         // raw M9 segments: the heads of the T ranges of every column, then the bucket slots of every column (zeroed in one go)
-        if ((rc = cx.seg9.reserve((size_t)K * ((size_t)T + tb) * 144)) != H2_OK) return rc;
-        H2_HIP(hipMemsetAsync(cx.seg9.as<u32>() + 36 * (size_t)T * K, 0, (size_t)K * tb * 144, st));
+        if ((rc = cx.seg9.reserve((head_slots + (size_t)K * tb) * 144)) != H2_OK) return rc;
+        H2_HIP(hipMemsetAsync(cx.seg9.as<u32>() + 36 * head_slots, 0, (size_t)K * tb * 144, st));
     } else {
         H2_HIP(hipMemsetAsync(cx.buckets.ptr, 0, (size_t)tb * 128, st));
     }
@@ -2544,9 +2575,9 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                                cx.bases9.as<u32>(), (u32)scalars_n);
             pts = cx.bases9.as<u32>();
         }
-        hipLaunchKernelGGL((msm_accumulate<FB, false, true>), dim3(T / 256, 1, K), dim3(256), 0, st, pts,
+        hipLaunchKernelGGL((msm_accumulate<FB, false, true>), dim3(T / 256, 1, joined ? 1 : K), dim3(256), 0, st, pts,
                            (const u32 *)nullptr, 0xFFFFFFFFu, cx.entries.as<u32>(), cx.starts.as<u32>(), cx.seg9.as<u32>(),
-                           cx.seg9.as<u32>() + 36 * (size_t)T * K, tb, T, lane_div, cs);
+                           cx.seg9.as<u32>() + 36 * head_slots, joined ? K * tb : tb, T, lane_div, cs);
         if (!fold9)
             hipLaunchKernelGGL((msm_segments_to_r256<FB>), dim3((T + tb + 255) / 256), dim3(256), 0, st, cx.seg9.as<u32>(),
                                cx.heads.as<u32>(), cx.buckets.as<u32>(), T, tb);
@@ -2560,12 +2591,13 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     prof_begin(PROF_MSM_REDUCE, st);
     if (fold9) {
         // wide slice: finish on the raw M9 segments, one lane per bucket (fold9_* above); the buckets stay in cx.seg9
-        u32 *heads9 = cx.seg9.as<u32>(), *buckets9 = cx.seg9.as<u32>() + 36 * (size_t)T * K;
-        hipLaunchKernelGGL((fold9_finish<FB>), dim3((tb + 255) / 256, 1, K), dim3(256), 0, st, (const u32 *)heads9, cx.starts.as<u32>(), buckets9,
-                           cx.heavy.as<u32>(), tb, T, lane_div, cs);
-        hipLaunchKernelGGL((fold9_finish_heavy<FB>), dim3(kHeavyBlocks, max_heavy, K), dim3(256), 0, st, (const u32 *)heads9, cx.starts.as<u32>(),
-                           cx.hscratch.as<u32>(), cx.heavy.as<u32>(), tb, T, lane_div, cs);
-        hipLaunchKernelGGL((fold9_finish_heavy2<FB>), dim3(max_heavy, 1, K), dim3(64), 0, st, cx.hscratch.as<u32>(), buckets9, cx.heavy.as<u32>(), cs);
+        u32 *heads9 = cx.seg9.as<u32>(), *buckets9 = cx.seg9.as<u32>() + 36 * head_slots;
+        const u32 fz = joined ? 1 : K, ftb = joined ? K * tb : tb;       // joined columns: one pass over the K x tb buckets
+        hipLaunchKernelGGL((fold9_finish<FB>), dim3((ftb + 255) / 256, 1, fz), dim3(256), 0, st, (const u32 *)heads9, cx.starts.as<u32>(), buckets9,
+                           cx.heavy.as<u32>(), ftb, T, lane_div, cs);
+        hipLaunchKernelGGL((fold9_finish_heavy<FB>), dim3(kHeavyBlocks, max_heavy, fz), dim3(256), 0, st, (const u32 *)heads9, cx.starts.as<u32>(),
+                           cx.hscratch.as<u32>(), cx.heavy.as<u32>(), ftb, T, lane_div, cs);
+        hipLaunchKernelGGL((fold9_finish_heavy2<FB>), dim3(max_heavy, 1, fz), dim3(64), 0, st, cx.hscratch.as<u32>(), buckets9, cx.heavy.as<u32>(), cs);
     } else {
     hipLaunchKernelGGL((msm_finish_buckets<FB>), dim3((tb * kGroup + 255) / 256), dim3(256), 0, st, cx.heads.as<u32>(),
                        cx.starts.as<u32>(), cx.buckets.as<u32>(), cx.heavy.as<u32>(), tb, T, lane_div);
@@ -2594,7 +2626,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
             int cb = 0;
             while ((1u << cb) < wideS) ++cb;
             hipLaunchKernelGGL((fold9_rowcol<FB>), dim3(wideS + wideNR - 1, sh.slices, K), dim3(256), 0, st,
-                               (const u32 *)(cx.seg9.as<u32>() + 36 * (size_t)T * K), lines9, wideS, wideNR, cs);
+                               (const u32 *)(cx.seg9.as<u32>() + 36 * head_slots), lines9, wideS, wideNR, cs);
             const bool windows = glv;                // the slices are window slices: their sums meet in msm_combine's Horner step
             hipLaunchKernelGGL((fold9_planes<FB>), dim3(sh.c - 1, sh.slices, K), dim3(256), 0, st, (const u32 *)lines9, planes9, cx.fold_ctr.as<u32>(),
                                wideS, wideNR, cb, windows ? cx.ssums.as<u32>() : (u32 *)a.d_out, windows ? kOutSliceSum : a.out_kind,

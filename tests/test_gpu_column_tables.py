@@ -4,6 +4,7 @@ on both curves, against the C restatement of `Params::commit` / `best_multiexp` 
 arithmetic.rs:143-180) -- dense and skewed columns, blinds, prefix lengths, the batch entry point -- and the blind base as a
 property of the handle (`Params::w`, commitment.rs:26-33): content-checked, never keyed by an address.  Also the pipelined
 host-pointer commit (column ranges committed as they cross PCIe)."""
+import os
 import ctypes as C
 
 import numpy as np
@@ -268,9 +269,10 @@ def test_column_batched_commit_matches_oracle(curve, k, bits):
     (w1,) = _points(curve, [0x4242])
     assert lib.h2_bases_set_blind_base(hd, _p(w1), h.FORM_MONTGOMERY) == 0
     cols = _skewed_columns(sf, sm, n)
-    names = list(cols) + ["dense2", "dense3", "dense4", "dense5"]
+    names = list(cols) + ["dense2", "dense3", "dense4", "dense5", "all_zero"]
     for i in range(2, 6):
         cols[f"dense{i}"] = co.random_field(sf, 5200 + i, n)
+    cols["all_zero"] = np.zeros_like(cols["dense"])         # no entries at all: an empty stretch in the middle of the joined sorted list
     blinds = co.random_field(sf, 0xB22D, len(names))
     dev = torch.device("cuda", 0)
     d_cols = {nm: torch.from_numpy(cols[nm].view(np.int64)).to(dev) for nm in names}
@@ -304,8 +306,10 @@ def test_column_batched_commit_matches_oracle(curve, k, bits):
     batch(names[:5], True, 0)                               # the five shapes in one launch set, Jacobian out
     batch(["dense", "dense2"], False, 1)                    # two columns, no blind, affine out
     batch(names[:8], True, 1)                               # a full group
+    batch(["dense", "all_zero", "dense2"], False, 0)        # a column without a single entry between two dense ones
+    batch(["all_zero", "all_zero"], True, 0)                # only the blinds
     if full:
-        batch(names, True, 0)                               # nine: two groups on two internal streams
+        batch(names[:9], True, 0)                           # nine: two groups on two internal streams
         batch(["all_equal", "all_equal", "zeros90"], True, 0)   # the same column twice (shared input, separate work areas)
         batch(["dense", "q-1-i", "dense3"], True, 0, n_used=n - 5)      # prefix of the table (IPA rounds commit over the first n' bases)
         batch(["dense", "zeros90"], False, 0, n_used=17)    # tiny prefix: the shape falls back to one commit per column
@@ -316,3 +320,13 @@ def test_column_batched_commit_matches_oracle(curve, k, bits):
     torch.cuda.synchronize()
     assert affine_of(curve, d_one.cpu().numpy().view(np.uint64)) == want("dense", True)
     assert lib.h2_bases_free(hd) == 0
+
+
+def test_column_batched_commit_one_launch_per_column_form():
+    """H2_BATCH_JOIN=0 keeps the form that launches msm_accumulate once per column (blockIdx.z); the switch is read once per process,
+    so the same parity test runs in a child process with it set."""
+    import subprocess, sys
+    env = dict(os.environ, H2_BATCH_JOIN="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_column_batched_commit_matches_oracle and 16-16"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
