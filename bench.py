@@ -665,13 +665,15 @@ def main():
                                   "top window of a scalar below q < 2^254 + 2^126 never exceeds 2^16, so the recode carries nothing out of it)",
                                   "achieved_Gmadd_per_s": round(madds * cols_per_launch / (avg_ms * 1e-3) / 1e9, 2) if acc_cnt else None,
                                   "isolated_Gmadd_per_s": round(madds / (iso["msm_accumulate"] * 1e-3) / 1e9, 2) if iso.get("msm_accumulate") else None,
-                                  "modmul_per_madd": 10, "montgomery_reductions_per_madd": 9, "v_mad_i64_i32_per_madd": 1151, "instructions_per_madd": 1800,
-                                  "issue_bound_Gmadd_per_s": 23.5,
-                                  "issue_bound_source": "the mixed addition is ~1800 instructions on its common path (hipcc -S), 1151 of them v_mad_i64_i32 (8 products, 2 squares, "
-                                                        "Y3's two products under ONE reduction); a SIMD retires one v_mad_i64_i32 per 5.8 cycles with the kernel's two waves "
-                                                        "resident (bench/ubench_madlat.hip, profiles/r03_ubench_madlat.txt): 1024 SIMDs x 2.4 GHz x 64 lanes / (1151 x 5.8) -- the "
-                                                        "bound if nothing but the multiply-adds took time; isolated_Gmadd_per_s is the kernel alone on the chip (DESIGN.md section 3.3)"},
-                         "note": "VALU integer-multiply bound, not HBM bound (DESIGN.md section 3): the HBM fraction is reported as the contract "
+                                  "modmul_per_madd": 10, "montgomery_reductions_per_madd": 9, "v_mad_i64_i32_per_madd": 1151, "instructions_per_madd": 1710,
+                                  "issue_bound_Gmadd_per_s": {"at_2.31_GHz_kernel_alone": 20.4, "at_1.92_GHz_sustained": 17.0},
+                                  "issue_bound_source": "the mixed addition is ~1710 instructions on its common path (hipcc -S), 1151 of them v_mad_i64_i32 (8 products, 2 squares, "
+                                                        "Y3's two products under ONE reduction); a SIMD issues one v_mad_i64_i32 per 4.85 cycles and the other instructions at 2.7-4.9 "
+                                                        "(bench/ubench_valu.hip, profiles/r04_ubench_valu.txt): ~7400 cycles per addition and wave, 1024 SIMDs x 64 lanes x clock / 7400. "
+                                                        "The clock is what the socket power limit leaves (rocm-smi under load, profiles/r04_clock_power.txt): 2.31 GHz while commits run "
+                                                        "one at a time, 1.92 GHz at ~1390 W once accumulates of several streams keep the SIMDs busy without a gap -- the sustained rate of "
+                                                        "the timed region is the issue bound at that clock (DESIGN.md section 4.3)"},
+                         "note": "VALU integer-multiply bound, not HBM bound (DESIGN.md section 4.3): the HBM fraction is reported as the contract "
                                  "asks, the VALU figures are what track kernel quality; traffic = PMC bytes of the registered-bases path (FETCH_SIZE calibrated on 64-byte random gathers, "
                                  "profiles/r04_pmc_traffic.json), which gathers 15 precomputed multiples per point from a 1 GiB table by design: a 64-byte point "
                                  "is half a 128-byte line, and the line is what moves"},
@@ -693,7 +695,7 @@ def main():
                 "frac": round(e_["algorithmic_GBps"] / HBM_PEAK_GBS, 5), "ms_per_transform": e_["ms"], "kernel_ms_per_transform": e_["kernel_ms"],
                 "traffic": (pmc or {}).get("ntt_2^20", {}).get("total_hbm_bytes_corrected"),
                 "note": "VALU-bound like the MSM: 10.5 M modular multiplications per 2^20 transform at ~200 G/s are 0.052 ms before any addition, carry pass "
-                        "or LDS round trip; the passes issue ~4800 instructions per lane and pass (DESIGN.md section 4)"})(ntt.get("2^20")),
+                        "or LDS round trip; the passes issue ~4800 instructions per lane and pass (DESIGN.md section 5.5)"})(ntt.get("2^20")),
             "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items() if v[1]},
             "kernel_ms_isolated": iso,
             "generic_best_multiexp": generic, "extra": extra, "skewed_columns": skew, "ntt": ntt, "cpu_baseline": cpu,
