@@ -1,7 +1,7 @@
 """Randomised soak of the round-4 paths against the C restatement (not part of the suite: its time is spent in the CPU oracle):
   * h2_commit_batch_device in its column-batched form: tables of random size 2^10 .. 2^17 (window width as Params would register
     it, or forced 13 / 16 / 17 bits), 2 .. 11 columns per call (one or two launch groups), random column patterns side by side
-    (dense, 90 % zeros, one repeated scalar, < 2^16, half repeated, 2^128 - 1), with / without blinds, full or prefix length,
+    (dense, 90 % zeros, one repeated scalar, < 2^16, half repeated, 2^128 - 1, all zero), with / without blinds, full or prefix length,
     identity and duplicate bases -- every output against orc_commit / orc_best_multiexp;
   * best_fft at random sizes 2^1 .. 2^21 on both fields with random (non-root) omegas, plus the fused ifft, elementwise.
 python bench/tools/soak4.py [seconds]"""
@@ -23,13 +23,14 @@ commits = ffts = fails = 0
 
 def pattern(sf, n, seed):
     col = co.random_field(sf, seed, n)
-    kind = int(rng.integers(0, 7))
+    kind = int(rng.integers(0, 8))
     if kind == 1: col[rng.random(n) < 0.9] = 0
     elif kind == 2: col[:] = col[0]
     elif kind == 3: col[:, 1:] = 0; col = co.to_mont(sf, col & 0xFFFF)
     elif kind == 4: col[rng.random(n) < 0.5] = col[0]
     elif kind == 5: col[rng.integers(0, n, size=max(1, n // 50))] = 0
     elif kind == 6: col = co.to_mont(sf, np.tile(np.array([[0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF, 0, 0]], dtype=np.uint64), (n, 1)))
+    elif kind == 7: col[:] = 0                     # no entries at all (an empty stretch of a joined batch)
     return np.ascontiguousarray(col), kind
 
 
