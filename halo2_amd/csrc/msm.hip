@@ -2023,6 +2023,81 @@ __global__ void __launch_bounds__(256) ipa_collapse_finish(const u32 *__restrict
     fe_store(out_xy + 16 * (size_t)i + 8, a.y);
 }
 
+// ---- the read-out with 8-bit sub-digits (the shipped form; H2_READOUT_NIBBLES=1 keeps the one above for A/B) ----------------
+// |d_w| = e_0 + 256 e_1 with e_0 in [-127, 128], e_1 in [0, 128]: 2 x 128 lists instead of 4 x 8, and 2^J * 32 terms per output
+// instead of 2^J * 64.  So that the 256 bucket sums per output neither travel through memory nor cost a lane each, a lane owns
+// SIXTEEN consecutive magnitudes of one position (workgroup row y = position * 8 + g: magnitudes 16 g + 1 .. 16 g + 16), walks
+// their lists from the largest down and keeps the two running sums of the bucket method in registers:
+//     run += B_v;  tot += run      =>      tot = sum_r r * B_{16 g + r},   run = sum_r B_{16 g + r}
+// (control flow and list reads are uniform across a wave, the gathers coalesced, as above).  ipa_readout_combine then forms, per
+// output and position, sum_g tot_g + 16 * sum_g g * run_g (a second running sum over the 8 groups), ipa_readout_finish
+// P_0 + 256 P_1 and the affine result.  Per output at J = 6: ~1800 mixed additions + 512 full ones against ~3800 + 64.
+template <int FB>
+__global__ void __launch_bounds__(256, 2) ipa_readout_groups(const u32 *__restrict__ table, const u32 *__restrict__ list,
+                                                             const u32 *__restrict__ list_start, u32 nJ, u32 *__restrict__ sums) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (i >= nJ) return;
+    const u32 first = (y >> 3) * 128 + (y & 7) * 16;          // the list of magnitude 16 g + 1 at this position
+    xyzz9<FB> run = xyzz9_identity<FB>(), tot = xyzz9_identity<FB>();
+    for (int r = 15; r >= 0; --r) {
+        const u32 lo = list_start[first + r], hi = list_start[first + r + 1];
+        xyzz9<FB> acc = xyzz9_identity<FB>();
+        if (lo < hi) {
+            u32 e0 = list[lo], e1 = list[min(lo + 1, hi - 1)];
+            affine<FB> nxt = aff_load<FB>(table + 16 * ((size_t)(e0 & 0x7FFFFFFFu) + i));
+            for (u32 t = lo; t < hi; ++t) {
+                const affine<FB> p = nxt;
+                const u32 neg = e0 >> 31;
+                const u32 e2 = list[min(t + 2, hi - 1)];
+                nxt = aff_load<FB>(table + 16 * ((size_t)(e1 & 0x7FFFFFFFu) + i));
+                e0 = e1;
+                e1 = e2;
+                if (!aff_is_identity(p)) {
+                    aff9<FB> q = aff9_unpack<FB>(p);
+                    if (neg) q.y = fe9_sub(fe9_zero(), q.y);
+                    xyzz9_madd<FB>(acc, q);
+                }
+            }
+        }
+        xyzz9_add<FB>(run, acc);
+        xyzz9_add<FB>(tot, run);
+    }
+    xyzz_store<FB>(sums + 32 * ((size_t)(2 * y) * nJ + i), xyzz9_is_identity(tot) ? xyzz_identity<FB>() : xyzz9_to_r256<FB>(tot));
+    xyzz_store<FB>(sums + 32 * ((size_t)(2 * y + 1) * nJ + i), xyzz9_is_identity(run) ? xyzz_identity<FB>() : xyzz9_to_r256<FB>(run));
+}
+// lane (i, position): sums[32 + position][i] <- sum_g tot_g + 16 * sum_g g * run_g
+template <int FB>
+__global__ void __launch_bounds__(256) ipa_readout_combine(u32 *__restrict__ sums, u32 nJ) {
+    H2_LATENCY_STAGE();
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * nJ) return;
+    const u32 pos = t / nJ, i = t % nJ;
+    xyzz<FB> P = xyzz_identity<FB>(), rr = xyzz_identity<FB>(), tt = xyzz_identity<FB>();
+    for (int g = 7; g >= 0; --g) {
+        const u32 y = pos * 8 + g;
+        xyzz_add<FB>(P, xyzz_load<FB>(sums + 32 * ((size_t)(2 * y) * nJ + i)));
+        if (g) {
+            xyzz_add<FB>(rr, xyzz_load<FB>(sums + 32 * ((size_t)(2 * y + 1) * nJ + i)));
+            xyzz_add<FB>(tt, rr);
+        }
+    }
+    for (int d = 0; d < 4; ++d) tt = xyzz_dbl<FB>(tt);
+    xyzz_add<FB>(P, tt);
+    xyzz_store<FB>(sums + 32 * ((size_t)(32 + pos) * nJ + i), P);
+}
+template <int FB>
+__global__ void __launch_bounds__(256) ipa_readout_finish(const u32 *__restrict__ sums, u32 nJ, u32 *__restrict__ out_xy) {
+    H2_LATENCY_STAGE();
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nJ) return;
+    xyzz<FB> acc = xyzz_load<FB>(sums + 32 * ((size_t)33 * nJ + i));
+    for (int d = 0; d < 8; ++d) acc = xyzz_dbl<FB>(acc);
+    xyzz_add<FB>(acc, xyzz_load<FB>(sums + 32 * ((size_t)32 * nJ + i)));
+    const affine<FB> a = xyzz_to_affine<FB>(acc);
+    fe_store(out_xy + 16 * (size_t)i, a.x);
+    fe_store(out_xy + 16 * (size_t)i + 8, a.y);
+}
+
 // ---- small helpers -----------------------------------------------------------------------------
 // canonical -> Montgomery for n field elements / affine coordinates (in place)
 template <int F> __global__ void __launch_bounds__(256) k_to_mont(u32 *a, size_t n) {
@@ -3010,7 +3085,9 @@ extern "C" int h2_ipa_collapsed_generators_device(h2_bases_t basis, unsigned k, 
     const u32 J = rounds, nJ = 1u << (k - J);
     u64 um[12 * 4];
     for (u32 r = 0; r < J; ++r) host_to_mont(sf, um + 4 * r, challenges + 4 * r, form);
-    std::vector<u32> lists[32];
+    static const bool nibbles = [] { const char *e = getenv("H2_READOUT_NIBBLES"); return e && e[0] == '1'; }();
+    const int nlists = nibbles ? 32 : 256;
+    std::vector<std::vector<u32>> lists(nlists);
     for (u32 h = 0; h < (1u << J); ++h) {
         u64 s[4], canon[4];
         memcpy(s, kHostField[sf].one, 32);
@@ -3024,6 +3101,19 @@ extern "C" int h2_ipa_collapsed_generators_device(h2_bases_t basis, unsigned k, 
             carry = neg ? 1 : 0;
             u32 mag = neg ? 0x10000u - raw : raw;                                 // |d| <= 2^15
             const u32 off = w * b->stride + h * nJ;
+            if (!nibbles) {                                                       // |d| = e_0 + 256 e_1, e_0 in [-127, 128], e_1 in [0, 128]
+                u32 e0 = mag & 255u, c8 = 0;
+                bool e0neg = false;
+                if (e0 > 128) {
+                    e0 = 256 - e0;
+                    e0neg = true;
+                    c8 = 1;
+                }
+                const u32 e1 = (mag >> 8) + c8;                                   // <= 128: mag <= 2^15, and mag = 2^15 has e_0 = 0
+                if (e0) lists[e0 - 1].push_back(off | ((neg != e0neg) ? 0x80000000u : 0u));
+                if (e1) lists[128 + e1 - 1].push_back(off | (neg ? 0x80000000u : 0u));
+                continue;
+            }
             u32 c4 = 0;
             for (u32 v = 0; v < 4; ++v) {                                         // |d| = sum_v 16^v e_v, e_v in [-7, 8]
                 u32 e = ((mag >> (4 * v)) & 15u) + c4;
@@ -3040,25 +3130,36 @@ extern "C" int h2_ipa_collapsed_generators_device(h2_bases_t basis, unsigned k, 
         }
         // carry is 0 here: the scalar is below 2^255, so the top digit takes it
     }
-    std::vector<u32> flat, start(33, 0);
-    for (int l = 0; l < 32; ++l) {
+    std::vector<u32> flat, start(nlists + 1, 0);
+    for (int l = 0; l < nlists; ++l) {
         start[l] = (u32)flat.size();
         flat.insert(flat.end(), lists[l].begin(), lists[l].end());
     }
-    start[32] = (u32)flat.size();
+    start[nlists] = (u32)flat.size();
     if (flat.empty()) flat.push_back(0);
     MsmContext &cx = msm_ctx(st);
     std::lock_guard<std::mutex> lk(cx.mu);
-    if ((rc = cx.collapse.reserve((size_t)32 * nJ * 128)) != H2_OK) return rc;
-    if ((rc = cx.collapse_list.reserve(33 * 4 + flat.size() * 4)) != H2_OK) return rc;
-    u32 *d_start = cx.collapse_list.as<u32>(), *d_list = d_start + 33;
+    if ((rc = cx.collapse.reserve((size_t)34 * nJ * 128)) != H2_OK) return rc;
+    if ((rc = cx.collapse_list.reserve((nlists + 1) * 4 + flat.size() * 4)) != H2_OK) return rc;
+    u32 *d_start = cx.collapse_list.as<u32>(), *d_list = d_start + nlists + 1;
     // pageable sources: consumed when hipMemcpyAsync returns; stream-ordered after the previous call's kernels
-    H2_HIP(hipMemcpyAsync(d_start, start.data(), 33 * 4, hipMemcpyHostToDevice, st));
+    H2_HIP(hipMemcpyAsync(d_start, start.data(), (nlists + 1) * 4, hipMemcpyHostToDevice, st));
     H2_HIP(hipMemcpyAsync(d_list, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, st));
     {   // the table's columns must be complete (a registration runs on the null stream and synchronises; nothing to wait for)
         dim3 blk(256), g1((nJ + 255) / 256, 32), g2((4 * nJ + 255) / 256), g3((nJ + 255) / 256);
         u32 *sums = cx.collapse.as<u32>();
-        if (b->curve == H2_PALLAS) {
+        if (!nibbles) {
+            dim3 r1((nJ + 255) / 256, 16), r2((2 * nJ + 255) / 256);
+            if (b->curve == H2_PALLAS) {
+                hipLaunchKernelGGL((ipa_readout_groups<FP>), r1, blk, 0, st, (const u32 *)b->d_table, d_list, d_start, nJ, sums);
+                hipLaunchKernelGGL((ipa_readout_combine<FP>), r2, blk, 0, st, sums, nJ);
+                hipLaunchKernelGGL((ipa_readout_finish<FP>), g3, blk, 0, st, (const u32 *)sums, nJ, (u32 *)d_out_xy);
+            } else {
+                hipLaunchKernelGGL((ipa_readout_groups<FQ>), r1, blk, 0, st, (const u32 *)b->d_table, d_list, d_start, nJ, sums);
+                hipLaunchKernelGGL((ipa_readout_combine<FQ>), r2, blk, 0, st, sums, nJ);
+                hipLaunchKernelGGL((ipa_readout_finish<FQ>), g3, blk, 0, st, (const u32 *)sums, nJ, (u32 *)d_out_xy);
+            }
+        } else if (b->curve == H2_PALLAS) {
             hipLaunchKernelGGL((ipa_collapse_buckets<FP>), g1, blk, 0, st, (const u32 *)b->d_table, d_list, d_start, nJ, sums);
             hipLaunchKernelGGL((ipa_collapse_windows<FP>), g2, blk, 0, st, sums, nJ);
             hipLaunchKernelGGL((ipa_collapse_finish<FP>), g3, blk, 0, st, (const u32 *)sums, nJ, (u32 *)d_out_xy);

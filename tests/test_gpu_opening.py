@@ -152,8 +152,8 @@ def test_opening_proof_full_size_schedules_agree_and_verify():
     blind = h.Blind(co.random_field(sf, 70, 1)[0])
     p = params.commit(px, blind, affine=True)
     proofs = []
-    assert params.default_hybrid_rounds(True) == 6
-    # "paired" alone moves to the collapsed generators after 6 rounds (the default); 0 keeps every round on the original ones
+    assert params.default_hybrid_rounds(True) == 5
+    # "paired" alone moves to the collapsed generators after 5 rounds (the default); 0 keeps every round on the original ones
     for schedule, hybrid in (("original", None), ("collapse", None), ("paired", 0), ("paired", None), ("paired", 9)):
         tr = Blake2bWrite(curve)
         tr.write_point(p)
