@@ -44,6 +44,62 @@ ALGO_BYTES_PER_PAIR = 96          # 32 B scalar + 64 B affine base, read once (S
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def _hwmon_dir(dev_index):
+    """amdgpu hwmon directory of the GPU behind cuda:dev_index (freq1_input = shader clock in Hz, power1_input = socket power in uW),
+    or None when sysfs does not show one."""
+    import glob
+    import torch
+    cands = [d for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*") if os.path.exists(os.path.join(d, "freq1_input"))]
+    if not cands:
+        return None
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        want = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        for d in cands:
+            if os.path.basename(os.path.realpath(os.path.join(d, "..", ".."))) == want:
+                return d
+    except Exception:
+        pass
+    return cands[0] if len(cands) == 1 else None
+
+
+class _ClockSampler:
+    """Samples the shader clock and the socket power from sysfs every ~2 ms on a thread while a load runs."""
+
+    def __init__(self, hwmon):
+        import threading
+        self.hwmon, self.f, self.p, self.stop = hwmon, [], [], False
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self, name):
+        with open(os.path.join(self.hwmon, name)) as fh:
+            return int(fh.read().strip())
+
+    def _run(self):
+        while not self.stop:
+            try:
+                self.f.append(self._read("freq1_input") / 1e6)
+                self.p.append(self._read("power1_input") / 1e6)
+            except Exception:
+                return
+            time.sleep(0.002)
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop = True
+        self.thread.join(timeout=1.0)
+
+    def summary(self):
+        if not self.f:
+            return None
+        f, p = sorted(self.f[len(self.f) // 4:]), sorted(self.p[len(self.p) // 4:])      # the first quarter: the clock still settling
+        return {"sclk_mhz_median": round(f[len(f) // 2]), "sclk_mhz_min_max": [round(f[0]), round(f[-1])], "power_w_median": round(p[len(p) // 2]),
+                "samples": len(f)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,6 +289,42 @@ def main():
             iso[name] = round(ms.value / max(cnt.value, 1), 4)
         lib.h2_profile_enable(0)
         check(lib.h2_set_option(b"msm_lane_fraction", lane_fraction), "h2_set_option")
+
+    # ---- shader clock and socket power under the two loads above (amdgpu hwmon, sampled from a thread): the sustained rate is the
+    # accumulate's issue bound AT THE CLOCK THE POWER LIMIT LEAVES, so the line carries that clock ----
+    clock = None
+    hw = _hwmon_dir(local_rank) if rank == 0 and not args.minimal else None
+    if hw:
+        def load(fn, seconds=0.4):
+            t_l = time.perf_counter()
+            cnt = 0
+            with _ClockSampler(hw) as smp:
+                while time.perf_counter() - t_l < seconds:
+                    cnt += fn()
+                    torch.cuda.synchronize()
+                dt = time.perf_counter() - t_l
+            r = smp.summary()
+            if r:
+                r["ms_per_commit"] = round(dt / max(cnt, 1) * 1e3, 4)
+            return r
+
+        def one_at_a_time():
+            for i in range(20):
+                c_ = i % len(d_cols)
+                check(lib.h2_commit_device(params_g, d_cols[c_].data_ptr(), n, None, d_blinds[c_].data_ptr(), h.FORM_MONTGOMERY, 0, d_out[0].data_ptr(), sps[0]),
+                      "h2_commit_device")
+            return 20
+
+        def timed_schedule():
+            run_steps(max(args.steps, 1))
+            return max(args.steps, 1)
+        try:
+            with open(os.path.join(hw, "power1_cap")) as fh:
+                cap_w = int(fh.read().strip()) / 1e6
+        except Exception:
+            cap_w = None
+        clock = {"source": "amdgpu hwmon freq1_input / power1_input of this GPU, sampled every ~2 ms for 0.4 s per load, after the timed region",
+                 "power_cap_w": cap_w, "commits_one_at_a_time": load(one_at_a_time), "timed_region_schedule": load(timed_schedule)}
 
     # ---- the same multiexp WITHOUT registered bases (`best_multiexp(coeffs, bases)` as the reference calls it, bases read
     # from HBM each time, endomorphism split instead of the precomputed table): reported beside the headline ----
@@ -698,7 +790,7 @@ def main():
                         "or LDS round trip; the passes issue ~4800 instructions per lane and pass (DESIGN.md section 5.5)"})(ntt.get("2^20")),
             "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items() if v[1]},
             "kernel_ms_isolated": iso,
-            "generic_best_multiexp": generic, "extra": extra, "skewed_columns": skew, "ntt": ntt, "cpu_baseline": cpu,
+            "clock": clock, "generic_best_multiexp": generic, "extra": extra, "skewed_columns": skew, "ntt": ntt, "cpu_baseline": cpu,
             "checks": {"split_sum_identity": None if split_ok is None else bool(split_ok), "split_msm_allgather": split_msm_ok, "split_msm_rccl_in_library": split_rccl_c},
             "config5": config5,
             "setup": {"bases_register_ms_max_over_ranks": round(register_ms, 1),

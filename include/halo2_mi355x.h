@@ -302,7 +302,8 @@ int h2_ipa_rounds(int curve, unsigned k, unsigned switch_rounds, h2_bases_t basi
 /* The generators after `rounds` collapses, without collapsing: G'[i] = sum_{h < 2^rounds} s(h) * G[i + h * 2^(k-rounds)] for
  * i < 2^(k-rounds), s(h) the challenge products of h2_ipa_round_scalars_device, read off the registered table of `basis` (its
  * first 2^k points are G; the table must use 16-bit windows, h2_commit_window_bits) as 2^(k-rounds) multiexps that share their
- * scalars: 64 * 2^k mixed additions in all, no sort (DESIGN.md section 8, step ao).  With h2_bases_register_device this is how
+ * scalars: every 16-bit table digit as two signed 8-bit sub-digits, ~28 * 2^k mixed additions plus 512 full additions per output
+ * for the bucket weights, no sort (csrc/msm.hip, ipa_readout_*).  With h2_bases_register_device this is how
  * h2_ipa_rounds_device moves to a 2^rounds times smaller table after its first rounds.
  * challenges: u_0 .. u_{rounds-1} in `form` (host); d_out_xy: 2^(k-rounds) affine points, Montgomery form.  rounds <= 12. */
 int h2_ipa_collapsed_generators_device(h2_bases_t basis, unsigned k, unsigned rounds, const uint64_t *challenges, int form,
