@@ -1186,6 +1186,20 @@ __global__ void __launch_bounds__(256) msm_bases_to_m9_glv(const u32 *__restrict
 // A 4-byte global load WITH its wait, as one statement the compiler cannot look into: used on the rare path of msm_accumulate
 // only.  A load the compiler tracks, issued under a condition and used after the join, makes it wait for EVERYTHING outstanding
 // at that join on every path (vmcnt counts in order) -- on the common path that would be the gathers issued a moment before.
+#ifndef H2_ACC_NT
+#define H2_ACC_NT 0         // 1: the table gathers of msm_accumulate carry the non-temporal hint (A/B only: profiles/r04_ab_gather_nt.txt)
+#endif
+template <int F> __device__ __forceinline__ affine<F> aff_gather(const u32 *p) {
+#if H2_ACC_NT
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    const v4u *q = reinterpret_cast<const v4u *>(p);
+    const v4u a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1), c = __builtin_nontemporal_load(q + 2),
+              d = __builtin_nontemporal_load(q + 3);
+    return affine<F>{fe{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}}, fe{{c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w}}};
+#else
+    return aff_load<F>(p);
+#endif
+}
 __device__ __forceinline__ u32 load_u32_waited(const u32 *p) {
     u32 v;
     asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
@@ -1228,7 +1242,7 @@ __global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(
             u32 t2_last = starts[b + 2];                 // starts[total_buckets + 1] is a sentinel (msm_scan_apply)
             bool first = true, pending = false, t2_ok = true;
             u32 e0 = entries[lo], e1 = entries[min(lo + 1, hi - 1)];
-            affine<FB> nxt = aff_load<FB>(bases + 16 * (size_t)(e0 & 0x7FFFFFFFu));
+            affine<FB> nxt = aff_gather<FB>(bases + 16 * (size_t)(e0 & 0x7FFFFFFFu));
             for (u32 i = lo; i < hi; ++i) {
                 // everything issued during the previous iteration -- the gather of this point, entry i + 1, the boundary read, a
                 // flush's stores -- has had a whole mixed addition to complete: this wait is free
@@ -1255,7 +1269,7 @@ __global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(
 #endif
                 const u32 neg = e0 >> 31;
                 const u32 e2 = entries[min(i + 2, hi - 1)];
-                nxt = aff_load<FB>(bases + 16 * (size_t)(e1 & 0x7FFFFFFFu));      // at the tail: a stale, valid entry
+                nxt = aff_gather<FB>(bases + 16 * (size_t)(e1 & 0x7FFFFFFFu));      // at the tail: a stale, valid entry
                 const u32 t2_cur = starts[b + 2];
                 e0 = e1;
                 e1 = e2;
