@@ -126,7 +126,7 @@ struct IpaContext {
     // the round loop (h2_ipa_rounds_device): its own lock (held for the whole argument; the launches it makes take `mu`),
     // device scratch { <p'_hi, b_lo>, <p'_lo, b_hi>, L_j, R_j } and the pinned landing pad of L_j, R_j
     std::mutex rounds_mu;
-    DevBuf rounds, gprime;
+    DevBuf rounds, gprime, rstab;      // rstab: the round loop's two s tables (the single-round entry point keeps `stab`)
     void *rounds_host = nullptr;
     void release_all() {
         naf.release();
@@ -138,6 +138,7 @@ struct IpaContext {
         if (!rl.owns_lock()) return;
         rounds.release();
         gprime.release();
+        rstab.release();
         if (rounds_host) (void)hipHostFree(rounds_host);
         rounds_host = nullptr;
     }
@@ -317,16 +318,86 @@ static int round_scalars_launch(int field, const void *d_p, unsigned k, unsigned
     return H2_OK;
 }
 
-// rows n .. of the round's column(s): [<p'_hi, b_lo> z] and [<p'_lo, b_hi> z] (the U scalars of L_j and R_j,
-// prover.rs:109-113) and the two blinds.  One lane; everything Montgomery.
+// ---- the round loop's own launches (h2_ipa_rounds_device): three per round beside the commit -----------------------------------
+// A round used to enqueue ten small launches and a copy around its commit (two inner products of two launches each, the challenge
+// upload, the s table, the round scalars, the tails, two folds); the rounds after the switch to the collapsed generators are chains
+// of short launches, so each one costs as much as the work it carries.
+static constexpr u32 kIpBlocks = 128;       // partial sums per inner product
+template <int F> __device__ __forceinline__ fe ipa_block_sum(u32 *sh, fe v) {       // 256 lanes; the sum lands in every lane of wave 0's lane 0
+    fe_store(sh + 8 * threadIdx.x, v);
+    __syncthreads();
+    for (u32 off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) fe_store(sh + 8 * threadIdx.x, fe_add<F>(fe_load(sh + 8 * threadIdx.x), fe_load(sh + 8 * (threadIdx.x + off))));
+        __syncthreads();
+    }
+    return fe_load(sh);
+}
+// blocks [0, 2 kIpBlocks): partial sums of <p'_hi, b_lo> (first kIpBlocks) and <p'_lo, b_hi>, raw Montgomery products;
+// the blocks after them: the round's scalars over the original generators (ipa_round_scalars' body; s = this round's table)
 template <int F>
-__global__ void ipa_round_tails(const u32 *__restrict__ ip, fe z, fe l_rand, fe r_rand, u32 *__restrict__ vl, u32 *__restrict__ vr,
-                                u32 *__restrict__ bl, u32 *__restrict__ br) {
-    if (blockIdx.x || threadIdx.x) return;
-    fe_store(vl, fe_mulx<F>(fe_load(ip), z));
-    fe_store(vr, fe_mulx<F>(fe_load(ip + 8), z));
-    fe_store(bl, l_rand);
-    fe_store(br, r_rand);
+__global__ void __launch_bounds__(256) ipa_round_prep(const u32 *__restrict__ p, const u32 *__restrict__ b, const u32 *__restrict__ s, u32 k, u32 j,
+                                                      u32 *__restrict__ partial, u32 *__restrict__ cl, u32 *__restrict__ cr) {
+    __shared__ __attribute__((aligned(16))) u32 sh[256 * 8];
+    const u32 blk = k - j, half = 1u << (blk - 1);
+    if (blockIdx.x < 2 * kIpBlocks) {
+        const u32 which = blockIdx.x / kIpBlocks, bi = blockIdx.x % kIpBlocks;
+        const u32 *pa = p + (which ? 0 : 8 * (size_t)half), *pb = b + (which ? 8 * (size_t)half : 0);
+        fe acc = fe_zero();
+        for (u32 i = bi * 256 + threadIdx.x; i < half; i += kIpBlocks * 256)
+            acc = fe_add<F>(acc, fe_mulx<F>(fe_load(pa + 8 * (size_t)i), fe_load(pb + 8 * (size_t)i)));
+        acc = ipa_block_sum<F>(sh, acc);
+        if (threadIdx.x == 0) fe_store(partial + 8 * (size_t)blockIdx.x, acc);
+        return;
+    }
+    const u32 m = (blockIdx.x - 2 * kIpBlocks) * 256 + threadIdx.x;
+    if (m >> k) return;
+    const u32 h = m >> blk, i = m & ((1u << blk) - 1);
+    const fe v = fe_mulx<F>(fe_load(p + 8 * (size_t)(i ^ half)), fe_load(s + 8 * (size_t)h));
+    if (cl == cr) {
+        fe_store(cl + 8 * (size_t)m, v);
+        return;
+    }
+    const bool lo = i < half;
+    fe_store(cl + 8 * (size_t)m, lo ? v : fe_zero());
+    fe_store(cr + 8 * (size_t)m, lo ? fe_zero() : v);
+}
+// one workgroup: the two inner products from their partial sums, then the rows behind the generators' (ipa_round_tails)
+template <int F>
+__global__ void __launch_bounds__(256) ipa_round_finish(const u32 *__restrict__ partial, fe z, fe l_rand, fe r_rand, u32 *__restrict__ vl,
+                                                        u32 *__restrict__ vr, u32 *__restrict__ bl, u32 *__restrict__ br) {
+    __shared__ __attribute__((aligned(16))) u32 sh[256 * 8];
+    // lanes 0..127 carry the first product's partial sums, 128..255 the second's: one tree, stopped one level early
+    fe_store(sh + 8 * threadIdx.x, fe_load(partial + 8 * (size_t)threadIdx.x));
+    __syncthreads();
+    for (u32 off = 64; off > 0; off >>= 1) {
+        const u32 g = threadIdx.x >> 7, l = threadIdx.x & 127;
+        if (l < off) fe_store(sh + 8 * threadIdx.x, fe_add<F>(fe_load(sh + 8 * threadIdx.x), fe_load(sh + 8 * (g * 128 + l + off))));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        fe_store(vl, fe_mulx<F>(fe_load(sh), z));
+        fe_store(bl, l_rand);
+    } else if (threadIdx.x == 128) {
+        fe_store(vr, fe_mulx<F>(fe_load(sh + 8 * 128), z));
+        fe_store(br, r_rand);
+    }
+}
+// blocks [0, fold_blocks): p'[i] += p'[i + half] u^-1 and b[i] += b[i + half] u (prover.rs:128-133); the blocks after them: the next
+// round's s table, s_{j+1}(h) = s_j(h >> 1) * u^{h & 1} (the definition at ipa_s_table), from one buffer into the other
+template <int F>
+__global__ void __launch_bounds__(256) ipa_round_fold(u32 *__restrict__ p, u32 *__restrict__ b, u32 half, u32 fold_blocks, fe u_inv, fe u,
+                                                      const u32 *__restrict__ s_old, u32 *__restrict__ s_new, u32 s_count) {
+    if (blockIdx.x < fold_blocks) {
+        const u32 i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= half) return;
+        fe_store(p + 8 * (size_t)i, fe_add<F>(fe_load(p + 8 * (size_t)i), fe_mulx<F>(fe_load(p + 8 * (size_t)(half + i)), u_inv)));
+        fe_store(b + 8 * (size_t)i, fe_add<F>(fe_load(b + 8 * (size_t)i), fe_mulx<F>(fe_load(b + 8 * (size_t)(half + i)), u)));
+        return;
+    }
+    const u32 h = (blockIdx.x - fold_blocks) * 256 + threadIdx.x;
+    if (h >= s_count) return;
+    const fe v = fe_load(s_old + 8 * (size_t)(h >> 1));
+    fe_store(s_new + 8 * (size_t)h, (h & 1) ? fe_mulx<F>(v, u) : v);
 }
 
 }  // namespace h2
@@ -424,9 +495,13 @@ static int ipa_rounds_impl(int curve, unsigned k, unsigned rounds, h2_bases_t ba
     const int sf = curve == H2_PALLAS ? H2_FQ : H2_FP, bf = curve == H2_PALLAS ? H2_FP : H2_FQ;
     const size_t n = (size_t)1 << k;
     IpaContext &cx = g_ipa_ctxs.get(st);           // the caller holds cx.rounds_mu
-    if ((rc = cx.rounds.reserve(64 + 192)) != H2_OK) return rc;
+    if ((rc = cx.rounds.reserve(64 + 192 + (size_t)2 * kIpBlocks * 32)) != H2_OK) return rc;
+    const size_t tab_words = (size_t)8 << (rounds ? rounds - 1 : 0);          // s_j has 2^j entries, j < rounds
+    if ((rc = cx.rstab.reserve(2 * tab_words * 4)) != H2_OK) return rc;         // two tables: a round reads one, its fold writes the next
     if (!cx.rounds_host) H2_HIP(hipHostMalloc(&cx.rounds_host, 256, hipHostMallocDefault));
-    u32 *d_ip = cx.rounds.as<u32>(), *d_lr = d_ip + 16;
+    u32 *d_ip = cx.rounds.as<u32>(), *d_lr = d_ip + 16, *d_partial = d_ip + 64;
+    u32 *stab[2] = {cx.rstab.as<u32>(), cx.rstab.as<u32>() + tab_words};
+    H2_HIP(hipMemcpyAsync(stab[0], kHostField[sf].one, 32, hipMemcpyHostToDevice, st));      // s_0 = [1]
     u64 *lr = (u64 *)cx.rounds_host;
     u64 challenges[32 * 4];
     u32 *col_l = (u32 *)d_column_l, *col_r = paired ? col_l : (u32 *)d_column_r;
@@ -434,17 +509,20 @@ static int ipa_rounds_impl(int curve, unsigned k, unsigned rounds, h2_bases_t ba
     memcpy(zf.v, z, 32);
     for (unsigned j = 0; j < rounds; ++j) {
         const size_t half = (size_t)1 << (k - j - 1);
-        char *p8 = (char *)d_p, *b8 = (char *)d_b;
-        if ((rc = h2_inner_product_device(sf, p8 + 32 * half, b8, half, H2_FORM_MONTGOMERY, d_ip, st)) != H2_OK) return rc;
-        if ((rc = h2_inner_product_device(sf, p8, b8 + 32 * half, half, H2_FORM_MONTGOMERY, d_ip + 8, st)) != H2_OK) return rc;
-        if ((rc = round_scalars_launch(sf, d_p, k, j, challenges, H2_FORM_MONTGOMERY, col_l, col_r, st)) != H2_OK) return rc;
         fe lf, rf;
         memcpy(lf.v, rands + 8 * j, 32);
         memcpy(rf.v, rands + 8 * j + 4, 32);
         u32 *vl = col_l + 8 * n, *vr = paired ? col_l + 8 * (n + 1) : col_r + 8 * n;
         u32 *bl = paired ? col_l + 8 * (n + 2) : col_l + 8 * (n + 1), *br = paired ? col_l + 8 * (n + 3) : col_r + 8 * (n + 1);
-        if (sf == H2_FP) hipLaunchKernelGGL((ipa_round_tails<FP>), dim3(1), dim3(64), 0, st, d_ip, zf, lf, rf, vl, vr, bl, br);
-        else hipLaunchKernelGGL((ipa_round_tails<FQ>), dim3(1), dim3(64), 0, st, d_ip, zf, lf, rf, vl, vr, bl, br);
+        // both inner products' partial sums and the round's scalars in one launch, the sums and the tail rows in a second
+        const dim3 gp(2 * kIpBlocks + (unsigned)((n + 255) / 256));
+        if (sf == H2_FP) {
+            hipLaunchKernelGGL((ipa_round_prep<FP>), gp, dim3(256), 0, st, (const u32 *)d_p, (const u32 *)d_b, (const u32 *)stab[j & 1], k, j, d_partial, col_l, col_r);
+            hipLaunchKernelGGL((ipa_round_finish<FP>), dim3(1), dim3(256), 0, st, (const u32 *)d_partial, zf, lf, rf, vl, vr, bl, br);
+        } else {
+            hipLaunchKernelGGL((ipa_round_prep<FQ>), gp, dim3(256), 0, st, (const u32 *)d_p, (const u32 *)d_b, (const u32 *)stab[j & 1], k, j, d_partial, col_l, col_r);
+            hipLaunchKernelGGL((ipa_round_finish<FQ>), dim3(1), dim3(256), 0, st, (const u32 *)d_partial, zf, lf, rf, vl, vr, bl, br);
+        }
         H2_HIP(hipGetLastError());
         if (paired) {
             rc = h2_commit_pair_device(basis, col_l, n + 4, k - j - 1, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_lr, st);
@@ -483,8 +561,20 @@ static int ipa_rounds_impl(int curve, unsigned k, unsigned rounds, h2_bases_t ba
             return H2_ERR_ARGS;
         }
         host_inv(sf, u_inv, u);
-        if ((rc = fold_launch(sf, d_p, half, u_inv, H2_FORM_MONTGOMERY, st)) != H2_OK) return rc;      // :128-133
-        if ((rc = fold_launch(sf, d_b, half, u, H2_FORM_MONTGOMERY, st)) != H2_OK) return rc;
+        {   // the two folds (:128-133) and the next round's s table in one launch
+            fe uf, uif;
+            memcpy(uf.v, u, 32);
+            memcpy(uif.v, u_inv, 32);
+            const u32 fold_blocks = (u32)((half + 255) / 256), s_count = j + 1 < rounds ? 2u << j : 0u;
+            const dim3 gf(fold_blocks + (s_count + 255) / 256);
+            if (sf == H2_FP)
+                hipLaunchKernelGGL((ipa_round_fold<FP>), gf, dim3(256), 0, st, (u32 *)d_p, (u32 *)d_b, (u32)half, fold_blocks, uif, uf, (const u32 *)stab[j & 1],
+                                   stab[(j + 1) & 1], s_count);
+            else
+                hipLaunchKernelGGL((ipa_round_fold<FQ>), gf, dim3(256), 0, st, (u32 *)d_p, (u32 *)d_b, (u32)half, fold_blocks, uif, uf, (const u32 *)stab[j & 1],
+                                   stab[(j + 1) & 1], s_count);
+            H2_HIP(hipGetLastError());
+        }
         host_mul(sf, t, rands + 8 * j, u_inv);                                                          // :140-141
         host_add(sf, f_acc, f_acc, t);
         host_mul(sf, t, rands + 8 * j + 4, u);

@@ -925,11 +925,12 @@ __device__ __forceinline__ void lds_ticket4(u32 *ctr, const u32 k[4], u32 nvalid
 }
 __global__ void __launch_bounds__(1024) msm_s2_bins(const u32 *__restrict__ tagged, const uint16_t *__restrict__ tagged_low, const u32 *__restrict__ bin_start,
                                                     Sort2 P, u32 total_buckets, u32 cap, u32 *__restrict__ starts, u32 *__restrict__ entries,
-                                                    u32 *__restrict__ big, ColStride cs) {
+                                                    u32 *__restrict__ big, u32 max_big, u32 *__restrict__ zero9, ColStride cs) {
     H2_LATENCY_STAGE();
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
     u32 cb = 0;                                                         // joined columns: where this column's entries begin
     if (gridDim.z > 1) {
+        if (zero9) zero9 = H2_COLZ(zero9, cs.buckets);
         cb = col_entry_base(bin_start, cs);
         tagged = H2_COLZ(tagged, cs.items);
         if (tagged_low) tagged_low = H2_COLZ(tagged_low, cs.items);
@@ -944,18 +945,27 @@ __global__ void __launch_bounds__(1024) msm_s2_bins(const u32 *__restrict__ tagg
     const u32 lowmask = nbk - 1, strip = P.side ? ~0u : ~(lowmask << P.lb);
     // M  (the sentinel behind it: msm_s1_prefix).  Joined columns: that slot is bucket 0 of the next column, which writes the same value.
     if (h == gridDim.x - 1 && threadIdx.x == 0) starts[total_buckets] = cb + bin_start[gridDim.x];
-    if (E > cap) {
+    if (zero9) {
+        // the raw bucket slots msm_accumulate parks segments in start from zero: this bin's buckets are cleared HERE (a memset node
+        // less on the stream of every commit; the slots are not touched again before the accumulate)
+        const u32 b0 = h << P.lowb, b1 = min(total_buckets, b0 + nbk);
+        if (b1 > b0) {
+            uint4 *z = reinterpret_cast<uint4 *>(zero9 + 36 * (size_t)b0);
+            for (u32 i = threadIdx.x; i < 9 * (b1 - b0); i += blockDim.x) z[i] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    if (E > cap && max_big) {
         // a bin that does not fit the stage (a degenerate column: every scalar equal, half of them 1 ...) goes on the list of big
         // bins, which msm_s2_big_* sort with kBigChunks workgroups each; only past kMaxBig such bins does this workgroup do it alone
         if (threadIdx.x == 0) {
             const u32 slot = atomicAdd(&big[0], 1u);
-            if (slot < kMaxBig) big[1 + slot] = h;
+            if (slot < max_big) big[1 + slot] = h;
             cnt[0] = slot;
         }
         __syncthreads();
         const u32 slot = cnt[0];
         __syncthreads();
-        if (slot < kMaxBig) return;
+        if (slot < max_big) return;
     }
     for (u32 k = threadIdx.x; k < nbk; k += blockDim.x) cnt[k] = 0;
     __syncthreads();
@@ -2508,6 +2518,14 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     const u32 m32 = (u32)m;
     u32 *grand = cx.bsums.as<u32>() + nblocks;
     const u32 tl_id = (u32)(((uintptr_t)st >> 4) & 0xFFFF) << 8;
+    // the one-launch pass 2 also clears the raw bucket slots (its workgroups own disjoint bucket ranges), so the slots must exist
+    // before the sort is enqueued; a reservation that grows frees and synchronises, which is harmless here, in front of everything
+    const bool zero_in_sort = m9 && use_sort2 && s2_bins_form && !fold_only;
+    if (zero_in_sort && (rc = cx.seg9.reserve((head_slots + (size_t)K * tb) * 144)) != H2_OK) return rc;
+    // oversized pass-2 bins (degenerate columns) go to the chunked msm_s2_big_* kernels only where a bin can be large enough for
+    // that to matter: below 3 * 2^20 entries per column (2^18 scalars) the bin's own workgroup streams it (<= 2^17 entries: tens of
+    // microseconds, and only for such columns), and every commit saves three launches that would find an empty list
+    const u32 max_big = all_items >= ((size_t)3 << 20) ? kMaxBig : 0u;
     if (!fold_only) {
     TL_STAMP(tl_id | 1);
     prof_begin(PROF_MSM_SORT, st);
@@ -2554,12 +2572,15 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
             // accumulate for 10-160 us (profiles/r03_kernel_stats_3streams.csv) before it could find out that it had nothing to do
             static const u32 big_threads = [] { const char *e = getenv("H2_S2_BIG_THREADS"); int v = e ? atoi(e) : 0; return (u32)(v == 256 || v == 512 || v == 1024 ? v : 256); }();
             hipLaunchKernelGGL(msm_s2_bins, dim3(S2.nh, 1, K), dim3(1024), (nbk * 2 + cap_entries) * 4, st, cx.tagged.as<u32>(),
-                               (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, tb, (u32)cap_entries, cx.starts.as<u32>(), cx.entries.as<u32>(), big, cs);
+                               (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, tb, (u32)cap_entries, cx.starts.as<u32>(), cx.entries.as<u32>(), big, max_big,
+                               zero_in_sort ? cx.seg9.as<u32>() + 36 * head_slots : (u32 *)nullptr, cs);
+            if (max_big) {
             hipLaunchKernelGGL(msm_s2_big_count, dim3(kBigChunks, kMaxBig, K), dim3(big_threads), nbk * 4, st, cx.tagged.as<u32>(),
                                (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, (const u32 *)big, gcnt, cs);
             hipLaunchKernelGGL(msm_s2_big_prefix, dim3(kMaxBig, 1, K), dim3(big_threads), nbk * 4, st, bin_start, S2, tb, (const u32 *)big, gcnt, cx.starts.as<u32>(), cs);
             hipLaunchKernelGGL(msm_s2_big_scatter, dim3(kBigChunks, kMaxBig, K), dim3(big_threads), nbk * 4, st, cx.tagged.as<u32>(),
                                (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, (const u32 *)big, (const u32 *)gcnt, cx.entries.as<u32>(), cs);
+            }
         } else {
         hipLaunchKernelGGL(msm_s2_plan, dim3(1), dim3(kScanBlock), 0, st, bin_start, S2, hlo, woff);
         const size_t hist2_words = ((size_t)S2.nh + S2.B2 + 1) << S2.lowb;
@@ -2646,7 +2667,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         if (glv && (rc = cx.bases9.reserve((size_t)scalars_n * 128 + 64)) != H2_OK) return rc;
         // raw M9 segments: the heads of the T ranges of every column, then the bucket slots of every column (zeroed in one go)
         if ((rc = cx.seg9.reserve((head_slots + (size_t)K * tb) * 144)) != H2_OK) return rc;
-        H2_HIP(hipMemsetAsync(cx.seg9.as<u32>() + 36 * head_slots, 0, (size_t)K * tb * 144, st));
+        if (!zero_in_sort) H2_HIP(hipMemsetAsync(cx.seg9.as<u32>() + 36 * head_slots, 0, (size_t)K * tb * 144, st));
     } else {
         H2_HIP(hipMemsetAsync(cx.buckets.ptr, 0, (size_t)tb * 128, st));
     }
