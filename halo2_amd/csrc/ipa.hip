@@ -22,6 +22,8 @@
 
 namespace h2 {
 
+int bases_refill_device(h2_bases_t handle, const void *d_bases_xy, size_t n, int form);      // msm.hip
+
 // naf1 / naf2: signed digits in {-1, 0, 1} of k1 and k2 (signs folded in), little-endian, uniform across lanes;
 // g[i] <- g[i] + [k1] g[half + i] + [k2] phi(g[half + i])
 template <int FB>
@@ -128,6 +130,9 @@ struct IpaContext {
     std::mutex rounds_mu;
     DevBuf rounds, gprime, rstab;      // rstab: the round loop's two s tables (the single-round entry point keeps `stab`)
     void *rounds_host = nullptr;
+    h2_bases_t gp_handle = 0;          // the table of the collapsed generators, kept between arguments (rebuilt in place while its shape repeats)
+    size_t gp_n = 0;
+    int gp_curve = -1;
     void release_all() {
         naf.release();
         stage.release();
@@ -139,6 +144,8 @@ struct IpaContext {
         rounds.release();
         gprime.release();
         rstab.release();
+        if (gp_handle) (void)h2_bases_free(gp_handle);
+        gp_handle = 0;
         if (rounds_host) (void)hipHostFree(rounds_host);
         rounds_host = nullptr;
     }
@@ -650,13 +657,23 @@ extern "C" int h2_ipa_rounds_device(int curve, unsigned k, unsigned switch_round
     for (size_t t = 0; t < tail; ++t) memcpy(tails + 8 * t, uw_xy + 8 * (pair2 ? t / 2 : t), 64);
     H2_HIP(hipMemcpyAsync(d_g + nj * 64, tails, tail * 64, hipMemcpyHostToDevice, st));
     H2_HIP(hipStreamSynchronize(st));                                // the registration reads the points on the null stream
-    h2_bases_t hj = 0;
-    if ((rc = h2_bases_register_device(curve, d_g, nj + tail, H2_FORM_MONTGOMERY, &hj)) != H2_OK) return rc;
+    static const bool keep_table = [] { const char *e = getenv("H2_IPA_KEEP_TABLE"); return !(e && e[0] == '0'); }();      // 0: register / free per argument (A/B)
+    if (cx.gp_handle && (!keep_table || cx.gp_curve != curve || cx.gp_n != nj + tail)) {
+        (void)h2_bases_free(cx.gp_handle);
+        cx.gp_handle = 0;
+    }
+    if (cx.gp_handle) {
+        if ((rc = bases_refill_device(cx.gp_handle, d_g, nj + tail, H2_FORM_MONTGOMERY)) != H2_OK) return rc;
+    } else {
+        if ((rc = h2_bases_register_device(curve, d_g, nj + tail, H2_FORM_MONTGOMERY, &cx.gp_handle)) != H2_OK) return rc;
+        cx.gp_curve = curve;
+        cx.gp_n = nj + tail;
+    }
+    const h2_bases_t hj = cx.gp_handle;
     // the columns of the second phase fit in the first phase's scratch (2 (nj + 2) <= 2^k + 4)
     void *col_l = d_column_l, *col_r = pair2 ? nullptr : (void *)((char *)d_column_l + 32 * (nj + 2));
     rc = ipa_rounds_impl(curve, kj, kj, hj, pair2 ? 1 : 0, d_p, d_b, z, rands + 8 * J, col_l, col_r, write_point, squeeze, user, nullptr,
                          c_out, f_acc, stream);
-    (void)h2_bases_free(hj);
     if (rc == H2_OK) memcpy(f_out, f_acc, 32);
     return rc;
 }

@@ -3106,6 +3106,27 @@ extern "C" int h2_bases_register_device(int curve, const void *d_bases_xy, size_
     return bases_register_impl(curve, d_bases_xy, true, n, form, handle);
 }
 
+// Internal (ipa.hip): rebuild the table of an existing handle from n new points in HBM -- same n, same window width, the allocation
+// is kept.  The opening argument registers a table for its collapsed generators in every proof; from the second proof on this
+// saves the allocation and the release (~0.35 ms of hipMalloc / hipFree, which also synchronise the device).  The handle's blind
+// column is cleared with the table.  Nothing else may be using the handle (the caller owns it).
+namespace h2 {
+int bases_refill_device(h2_bases_t handle, const void *d_bases_xy, size_t n, int form) {
+    auto b = find_bases(handle);
+    if (!b || b->n != n || !d_bases_xy || (form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY)) return H2_ERR_ARGS;
+    int rc = ensure_device();
+    if (rc != H2_OK) return rc;
+    std::lock_guard<std::mutex> bl(b->mu);
+    H2_HIP(hipMemsetAsync(b->d_table, 0, (size_t)b->W * b->stride * 64, 0));
+    H2_HIP(hipMemcpyAsync(b->d_table, d_bases_xy, n * 64, hipMemcpyDeviceToDevice, 0));
+    if (form == H2_FORM_CANONICAL) to_mont_async(b->curve, (u32 *)b->d_table, n * 2, 0);
+    b->blind_set = b->blind_host_known = false;
+    if ((rc = table_fill(*b, 0, (u32)n, 0)) != H2_OK) return rc;
+    H2_HIP(hipStreamSynchronize(0));
+    return H2_OK;
+}
+}  // namespace h2
+
 extern "C" int h2_ipa_collapsed_generators_device(h2_bases_t basis, unsigned k, unsigned rounds, const uint64_t *challenges, int form,
                                                   void *d_out_xy, void *stream) {
     auto b = find_bases(basis);
