@@ -386,29 +386,7 @@ def main():
         whole = h.best_multiexp(shared, bases, curve) if rank == 0 else None
         if rank == 0:
             split_msm_ok = co.jac_to_affine_ints(curve, total) == co.jac_to_affine_ints(curve, whole)
-    # the same exchange step inside the library: its own RCCL communicator (dlopen), one 96-byte ncclAllGather, local sum.
-    # Verification only; guarded by a watchdog so that a communicator that fails to form cannot take the bench line with it.
-    split_rccl_c = None
-    if world > 1 and backend == "nccl" and os.environ.get("H2_BENCH_RCCL_C", "1") != "0":
-        import threading
-        box = {}
-
-        def _rccl_leg():
-            try:
-                torch.cuda.set_device(local_rank)          # the current device is per host thread
-                parallel.rccl_init(rank, world)
-                d_sh = torch.from_numpy(shared.view(np.int64)).to(dev)
-                d_bs = torch.from_numpy(bases.view(np.int64)).to(dev)
-                out_c = parallel.split_msm_rccl(d_sh, d_bs, curve)
-                torch.cuda.synchronize()
-                box["ok"] = bool(co.jac_to_affine_ints(curve, out_c.cpu().numpy().view(np.uint64)) == co.jac_to_affine_ints(curve, total))
-                parallel.rccl_finalize()
-            except Exception as exc:           # reported, never fatal
-                box["ok"] = f"error: {exc}"
-        th = threading.Thread(target=_rccl_leg, daemon=True)
-        th.start()
-        th.join(timeout=90)
-        split_rccl_c = box.get("ok", "timeout after 90 s")
+    split_rccl_c = None       # the in-library exchange (the library's own RCCL communicator) runs LAST, see _library_rccl_legs below
 
     # ---- BASELINE configs[4], TIMED: 64 independent 2^20 column commits over the node (64 / world per GPU, one batched call per
     # rank, no collective) and ONE commit over the registered bases split by table-column range over the ranks, its 96-byte
@@ -478,32 +456,7 @@ def main():
         torch.cuda.synchronize()
         whole_ms = (time.perf_counter() - t5) / reps5 * 1e3
         split_ok5 = bool(co.jac_to_affine_ints(curve, total5.cpu().numpy().view(np.uint64)) == co.jac_to_affine_ints(curve, whole5.cpu().numpy().view(np.uint64)))
-        # the same split with the exchange inside the library (its own RCCL communicator); watchdog as above
-        lib_ms, lib_ok = None, None
-        if backend == "nccl" and os.environ.get("H2_BENCH_RCCL_C", "1") != "0":
-            import threading
-            box5 = {}
-
-            def _rccl_commit_leg():
-                try:
-                    torch.cuda.set_device(local_rank)
-                    parallel.rccl_init(rank, world)
-                    o_ = parallel.split_commit_rccl(params_g, d_shared, d_shbl)
-                    torch.cuda.synchronize()
-                    t_ = time.perf_counter()
-                    for _ in range(reps5):
-                        o_ = parallel.split_commit_rccl(params_g, d_shared, d_shbl)
-                    torch.cuda.synchronize()
-                    box5["ms"] = (time.perf_counter() - t_) / reps5 * 1e3
-                    box5["ok"] = bool(co.jac_to_affine_ints(curve, o_.cpu().numpy().view(np.uint64)) == co.jac_to_affine_ints(curve, whole5.cpu().numpy().view(np.uint64)))
-                    parallel.rccl_finalize()
-                except Exception as exc:
-                    box5["ok"] = f"error: {exc}"
-            th5 = threading.Thread(target=_rccl_commit_leg, daemon=True)
-            th5.start()
-            th5.join(timeout=90)
-            lib_ok = box5.get("ok", "timeout after 90 s")
-            lib_ms = box5.get("ms")
+        lib_ms, lib_ok = None, None      # filled in by _library_rccl_legs at the very end
         config5 = {"what": "BASELINE configs[4]: 64 independent 2^20-point column commits (with blinds) spread over the ranks, then one commit "
                            "split by table-column range over the ranks + one 96-byte all-gather + local sum",
                    "columns_total": per_rank * world, "columns_per_gpu": per_rank, "columns_ms": round(cols_ms, 3),
@@ -513,7 +466,6 @@ def main():
                    "allgather_96B_us": None if ag_us is None else round(ag_us, 1),
                    "split_commit_rccl_in_library_ms": None if lib_ms is None else round(lib_ms, 4), "split_commit_rccl_in_library_ok": lib_ok,
                    "exchange_backend": backend}
-        del d_shared
 
     # ---- NTT leg (reported beside the headline value; Fp, k = 20 and 2^22 round trip) ----
     ntt = {}
@@ -798,11 +750,54 @@ def main():
                               f"({255 // col_bits + (1 if 255 % col_bits else 0)} rows of {n} + 1 points, 64 B each); once per Params per device"},
             "input_gen_s": round(gen_s, 2),
         }
+
+    # ---- the exchange step INSIDE the library (its own RCCL communicator: h2_rccl_init, one 96-byte ncclAllGather, local sum) ----
+    # Verification + one timing, and the only leg of this file that has never met more than one rank on hardware -- so it runs LAST,
+    # when every other figure of the line is already computed, in a watchdog thread, and NOTHING collective follows it: a communicator
+    # that fails to form, or forms on some ranks only, can cost this leg its two fields but not the line.  (Where it used to sit --
+    # before the config-5 timings -- a late rank would have left its thread issuing torch.distributed calls beside the main thread's.)
+    rccl_hung = rccl_leg_ran = False
+    if world > 1 and backend == "nccl" and os.environ.get("H2_BENCH_RCCL_C", "1") != "0" and config5 is not None:
+        import threading
+        box = {}
+        rccl_leg_ran = True
+        dist.barrier()           # rank 0 arrives from its solo legs (NTT, Vesta, host seam, create_proof): enter the leg together
+        torch.cuda.synchronize()
+
+        def _library_rccl_legs():
+            try:
+                torch.cuda.set_device(local_rank)          # the current device is per host thread
+                parallel.rccl_init(rank, world)
+                d_sh = torch.from_numpy(shared.view(np.int64)).to(dev)
+                d_bs = torch.from_numpy(bases.view(np.int64)).to(dev)
+                out_c = parallel.split_msm_rccl(d_sh, d_bs, curve)
+                torch.cuda.synchronize()
+                box["msm_ok"] = bool(co.jac_to_affine_ints(curve, out_c.cpu().numpy().view(np.uint64)) == co.jac_to_affine_ints(curve, total))
+                o_ = parallel.split_commit_rccl(params_g, d_shared, d_shbl)
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                for _ in range(reps5):
+                    o_ = parallel.split_commit_rccl(params_g, d_shared, d_shbl)
+                torch.cuda.synchronize()
+                box["commit_ms"] = (time.perf_counter() - t_) / reps5 * 1e3
+                box["commit_ok"] = bool(co.jac_to_affine_ints(curve, o_.cpu().numpy().view(np.uint64)) == co.jac_to_affine_ints(curve, whole5.cpu().numpy().view(np.uint64)))
+                parallel.rccl_finalize()
+                box["done"] = True
+            except Exception as exc:           # reported, never fatal
+                box["error"] = f"error: {exc}"
+                box["done"] = True
+        th = threading.Thread(target=_library_rccl_legs, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("H2_BENCH_RCCL_C_TIMEOUT", "90")))
+        rccl_hung = not box.get("done", False)
+        if rank == 0:
+            miss = "timeout" if rccl_hung else box.get("error")
+            out["checks"]["split_msm_rccl_in_library"] = box.get("msm_ok", miss)
+            out["config5"]["split_commit_rccl_in_library_ok"] = box.get("commit_ok", miss)
+            if "commit_ms" in box:
+                out["config5"]["split_commit_rccl_in_library_ms"] = round(box["commit_ms"], 4)
+    if rank == 0:
         final_line = json.dumps(out)
-    lib.h2_bases_free(params_g)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
         # The JSON line is the LAST thing on stdout: RCCL (torch's communicator, the library's own) prints a version banner through
         # C stdio, which sits in the C buffer until the process exits -- i.e. it would land AFTER a line printed from Python.  Flush
@@ -816,6 +811,14 @@ def main():
         print(final_line)
         sys.stdout.flush()
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    if not rccl_hung:
+        lib.h2_bases_free(params_g)
+        if world > 1:
+            if not rccl_leg_ran:
+                dist.barrier()                    # (after the in-library leg nothing collective follows: a peer may have left through the branch below)
+            dist.destroy_process_group()
+    if rccl_hung:
+        os._exit(0)          # a thread is stuck inside a collective: no interpreter / communicator teardown, the line is out
 
 
 if __name__ == "__main__":
