@@ -101,11 +101,6 @@ struct PassArgs {
     size_t n_in;     // valid input elements (first pass); elements beyond are read as zero
     feparam lk0, lk1;       // load multipliers
     feparam k0, k1, k2;     // store multipliers
-    // carry-free passes only (ntt_pass9): the vector BETWEEN two passes in RAW9 form (raw9_load / raw9_store below) instead of packed
-    // 256-bit words.  raw_in / raw_out: this pass reads / writes that form; fold_out: the stored value is folded first (and so
-    // normalised); norm_in: the values read were stored unfolded, limbs RAW -- the first round gives them the carry passes any later
-    // round gives what it reads from LDS; qh: the fold's quotient range, |q| <= qh (64, or 128 when a fold may meet 2^261).
-    int raw_in, raw_out, fold_out, norm_in, qh;
 };
 
 // LDS planes: lo16[slot], hi16[slot], slot = mid * T + col.
@@ -349,11 +344,11 @@ __device__ __forceinline__ void lds9_put(const Lds9 &l, u32 s, const fe9 &v) {
     l.b[s] = make_uint4((u32)v.v[4], (u32)v.v[5], (u32)v.v[6], (u32)v.v[7]);
     l.c[s] = (u32)v.v[8];
 }
-__device__ __forceinline__ fe9 ntt_fold9(const fe9 &v, const i32 *qp, int qh) {
-    const i32 q = (v.v[8] + (1 << 21)) >> 22;            // |value| < 2^260: q in [-64, 64]   (qh = 128: |value| < 2^261)
-    const uint4 *e = reinterpret_cast<const uint4 *>(qp + 12 * (q + qh));
+__device__ __forceinline__ fe9 ntt_fold9(const fe9 &v, const i32 *qp) {
+    const i32 q = (v.v[8] + (1 << 21)) >> 22;            // |value| < 2^260: q in [-64, 64]
+    const uint4 *e = reinterpret_cast<const uint4 *>(qp + 12 * (q + 64));
     const uint4 x = e[0], y = e[1];
-    const i32 z = qp[12 * (q + qh) + 8];
+    const i32 z = qp[12 * (q + 64) + 8];
     fe9 r;
     r.v[0] = v.v[0] - (i32)x.x; r.v[1] = v.v[1] - (i32)x.y; r.v[2] = v.v[2] - (i32)x.z; r.v[3] = v.v[3] - (i32)x.w;
     r.v[4] = v.v[4] - (i32)y.x; r.v[5] = v.v[5] - (i32)y.y; r.v[6] = v.v[6] - (i32)y.z; r.v[7] = v.v[7] - (i32)y.w;
@@ -384,28 +379,6 @@ __device__ __forceinline__ fe9 ntt_unpack_signed9(const fe &a) {
     return r;
 }
 
-// RAW9 form of the vector between two passes (H2_NTT_RAW9, ntt_run): the nine 32-bit limb words as they are, no packing into 256
-// bits at the store and no unpacking at the next pass's load (17 + 19 instructions per element), and -- when the rounds of the two
-// passes together stay inside what limb 8 absorbs -- no fold either (40 more): two passes then behave like one long pass whose tile
-// went through HBM.  Layout: blocks of FOUR consecutive elements, 144 bytes: [limbs 0-3 of the four | limbs 4-7 of the four | limb 8
-// of the four], so a tile row of four columns is one contiguous 144-byte run (the packed form's run is 128) and the tiles that
-// share a cache line are the neighbours in `lo` that the tile -> XCD map already keeps on one L2.  36 instead of 32 bytes per
-// element on the intermediate vector only: the passes are VALU-bound at a quarter of the HBM rate.
-__device__ __forceinline__ fe9 raw9_load(const u32 *base, size_t x) {
-    const char *blk = reinterpret_cast<const char *>(base) + (x >> 2) * 144;
-    const u32 k = (u32)x & 3u;
-    const uint4 a = *reinterpret_cast<const uint4 *>(blk + 16 * k), b = *reinterpret_cast<const uint4 *>(blk + 64 + 16 * k);
-    const u32 c = *reinterpret_cast<const u32 *>(blk + 128 + 4 * k);
-    return fe9{{(i32)a.x, (i32)a.y, (i32)a.z, (i32)a.w, (i32)b.x, (i32)b.y, (i32)b.z, (i32)b.w, (i32)c}};
-}
-__device__ __forceinline__ void raw9_store(u32 *base, size_t x, const fe9 &v) {
-    char *blk = reinterpret_cast<char *>(base) + (x >> 2) * 144;
-    const u32 k = (u32)x & 3u;
-    *reinterpret_cast<uint4 *>(blk + 16 * k) = make_uint4((u32)v.v[0], (u32)v.v[1], (u32)v.v[2], (u32)v.v[3]);
-    *reinterpret_cast<uint4 *>(blk + 64 + 16 * k) = make_uint4((u32)v.v[4], (u32)v.v[5], (u32)v.v[6], (u32)v.v[7]);
-    *reinterpret_cast<u32 *>(blk + 128 + 4 * k) = (u32)v.v[8];
-}
-
 template <int F, int R, bool FIRST>
 __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u32 *__restrict__ out, Tw9 tw, PassArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
@@ -419,8 +392,8 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
     i32 *qp_w = reinterpret_cast<i32 *>(S.c + tile);
     S.qp = qp_w;
     const u32 tid = threadIdx.x, nthr = blockDim.x;
-    for (u32 j = tid; j < 2u * (u32)A.qh + 1u; j += nthr) {     // q p as signed limbs (|q| <= 128: every limb of the product fits 37 bits before the carry pass)
-        const i64 q = (i64)j - A.qh;
+    for (u32 j = tid; j < 129; j += nthr) {     // q p as signed limbs (|q| <= 64: every limb of the product fits 36 bits before the carry pass)
+        const i64 q = (i64)j - 64;
         const fe9 pk = fe9_p_shl<F>(0);
         i64 c = 0;
 #pragma unroll
@@ -460,9 +433,7 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
             }
             return v;
         }
-        const size_t x = (hi_idx << (s0 + r)) + lo0 + ((size_t)row << s0) + col;
-        if (A.raw_in) return raw9_load(in, x);
-        return ntt_unpack_signed9(fe_load(in + 8 * x));      // ntt_pack_signed9 wrote it
+        return ntt_unpack_signed9(fe_load(in + 8 * ((hi_idx << (s0 + r)) + lo0 + ((size_t)row << s0) + col)));      // ntt_pack_signed9 wrote it
     };
     auto load_factors = [&](fe9 &lk0, fe9 &lk1) {
         lk0 = lk1 = fe9_zero();
@@ -484,12 +455,7 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
     // the element of LDS row `mid`, column `col` leaves the pass
     auto store_elem = [&](u32 mid, u32 col, fe9 v, const fe9 &k0, const fe9 &k1, const fe9 &k2) {
         const size_t x = FIRST ? ((size_t)bitrev(c0 + col, L - r) << r) + mid : (hi_idx << (s0 + r)) + ((size_t)mid << s0) + lo0 + col;
-        if (A.raw_out) {                                    // (never the last pass: no store factor here)
-            if (A.fold_out) v = ntt_fold9(v, S.qp, A.qh);
-            raw9_store(out, x, v);
-            return;
-        }
-        if (!A.store_mode) v = ntt_fold9(v, S.qp, A.qh);    // (a multiplication by the store factor takes the unfolded value)
+        if (!A.store_mode) v = ntt_fold9(v, S.qp);          // (a multiplication by the store factor takes the unfolded value)
         fe w;
         if (A.store_mode) {
             const u32 m3 = A.store_mode == 2 ? (u32)(x % 3) : 0;
@@ -555,10 +521,6 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
                 e1 = load_elem(mid00 + 1, col, lk0, lk1);
                 e2 = load_elem(mid00 + 2, col, lk0, lk1);
                 e3 = load_elem(mid00 + 3, col, lk0, lk1);
-                if (!FIRST && A.norm_in) {                  // stored unfolded by the pass before: RAW limbs, as if they came from LDS
-                    e0 = fe9_norm(e0);
-                    e2 = fe9_norm(e2);
-                }
             } else {
                 // RAW limbs in LDS (header comment): the two elements that are added before anything multiplies them take the carry pass
                 e0 = fe9_norm(lds9_get(S, s00)), e1 = lds9_get(S, s01), e2 = fe9_norm(lds9_get(S, s10)), e3 = lds9_get(S, s11);
@@ -691,7 +653,7 @@ struct NttContext {
     std::map<TwKey, std::shared_ptr<TwEntry>> cache;
     std::list<TwKey> lru;
     size_t cache_bytes = 0;
-    std::map<std::pair<int, hipStream_t>, DevBuf> tmp, tmp9, stage;
+    std::map<std::pair<int, hipStream_t>, DevBuf> tmp, stage;
     bool attr_set = false;
 };
 static NttContext &ntt_ctx() {
@@ -703,7 +665,6 @@ void ntt_release_workspaces() {   // h2_trim: scratch vectors and cached twiddle
     NttContext &cx = ntt_ctx();
     std::lock_guard<std::mutex> lk(cx.mu);
     for (auto &kv : cx.tmp) kv.second.release();
-    for (auto &kv : cx.tmp9) kv.second.release();
     for (auto &kv : cx.stage) kv.second.release();
     cx.cache.clear();
     cx.lru.clear();
@@ -791,7 +752,7 @@ static int launch_pass_t(const PassArgs &A, unsigned tiles, u32 threads, size_t 
         t9.a = (const uint4 *)tw;
         t9.b = t9.a + 2 * count;
         t9.c = (const u32 *)(t9.b + 2 * count);
-        const size_t lds9 = lds / 32 * 36 + (2 * (size_t)A.qh + 1) * 48;
+        const size_t lds9 = lds / 32 * 36 + 129 * 48;
         hipLaunchKernelGGL((ntt_pass9<F, R, FIRST>), dim3(tiles), dim3(threads), lds9, st, src, dst, t9, A);
         return H2_OK;
     }
@@ -900,27 +861,8 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
     const size_t n = (size_t)1 << L;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    // H2_NTT_RAW9 (default 0): the vector between two passes in RAW9 form (raw9_load / raw9_store) in a scratch vector of 36 bytes
-    // per element.  1: folded, normalised limbs -- saves the packing and unpacking; 2: unfolded wherever the rounds on both sides of
-    // the boundary together are at most 11 (a radix-4 round adds two products of magnitude < 2^256.3 to an element that entered
-    // the transform below 2^255: after 11 rounds |value| < 2^260.9, and what meets a twiddle, e2 + e3 wA, stays below the multiplier's
-    // 2^261), folded otherwise; the folds that follow then see |q| <= 128.
-    static const int raw9_env = [] { const char *e = getenv("H2_NTT_RAW9"); int v = e ? atoi(e) : 0; return v >= 0 && v <= 2 ? v : 0; }();
-    const bool raw9 = raw9_env != 0 && ntt_use_fe9(L) && P > 1;
-    int fold_after[40];
-    for (int i = 0, acc = 0; i + 1 < P; ++i) {
-        acc += (stages[i] + 1) / 2;
-        fold_after[i] = (raw9_env == 1 || acc + (stages[i + 1] + 1) / 2 > 11) ? 1 : 0;
-        if (fold_after[i]) acc = 0;
-    }
-    void *tmp9 = nullptr;
-    if (raw9) {
-        DevBuf &tb = cx.tmp9[std::make_pair(dev, st)];
-        if ((rc = tb.reserve((n + 3) / 4 * 144)) != H2_OK) return rc;
-        tmp9 = tb.ptr;
-    }
     void *tmp = nullptr;
-    if (P > 1 && J.d_in == J.d_out && !raw9) {
+    if (P > 1 && J.d_in == J.d_out) {
         DevBuf &tb = cx.tmp[std::make_pair(dev, st)];
         if ((rc = tb.reserve(n * 32)) != H2_OK) return rc;
         tmp = tb.ptr;
@@ -936,13 +878,6 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
         A.n_in = J.n_in;
         const bool last = i == P - 1;
         A.last = last;
-        A.qh = raw9 && raw9_env == 2 ? 128 : 64;
-        if (raw9) {
-            A.raw_in = i > 0;
-            A.raw_out = !last;
-            A.fold_out = !last && fold_after[i];
-            A.norm_in = i > 0 && !fold_after[i - 1];
-        }
         int colbits = A.first ? (L - A.r) : s0;
         static const int first_logT = [] { const char *e = getenv("H2_NTT_LOGT_FIRST"); int v = e ? atoi(e) : -1; return v >= 0 && v <= 5 ? v : -1; }();   // sweeps only
         A.logT = std::min(A.first && first_logT >= 0 ? first_logT : want_logT, colbits);
@@ -973,9 +908,6 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
         if (P == 1) {
             src = J.d_in;
             dst = J.d_out;  // a single workgroup owns the whole vector: load-all then store-all
-        } else if (raw9) {
-            src = A.first ? J.d_in : tmp9;      // later passes update their tiles of the scratch vector in place
-            dst = last ? J.d_out : tmp9;
         } else if (J.d_in != J.d_out) {
             src = A.first ? J.d_in : J.d_out;
             dst = J.d_out;
