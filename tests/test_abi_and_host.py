@@ -127,6 +127,18 @@ def test_cpp_host_mirror_header_compiles():
     assert out.returncode == 0, out.stderr
 
 
+def test_native_bench_driver_binds_the_abi_and_refuses_without_device():
+    """bench/native/h2bench.cpp (built by __graft_entry__.build()) binds the entry points it drives from the in-tree library by name and,
+    like the library itself, has no CPU path: without a GPU it says so and leaves with status 2."""
+    exe = os.path.join(ROOT, "build", "h2bench")
+    if not os.path.exists(exe):
+        pytest.skip("build/h2bench not built (run __graft_entry__.build())")
+    if h.lib().h2_device_count() > 0:
+        pytest.skip("a GPU is present")
+    out = subprocess.run([exe, "commit", "10"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and "library:" in out.stdout and "no GPU" in out.stdout, out.stdout + out.stderr
+
+
 def test_transcript_mirror_matches_oracle_restatement():
     """halo2_amd.transcript (host logic) against the oracle's independent copy of transcript.rs:150-300, and the oracle's
     opening-argument prover against its verifier (CPU only, k = 3)."""

@@ -316,6 +316,19 @@ def test_native_drivers(binary, marker):
     assert out.returncode == 0 and marker in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_native_h2bench_parity():
+    """bench/native/h2bench.cpp `parity`: the native timing / A-B driver's own sweep through the C ABI -- generic multiexps of small and
+    odd sizes from device and from host pointers on both curves, device-resident transforms 2^1 .. 2^21 on both fields with a random
+    (non-root) omega, registered commits with blinds at 2^14 and 2^18 over three streams -- every result against the C oracle."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "h2bench")
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} not built (run __graft_entry__.build())")
+    out = subprocess.run([exe, "parity"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "H2BENCH OK" in out.stdout and "FAIL" not in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("config,k", [("plonk-bench", 8), ("simple-example", 10)])
 def test_create_proof_trace_replay(config, k):
     """BASELINE configs[0] / configs[3] at test size: the whole MSM / FFT call trace of one create_proof
