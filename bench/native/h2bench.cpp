@@ -9,6 +9,8 @@
 //     build/h2bench ntt [sizes=16,18,20,22] [field=0|1] [check=1]                    device-resident best_fft: warm timing, elementwise parity
 //     build/h2bench msm [log_n=20] [curve=0|1]                                       generic best_multiexp (no registered table): time + parity
 //     build/h2bench host [log_n=20]                                                   the host-pointer seam: h2_msm / h2_ntt / h2_commit incl. PCIe
+//     build/h2bench batch [log_n=13] [columns=8] [curve=0|1]                          h2_commit_batch_device: K columns + blinds in one call, against K single commits
+//     build/h2bench domain [k=20] [ext=1|2] [field=0|1]                               ifft / coeff_to_extended / extended_to_coeff, device-resident: parity + time
 //     build/h2bench parity                                                           a sweep of small and odd sizes through every entry point above
 //
 // Every mode checks its results against the oracle (bit-exact: canonical affine coordinates / every element) and prints one summary
@@ -37,6 +39,10 @@ int orc_commit(int curve, const uint64_t *g, const uint64_t *w, const uint64_t *
 void orc_point_to_affine(int curve, uint64_t *out_xy, const uint64_t *in_xyz);
 int orc_best_fft(int field, uint64_t *a, const uint64_t *omega, unsigned log_n);
 void orc_to_mont(int field, uint64_t *a, size_t n);
+int orc_ifft(int field, uint64_t *a, const uint64_t *omega_inv, unsigned log_n, const uint64_t *divisor);
+int orc_coeff_to_extended(int field, uint64_t *a_ext, unsigned k, unsigned ext_k, const uint64_t *g_coset, const uint64_t *g_coset_inv, const uint64_t *extended_omega);
+int orc_extended_to_coeff(int field, uint64_t *a_ext, unsigned ext_k, const uint64_t *g_coset, const uint64_t *g_coset_inv, const uint64_t *extended_omega_inv,
+                          const uint64_t *extended_ifft_divisor);
 }
 
 // ---- the library, bound at run time so that H2BENCH_LIB can point at another build --------------------------------------------
@@ -44,6 +50,7 @@ void orc_to_mont(int field, uint64_t *a, size_t n);
 H2_FN(h2_init); H2_FN(h2_last_error); H2_FN(h2_device_count); H2_FN(h2_bases_register_ex); H2_FN(h2_commit_column_window_bits);
 H2_FN(h2_bases_set_blind_base); H2_FN(h2_bases_free); H2_FN(h2_commit_device); H2_FN(h2_commit); H2_FN(h2_msm_device); H2_FN(h2_msm);
 H2_FN(h2_ntt_device); H2_FN(h2_ntt); H2_FN(h2_profile_enable); H2_FN(h2_profile_read); H2_FN(h2_profile_read_busy); H2_FN(h2_commit_batch_device);
+H2_FN(h2_ifft_device); H2_FN(h2_coeff_to_extended_device); H2_FN(h2_extended_to_coeff_device);
 static bool load_library(const char *argv0) {
     std::string path;
     if (const char *e = getenv("H2BENCH_LIB")) path = e;
@@ -58,6 +65,7 @@ static bool load_library(const char *argv0) {
     H2_BIND(h2_init) H2_BIND(h2_last_error) H2_BIND(h2_device_count) H2_BIND(h2_bases_register_ex) H2_BIND(h2_commit_column_window_bits)
     H2_BIND(h2_bases_set_blind_base) H2_BIND(h2_bases_free) H2_BIND(h2_commit_device) H2_BIND(h2_commit) H2_BIND(h2_msm_device) H2_BIND(h2_msm)
     H2_BIND(h2_ntt_device) H2_BIND(h2_ntt) H2_BIND(h2_profile_enable) H2_BIND(h2_profile_read) H2_BIND(h2_profile_read_busy) H2_BIND(h2_commit_batch_device)
+    H2_BIND(h2_ifft_device) H2_BIND(h2_coeff_to_extended_device) H2_BIND(h2_extended_to_coeff_device)
     printf("library: %s\n", path.c_str());
     return true;
 }
@@ -303,6 +311,128 @@ static void mode_host(unsigned log_n) {
     printf("h2_ntt 2^%u from host pointers: %.4f ms (H2D + passes + D2H)\n", log_n, (now_ms() - t0) / 5);
 }
 
+// ---- column-batched commits ---------------------------------------------------------------------------------------------------
+static void mode_batch(unsigned log_n, int K, int curve) {
+    const size_t n = (size_t)1 << log_n;
+    const int sf = scalar_field(curve);
+    uint64_t gen[8];
+    generator(curve, gen);
+    std::vector<uint64_t> bases(n * 8), w(8), blinds((size_t)K * 4);
+    std::vector<std::vector<uint64_t>> cols(K, std::vector<uint64_t>(n * 4));
+    orc_generate_bases(curve, gen, 0xBA7C4 + log_n, bases.data(), n);
+    orc_generate_bases(curve, gen, 0x78, w.data(), 1);
+    for (int c = 0; c < K; ++c) orc_random_field(sf, 2000 + c, cols[c].data(), n);
+    if (K > 2) std::fill(cols[2].begin(), cols[2].end(), 0);            // an all-zero column inside the batch
+    orc_random_field(sf, 0xB11E, blinds.data(), K);
+    h2_bases_t g = 0;
+    CHECK_RC(p_h2_bases_register_ex(curve, bases.data(), n, H2_FORM_MONTGOMERY, p_h2_commit_column_window_bits(n), &g));
+    CHECK_RC(p_h2_bases_set_blind_base(g, w.data(), H2_FORM_MONTGOMERY));
+    std::vector<void *> d_cols(K), d_bl(K), d_outs(K);
+    void *d_blinds = nullptr, *d_out = nullptr;
+    HIPCK(hipMalloc(&d_blinds, (size_t)K * 32));
+    HIPCK(hipMalloc(&d_out, (size_t)K * 96));
+    HIPCK(hipMemcpy(d_blinds, blinds.data(), (size_t)K * 32, hipMemcpyHostToDevice));
+    for (int c = 0; c < K; ++c) {
+        HIPCK(hipMalloc(&d_cols[c], n * 32));
+        HIPCK(hipMemcpy(d_cols[c], cols[c].data(), n * 32, hipMemcpyHostToDevice));
+        d_bl[c] = (char *)d_blinds + 32 * c;
+        d_outs[c] = (char *)d_out + 96 * c;
+    }
+    auto batched = [&]() {
+        return p_h2_commit_batch_device(g, d_cols.data(), (size_t)K, n, nullptr, d_bl.data(), H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_outs.data(), nullptr);
+    };
+    CHECK_RC(batched());
+    HIPCK(hipDeviceSynchronize());
+    std::vector<uint64_t> got((size_t)K * 12);
+    HIPCK(hipMemcpy(got.data(), d_out, (size_t)K * 96, hipMemcpyDeviceToHost));
+    bool all = true;
+    for (int c = 0; c < K; ++c) {
+        uint64_t want[12];
+        orc_commit(curve, bases.data(), w.data(), cols[c].data(), blinds.data() + 4 * c, n, want);
+        all = all && same_point(curve, got.data() + 12 * c, want);
+    }
+    char msg[128];
+    snprintf(msg, sizeof msg, "h2_commit_batch_device: %d columns of 2^%u (curve %d, one all-zero column) == oracle Params::commit each", K, log_n, curve);
+    expect(all, msg);
+    for (int i = 0; i < 5; ++i) CHECK_RC(batched());
+    HIPCK(hipDeviceSynchronize());
+    const int R = 20;
+    double t0 = now_ms();
+    for (int i = 0; i < R; ++i) CHECK_RC(batched());
+    HIPCK(hipDeviceSynchronize());
+    const double b_ms = (now_ms() - t0) / R;
+    t0 = now_ms();
+    for (int i = 0; i < R; ++i)
+        for (int c = 0; c < K; ++c) CHECK_RC(p_h2_commit_device(g, d_cols[c], n, nullptr, d_bl[c], H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_outs[c], nullptr));
+    HIPCK(hipDeviceSynchronize());
+    const double s_ms = (now_ms() - t0) / R;
+    printf("batch: %d columns of 2^%u in one call %.4f ms; the same as %d single commits on one stream %.4f ms\n", K, log_n, b_ms, K, s_ms);
+    for (void *p : d_cols) (void)hipFree(p);
+    (void)hipFree(d_blinds);
+    (void)hipFree(d_out);
+    p_h2_bases_free(g);
+}
+
+// ---- EvaluationDomain transforms (poly/domain.rs:227-255, 303-325, 375-383) ---------------------------------------------------------
+// The constants (omega, zeta, divisors) are RANDOM field elements here: the transforms are the same formulas on both sides for any
+// values (the parity contract for best_fft already holds for any omega), and the driver needs no field arithmetic of its own.
+static void mode_domain(unsigned k, unsigned ext, int field) {
+    const unsigned ek = k + ext;
+    const size_t n = (size_t)1 << k, ne = (size_t)1 << ek;
+    std::vector<uint64_t> a(n * 4), c(5 * 4);
+    orc_random_field(field, 41 + k, a.data(), n);
+    orc_random_field(field, 42 + k, c.data(), 5);
+    const uint64_t *omega = c.data(), *divisor = c.data() + 4, *zeta = c.data() + 8, *zeta_inv = c.data() + 12, *ext_omega = c.data() + 16;
+    void *d_a = nullptr, *d_e = nullptr;
+    HIPCK(hipMalloc(&d_a, n * 32));
+    HIPCK(hipMalloc(&d_e, ne * 32));
+    // ifft
+    HIPCK(hipMemcpy(d_a, a.data(), n * 32, hipMemcpyHostToDevice));
+    CHECK_RC(p_h2_ifft_device(field, d_a, k, omega, divisor, H2_FORM_MONTGOMERY, nullptr));
+    HIPCK(hipDeviceSynchronize());
+    std::vector<uint64_t> coeff(n * 4), want = a;
+    HIPCK(hipMemcpy(coeff.data(), d_a, n * 32, hipMemcpyDeviceToHost));
+    orc_ifft(field, want.data(), omega, k, divisor);
+    expect(coeff == want, "h2_ifft_device == oracle ifft at every index");
+    // coeff_to_extended
+    CHECK_RC(p_h2_coeff_to_extended_device(field, d_a, d_e, k, ek, zeta, zeta_inv, ext_omega, H2_FORM_MONTGOMERY, nullptr));
+    HIPCK(hipDeviceSynchronize());
+    std::vector<uint64_t> extv(ne * 4), ext_want(ne * 4, 0);
+    HIPCK(hipMemcpy(extv.data(), d_e, ne * 32, hipMemcpyDeviceToHost));
+    memcpy(ext_want.data(), want.data(), n * 32);
+    orc_coeff_to_extended(field, ext_want.data(), k, ek, zeta, zeta_inv, ext_omega);
+    expect(extv == ext_want, "h2_coeff_to_extended_device == oracle coeff_to_extended at every index");
+    // extended_to_coeff of a generic extended vector
+    std::vector<uint64_t> e(ne * 4);
+    orc_random_field(field, 43 + k, e.data(), ne);
+    HIPCK(hipMemcpy(d_e, e.data(), ne * 32, hipMemcpyHostToDevice));
+    CHECK_RC(p_h2_extended_to_coeff_device(field, d_e, ek, zeta, zeta_inv, omega, divisor, H2_FORM_MONTGOMERY, nullptr));
+    HIPCK(hipDeviceSynchronize());
+    std::vector<uint64_t> back(ne * 4);
+    HIPCK(hipMemcpy(back.data(), d_e, ne * 32, hipMemcpyDeviceToHost));
+    orc_extended_to_coeff(field, e.data(), ek, zeta, zeta_inv, omega, divisor);
+    expect(back == e, "h2_extended_to_coeff_device == oracle extended_to_coeff at every index");
+    // warm timings
+    auto time_it = [&](const char *what, auto fn) {
+        for (int i = 0; i < 10; ++i) fn();
+        (void)hipDeviceSynchronize();
+        const int R = 30;
+        const double t0 = now_ms();
+        for (int i = 0; i < R; ++i) fn();
+        (void)hipDeviceSynchronize();
+        printf("%s: %.4f ms\n", what, (now_ms() - t0) / R);
+    };
+    char lbl[96];
+    snprintf(lbl, sizeof lbl, "ifft 2^%u", k);
+    time_it(lbl, [&] { p_h2_ifft_device(field, d_a, k, omega, divisor, H2_FORM_MONTGOMERY, nullptr); });
+    snprintf(lbl, sizeof lbl, "coeff_to_extended 2^%u -> 2^%u", k, ek);
+    time_it(lbl, [&] { p_h2_coeff_to_extended_device(field, d_a, d_e, k, ek, zeta, zeta_inv, ext_omega, H2_FORM_MONTGOMERY, nullptr); });
+    snprintf(lbl, sizeof lbl, "extended_to_coeff 2^%u", ek);
+    time_it(lbl, [&] { p_h2_extended_to_coeff_device(field, d_e, ek, zeta, zeta_inv, omega, divisor, H2_FORM_MONTGOMERY, nullptr); });
+    (void)hipFree(d_a);
+    (void)hipFree(d_e);
+}
+
 static std::vector<unsigned> parse_list(const char *s) {
     std::vector<unsigned> v;
     for (const char *p = s; *p;) {
@@ -322,6 +452,8 @@ int main(int argc, char **argv) {
     else if (mode == "ntt") mode_ntt(parse_list(argc > 2 ? argv[2] : "16,18,20,22"), (int)arg(3, H2_FP), arg(4, 1) != 0);
     else if (mode == "msm") mode_msm((unsigned)arg(2, 20), (int)arg(3, H2_PALLAS));
     else if (mode == "host") mode_host((unsigned)arg(2, 20));
+    else if (mode == "batch") mode_batch((unsigned)arg(2, 13), (int)arg(3, 8), (int)arg(4, H2_PALLAS));
+    else if (mode == "domain") mode_domain((unsigned)arg(2, 20), (unsigned)arg(3, 1), (int)arg(4, H2_FP));
     else if (mode == "parity") {
         for (int curve : {H2_PALLAS, H2_VESTA})
             for (size_t n : {(size_t)0, (size_t)1, (size_t)2, (size_t)255, (size_t)4097, (size_t)65535, (size_t)65536, (size_t)65537, (size_t)300001})
@@ -329,8 +461,12 @@ int main(int argc, char **argv) {
         for (int field : {H2_FP, H2_FQ}) mode_ntt({1, 2, 5, 10, 11, 13, 16, 19, 20, 21}, field, true);
         mode_commit(14, 8, 2, 3, H2_VESTA);
         mode_commit(18, 8, 2, 3, H2_PALLAS);
+        mode_batch(12, 8, H2_VESTA);
+        mode_batch(16, 3, H2_PALLAS);
+        mode_domain(12, 2, H2_FQ);
+        mode_domain(17, 1, H2_FP);
     } else {
-        printf("usage: h2bench commit|ntt|msm|host|parity ... (see the head of bench/native/h2bench.cpp)\n");
+        printf("usage: h2bench commit|ntt|msm|host|batch|domain|parity ... (see the head of bench/native/h2bench.cpp)\n");
         return 2;
     }
     printf(g_fail ? "H2BENCH FAIL (%d)\n" : "H2BENCH OK\n", g_fail);
