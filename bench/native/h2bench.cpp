@@ -4,8 +4,9 @@
 // library, the C oracle (the checker: oracle/h2_oracle.c, test infrastructure) and the HIP runtime and is measuring within a second,
 // so a same-box A/B of two library builds costs seconds of GPU time:
 //
-//     build/h2bench commit [log_n=20] [steps=20] [warmup=5] [streams=3] [curve=0|1]   the bench line's workload: registered table, blinds,
-//                                                                               independent column commits round-robin over streams
+//     build/h2bench commit [log_n=20] [steps=20] [warmup=5] [streams=3] [curve=0|1] [reps=1]   the bench line's workload: registered table, blinds,
+//                                                                               independent column commits round-robin over streams; `steps` and
+//                                                                               `streams` may be lists (20,100 and 2,3,4): every pair, median of reps
 //     build/h2bench ntt [sizes=16,18,20,22] [field=0|1] [check=1]                    device-resident best_fft: warm timing, elementwise parity
 //     build/h2bench msm [log_n=20] [curve=0|1]                                       generic best_multiexp (no registered table): time + parity
 //     build/h2bench host [log_n=20]                                                   the host-pointer seam: h2_msm / h2_ntt / h2_commit incl. PCIe
@@ -115,7 +116,7 @@ static bool same_point(int curve, const uint64_t *a_xyz, const uint64_t *b_xyz) 
 }
 
 // ---- commit: the bench line's workload ------------------------------------------------------------------------------------------
-static void mode_commit(unsigned log_n, int steps, int warmup, int nstreams, int curve) {
+static void mode_commit(unsigned log_n, const std::vector<unsigned> &steps_list, int warmup, const std::vector<unsigned> &stream_list, int curve, int reps = 1) {
     const size_t n = (size_t)1 << log_n;
     const int sf = scalar_field(curve), ncols = 4;
     uint64_t gen[8];
@@ -143,37 +144,60 @@ static void mode_commit(unsigned log_n, int steps, int warmup, int nstreams, int
     }
     HIPCK(hipMalloc(&d_blinds, (size_t)ncols * 32));
     HIPCK(hipMemcpy(d_blinds, blinds.data(), (size_t)ncols * 32, hipMemcpyHostToDevice));
-    const int outs = std::max(steps, 8);
+    int max_steps = 8;
+    for (unsigned k : steps_list) max_steps = std::max<int>(max_steps, (int)k);
+    const int outs = max_steps;
     HIPCK(hipMalloc(&d_out, (size_t)outs * 96));
-    std::vector<hipStream_t> st(nstreams);
+    unsigned max_streams = 1;
+    for (unsigned k : stream_list) max_streams = std::max(max_streams, k);
+    std::vector<hipStream_t> st(max_streams);
     for (auto &s : st) HIPCK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     bool launch_failed = false;
+    int nstreams = (int)stream_list[0];
     auto step = [&](int i) {
         const int c = i % ncols;
         const int rc = p_h2_commit_device(g, d_cols[c], n, nullptr, (char *)d_blinds + 32 * c, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN,
                                           (char *)d_out + 96 * (size_t)(i % outs), st[i % nstreams]);
         if (rc != H2_OK && !launch_failed) { printf("FAIL: h2_commit_device -> %d (%s)\n", rc, p_h2_last_error()); launch_failed = true; g_fail++; }
     };
-    for (int i = 0; i < 2 * nstreams; ++i) step(i);           // workspaces are allocated on first use
-    HIPCK(hipDeviceSynchronize());
-    t0 = now_ms();
-    while (now_ms() - t0 < 400.0) {                            // the clocks settle over a few hundred ms of load (bench.py --prewarm-ms)
-        for (int i = 0; i < 2 * nstreams; ++i) step(i);
+    // every (streams, steps) pair of the lists, `reps` timed regions each (the median is printed last); before each region the clocks
+    // settle under the same schedule (400 ms before the first, 150 ms before the others: bench.py --prewarm-ms) and `warmup` steps run untimed
+    bool first_region = true;
+    for (unsigned S : stream_list) {
+        nstreams = (int)S;
+        for (int i = 0; i < 2 * nstreams; ++i) step(i);           // workspaces are allocated on first use
         HIPCK(hipDeviceSynchronize());
+        for (unsigned steps : steps_list) {
+            std::vector<double> per_step;
+            double union_ms = 0, mean_ms = 0;
+            for (int rep = 0; rep < reps; ++rep) {
+                t0 = now_ms();
+                while (now_ms() - t0 < (first_region ? 400.0 : 150.0)) {
+                    for (int i = 0; i < 2 * nstreams; ++i) step(i);
+                    HIPCK(hipDeviceSynchronize());
+                }
+                first_region = false;
+                for (int i = 0; i < warmup; ++i) step(i);
+                HIPCK(hipDeviceSynchronize());
+                p_h2_profile_enable(2);
+                t0 = now_ms();
+                for (unsigned i = 0; i < steps; ++i) step((int)i);
+                HIPCK(hipDeviceSynchronize());
+                const double ms = now_ms() - t0;
+                double tot = 0, busy = 0;
+                uint64_t cnt = 0;
+                p_h2_profile_read_busy(H2_PROF_MSM_ACCUMULATE, &tot, &busy, &cnt);
+                p_h2_profile_enable(0);
+                per_step.push_back(ms / steps);
+                union_ms = cnt ? busy / cnt : 0.0;
+                mean_ms = cnt ? tot / cnt : 0.0;
+            }
+            std::sort(per_step.begin(), per_step.end());
+            const double med = per_step[per_step.size() / 2];
+            printf("commit 2^%u x %u steps over %d streams: %.4f ms per step = %.1f M scalar-mults/s   (median of %d regions, %.4f .. %.4f; accumulate of the last: union %.4f ms per launch, mean %.4f)\n",
+                   log_n, steps, nstreams, med, n / med / 1e3, reps, per_step.front(), per_step.back(), union_ms, mean_ms);
+        }
     }
-    for (int i = 0; i < warmup; ++i) step(i);
-    HIPCK(hipDeviceSynchronize());
-    p_h2_profile_enable(2);
-    t0 = now_ms();
-    for (int i = 0; i < steps; ++i) step(i);
-    HIPCK(hipDeviceSynchronize());
-    const double ms = now_ms() - t0;
-    double tot = 0, busy = 0;
-    uint64_t cnt = 0;
-    p_h2_profile_read_busy(H2_PROF_MSM_ACCUMULATE, &tot, &busy, &cnt);
-    p_h2_profile_enable(0);
-    printf("commit 2^%u x %d steps over %d streams: %.4f ms per step = %.1f M scalar-mults/s   (accumulate: union %.4f ms per launch, mean %.4f, %llu launches)\n",
-           log_n, steps, nstreams, ms / steps, n * (double)steps / ms / 1e3, cnt ? busy / cnt : 0.0, cnt ? tot / cnt : 0.0, (unsigned long long)cnt);
     // one commit at a time on one stream
     for (int i = 0; i < 4; ++i) { const int rc = p_h2_commit_device(g, d_cols[0], n, nullptr, d_blinds, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_out, st[0]); (void)rc; }
     HIPCK(hipDeviceSynchronize());
@@ -448,7 +472,7 @@ int main(int argc, char **argv) {
     if (p_h2_init(0) != H2_OK) { printf("h2_init: %s\n", p_h2_last_error()); return 2; }
     const std::string mode = argc > 1 ? argv[1] : "commit";
     auto arg = [&](int i, long dflt) { return argc > i ? atol(argv[i]) : dflt; };
-    if (mode == "commit") mode_commit((unsigned)arg(2, 20), (int)arg(3, 20), (int)arg(4, 5), (int)arg(5, 3), (int)arg(6, H2_PALLAS));
+    if (mode == "commit") mode_commit((unsigned)arg(2, 20), parse_list(argc > 3 ? argv[3] : "20"), (int)arg(4, 5), parse_list(argc > 5 ? argv[5] : "3"), (int)arg(6, H2_PALLAS), (int)arg(7, 1));
     else if (mode == "ntt") mode_ntt(parse_list(argc > 2 ? argv[2] : "16,18,20,22"), (int)arg(3, H2_FP), arg(4, 1) != 0);
     else if (mode == "msm") mode_msm((unsigned)arg(2, 20), (int)arg(3, H2_PALLAS));
     else if (mode == "host") mode_host((unsigned)arg(2, 20));
@@ -459,8 +483,8 @@ int main(int argc, char **argv) {
             for (size_t n : {(size_t)0, (size_t)1, (size_t)2, (size_t)255, (size_t)4097, (size_t)65535, (size_t)65536, (size_t)65537, (size_t)300001})
                 mode_msm_n(n, curve, false);         // (n = 0: the identity)
         for (int field : {H2_FP, H2_FQ}) mode_ntt({1, 2, 5, 10, 11, 13, 16, 19, 20, 21}, field, true);
-        mode_commit(14, 8, 2, 3, H2_VESTA);
-        mode_commit(18, 8, 2, 3, H2_PALLAS);
+        mode_commit(14, {8}, 2, {3}, H2_VESTA);
+        mode_commit(18, {8}, 2, {3}, H2_PALLAS);
         mode_batch(12, 8, H2_VESTA);
         mode_batch(16, 3, H2_PALLAS);
         mode_domain(12, 2, H2_FQ);
