@@ -2,6 +2,7 @@
 // Written the way the reference's own tests read (arithmetic.rs:440 test_multiexp, commitment.rs:258
 // test_commit_lagrange, domain.rs iFFT checks).  TEST CODE: links oracle/h2_oracle.c as the checker.
 // Build: g++ -O2 -std=c++17 tests/native/host_mirror_check.cpp -Lhalo2_amd -lhalo2_mi355x -Loracle -lh2oracle (see __graft_entry__.build)
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <sstream>
@@ -57,9 +58,42 @@ static int opening_mode(uint32_t k) {
     return 0;
 }
 
+// `host_mirror_check opening-time <k> [reps]`: the same opening argument timed natively (no Python in the process: a fresh GPU box is
+// measuring within a second) -- Params::new(k) once, then `reps` arguments over the same polynomial; prints the wall time of each and
+// whether every repetition wrote the same bytes.  A measurement aid for the round loop of csrc/ipa.hip; not run by the test suite.
+static int opening_time_mode(uint32_t k, int reps) {
+    constexpr int CURVE = H2_VESTA, SF = H2_FP;
+    const auto t_p = std::chrono::steady_clock::now();
+    Params<CURVE> params = Params<CURVE>::new_params(k);
+    printf("Params::new(%u): %.1f ms\n", k, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p).count());
+    std::vector<Fe> px(params.n);
+    for (size_t i = 0; i < params.n; i++) px[i] = field::from_u64(SF, i);
+    const Blind<CURVE> blind{field::from_u64(SF, 7)};
+    std::vector<uint8_t> first;
+    bool same = true;
+    for (int rep = 0; rep < reps; ++rep) {
+        uint64_t ctr = 0;
+        auto rng = [&]() { ++ctr; return field::from_u64(SF, ctr * 0x9E3779B97F4A7C15ULL + 1); };
+        Blake2bWrite<CURVE> tr;
+        tr.write_point(to_affine<CURVE>(params.commit(px, blind)));
+        const Fe x = tr.squeeze_challenge_scalar();
+        tr.write_scalar(eval_polynomial<SF>(px, x));
+        const auto t0 = std::chrono::steady_clock::now();
+        create_proof<CURVE>(params, rng, tr, px, blind, x);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        const std::vector<uint8_t> bytes = tr.finalize();
+        if (rep == 0) first = bytes;
+        same = same && bytes == first;
+        printf("opening argument k = %u, repetition %d: %.3f ms (%zu bytes)\n", k, rep, ms, bytes.size());
+    }
+    printf(same ? "every repetition wrote the same bytes\n" : "FAIL: repetitions differ\n");
+    return same ? 0 : 1;
+}
+
 int main(int argc, char **argv) {
     if (h2_device_count() <= 0) { printf("no GPU: host mirror check needs an MI355X\n"); return 2; }
     if (argc == 3 && std::string(argv[1]) == "opening") return opening_mode((uint32_t)atoi(argv[2]));
+    if (argc >= 3 && std::string(argv[1]) == "opening-time") return opening_time_mode((uint32_t)atoi(argv[2]), argc > 3 ? atoi(argv[3]) : 5);
     constexpr int CURVE = H2_VESTA, FIELD = H2_FP;   // every proof in the reference runs on Vesta / Fp
     const uint32_t k = 8;
     const size_t n = (size_t)1 << k;
