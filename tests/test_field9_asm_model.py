@@ -160,3 +160,42 @@ def test_generated_multipliers_against_big_integers(field):
     neg = [-x for x in top]
     r, peak = _run(dot2, {"a": top, "b": top, "c": neg, "d": neg}, field)
     assert peak < 1 << 63 and _value(r) % p == (2 * _value(top) ** 2 * rinv) % p
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_ntt_operand_regime_of_the_multiplier(field):
+    """The carry-free NTT passes (csrc/ntt.hip, header of ntt_pass9) multiply data whose limbs are RAW -- the outputs of a radix-4 round,
+    o = (e0 +- e1 wA) +- (e2 +- e3 wA) wB with e0 normalised and every product's limbs in [0, 2^29]: limbs in (-2^30, 3 x 2^29), limb 8
+    carrying the growth of up to |value| < 2^261 -- by a NORMALISED twiddle in [0, p), with no carry pass in between.  Checked on the
+    generated statement itself: the 64-bit column accumulator stays below 2^63, the product is congruent and leaves normalised, and it
+    is small again (below 2^255 + p: what the next rounds add to an element), also at the corners of the limb range."""
+    p = P[field]
+    rinv = pow(1 << 261, -1, p)
+    rng = random.Random(0x4E5454 + field)
+    mul = _statement("field9_mul.inc")
+    lo, hi = -(1 << 30) + 1, 3 * (1 << 29) - 1
+
+    def twiddle(v):
+        return [(v >> (29 * i)) & M29 for i in range(8)] + [v >> 232]
+
+    worst = 0
+    for trial in range(80):
+        a = [rng.randrange(lo, hi + 1) for _ in range(8)] + [rng.randrange(-(1 << 29), (1 << 29) + 1)]
+        if trial == 0:
+            a = [hi] * 8 + [1 << 29]                   # every limb at the top of the RAW range
+        elif trial == 1:
+            a = [lo] * 8 + [-(1 << 29)]                # ... at the bottom
+        elif trial == 2:
+            a = [hi if i % 2 else lo for i in range(8)] + [1 << 29]
+        w = p - 1 - trial if trial < 4 else rng.randrange(0, p)
+        b = twiddle(w)
+        assert _value(b) == w and all(0 <= x < (1 << 29) for x in b[:8])
+        r, peak = _run(mul, {"a": a, "b": b}, field)
+        worst = max(worst, peak)
+        assert peak < 1 << 63, (trial, peak.bit_length())
+        assert all(0 <= x < (1 << 29) for x in r[1:8]) and 1 <= r[0] <= (1 << 29), r
+        v = _value(r)
+        assert v % p == (_value(a) * w * rinv) % p
+        # |a| < 2^261 (limb 8 within +-2^29) plus what raw low limbs add: the product stays within a few p
+        assert abs(v) < (1 << 255) + 4 * p, v.bit_length()
+    assert worst > 1 << 61                             # the corners do come close: the bound is tight, not vacuous
