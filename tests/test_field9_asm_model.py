@@ -199,3 +199,129 @@ def test_ntt_operand_regime_of_the_multiplier(field):
         # |a| < 2^261 (limb 8 within +-2^29) plus what raw low limbs add: the product stays within a few p
         assert abs(v) < (1 << 255) + 4 * p, v.bit_length()
     assert worst > 1 << 61                             # the corners do come close: the bound is tight, not vacuous
+
+
+# ---- a whole 10-stage NTT pass at limb level ----------------------------------------------------------------------------------------
+# csrc/ntt.hip, ntt_pass9<F, 10, FIRST>: the arithmetic of a 2^10-point transform exactly as the kernel sequences it -- unpack, five radix-4
+# rounds with the consumer-side carry passes (e0 and e2 normalised when read, e1 and e3 multiplied RAW), the transform's first round
+# without its multiplications by omega^0, one fold by the q p table and one sign-selected carry pass to the canonical value -- with the
+# multiplications done by the generated statement under the interpreter above.  What the kernel's comments argue (limb ranges, |value|
+# < 2^260 after five rounds, |q| <= 64, one conditional addition of p) is asserted on the way, and the output is compared index by index
+# with the reference's radix-2 network on big integers (arithmetic.rs:192-255) for a RANDOM omega (benches/fft.rs:17).
+def _norm(a):
+    r, c = [], 0
+    for i in range(8):
+        t = a[i] + c
+        assert -(1 << 31) <= t < (1 << 31)
+        r.append(t & M29)
+        c = t >> 29
+    t8 = a[8] + c
+    assert -(1 << 31) <= t8 < (1 << 31)
+    return r + [t8]
+
+
+def _i32(v):
+    assert all(-(1 << 31) <= x < (1 << 31) for x in v), v
+    return v
+
+
+def _reference_network(a, omega, log_n, p):
+    """best_fft of the reference: bit reversal, then log n butterfly stages with twiddle omega^(j n / 2m) for the j-th pair of a block"""
+    n = 1 << log_n
+    a = list(a)
+    for k in range(n):
+        rk = int(format(k, f"0{log_n}b")[::-1], 2)
+        if k < rk:
+            a[k], a[rk] = a[rk], a[k]
+    m = 1
+    for _ in range(log_n):
+        w_m = pow(omega, n // (2 * m), p)
+        for k in range(0, n, 2 * m):
+            w = 1
+            for j in range(m):
+                t = a[k + j + m] * w % p
+                a[k + j + m] = (a[k + j] - t) % p
+                a[k + j] = (a[k + j] + t) % p
+                w = w * w_m % p
+        m *= 2
+    return a
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_ntt_pass_limb_model_against_reference_network(field):
+    p = P[field]
+    L, n = 10, 1 << 10
+    rng = random.Random(0x70A55 + field)
+    mul = _statement("field9_mul.inc")
+    omega = rng.randrange(2, p)                                    # any field element: the network is the contract, not the DFT
+    data = [rng.randrange(0, p) for _ in range(n)]
+    data[3], data[5], data[7] = 0, p - 1, 1                        # edge residues among the inputs
+    want = _reference_network(data, omega, L, p)
+    R9 = pow(2, 261, p)
+    plimbs = [(p >> (29 * i)) & M29 for i in range(8)] + [p >> 232]
+
+    def tw(e):                                                     # omega^e in M9 form, normalised limbs (ntt_twiddles9)
+        v = pow(omega, e, p) * R9 % p
+        return [(v >> (29 * i)) & M29 for i in range(8)] + [v >> 232]
+
+    peak_all, max_abs_value = 0, 0
+
+    def fmul(a, b):
+        nonlocal peak_all
+        r, peak = _run(mul, {"a": _i32(a), "b": b}, field)
+        peak_all = max(peak_all, peak)
+        assert all(0 <= x < (1 << 29) for x in r[1:8]) and 1 <= r[0] <= (1 << 29)
+        return r
+
+    add = lambda x, y: [s + t for s, t in zip(x, y)]
+    sub = lambda x, y: [s - t for s, t in zip(x, y)]
+    raw_ok = lambda v: all(-(1 << 30) < x < 3 * (1 << 29) for x in v[:8])
+    # first pass: LDS row `row` holds input element bitrev(row) (the bit reversal is folded into the gather)
+    rev = lambda k: int(format(k, f"0{L}b")[::-1], 2)
+    x = [[(data[rev(k)] >> (29 * i)) & M29 for i in range(8)] + [data[rev(k)] >> 232] for k in range(n)]     # fe9_unpack
+    for u in range(0, L, 2):                                       # round u: stages t = u and u + 1
+        t = u
+        nxt = list(x)
+        for base in range(n):
+            if base & (3 << t):
+                continue
+            low = base & ((1 << t) - 1)
+            i00, i01, i10, i11 = base, base + (1 << t), base + (2 << t), base + (3 << t)
+            first = u == 0
+            # inputs of the transform's first round come unpacked (normalised); later rounds read RAW limbs and normalise e0, e2
+            e0, e1, e2, e3 = (x[i00], x[i01], x[i10], x[i11]) if first else (_norm(x[i00]), x[i01], _norm(x[i10]), x[i11])
+            if not first:
+                assert raw_ok(x[i01]) and raw_ok(x[i11])
+                wA = tw(low << (L - t - 1))
+                e1, e3 = fmul(e1, wA), fmul(e3, wA)
+            a0, a1 = add(e0, e1), sub(e0, e1)
+            wB0, wB1 = tw(low << (L - t - 2)), tw((low + (1 << t)) << (L - t - 2))
+            a2 = _norm(add(e2, e3)) if first else fmul(add(e2, e3), wB0)      # stage 1's omega^0: a carry pass stands in
+            a3 = fmul(sub(e2, e3), wB1)
+            nxt[i00], nxt[i10] = _i32(add(a0, a2)), _i32(sub(a0, a2))
+            nxt[i01], nxt[i11] = _i32(add(a1, a3)), _i32(sub(a1, a3))
+            for o in (nxt[i00], nxt[i10], nxt[i01], nxt[i11]):
+                assert raw_ok(o), o                                # RAW: limbs in (-2^30, 3 x 2^29)
+                max_abs_value = max(max_abs_value, abs(_value(o)))
+        x = nxt
+    assert max_abs_value < 1 << 260                                # five rounds of two products each, absorbed by limb 8
+    assert peak_all < 1 << 63
+    got = []
+    for k in range(n):
+        v = x[k]
+        q = (v[8] + (1 << 21)) >> 22                               # ntt_fold9: q = round(value / 2^254)
+        assert -64 <= q <= 64
+        qp, c = [], 0
+        for i in range(8):                                         # the q p table entry as the kernel builds it
+            tq = q * plimbs[i] + c
+            qp.append(tq & M29)
+            c = tq >> 29
+        qp.append(q * plimbs[8] + c)
+        f = _norm(_i32(sub(v, qp)))
+        assert abs(_value(f)) < (1 << 253) + (1 << 133)
+        neg = f[8] >> 31                                           # ntt_canonical_folded9: add p exactly when negative, ONE carry pass
+        g = _norm([f[i] + (plimbs[i] if neg else 0) for i in range(9)])
+        val = _value(g)
+        assert 0 <= val < p and all(0 <= y < (1 << 29) for y in g[:8]) and 0 <= g[8] < (1 << 24)
+        got.append(val)
+    assert got == want
