@@ -325,3 +325,62 @@ def test_ntt_pass_limb_model_against_reference_network(field):
         assert 0 <= val < p and all(0 <= y < (1 << 29) for y in g[:8]) and 0 <= g[8] < (1 << 24)
         got.append(val)
     assert got == want
+
+
+# ---- the accumulate loop's mixed addition at limb level -----------------------------------------------------------------------------
+# csrc/curve9.cuh, xyzz9_madd (the inner loop of msm_accumulate: madd-2008-s, 8M + 2S with X3 and Y3 in the fused forms): a bucket's
+# chain of additions sequenced exactly as the kernel does, every product by the generated statement under the interpreter, against
+# affine big-integer addition (Buckets::sum adds with `+=` on the curve, arithmetic.rs:29-58).  Asserts what curve9.cuh's header argues:
+# every intermediate a valid operand (32-bit limbs, column accumulator below 2^63) and X, Y, ZZ, ZZZ normalised after every addition,
+# with no carry pass anywhere.
+@pytest.mark.parametrize("field", [0, 1])
+def test_mixed_addition_limb_model_against_affine_addition(field):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import pasta
+    p = P[field]
+    rng = random.Random(0xADD + field)
+    mul, sqr = _statement("field9_mul.inc"), _statement("field9_sqr.inc")
+    dot2, sqr_minus = _statement("field9_dot2.inc"), _statement("field9_sqr_minus.inc")
+    R9 = pow(2, 261, p)
+    peak_all = 0
+
+    def run(stmt, ops):
+        nonlocal peak_all
+        r, peak = _run(stmt, {k: _i32(v) for k, v in ops.items()}, field)
+        peak_all = max(peak_all, peak)
+        assert all(0 <= x < (1 << 29) for x in r[1:8]) and 1 <= r[0] <= (1 << 29), r          # every result leaves normalised
+        return r
+
+    def m9(v):                                                      # a coordinate in M9 form, normalised limbs (a table entry)
+        v = v * R9 % p
+        return [(v >> (29 * i)) & M29 for i in range(8)] + [v >> 232]
+
+    add = lambda x, y: [s + t for s, t in zip(x, y)]
+    sub = lambda x, y: [s - t for s, t in zip(x, y)]
+    g = ((p - 1) % p, 2)                                            # (-1, 2): on y^2 = x^3 + 5 over both base fields
+    assert pasta.on_curve(g, p)
+    pts = [pasta.ec_mul(rng.randrange(1, 1 << 64), g, p) for _ in range(24)]
+    pts[5] = pasta.ec_neg(pts[2], p)                                # a negated earlier point further down the chain (not adjacent: no P - P)
+    acc, want = None, None
+    for q in pts:
+        qx, qy = m9(q[0]), m9(q[1])
+        want = pasta.ec_add(want, q, p)
+        if acc is None:                                             # first entry of a bucket: the point itself, ZZ = ZZZ = one
+            acc = {"x": qx, "y": qy, "zz": m9(1), "zzz": m9(1)}
+            continue
+        u2, s2 = run(mul, {"a": qx, "b": acc["zz"]}), run(mul, {"a": qy, "b": acc["zzz"]})
+        pd, r = sub(u2, acc["x"]), sub(s2, acc["y"])
+        assert _value(pd) % p != 0                                  # (the rare P = +-Q branch is not what this test is about)
+        pp = run(sqr, {"a": pd})
+        ppp = run(mul, {"a": pd, "b": pp})
+        qq = run(mul, {"a": acc["x"], "b": pp})
+        x3 = run(sqr_minus, {"a": r, "s": add([2 * v for v in qq], ppp)})
+        y3 = run(dot2, {"a": r, "b": sub(qq, x3), "c": [-v for v in acc["y"]], "d": ppp})
+        acc = {"x": x3, "y": y3, "zz": run(mul, {"a": acc["zz"], "b": pp}), "zzz": run(mul, {"a": acc["zzz"], "b": ppp})}
+        for c in acc.values():
+            assert abs(_value(c)) < 1 << 258                        # a valid operand of the next addition (field9.cuh)
+        zz, zzz = _value(acc["zz"]) % p, _value(acc["zzz"]) % p
+        got = (_value(acc["x"]) * pow(zz, -1, p) % p, _value(acc["y"]) * pow(zzz, -1, p) % p)
+        assert got == want
+    assert peak_all < 1 << 63
