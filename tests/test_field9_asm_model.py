@@ -384,3 +384,60 @@ def test_mixed_addition_limb_model_against_affine_addition(field):
         got = (_value(acc["x"]) * pow(zz, -1, p) % p, _value(acc["y"]) * pow(zzz, -1, p) % p)
         assert got == want
     assert peak_all < 1 << 63
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_full_addition_limb_model_against_affine_addition(field):
+    """csrc/curve9.cuh, xyzz9_add (add-2008-s, 12M + 2S: the bucket fold's addition -- fold9_finish, the line sums, the bit planes): a
+    binary tree of XYZZ + XYZZ additions over partial sums that are themselves results of mixed / full additions, sequenced as the kernel
+    does and multiplied by the generated statements, against affine big-integer addition."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import pasta
+    p = P[field]
+    rng = random.Random(0xF011 + field)
+    mul, sqr = _statement("field9_mul.inc"), _statement("field9_sqr.inc")
+    dot2, sqr_minus = _statement("field9_dot2.inc"), _statement("field9_sqr_minus.inc")
+    R9 = pow(2, 261, p)
+    peak_all = 0
+
+    def run(stmt, ops):
+        nonlocal peak_all
+        r, peak = _run(stmt, {k: _i32(v) for k, v in ops.items()}, field)
+        peak_all = max(peak_all, peak)
+        assert all(0 <= x < (1 << 29) for x in r[1:8]) and 1 <= r[0] <= (1 << 29), r
+        return r
+
+    def m9(v):
+        v = v * R9 % p
+        return [(v >> (29 * i)) & M29 for i in range(8)] + [v >> 232]
+
+    add = lambda x, y: [s + t for s, t in zip(x, y)]
+    sub = lambda x, y: [s - t for s, t in zip(x, y)]
+
+    def full_add(a, b):
+        u1, u2 = run(mul, {"a": a["x"], "b": b["zz"]}), run(mul, {"a": b["x"], "b": a["zz"]})
+        s1, s2 = run(mul, {"a": a["y"], "b": b["zzz"]}), run(mul, {"a": b["y"], "b": a["zzz"]})
+        pd, r = sub(u2, u1), sub(s2, s1)
+        assert _value(pd) % p != 0
+        pp = run(sqr, {"a": pd})
+        ppp = run(mul, {"a": pd, "b": pp})
+        qq = run(mul, {"a": u1, "b": pp})
+        x3 = run(sqr_minus, {"a": r, "s": add([2 * v for v in qq], ppp)})
+        y3 = run(dot2, {"a": r, "b": sub(qq, x3), "c": [-v for v in s1], "d": ppp})
+        return {"x": x3, "y": y3, "zz": run(mul, {"a": run(mul, {"a": a["zz"], "b": b["zz"]}), "b": pp}),
+                "zzz": run(mul, {"a": run(mul, {"a": a["zzz"], "b": b["zzz"]}), "b": ppp})}
+
+    g = ((p - 1) % p, 2)
+    pts = [pasta.ec_mul(rng.randrange(1, 1 << 64), g, p) for _ in range(16)]
+    level = [({"x": m9(q[0]), "y": m9(q[1]), "zz": m9(1), "zzz": m9(1)}, q) for q in pts]       # leaves: affine points as XYZZ
+    while len(level) > 1:
+        nxt = []
+        for (a, wa), (b, wb) in zip(level[0::2], level[1::2]):
+            c, wc = full_add(a, b), pasta.ec_add(wa, wb, p)
+            zz, zzz = _value(c["zz"]) % p, _value(c["zzz"]) % p
+            assert (_value(c["x"]) * pow(zz, -1, p) % p, _value(c["y"]) * pow(zzz, -1, p) % p) == wc
+            assert pow(zz, 3, p) == pow(zzz, 2, p)                  # the XYZZ invariant ZZ^3 = ZZZ^2
+            nxt.append((c, wc))
+        level = nxt
+    assert peak_all < 1 << 63
