@@ -437,7 +437,8 @@ def test_full_addition_limb_model_against_affine_addition(field):
             c, wc = full_add(a, b), pasta.ec_add(wa, wb, p)
             zz, zzz = _value(c["zz"]) % p, _value(c["zzz"]) % p
             assert (_value(c["x"]) * pow(zz, -1, p) % p, _value(c["y"]) * pow(zzz, -1, p) % p) == wc
-            assert pow(zz, 3, p) == pow(zzz, 2, p)                  # the XYZZ invariant ZZ^3 = ZZZ^2
+            rinv = pow(R9, -1, p)                                   # (limbs hold M9 forms: ZZ R and ZZZ R)
+            assert pow(zz * rinv, 3, p) == pow(zzz * rinv, 2, p)    # the XYZZ invariant ZZ^3 = ZZZ^2
             nxt.append((c, wc))
         level = nxt
     assert peak_all < 1 << 63
