@@ -442,3 +442,107 @@ def test_full_addition_limb_model_against_affine_addition(field):
             nxt.append((c, wc))
         level = nxt
     assert peak_all < 1 << 63
+
+
+# ---- two passes and the vector between them ----------------------------------------------------------------------------------------------
+def _unpack9(words):                                               # field9.cuh fe9_unpack: nine 29-bit fields of a 256-bit word
+    v = sum(w << (32 * i) for i, w in enumerate(words))
+    return [(v >> (29 * i)) & M29 for i in range(9)]
+
+
+def _pack9(limbs):                                                 # field9.cuh fe9_pack: shifts and ors of the 32-bit limb words
+    words = []
+    for w in range(8):
+        x = 0
+        for i in range(9):
+            lo = 29 * i - 32 * w
+            if -29 < lo < 32:
+                u = limbs[i] & 0xFFFFFFFF
+                x |= (u << lo) & 0xFFFFFFFF if lo >= 0 else u >> (-lo)
+        words.append(x)
+    return words
+
+
+@pytest.mark.parametrize("field", [0])
+def test_ntt_two_pass_limb_model_with_signed_intermediate(field):
+    """A 2^12-point transform as TWO passes of six stages, as ntt_run plans larger ones (2^20 = 10 + 10): the first pass ends in the fold and
+    ntt_pack_signed9 (the folded value, possibly NEGATIVE, as a 256-bit two's-complement word), the second starts from
+    ntt_unpack_signed9 (limb 8 by an arithmetic shift) and takes no carry pass in its first round.  Same checks as the one-pass model."""
+    p = P[field]
+    L, n, R = 12, 1 << 12, 6
+    rng = random.Random(0x2A55)
+    mul = _statement("field9_mul.inc")
+    omega = rng.randrange(2, p)
+    data = [rng.randrange(0, p) for _ in range(n)]
+    want = _reference_network(data, omega, L, p)
+    R9 = pow(2, 261, p)
+    plimbs = [(p >> (29 * i)) & M29 for i in range(8)] + [p >> 232]
+    tw_cache = {}
+
+    def tw(e):
+        if e not in tw_cache:
+            v = pow(omega, e, p) * R9 % p
+            tw_cache[e] = [(v >> (29 * i)) & M29 for i in range(8)] + [v >> 232]
+        return tw_cache[e]
+
+    def fmul(a, b):
+        r, _ = _run(mul, {"a": _i32(a), "b": b}, field)
+        return r
+
+    add = lambda x, y: [s + t for s, t in zip(x, y)]
+    sub = lambda x, y: [s - t for s, t in zip(x, y)]
+
+    def fold(v):
+        q = (v[8] + (1 << 21)) >> 22
+        assert -64 <= q <= 64
+        qp, c = [], 0
+        for i in range(8):
+            tq = q * plimbs[i] + c
+            qp.append(tq & M29)
+            c = tq >> 29
+        qp.append(q * plimbs[8] + c)
+        return _norm(_i32(sub(v, qp)))
+
+    rev = lambda k: int(format(k, f"0{L}b")[::-1], 2)
+    x = [_unpack9([(data[rev(k)] >> (32 * i)) & 0xFFFFFFFF for i in range(8)]) for k in range(n)]
+    negatives = 0
+    for s0 in (0, R):
+        for u in range(0, R, 2):
+            t = s0 + u
+            nxt = list(x)
+            for base in range(n):
+                if base & (3 << t):
+                    continue
+                low = base & ((1 << t) - 1)
+                i00, i01, i10, i11 = base, base + (1 << t), base + (2 << t), base + (3 << t)
+                from_memory = u == 0                               # a pass's first round: unpacked (normalised) inputs, no carry pass
+                e0, e1, e2, e3 = (x[i00], x[i01], x[i10], x[i11]) if from_memory else (_norm(x[i00]), x[i01], _norm(x[i10]), x[i11])
+                if t > 0:
+                    wA = tw(low << (L - t - 1))
+                    e1, e3 = fmul(e1, wA), fmul(e3, wA)
+                a0, a1 = add(e0, e1), sub(e0, e1)
+                a2 = _norm(add(e2, e3)) if t == 0 else fmul(add(e2, e3), tw(low << (L - t - 2)))
+                a3 = fmul(sub(e2, e3), tw((low + (1 << t)) << (L - t - 2)))
+                nxt[i00], nxt[i10] = _i32(add(a0, a2)), _i32(sub(a0, a2))
+                nxt[i01], nxt[i11] = _i32(add(a1, a3)), _i32(sub(a1, a3))
+            x = nxt
+        if s0 == 0:                                                # between the passes: fold, pack as two's complement, unpack with the sign
+            mid = []
+            for v in x:
+                f = fold(v)
+                negatives += f[8] < 0
+                words = _pack9(f)
+                back = _unpack9(words)
+                back[8] = _s32(words[7]) >> 8                      # ntt_unpack_signed9
+                assert back == f, (f, back)
+                mid.append(back)
+            x = mid
+    assert negatives > n // 8                                      # the signed path is really exercised
+    got = []
+    for v in x:
+        f = fold(v)
+        g = _norm([f[i] + (plimbs[i] if f[8] < 0 else 0) for i in range(9)])
+        val = _value(g)
+        assert 0 <= val < p
+        got.append(val)
+    assert got == want
