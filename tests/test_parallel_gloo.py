@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n=300):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from halo2_amd import parallel
@@ -27,10 +27,10 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    curve, n = 0, 300
+    curve = 0
     sf = co.field_of_curve(curve, "scalar")
-    scal = co.random_field(sf, 11, n)
-    bases = co.generate_bases(curve, 12, n)
+    scal = co.random_field(sf, 11, max(n, 1))[:n]
+    bases = co.generate_bases(curve, 12, max(n, 1))[:n]
 
     def msm(s, b):
         return co.best_multiexp(curve, np.ascontiguousarray(s), np.ascontiguousarray(b))
@@ -66,6 +66,27 @@ def test_split_msm_world2_gloo():
     assert all(r[1] for r in res)
     assert res[0][2] == [0, 2, 4, 6] and res[1][2] == [1, 3, 5]
     assert res[0][3] == (0, 150) and res[1][3] == (150, 300)
+
+
+@pytest.mark.parametrize("n", [301, 5])
+def test_split_msm_world8_gloo(n):
+    """the node's size: eight ranks, ragged ranges (301 = 5 x 38 + 3 x 37) and fewer points than ranks (three ranks contribute the
+    identity): the 96-byte all-gather and the local sum return the whole multiexp on every rank"""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
+    spans = [r[3] for r in res]
+    assert spans[0][0] == 0 and spans[-1][1] == n and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+    assert sorted(c for r in res for c in r[2]) == list(range(7))          # seven columns dealt round-robin over eight ranks
 
 
 def test_shard_range_covers_everything():
