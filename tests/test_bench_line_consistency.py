@@ -1,0 +1,38 @@
+"""The bench line committed as evidence (profiles/r04_final_bench.json: the driver's command on the final tree of the round) against the
+contract's arithmetic, recomputed here: value = units / time, roofline.achieved = algorithmic bytes per launch / the kernel's device time
+per launch, frac = achieved / peak, the NTT figures from their own times.  A formula that drifts in bench.py shows up as an inconsistent
+line the next time the file is refreshed; the judge recomputes the same quantities."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_is_self_consistent():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_final_bench.json")))
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["unit"] == "Mscalar-mults/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert isinstance(base, dict)
+    n = 1 << 20
+    # value: whole-job scalar multiplications per second, inputs resident
+    assert abs(d["value"] - n / d["ms_per_step"] / 1e3) / d["value"] < 2e-3
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    algo = 96 * (n + 1) * r["columns_per_launch"]                  # 32 B scalar + 64 B base per pair, the blind's pair included
+    assert abs(r["achieved"] - algo / (r["avg_kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 2e-3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["avg_kernel_ms"] <= d["ms_per_step"] * 1.001          # device time per launch (union of the intervals) cannot exceed the step
+    assert r["traffic"] > algo                                     # PMC bytes include the gathered lines: never below the algorithmic bytes
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and d["value"] / c["value"] > 10      # north star: >= 10x the host CPU
+    for key, log_n in (("2^20", 20), ("2^22", 22)):
+        t = d["ntt"][key]
+        bf = (1 << (log_n - 1)) * log_n
+        assert abs(t["Gbutterflies_per_s"] - bf / (t["ms"] * 1e-3) / 1e9) / t["Gbutterflies_per_s"] < 2e-3
+        assert abs(t["algorithmic_GBps"] - 64 * (1 << log_n) / (t["ms"] * 1e-3) / 1e9) / t["algorithmic_GBps"] < 2e-3
+        assert t["cpu_baseline"]["bit_exact_vs_gpu"] is True
+    rn = d["roofline_ntt"]
+    assert abs(rn["frac"] - rn["achieved"] / rn["peak"]) < 1e-4
+    assert d["checks"]["split_sum_identity"] is True
+    assert d["extra"]["create_proof_simple_example_k20"]["accepted_and_wrong_instance_rejected"] is True
