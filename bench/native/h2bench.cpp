@@ -115,6 +115,58 @@ static bool same_point(int curve, const uint64_t *a_xyz, const uint64_t *b_xyz) 
     return memcmp(x, y, 64) == 0;
 }
 
+// ---- shader clock and socket power while a region runs (amdgpu hwmon of the first GPU that has one: freq1_input in Hz, power1_input
+// in uW; sampled every ~2 ms from a thread -- what bench.py's `clock` object reads).  The sustained commit rate is a clock story.
+#include <glob.h>
+#include <atomic>
+#include <thread>
+struct ClockWatch {
+    std::string dir;
+    std::vector<double> f, p;
+    std::atomic<bool> stop{false};
+    std::thread th;
+    ClockWatch() {
+        // the hwmon node of the GPU HIP device 0 is (sysfs shows every card of the host, the process sees one): by PCI address
+        char bus[32] = {0};
+        if (hipDeviceGetPCIBusId(bus, sizeof bus, 0) != hipSuccess) return;
+        for (char *c = bus; *c; ++c) *c = (char)tolower(*c);
+        const std::string pat = std::string("/sys/bus/pci/devices/") + bus + "/hwmon/hwmon*/freq1_input";
+        glob_t g;
+        if (glob(pat.c_str(), 0, nullptr, &g) == 0 && g.gl_pathc) {
+            dir = g.gl_pathv[0];
+            dir.resize(dir.rfind('/'));
+        }
+        globfree(&g);
+    }
+    static double read1(const std::string &path) {
+        FILE *fh = fopen(path.c_str(), "r");
+        double v = 0;
+        if (fh) { if (fscanf(fh, "%lf", &v) != 1) v = 0; fclose(fh); }
+        return v;
+    }
+    void start() {
+        if (dir.empty()) return;
+        f.clear(); p.clear(); stop = false;
+        th = std::thread([this] {
+            while (!stop) {
+                f.push_back(read1(dir + "/freq1_input") / 1e6);
+                p.push_back(read1(dir + "/power1_input") / 1e6);
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+        });
+    }
+    std::string finish() {
+        if (dir.empty()) return "clock: no hwmon";
+        stop = true;
+        th.join();
+        if (f.empty()) return "clock: no samples";
+        std::sort(f.begin(), f.end()); std::sort(p.begin(), p.end());
+        char buf[160];
+        snprintf(buf, sizeof buf, "sclk %.0f MHz (%.0f..%.0f), %.0f W (%zu samples)", f[f.size() / 2], f.front(), f.back(), p[p.size() / 2], f.size());
+        return buf;
+    }
+};
+
 // ---- commit: the bench line's workload ------------------------------------------------------------------------------------------
 static void mode_commit(unsigned log_n, const std::vector<unsigned> &steps_list, int warmup, const std::vector<unsigned> &stream_list, int curve, int reps = 1) {
     const size_t n = (size_t)1 << log_n;
@@ -170,6 +222,7 @@ static void mode_commit(unsigned log_n, const std::vector<unsigned> &steps_list,
         for (unsigned steps : steps_list) {
             std::vector<double> per_step;
             double union_ms = 0, mean_ms = 0;
+            std::string clock_note;
             for (int rep = 0; rep < reps; ++rep) {
                 t0 = now_ms();
                 while (now_ms() - t0 < (first_region ? 400.0 : 150.0)) {
@@ -180,10 +233,13 @@ static void mode_commit(unsigned log_n, const std::vector<unsigned> &steps_list,
                 for (int i = 0; i < warmup; ++i) step(i);
                 HIPCK(hipDeviceSynchronize());
                 p_h2_profile_enable(2);
+                ClockWatch cw;
+                if (rep == reps - 1 && steps >= 200) cw.start();            // long regions only: a 20 ms region is ten samples
                 t0 = now_ms();
                 for (unsigned i = 0; i < steps; ++i) step((int)i);
                 HIPCK(hipDeviceSynchronize());
                 const double ms = now_ms() - t0;
+                if (rep == reps - 1 && steps >= 200) clock_note = cw.finish();
                 double tot = 0, busy = 0;
                 uint64_t cnt = 0;
                 p_h2_profile_read_busy(H2_PROF_MSM_ACCUMULATE, &tot, &busy, &cnt);
@@ -196,6 +252,7 @@ static void mode_commit(unsigned log_n, const std::vector<unsigned> &steps_list,
             const double med = per_step[per_step.size() / 2];
             printf("commit 2^%u x %u steps over %d streams: %.4f ms per step = %.1f M scalar-mults/s   (median of %d regions, %.4f .. %.4f; accumulate of the last: union %.4f ms per launch, mean %.4f)\n",
                    log_n, steps, nstreams, med, n / med / 1e3, reps, per_step.front(), per_step.back(), union_ms, mean_ms);
+            if (!clock_note.empty()) printf("    under that load: %s\n", clock_note.c_str());
         }
     }
     // one commit at a time on one stream
@@ -269,6 +326,19 @@ static void mode_ntt(const std::vector<unsigned> &sizes, int field, bool check) 
         }
         const double bf = (double)(n / 2) * L;
         printf("ntt 2^%u: %.4f ms  %.1f G butterflies/s\n", L, best, bf / best / 1e6);
+        if (getenv("H2BENCH_CLOCK") && L >= 18) {      // shader clock / socket power with transforms back to back for ~0.4 s
+            ClockWatch cw;
+            cw.start();
+            const double tc = now_ms();
+            int done = 0;
+            while (now_ms() - tc < 400.0) {
+                for (int i = 0; i < 50; ++i) CHECK_RC(p_h2_ntt_device(field, d, L, omega.data(), H2_FORM_MONTGOMERY, nullptr));
+                HIPCK(hipDeviceSynchronize());
+                done += 50;
+            }
+            const double per = (now_ms() - tc) / done;
+            printf("    back to back for 0.4 s: %.4f ms per transform; %s\n", per, cw.finish().c_str());
+        }
         (void)hipFree(d);
     }
 }

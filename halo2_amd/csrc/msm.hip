@@ -1216,6 +1216,13 @@ __device__ __forceinline__ u32 load_u32_waited(const u32 *p) {
     return v;
 }
 
+// A/B only (profiles/r05_acc_power_vs_traffic.txt): -DH2_ACC_GATHER_MASK=0x3FFF folds every table index of the registered path's
+// accumulate into the table's first 16384 points (1 MiB: resident in every XCD's L2) -- the same instruction stream with ~no HBM
+// traffic, WRONG results (the native driver's parity line fails by design): does the 2.4 GB per launch of half-used gather lines
+// cost shader clock under the socket's power limit?
+#ifndef H2_ACC_GATHER_MASK
+#define H2_ACC_GATHER_MASK 0x7FFFFFFFu
+#endif
 template <int FB, bool GLV, bool M9 = false>
 __global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
                                                       u32 extra_index, const u32 *__restrict__ entries,
@@ -1252,7 +1259,7 @@ __global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(
             u32 t2_last = starts[b + 2];                 // starts[total_buckets + 1] is a sentinel (msm_scan_apply)
             bool first = true, pending = false, t2_ok = true;
             u32 e0 = entries[lo], e1 = entries[min(lo + 1, hi - 1)];
-            affine<FB> nxt = aff_gather<FB>(bases + 16 * (size_t)(e0 & 0x7FFFFFFFu));
+            affine<FB> nxt = aff_gather<FB>(bases + 16 * (size_t)(e0 & H2_ACC_GATHER_MASK));
             for (u32 i = lo; i < hi; ++i) {
                 // everything issued during the previous iteration -- the gather of this point, entry i + 1, the boundary read, a
                 // flush's stores -- has had a whole mixed addition to complete: this wait is free
@@ -1279,7 +1286,7 @@ __global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(
 #endif
                 const u32 neg = e0 >> 31;
                 const u32 e2 = entries[min(i + 2, hi - 1)];
-                nxt = aff_gather<FB>(bases + 16 * (size_t)(e1 & 0x7FFFFFFFu));      // at the tail: a stale, valid entry
+                nxt = aff_gather<FB>(bases + 16 * (size_t)(e1 & H2_ACC_GATHER_MASK));      // at the tail: a stale, valid entry
                 const u32 t2_cur = starts[b + 2];
                 e0 = e1;
                 e1 = e2;

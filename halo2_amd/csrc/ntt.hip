@@ -355,18 +355,23 @@ __device__ __forceinline__ fe9 ntt_fold9(const fe9 &v, const i32 *qp) {
     r.v[8] = v.v[8] - z;
     return fe9_norm(r);
 }
-// canonical packed value of a FOLDED element: |value| < 2^253 + 2^132 (ntt_fold9), so value + p lies in (0, 2p) and ONE conditional
-// subtraction is exact (fe9_canonical_small covers (-p, 2p) with two)
-// v is NORMALISED (ntt_fold9 ends in a carry pass), so its sign is the sign of limb 8 (limbs 0..7 are non-negative and
-// below 2^29, i.e. the low part lies in [0, 2^232)): add p exactly when it is negative -- ONE carry pass, no trial subtraction
-// (round 3 added p, carried, subtracted p again, carried again and selected: 135 instructions per element; this is ~70).
+// canonical packed value of a FOLDED element: |value| < 2^253 + 2^132 (ntt_fold9) and v is NORMALISED (the fold ends in a carry
+// pass), so fe9_pack's shifts and ors make the 256-bit TWO'S COMPLEMENT word of the value and its sign is bit 255: add p exactly
+// when that bit is set, as one 8-word carry chain on the packed words (p = 2^254 + t has five non-zero words: ~14 instructions).
+// Round 3 added p, carried, subtracted p again, carried again and selected (135 instructions per element); round 4 selected on
+// limb 8's sign and spent one more 24-instruction carry pass on the limbs before packing (~70); this is ~45.
 template <int F> __device__ __forceinline__ fe ntt_canonical_folded9(const fe9 &v) {
-    const fe9 pk = fe9_p_shl<F>(0);
-    const i32 neg = v.v[8] >> 31;                 // all ones iff value < 0
-    fe9 t;
+    const fe w = fe9_pack(v);
+    const u32 neg = (u32)((i32)w.v[7] >> 31);     // all ones iff value < 0
+    fe r;
+    u32 c = 0;
 #pragma unroll
-    for (int i = 0; i < 9; i++) t.v[i] = v.v[i] + (pk.v[i] & neg);      // (p has six non-zero limbs: the others fold away)
-    return fe9_pack(fe9_norm(t));                 // value in [0, p)
+    for (int i = 0; i < 8; i++) {
+        u32 co;
+        r.v[i] = __builtin_addc(w.v[i], mod_limb<F>(i) & neg, c, &co);
+        c = co;
+    }
+    return r;                                     // value in [0, p)
 }
 // What leaves a pass that is not the last: the folded value as a 256-bit TWO'S COMPLEMENT word (|value| < 2^253.1 fits with room
 // to spare; fe9_pack's shifts and ors are already that for a negative limb 8), read back by ntt_unpack_signed9 with an arithmetic
@@ -414,10 +419,14 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
         hi_idx = tile_id / tiles_per_hi;
         lo0 = (size_t)(tile_id % tiles_per_hi) << logT;
     }
-    // With an even number of stages the first radix-4 round takes its four elements straight from global memory and the last
-    // one stores straight to it: no load-all / barrier / store-all phases, a wave starts multiplying as soon as ITS loads are
-    // back, and two of the LDS round trips disappear.  (An odd stage count ends in a radix-2 round and keeps the store loop.)
-    constexpr bool FUSE_LOAD = R >= 2, FUSE_STORE = R >= 2 && (R % 2 == 0);
+    // The first round takes its four elements straight from global memory and the last one stores straight to it: no load-all /
+    // barrier / store-all phases, a wave starts multiplying as soon as ITS loads are back, and two of the LDS round trips
+    // disappear.  An ODD stage count (round 5: 11- and 12-stage passes make 2^21 .. 2^24 two-pass transforms) opens with a
+    // radix-2 round on the same four elements per lane -- the first HALF of a radix-4 round: both pairs (rows 4q, 4q + 1 and
+    // 4q + 2, 4q + 3) share the stage's twiddle -- and continues with radix-4 rounds from stage 1; the transform's very first
+    // stage multiplies by omega^0 only, so there that round is four loads, four additions and four LDS writes.
+    constexpr bool FUSE_LOAD = R >= 2, FUSE_STORE = R >= 2;
+    constexpr int U0 = (R >= 3 && (R & 1)) ? 1 : 0;      // first stage of the radix-4 rounds
     const u32 ngrp = tile >> 2;
     // the element that sits in LDS row `row` (after the first pass's bit reversal), column `col`
     auto load_elem = [&](u32 row, u32 col, const fe9 &lk0, const fe9 &lk1) -> fe9 {
@@ -502,8 +511,31 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
     fe9 wA = fe9_zero();
     if (R >= 2 && tid < ngrp && !FIRST) wA = tw_get(0, 0);
     __syncthreads();                                   // the q p table (and, unfused, the tile) is in LDS
+    if (U0) {                                          // odd stage count: stage 0 as a radix-2 round on four elements per lane
+        if (tid < ngrp) {
+            const fe9 nA = tw_get(1, 0);
+            u32 q, col;
+            lane_of(0, q, col);
+            const u32 mid00 = q << 2, s00 = (mid00 << logT) + col;
+            fe9 lk0, lk1;
+            load_factors(lk0, lk1);
+            const fe9 e0 = load_elem(mid00, col, lk0, lk1), e2 = load_elem(mid00 + 2, col, lk0, lk1);
+            fe9 e1 = load_elem(mid00 + 1, col, lk0, lk1), e3 = load_elem(mid00 + 3, col, lk0, lk1);
+            if (!FIRST) {
+                e1 = fe9_mul<F>(e1, wA);
+                e3 = fe9_mul<F>(e3, wA);
+            }
+            // unpacked element (limbs in [0, 2^29), limb 8 small) +- product or unpacked element: RAW
+            lds9_put(S, s00, fe9_add(e0, e1));
+            lds9_put(S, s00 + T, fe9_sub(e0, e1));
+            lds9_put(S, s00 + 2 * T, fe9_add(e2, e3));
+            lds9_put(S, s00 + 3 * T, fe9_sub(e2, e3));
+            wA = nA;
+        }
+        __syncthreads();
+    }
 #pragma unroll
-    for (int u = 0; u + 1 < R; u += 2) {
+    for (int u = U0; u + 1 < R; u += 2) {
         if (tid < ngrp) {
             const fe9 wB0 = (FIRST && u == 0) ? fe9_zero() : tw_get(u, 1), wB1 = tw_get(u, 2);
             fe9 nA = fe9_zero();
@@ -514,7 +546,7 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
             const u32 mid00 = ((q >> u) << (u + 2)) | low;
             const u32 s00 = (mid00 << logT) + col, s01 = s00 + (T << u), s10 = s00 + (T << (u + 1)), s11 = s10 + (T << u);
             fe9 e0, e1, e2, e3;
-            if (FUSE_LOAD && u == 0) {
+            if (FUSE_LOAD && u == 0) {                 // (even stage counts: an odd one has its elements in LDS by now)
                 fe9 lk0, lk1;
                 load_factors(lk0, lk1);
                 e0 = load_elem(mid00, col, lk0, lk1);
@@ -553,7 +585,7 @@ __global__ void __launch_bounds__(1024) ntt_pass9(const u32 *__restrict__ in, u3
         }
         if (!(FUSE_STORE && u == R - 2)) __syncthreads();
     }
-    if (R & 1) {
+    if (R == 1) {                                      // a lone stage (the tail of a plan whose stage count does not split evenly)
         constexpr int u = R - 1;
         const int t = s0 + u;
         const u32 nbf = tile >> 1;
@@ -778,6 +810,8 @@ static int launch_pass_r(const PassArgs &A, unsigned tiles, u32 threads, size_t 
         case 8: return launch_pass_t<F, 8, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
         case 9: return launch_pass_t<F, 9, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
         case 10: return launch_pass_t<F, 10, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
+        case 11: return launch_pass_t<F, 11, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
+        case 12: return launch_pass_t<F, 12, FIRST>(A, tiles, threads, lds, st, src, dst, tw);
     }
     return H2_ERR_ARGS;
 }
@@ -840,10 +874,17 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
     // Plan 1 (the batch entry points: independent column transforms on internal streams): at most 8 stages and 64 KiB, so
     // workgroups of several transforms share a CU and one column's load / store phases hide under another's butterflies
     // (0.105 ms per 2^20 transform over 3 streams, against 0.131 with plan 0).  H2_NTT_MAXR / _LOGT / _LDS: sweeps only.
-    static const int env_maxr = [] { const char *e = getenv("H2_NTT_MAXR"); int v = e ? atoi(e) : 10; return v >= 1 && v <= 10 ? v : 10; }();
+    // Round 5: 11- and 12-stage passes exist (2048 rows x 2 columns / 4096 rows x 1 column of nine-limb elements = 147 KiB, 1024
+    // lanes; odd stage counts open with a radix-2 round), so 2^21 .. 2^24 CAN run as two passes -- and measured on the same box
+    // (profiles/r05_ntt_two_pass_ab.txt) that is SLOWER: 2^22 as 11 + 11 0.398 ms against 0.342 as 8 + 8 + 6, 2^24 as 12 + 12 2.09
+    // against 1.45.  The passes are issue-bound, not byte-bound: two passes carry ~10 800 instructions per lane-quadruple against
+    // ~11 170 for three (3 % fewer), while their 64- / 32-byte rows and one-workgroup-per-CU tiles lose more than that to the
+    // memory phases no second workgroup covers.  The default stays at 10 stages; H2_NTT_MAXR=11 / 12 reproduces the A/B.
+    static const int env_maxr = [] { const char *e = getenv("H2_NTT_MAXR"); int v = e ? atoi(e) : 0; return v >= 1 && v <= 12 ? v : 0; }();
     static const int want_logT = [] { const char *e = getenv("H2_NTT_LOGT"); int v = e ? atoi(e) : 3; return v >= 0 && v <= 5 ? v : 3; }();
     static const u32 env_lds = [] { const char *e = getenv("H2_NTT_LDS"); int v = e ? atoi(e) : 131072; return (u32)(v >= 32768 && v <= 131072 ? v : 131072); }();
-    const int maxr = J.plan == 1 ? std::min(env_maxr, 8) : env_maxr;
+    const int dflt_maxr = env_maxr ? env_maxr : 10;
+    const int maxr = J.plan == 1 ? std::min(dflt_maxr, 8) : dflt_maxr;
     const u32 lds_cap = J.plan == 1 ? std::min<u32>(env_lds, 65536u) : env_lds;
     const int P = (L + maxr - 1) / maxr;
     int stages[40];
