@@ -7,7 +7,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-H2_OK, H2_ERR_ARGS, H2_ERR_HIP, H2_ERR_NODEV, H2_ERR_HANDLE, H2_ERR_DECODE, H2_ERR_LOOKUP = 0, 1, 2, 3, 4, 5, 6
+H2_OK, H2_ERR_ARGS, H2_ERR_HIP, H2_ERR_NODEV, H2_ERR_HANDLE, H2_ERR_DECODE, H2_ERR_LOOKUP, H2_ERR_PEER = 0, 1, 2, 3, 4, 5, 6, 7
 FP, FQ = 0, 1
 PALLAS, VESTA = 0, 1
 FORM_CANONICAL, FORM_MONTGOMERY = 0, 1
@@ -182,5 +182,5 @@ def check(rc: int, what: str):
     if rc == H2_ERR_DECODE:
         raise ValueError(f"{what}: invalid point encoding")      # the reference returns io::Error (commitment.rs:193-198)
     msg = lib().h2_last_error().decode()
-    names = {H2_ERR_HIP: "HIP failure", H2_ERR_NODEV: "no MI355X device", H2_ERR_HANDLE: "bad handle"}
+    names = {H2_ERR_HIP: "HIP failure", H2_ERR_NODEV: "no MI355X device", H2_ERR_HANDLE: "bad handle", H2_ERR_PEER: "another rank failed"}
     raise H2Error(f"{what}: {names.get(rc, rc)}: {msg}")

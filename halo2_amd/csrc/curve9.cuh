@@ -108,7 +108,9 @@ template <int F> __device__ __noinline__ bool xyzz9_madd_rare(fe9 p, fe9 r, aff9
 // ors of the first, per addition.
 template <int F, bool HOT = false> __device__ __forceinline__ void xyzz9_madd(xyzz9<F> &acc, const aff9<F> &q) {
     if (!HOT && aff9_is_identity(q)) return;
-    if (HOT ? acc.zz.v[0] == 0 : xyzz9_is_identity(acc)) {
+    // (the one-limb test leans on the GENERATED multiplier's limb 0 in [1, 2^29]; the plain-C multiplier of the -DH2_FE9_IMPL=0 A/B
+    // build returns limb 0 = acc & M29, zero once in 2^29 products: that build takes the full test)
+    if ((HOT && H2_FE9_IMPL != 0) ? acc.zz.v[0] == 0 : xyzz9_is_identity(acc)) {
         acc.x = q.x;
         acc.y = q.y;
         acc.zz = fe9_one_here<F>();      // (as plain constants hipcc hoists their 12 v_mov to the top of the accumulation loop: every

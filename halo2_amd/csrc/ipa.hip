@@ -675,6 +675,14 @@ extern "C" int h2_ipa_rounds_device(int curve, unsigned k, unsigned switch_round
     rc = ipa_rounds_impl(curve, kj, kj, hj, pair2 ? 1 : 0, d_p, d_b, z, rands + 8 * J, col_l, col_r, write_point, squeeze, user, nullptr,
                          c_out, f_acc, stream);
     if (rc == H2_OK) memcpy(f_out, f_acc, 32);
+    // Retention: the table (16 rows x (nj + tail) x 64 B) stays with this (device, stream) context for the next argument of the same
+    // shape -- up to 2^17 points (128 MiB); beyond that, and with H2_IPA_KEEP_TABLE=0 (the A/B arm: register / free per argument), it
+    // goes back at the END of the call.  h2_trim releases what is kept.  (ipa_rounds_impl synchronised the stream before returning
+    // c and f to the host, so nothing is reading the table any more.)
+    if (!keep_table || nj + tail > ((size_t)1 << 17) + 4) {
+        (void)h2_bases_free(cx.gp_handle);
+        cx.gp_handle = 0;
+    }
     return rc;
 }
 

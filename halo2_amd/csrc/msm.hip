@@ -2206,6 +2206,10 @@ struct MsmContext {
         for (DevBuf *b : {&digits, &hist, &counts, &starts, &bsums, &entries, &heads, &heavy, &hscratch, &buckets, &partial, &ssums,
                           &stage_s, &stage_b, &out, &small, &tagged, &tagged_low, &plan, &seg9, &bases9, &collapse, &collapse_list, &fold_ctr})
             b->release();
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);      // (h2_trim: the device is idle)
+        if (copy_done) (void)hipEventDestroy(copy_done);
+        copy_stream = nullptr;
+        copy_done = nullptr;
     }
     bool attr_set = false, attr2_set = false, attr_bins_set = false;
     hipStream_t copy_stream = nullptr;      // h2_msm: the bases cross PCIe on this one while the sort runs (null-stream context only)
@@ -2535,7 +2539,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     const u32 max_big = all_items >= ((size_t)3 << 20) ? kMaxBig : 0u;
     if (!fold_only) {
     TL_STAMP(tl_id | 1);
-    prof_begin(PROF_MSM_SORT, st);
+    if (a.phase != 2) prof_begin(PROF_MSM_SORT, st);          // (phase 2 resumes behind a sort the phase-1 call enqueued and timed)
     const u32 extra_col = a.d_extra_scalar ? (a.table ? a.extra_col : (u32)a.n_used) : 0xFFFFFFFFu;
     if (a.phase == 2) {
         // the sort was enqueued by the phase-1 call
@@ -2679,7 +2683,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         H2_HIP(hipMemsetAsync(cx.buckets.ptr, 0, (size_t)tb * 128, st));
     }
     if (!use_sort2) H2_HIP(hipMemsetAsync(cx.heavy.ptr, 0, 8, st));          // (the two-pass sort's msm_s1_prefix zeroed it)
-    prof_end(PROF_MSM_SORT, st);
+    if (a.phase != 2) prof_end(PROF_MSM_SORT, st);
     TL_STAMP(tl_id | 2);
     prof_begin(PROF_MSM_ACCUMULATE, st);
     if (glv && !m9)

@@ -28,6 +28,8 @@
 
 #include "common.h"
 
+typedef uint32_t u32;
+
 namespace h2 {
 namespace {
 
@@ -168,7 +170,15 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 0;
-    void *d_buf = nullptr;     // [world + 1] Jacobian points (12 limbs each): slot `world` = this rank's partial
+    // exchange buffer: [world + 1] slots of kSlot bytes -- a Jacobian point (96 B) and a STATUS word behind it (0 = this rank's partial is
+    // good); slot `world` = this rank's payload.  Behind the slots: [world] packed points (96 B each) for the sum, then one word that
+    // counts the failed ranks.  A rank whose local work failed still enters the all-gather (its peers would wait for ever) with its
+    // status set, and EVERY rank then returns an error: a peer's HIP error must not become a plausible-looking wrong commitment.
+    static constexpr size_t kSlot = 128;
+    void *d_buf = nullptr;
+    u32 *h_failed = nullptr;   // pinned: the failed-rank count read back after the exchange
+    size_t packed_off() const { return (size_t)(world + 1) * kSlot; }
+    size_t failed_off() const { return packed_off() + (size_t)world * 96; }
     int load() {
         if (lib) return H2_OK;
         const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
@@ -229,7 +239,8 @@ extern "C" int h2_rccl_init(const uint8_t id[128], int rank, int world) {
     }
     g_rccl.rank = rank;
     g_rccl.world = world;
-    H2_HIP(hipMalloc(&g_rccl.d_buf, (size_t)(world + 1) * 96));
+    H2_HIP(hipMalloc(&g_rccl.d_buf, g_rccl.failed_off() + 16));
+    H2_HIP(hipHostMalloc((void **)&g_rccl.h_failed, 16, hipHostMallocDefault));
     return H2_OK;
 }
 
@@ -241,32 +252,73 @@ extern "C" int h2_rccl_finalize(void) {
         g_rccl.comm = nullptr;
         if (g_rccl.d_buf) (void)hipFree(g_rccl.d_buf);
         g_rccl.d_buf = nullptr;
+        if (g_rccl.h_failed) (void)hipHostFree(g_rccl.h_failed);
+        g_rccl.h_failed = nullptr;
     }
     return H2_OK;
 }
 
+// after the all-gather: slot r (kSlot bytes: point + status) -> packed point r, and the number of ranks whose status is set
+__global__ void rccl_unpack_slots(const u32 *__restrict__ slots, u32 *__restrict__ packed, u32 *__restrict__ failed, int world, u32 slot_words) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        u32 bad = 0;
+        for (int r = 0; r < world; ++r) bad += slots[(size_t)r * slot_words + 24] != 0u;
+        *failed = bad;
+    }
+    for (u32 i = threadIdx.x; i < (u32)world * 24u; i += blockDim.x) packed[i] = slots[(size_t)(i / 24u) * slot_words + i % 24u];
+}
+namespace {
+// `mine` (slot `world`) holds this rank's partial, written by work enqueued on `st` that returned local_rc.  Sets the status word,
+// all-gathers the slots, unpacks, reads the failed-rank count back (ONE stream synchronisation: the price of never returning a
+// wrong point) and adds the partials.  Every rank returns an error when any rank failed.
+int rccl_exchange_and_sum(int curve, int local_rc, int form, int out_kind, void *d_out, hipStream_t st, const char *what) {
+    Rccl &R = g_rccl;
+    char *buf = (char *)R.d_buf, *mine = buf + (size_t)R.world * Rccl::kSlot;
+    const u32 status = local_rc == H2_OK ? 0u : 1u;
+    if (status) (void)hipMemsetAsync(mine, 0, 96, st);
+    hipError_t he = hipMemcpyAsync(mine + 96, &status, 4, hipMemcpyHostToDevice, st);        // (pageable source: staged before the call returns)
+    int e = R.AllGather(mine, buf, Rccl::kSlot, /*ncclChar*/ 0, R.comm, st);
+    if (local_rc != H2_OK) return local_rc;                 // the peers learn of it from the status word
+    if (he != hipSuccess) { set_last_hip_error(he, __FILE__, __LINE__); return H2_ERR_HIP; }
+    if (e) return R.fail(e, "ncclAllGather");
+    u32 *packed = (u32 *)(buf + R.packed_off()), *failed = (u32 *)(buf + R.failed_off());
+    hipLaunchKernelGGL(rccl_unpack_slots, dim3(1), dim3(256), 0, st, (const u32 *)buf, packed, failed, R.world, (u32)(Rccl::kSlot / 4));
+    H2_HIP(hipGetLastError());
+    H2_HIP(hipMemcpyAsync(R.h_failed, failed, 4, hipMemcpyDeviceToHost, st));
+    H2_HIP(hipStreamSynchronize(st));
+    if (*R.h_failed) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "%s: %u of %d ranks failed their range; no result (a partial sum would be a wrong point)", what, *R.h_failed, R.world);
+        set_last_error_msg(msg);
+        return H2_ERR_PEER;
+    }
+    return h2_points_sum_device(curve, packed, (size_t)R.world, form, out_kind, d_out, st);
+}
+}  // namespace
+
 // Every rank passes the WHOLE problem's device arrays (or at least its own range at the right offsets): rank r multiplies
-// points [n r / world, n (r + 1) / world), the partials are all-gathered (96 B per rank), and every rank writes the total.
+// points [n r / world, n (r + 1) / world), the partials are all-gathered (a 128-byte slot per rank: 96-byte point + status), and
+// every rank writes the total.
 extern "C" int h2_msm_split_rccl_device(int curve, const void *d_scalars, const void *d_bases_xy, size_t n, int form, int out_kind,
                                         void *d_out, void *stream) {
     if ((curve != H2_PALLAS && curve != H2_VESTA) || !d_out || (n && (!d_scalars || !d_bases_xy))) return H2_ERR_ARGS;
+    if ((form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY) || (out_kind != H2_OUT_JACOBIAN && out_kind != H2_OUT_AFFINE)) return H2_ERR_ARGS;
     std::lock_guard<std::mutex> lk(g_rccl.mu);
     if (!g_rccl.comm) return H2_ERR_HANDLE;
     hipStream_t st = (hipStream_t)stream;
     const int world = g_rccl.world, rank = g_rccl.rank;
     const size_t lo = n * (size_t)rank / (size_t)world, hi = n * (size_t)(rank + 1) / (size_t)world;
-    char *buf = (char *)g_rccl.d_buf, *mine = buf + (size_t)world * 96;
+    char *mine = (char *)g_rccl.d_buf + (size_t)world * Rccl::kSlot;
     // partial in Montgomery Jacobian form whatever the caller's form is: the sum kernel below reads Montgomery limbs
-    int rc = h2_msm_device(curve, (const char *)d_scalars + 32 * lo, (const char *)d_bases_xy + 64 * lo, hi - lo, form, H2_OUT_JACOBIAN, mine, st);
-    if (rc != H2_OK) return rc;
-    int e = g_rccl.AllGather(mine, buf, 96, /*ncclChar*/ 0, g_rccl.comm, st);
-    if (e) return g_rccl.fail(e, "ncclAllGather");
-    return h2_points_sum_device(curve, buf, (size_t)world, form, out_kind, d_out, st);
+    const int rc = h2_msm_device(curve, (const char *)d_scalars + 32 * lo, (const char *)d_bases_xy + 64 * lo, hi - lo, form, H2_OUT_JACOBIAN, mine, st);
+    // (argument errors above are rank-independent: every rank returns before the exchange; from here on a failure is rank-LOCAL and
+    // the rank still takes part)
+    return rccl_exchange_and_sum(curve, rc, form, out_kind, d_out, st, "h2_msm_split_rccl_device");
 }
 
 // The same exchange for a commit over REGISTERED bases (Params::commit, an opening-argument round): every rank holds the table
 // (h2_bases_register on its GPU) and the column; rank r commits table columns [n r / world, n (r + 1) / world) -- no doubling
-// chain, no per-call base traffic -- the last rank carries the blind term, then ONE 96-byte all-gather and the local sum.
+// chain, no per-call base traffic -- the last rank carries the blind term, then ONE all-gather and the local sum.
 extern "C" int h2_commit_split_rccl_device(h2_bases_t g, const void *d_scalars, size_t n, const void *d_blind, int form, int out_kind,
                                            void *d_out, void *stream) {
     if (!d_out || (n && !d_scalars)) return H2_ERR_ARGS;
@@ -287,15 +339,15 @@ extern "C" int h2_commit_split_rccl_device(h2_bases_t g, const void *d_scalars, 
     hipStream_t st = (hipStream_t)stream;
     const int world = g_rccl.world, rank = g_rccl.rank;
     const size_t lo = n * (size_t)rank / (size_t)world, hi = n * (size_t)(rank + 1) / (size_t)world;
-    char *buf = (char *)g_rccl.d_buf, *mine = buf + (size_t)world * 96;
+    char *mine = (char *)g_rccl.d_buf + (size_t)world * Rccl::kSlot;
     rc = h2_commit_range_device(g, (const char *)d_scalars + 32 * lo, lo, hi - lo, rank == world - 1 ? d_blind : nullptr, form, H2_OUT_JACOBIAN,
                                 mine, st);
-    // a rank-LOCAL failure (a HIP error, an allocation) still takes part in the exchange, with the identity as its partial (Z = 0),
-    // so that the peers leave the collective; it then reports its own status
-    const int local_rc = rc;
-    if (local_rc != H2_OK) (void)hipMemsetAsync(mine, 0, 96, st);
-    int e = g_rccl.AllGather(mine, buf, 96, /*ncclChar*/ 0, g_rccl.comm, st);
-    if (local_rc != H2_OK) return local_rc;
-    if (e) return g_rccl.fail(e, "ncclAllGather");
-    return h2_points_sum_device(curve, buf, (size_t)world, form, out_kind, d_out, st);
+    // fault injection for the tests (H2_TEST_FAIL_RANK=r: rank r reports a local failure after its range commit): every rank must
+    // come back with an error and nobody may hang
+    static const int fail_rank = [] { const char *e = getenv("H2_TEST_FAIL_RANK"); return e ? atoi(e) : -1; }();
+    if (rc == H2_OK && fail_rank == rank) {
+        set_last_error_msg("H2_TEST_FAIL_RANK: injected local failure");
+        rc = H2_ERR_HIP;
+    }
+    return rccl_exchange_and_sum(curve, rc, form, out_kind, d_out, st, "h2_commit_split_rccl_device");
 }

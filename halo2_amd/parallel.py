@@ -27,30 +27,57 @@ def columns_for_rank(num_columns: int, rank: int, world: int) -> list[int]:
     return list(range(rank, num_columns, world))
 
 
-def allgather_points(local_xyz: np.ndarray, device=None) -> np.ndarray:
-    """All-gather one Jacobian point (12 uint64 limbs) per rank -> (world, 12)."""
+class PeerFailure(RuntimeError):
+    """A rank of a split multiexp / commit failed: EVERY rank raises (the failing rank its own error, the others this one)
+    instead of summing the partials that did arrive into a plausible-looking wrong point."""
+
+
+def allgather_points(local_xyz: np.ndarray, device=None, status: int = 0):
+    """All-gather one Jacobian point (12 uint64 limbs) per rank -> (world, 12).  The payload carries a status word behind the
+    point (13 words per rank): a rank whose local work failed still enters the collective -- its peers would wait for it forever
+    otherwise -- with status != 0, and the caller on every rank sees which ranks failed.  Returns (points (world, 12), statuses
+    (world,))."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
-    t = torch.from_numpy(np.ascontiguousarray(local_xyz, dtype=np.uint64).view(np.int64).reshape(12).copy())
+    payload = np.zeros(13, dtype=np.uint64)
+    if local_xyz is not None:
+        payload[:12] = np.ascontiguousarray(local_xyz, dtype=np.uint64).reshape(12)
+    payload[12] = np.uint64(status & 0xFFFFFFFF)
+    t = torch.from_numpy(payload.view(np.int64).copy())
     if device is not None:
         t = t.to(device)
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t)
-    return np.stack([o.cpu().numpy().view(np.uint64) for o in out])
+    got = np.stack([o.cpu().numpy().view(np.uint64) for o in out])
+    return np.ascontiguousarray(got[:, :12]), got[:, 12].astype(np.int64)
+
+
+def _raise_if_any_failed(statuses, what: str, local_exc=None):
+    bad = [int(r) for r in np.nonzero(np.asarray(statuses))[0]]
+    if local_exc is not None:
+        raise local_exc
+    if bad:
+        raise PeerFailure("%s: rank(s) %s failed; no result (a partial sum would be a wrong point)" % (what, bad))
 
 
 def split_msm(scalars: np.ndarray, bases: np.ndarray, curve: int, rank: int, world: int, device=None,
               msm=None, points_sum=None) -> np.ndarray:
     """One MSM split by point range across ranks.  `msm` / `points_sum` default to the HIP path; the CPU
-    (gloo) tests inject the oracle so the sharding logic is covered without a GPU."""
+    (gloo) tests inject the oracle so the sharding logic is covered without a GPU.  A rank whose multiexp raises still joins the
+    all-gather (status word set) and every rank raises: nobody hangs, nobody returns a sum with a range missing."""
     if msm is None or points_sum is None:
         from . import arithmetic
         msm = msm or (lambda s, b: arithmetic.best_multiexp(s, b, curve))
         points_sum = points_sum or (lambda pts: arithmetic.points_sum(pts, curve))
     lo, hi = shard_range(scalars.shape[0], rank, world)
-    partial = msm(scalars[lo:hi], bases[lo:hi])
-    gathered = allgather_points(np.asarray(partial), device=device)
+    partial, exc = None, None
+    try:
+        partial = np.asarray(msm(scalars[lo:hi], bases[lo:hi]))
+    except Exception as e:                          # noqa: BLE001 -- reported after the exchange, on every rank
+        exc = e
+    gathered, statuses = allgather_points(partial, device=device, status=0 if exc is None else 1)
+    _raise_if_any_failed(statuses, "split_msm", exc)
     return points_sum(gathered)
 
 
@@ -171,23 +198,30 @@ def split_commit(handle, d_scalars, rank: int, world: int, d_blind=None):
     # its failure alone would leave the others waiting in the collective
     if d_blind is not None and lib().h2_bases_blind_base_set(hv) != 1:
         raise ValueError("split_commit: a blind scalar but the handle has no blind base (h2_bases_set_blind_base on every rank)")
-    # a rank-LOCAL failure still takes part in the exchange (with the identity), then raises
+    # a rank-LOCAL failure still takes part in the exchange -- with its status word set (word 12 of the payload), so that EVERY rank
+    # raises instead of adding up the partials that did arrive
     local_rc = lib().h2_commit_range_device(hv, d_scalars[lo:].data_ptr() if hi > lo else None, lo, hi - lo,
                                             d_blind.data_ptr() if (d_blind is not None and rank == world - 1) else None, FORM_MONTGOMERY,
                                             OUT_JACOBIAN, mine.data_ptr(), _stream_ptr())
-    if local_rc != 0:
-        mine.zero_()
-    gathered = torch.empty((world, 12), dtype=torch.int64, device=dev)
+    payload = torch.zeros(13, dtype=torch.int64, device=dev)
+    if local_rc == 0:
+        payload[:12].copy_(mine)
+    else:
+        payload[12] = 1
+    gathered13 = torch.empty((world, 13), dtype=torch.int64, device=dev)
     if world > 1:
         if dist.get_backend() == "nccl":
-            dist.all_gather_into_tensor(gathered, mine)
+            dist.all_gather_into_tensor(gathered13, payload)
         else:
-            parts = [torch.empty(12, dtype=torch.int64) for _ in range(world)]
-            dist.all_gather(parts, mine.cpu())
-            gathered.copy_(torch.stack(parts))
+            parts = [torch.empty(13, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(parts, payload.cpu())
+            gathered13.copy_(torch.stack(parts))
     else:
-        gathered[0].copy_(mine)
+        gathered13[0].copy_(payload)
     check(local_rc, "h2_commit_range_device")
+    statuses = gathered13[:, 12].cpu().numpy()                       # one small read-back: a peer's failure must not become a wrong point
+    _raise_if_any_failed(statuses, "split_commit")
+    gathered = gathered13[:, :12].contiguous()
     out = torch.empty(12, dtype=torch.int64, device=dev)
     curve = C.c_int(0)
     check(lib().h2_bases_info(hv, None, None, C.byref(curve)), "h2_bases_info")

@@ -45,6 +45,7 @@ extern "C" {
 #define H2_ERR_HANDLE 4 /* unknown or freed handle */
 #define H2_ERR_DECODE 5 /* a compressed point does not decode (where pasta_curves' from_bytes returns None) */
 #define H2_ERR_LOOKUP 6 /* permute_expression_pair: an input value does not occur in the table (Error::ConstraintSystemFailure) */
+#define H2_ERR_PEER 7   /* a split multiexp / commit: ANOTHER rank failed its range; no result is written (a partial sum would be a wrong point) */
 
 #define H2_FP 0
 #define H2_FQ 1
@@ -230,8 +231,10 @@ int h2_msm_split_multi(int curve, const uint64_t *scalars, const uint64_t *bases
  * Rank 0 calls h2_rccl_unique_id and hands the 128 bytes to the other ranks by whatever means its launcher offers
  * (a broadcast of its process group, MPI, a file); every rank then calls h2_rccl_init(id, rank, world) with its GPU current.
  * h2_msm_split_rccl_device: every rank passes the same device-resident problem; rank r multiplies points
- * [n r / world, n (r + 1) / world), ONE ncclAllGather of 96 bytes per rank, and every rank writes the total to d_out
- * (asynchronous on `stream`). */
+ * [n r / world, n (r + 1) / world), ONE ncclAllGather of a 128-byte slot per rank (the 96-byte partial + a status word), and
+ * every rank writes the total to d_out.  A rank whose range fails still enters the exchange with its status set: it returns its
+ * own error and EVERY other rank returns H2_ERR_PEER -- nobody hangs, nobody sums the partials that did arrive.  The status read-back
+ * synchronises `stream` once per call (the sum itself is enqueued behind it). */
 int h2_rccl_unique_id(uint8_t id_out[128]);
 int h2_rccl_init(const uint8_t id[128], int rank, int world);
 int h2_rccl_finalize(void);
@@ -239,8 +242,8 @@ int h2_msm_split_rccl_device(int curve, const void *d_scalars, const void *d_bas
                              int out_kind, void *d_out, void *stream);
 /* The same exchange for a commit over REGISTERED bases (Params::commit, an opening-argument round; BASELINE configs[4]'s
  * "RCCL-summed final commit"): every rank holds the table and the column, rank r commits table columns
- * [n r / world, n (r + 1) / world), the last rank carries the blind term (the handle's blind base), ONE 96-byte ncclAllGather,
- * every rank writes the total to d_out. */
+ * [n r / world, n (r + 1) / world), the last rank carries the blind term (the handle's blind base), ONE ncclAllGather (128-byte
+ * slots: partial + status, as above -- H2_ERR_PEER on every rank when any rank failed), every rank writes the total to d_out. */
 int h2_commit_split_rccl_device(h2_bases_t g, const void *d_scalars, size_t n, const void *d_blind, int form, int out_kind,
                                 void *d_out, void *stream);
 

@@ -121,6 +121,40 @@ def test_split_commit_over_registered_bases_world_of_one():
     assert lib().h2_bases_free(hd) == 0
 
 
+def test_split_commit_rccl_injected_local_failure_is_an_error_not_a_point():
+    """h2_commit_split_rccl_device with a rank-LOCAL failure injected after the range commit (H2_TEST_FAIL_RANK, read once per
+    process: a fresh interpreter): the failing rank still runs the exchange (status word behind its partial) and returns ITS error;
+    the output buffer is never written.  (With a world of one there is no peer to see H2_ERR_PEER; the gloo test
+    test_split_msm_one_rank_fails_every_rank_raises covers the all-ranks-raise side on the torch.distributed path.)"""
+    import subprocess
+    code = r"""
+import ctypes as C, numpy as np, torch, sys
+sys.path.insert(0, %r)
+import halo2_amd as h
+from halo2_amd import parallel
+from halo2_amd._lib import lib, H2Error
+from halo2_amd.arithmetic import _p
+from oracle import c_oracle as co
+curve, n = h.PALLAS, 5000
+sf = co.field_of_curve(curve, "scalar")
+g, col = co.generate_bases(curve, 3, n), co.random_field(sf, 4, n)
+hd = C.c_uint64(0)
+assert lib().h2_bases_register(curve, _p(g), n, h.FORM_MONTGOMERY, C.byref(hd)) == 0
+d_col = torch.from_numpy(col.view(np.int64)).cuda()
+parallel.rccl_init(0, 1)
+try:
+    parallel.split_commit_rccl(hd, d_col)
+    print("RETURNED")
+except H2Error as e:
+    print("H2ERROR", e)
+finally:
+    parallel.rccl_finalize()
+""" % ROOT
+    env = dict(os.environ, H2_TEST_FAIL_RANK="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "H2ERROR" in out.stdout and "injected local failure" in out.stdout and "RETURNED" not in out.stdout, out.stdout + out.stderr
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -89,6 +89,59 @@ def test_split_msm_world8_gloo(n):
     assert sorted(c for r in res for c in r[2]) == list(range(7))          # seven columns dealt round-robin over eight ranks
 
 
+def _failing_worker(rank, world, port, q, bad_rank):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from halo2_amd import parallel
+    from oracle import c_oracle as co
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    curve, n = 0, 64
+    sf = co.field_of_curve(curve, "scalar")
+    scal, bases = co.random_field(sf, 21, n), co.generate_bases(curve, 22, n)
+
+    def msm(s, b):
+        if rank == bad_rank:
+            raise RuntimeError("injected: this rank's multiexp failed")
+        return co.best_multiexp(curve, np.ascontiguousarray(s), np.ascontiguousarray(b))
+
+    summed = []
+    try:
+        parallel.split_msm(scal, bases, curve, rank, world, msm=msm, points_sum=lambda pts: summed.append(1) or pts[0])
+        outcome = "returned"
+    except parallel.PeerFailure as e:
+        outcome = "peer:" + str(e)
+    except RuntimeError as e:
+        outcome = "own:" + str(e)
+    q.put((rank, outcome, len(summed)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bad_rank", [(2, 1), (3, 0)])
+def test_split_msm_one_rank_fails_every_rank_raises(world, bad_rank):
+    """A rank whose range multiexp fails still joins the all-gather (status word behind its point): IT raises its own error, every
+    OTHER rank raises PeerFailure naming it, nobody hangs in the collective and nobody sums the partials that did arrive into a
+    plausible-looking wrong point (the round-4 advisor's finding on the identity-as-partial scheme)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q, bad_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outcome, nsum in res:
+        assert nsum == 0, (rank, outcome)                          # no rank added anything up
+        if rank == bad_rank:
+            assert outcome.startswith("own:injected"), outcome
+        else:
+            assert outcome.startswith("peer:") and ("[%d]" % bad_rank) in outcome, outcome
+
+
 def test_shard_range_covers_everything():
     from halo2_amd import parallel
     for n in (0, 1, 7, 8, 1 << 20, (1 << 20) + 1):
