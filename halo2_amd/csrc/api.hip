@@ -6,6 +6,8 @@
 #include <vector>
 
 #include <algorithm>
+#include <atomic>
+
 #include "common.h"
 
 namespace h2 {
@@ -43,6 +45,10 @@ int ensure_device() {
     checked = 1;
     return H2_OK;
 }
+
+static std::atomic<unsigned long> g_devbuf_epoch{0};
+unsigned long devbuf_epoch() { return g_devbuf_epoch.load(std::memory_order_acquire); }
+void devbuf_epoch_bump() { g_devbuf_epoch.fetch_add(1, std::memory_order_acq_rel); }
 
 // ---- event profiler ---------------------------------------------------------------------------
 struct ProfState {

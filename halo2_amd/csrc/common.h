@@ -27,11 +27,16 @@ void set_last_hip_error(hipError_t e, const char *file, int line);
 void set_last_error_msg(const char *msg);   // what h2_last_error() returns on this thread
 
 // Grow-only device buffer.  One instance per use site, guarded by the owning context's mutex.
+// counts every (re)allocation and release of a DevBuf in the process: a captured hipGraph names device pointers, and is replayed
+// only while the count it was captured under still stands (msm.hip, the range pipeline of h2_msm)
+unsigned long devbuf_epoch();
+void devbuf_epoch_bump();
 struct DevBuf {
     void *ptr = nullptr;
     size_t cap = 0;
     int reserve(size_t bytes) {
         if (bytes <= cap) return H2_OK;
+        devbuf_epoch_bump();
         if (ptr) {
             hipError_t e = hipFree(ptr);
             ptr = nullptr;
@@ -45,7 +50,10 @@ struct DevBuf {
         return H2_OK;
     }
     void release() {
-        if (ptr) (void)hipFree(ptr);
+        if (ptr) {
+            devbuf_epoch_bump();
+            (void)hipFree(ptr);
+        }
         ptr = nullptr;
         cap = 0;
     }

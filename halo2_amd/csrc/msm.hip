@@ -39,6 +39,8 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -1868,6 +1870,48 @@ __global__ void __launch_bounds__(64) msm_combine(const u32 *__restrict__ slice_
     }
 }
 
+// The Horner step over the window slices of SEVERAL ranges of one multiexp (h2_msm's range pipeline): slice sums are linear in the
+// points, so sum_q Horner(S_q) = Horner(sum_q S_q) -- quad w adds slice w's sums over the ranges (side by side), then quad 0 runs ONE
+// chain of (slices - 1) c doublings instead of one chain per range.
+struct RangeSums {
+    const u32 *p[16];
+};
+template <int FB>
+__global__ void __launch_bounds__(64) msm_combine_ranges(RangeSums rs, int ranges, int slices, int c, u32 *__restrict__ out, int out_kind, int out_mont) {
+    H2_LATENCY_STAGE();
+    __shared__ __attribute__((aligned(16))) u32 sh[16 * 36];
+    const int w = threadIdx.x / kGroup;
+    const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
+    if (w < slices) {
+        xyzz9<FB> acc = xyzz9_identity<FB>();
+        for (int q = 0; q < ranges; ++q) xyzz9_add_wide<FB>(acc, xyzz9_from_r256_wide<FB>(xyzz_load<FB>(rs.p[q] + 32 * (size_t)w)));
+        if (lead) xyzz9_store_raw<FB>(sh + 36 * w, acc);
+    }
+    __syncthreads();
+    if (threadIdx.x >= kGroup) return;
+    xyzz9<FB> r9 = xyzz9_identity<FB>();
+    for (int s = slices - 1; s >= 0; --s) {
+        if (s != slices - 1)
+            for (int k = 0; k < c; ++k) r9 = xyzz9_dbl_wide<FB>(r9);
+        xyzz9_add_wide<FB>(r9, xyzz9_load_raw<FB>(sh + 36 * s));
+    }
+    const xyzz<FB> r = xyzz9_to_r256_wide<FB>(r9);
+    if (threadIdx.x != 0) return;
+    if (out_kind == H2_OUT_AFFINE) {
+        affine<FB> a = xyzz_to_affine<FB>(r);
+        if (!out_mont) { a.x = fe_from_mont<FB>(a.x); a.y = fe_from_mont<FB>(a.y); }
+        fe_store(out, a.x);
+        fe_store(out + 8, a.y);
+    } else {
+        fe X, Y, Z;
+        xyzz_to_jacobian<FB>(r, X, Y, Z);
+        if (!out_mont) { X = fe_from_mont<FB>(X); Y = fe_from_mont<FB>(Y); Z = fe_from_mont<FB>(Z); }
+        fe_store(out, X);
+        fe_store(out + 8, Y);
+        fe_store(out + 16, Z);
+    }
+}
+
 // ---- precomputed table for registered bases: row w holds 2^(c*w) * P_i as affine points --------------
 // chain: one lane per point walks w = 1 .. W-1 with c doublings each, parking XYZZ in `tmp`
 template <int FB>
@@ -2230,8 +2274,10 @@ static MsmContext &msm_ctx(hipStream_t st = nullptr) {
 }
 // h2_trim: the per-(device, stream) scratch of this device goes back to the allocator (the device is idle by then)
 void msm_release_host_pipe();
+void msm_release_host_msm_pipe();
 void msm_release_workspaces() {
     msm_release_host_pipe();
+    msm_release_host_msm_pipe();
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -2267,8 +2313,14 @@ struct MsmArgs {
     // launch set, blockIdx.z = column (ColIn / ColOut / ColStride above).  Host arrays of device pointers; col_blinds may be null.
     // msm_launch answers H2_ERR_BATCH_SHAPE before launching anything when the shape does not take the batched form.
     // phase: 0 the whole multiexp; 1 stop after the sort (nothing has read d_bases yet); 2 resume after it (same arguments, same stream).
-    // h2_msm uses 1 / 2 to run the sort -- which needs the scalars only -- while the bases are still crossing PCIe.
+    // h2_msm uses 1 / 2 to run the sort -- which needs the scalars only -- while the bases are still crossing PCIe.  Its range
+    // pipeline cuts finer: 3 = resume after the sort and stop after the accumulate (the full-chip part); 4 = the fold alone, behind a
+    // phase-3 call of the same arguments (possibly on ANOTHER stream, ordered by the caller's events).  slice_sums_only (generic
+    // path with window slices on the carry-free fold): the fold stops at the per-slice sums in cx.ssums (XYZZ, 32 words per slice) --
+    // the caller runs ONE Horner step over the sums of several ranges (msm_combine_ranges) instead of one chain of ~128 doublings
+    // per range; H2_ERR_BATCH_SHAPE, before anything is launched, when the shape does not take that form.
     int phase = 0;
+    bool slice_sums_only = false;
     int ncols = 1;
     const void *const *col_scalars = nullptr;
     const void *const *col_blinds = nullptr;
@@ -2439,6 +2491,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     static const u32 fold9_min_nb = [] { const char *e = getenv("H2_FOLD9_MIN_NB"); int v = e ? atoi(e) : 0; return (u32)(v >= 64 ? v : 128); }();
     const bool fold9 = fold9_on && sh.NB >= fold9_min_nb && sh.slices <= 16 && m9 && !a.add_into && !fold_only;      // (16: arrival counters of fold9_planes)
     if (K > 1 && !fold9) return H2_ERR_BATCH_SHAPE;
+    if (a.slice_sums_only && !(fold9 && glv)) return H2_ERR_BATCH_SHAPE;
     // pass 2 of the two-pass sort in its one-launch form (a workgroup per pass-1 bin)?  Decided here, before anything is launched,
     // because a column-batched commit exists in that form only.
     bool s2_bins_form = false;
@@ -2539,9 +2592,9 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     const u32 max_big = all_items >= ((size_t)3 << 20) ? kMaxBig : 0u;
     if (!fold_only) {
     TL_STAMP(tl_id | 1);
-    if (a.phase != 2) prof_begin(PROF_MSM_SORT, st);          // (phase 2 resumes behind a sort the phase-1 call enqueued and timed)
+    if (a.phase < 2) prof_begin(PROF_MSM_SORT, st);          // (phases >= 2 resume behind a sort the phase-1 call enqueued and timed)
     const u32 extra_col = a.d_extra_scalar ? (a.table ? a.extra_col : (u32)a.n_used) : 0xFFFFFFFFu;
-    if (a.phase == 2) {
+    if (a.phase >= 2) {
         // the sort was enqueued by the phase-1 call
     } else if (use_sort2) {
         u32 *hist1 = cx.hist.as<u32>(), *bin_count = cx.plan.as<u32>(), *bin_start = bin_count + S2.nh, *hlo = bin_start + S2.nh + 1,
@@ -2674,6 +2727,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         H2_HIP(hipGetLastError());
         return H2_OK;
     }
+    if (a.phase != 4) {              // (phase 4: the accumulate ran in a phase-3 call)
     if (m9) {
         if (glv && (rc = cx.bases9.reserve((size_t)scalars_n * 128 + 64)) != H2_OK) return rc;
         // raw M9 segments: the heads of the T ranges of every column, then the bucket slots of every column (zeroed in one go)
@@ -2683,7 +2737,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         H2_HIP(hipMemsetAsync(cx.buckets.ptr, 0, (size_t)tb * 128, st));
     }
     if (!use_sort2) H2_HIP(hipMemsetAsync(cx.heavy.ptr, 0, 8, st));          // (the two-pass sort's msm_s1_prefix zeroed it)
-    if (a.phase != 2) prof_end(PROF_MSM_SORT, st);
+    if (a.phase < 2) prof_end(PROF_MSM_SORT, st);
     TL_STAMP(tl_id | 2);
     prof_begin(PROF_MSM_ACCUMULATE, st);
     if (glv && !m9)
@@ -2709,6 +2763,11 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
                            cx.entries.as<u32>(), cx.starts.as<u32>(), cx.heads.as<u32>(), cx.buckets.as<u32>(), tb, T, lane_div, cs);
     prof_end(PROF_MSM_ACCUMULATE, st);
     TL_STAMP(tl_id | 3);
+    if (a.phase == 3) {
+        H2_HIP(hipGetLastError());
+        return H2_OK;
+    }
+    }
     prof_begin(PROF_MSM_REDUCE, st);
     if (fold9) {
         // wide slice: finish on the raw M9 segments, one lane per bucket (fold9_* above); the buckets stay in cx.seg9
@@ -2752,7 +2811,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
             hipLaunchKernelGGL((fold9_planes<FB>), dim3(sh.c - 1, sh.slices, K), dim3(256), 0, st, (const u32 *)lines9, planes9, cx.fold_ctr.as<u32>(),
                                wideS, wideNR, cb, windows ? cx.ssums.as<u32>() : (u32 *)a.d_out, windows ? kOutSliceSum : a.out_kind,
                                a.form == H2_FORM_MONTGOMERY, co, cs);
-            if (windows)
+            if (windows && !a.slice_sums_only)
                 hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, cx.ssums.as<u32>(), (int)sh.slices, sh.c, (u32 *)a.d_out, a.out_kind,
                                    a.form == H2_FORM_MONTGOMERY);
             prof_end(PROF_MSM_REDUCE, st);
@@ -3000,6 +3059,293 @@ extern "C" int h2_msm_device(int curve, const void *d_scalars, const void *d_bas
     return msm_dispatch(cx, curve, a, st);
 }
 
+// ---- h2_msm from host slices, large: the multiexp is cut into point RANGES that start as their bases land ------------------------
+// 96 bytes per point cross PCIe (2^20 points: ~1.8 ms) and the multiexp behind them is ~1.5 ms of device time; run one after the
+// other (round 4: 3.45 ms with only the sort under the upload) the accumulate waits for the LAST base.  Here the scalars cross first,
+// every range's sort is enqueued at once (it reads scalars only), then the bases cross range by range and range q's conversion +
+// accumulate run behind the event of ITS bases: sum_i k_i P_i = sum_q (sum_{i in range q} k_i P_i).  Three streams: `copy` (the
+// bases), `heavy` (sorts, conversions, accumulates: the full-chip kernels, in range order) and `light` (each range's fold down to its
+// window-slice sums -- short latency-bound launches that must not sit in front of the next accumulate -- and, at the end, ONE Horner
+// step over the slice sums of all ranges, msm_combine_ranges: the 128-doubling chain is paid once, not per range).
+// The pageable host-to-device copies hold the calling thread, and every launch enqueued between two of them is PCIe idle time (a
+// helper thread does not help: launches and a pageable copy contend inside the runtime, bench/ubench_h2d.hip), so the launch
+// sequences are captured ONCE per shape as hipGraphs -- one for the sorts, one per range for its accumulate and for its fold, one for
+// the final step -- and replayed with one call each (profiles/r05_h2_msm_host_ranges.txt).  A graph bakes in its kernels' pointer
+// arguments: it is replayed only while every buffer it names is where it was (DevBuf epoch), and never while the event profiler or the
+// debug timeline is on.  What stays exposed behind the upload: the LAST range's accumulate, its fold and the Horner step (~0.75 ms).
+namespace {
+struct HostMsmPipe {
+    std::mutex mu;
+    hipStream_t copy = nullptr, heavy = nullptr, light = nullptr;
+    hipEvent_t scalars_in = nullptr, folds_done = nullptr;
+    std::vector<hipEvent_t> landed, acc_done;
+    std::vector<std::unique_ptr<MsmContext>> ctx;       // one workspace per range (they share the `heavy` stream, not scratch)
+    // captured launch sequences of the last shape seen
+    struct Shape {
+        int curve = -1, form = -1, out_kind = -1, c = 0;
+        size_t n = 0;
+        unsigned Q = 0;
+        const void *s = nullptr, *b = nullptr, *o = nullptr;
+        unsigned long epoch = 0;
+        bool operator==(const Shape &x) const {
+            return curve == x.curve && form == x.form && out_kind == x.out_kind && c == x.c && n == x.n && Q == x.Q && s == x.s && b == x.b && o == x.o && epoch == x.epoch;
+        }
+    } shape;
+    int warm = 0;                                       // calls seen with `shape`: the first runs plain launches (allocations, attributes), the second captures
+    hipGraphExec_t g_sort = nullptr, g_final = nullptr;
+    std::vector<hipGraphExec_t> g_acc, g_fold;
+    void drop_graphs() {
+        if (g_sort) (void)hipGraphExecDestroy(g_sort);
+        if (g_final) (void)hipGraphExecDestroy(g_final);
+        for (auto g : g_acc) if (g) (void)hipGraphExecDestroy(g);
+        for (auto g : g_fold) if (g) (void)hipGraphExecDestroy(g);
+        g_sort = g_final = nullptr;
+        g_acc.clear();
+        g_fold.clear();
+    }
+    int ensure(unsigned q) {
+        if (!copy) {
+            H2_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+            H2_HIP(hipStreamCreateWithFlags(&heavy, hipStreamNonBlocking));
+            H2_HIP(hipStreamCreateWithFlags(&light, hipStreamNonBlocking));
+            H2_HIP(hipEventCreateWithFlags(&scalars_in, hipEventDisableTiming));
+            H2_HIP(hipEventCreateWithFlags(&folds_done, hipEventDisableTiming));
+        }
+        while (landed.size() < q) {
+            hipEvent_t a, b;
+            H2_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+            H2_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            landed.push_back(a);
+            acc_done.push_back(b);
+            ctx.emplace_back(new MsmContext());
+        }
+        return H2_OK;
+    }
+};
+HostMsmPipe g_host_msm[16];      // per device
+}  // namespace
+// ranges of a host-pointer multiexp of n points: three from 2^19 points on (2^20: 2 / 3 / 4 / 8 ranges = 3.08-3.19 / 3.07-3.13 /
+// 3.11-3.26 / 3.63 ms against 3.44-3.46 in one piece: finer ranges lose more to the per-copy cost of pageable memory and to narrower
+// windows than their shorter tail wins -- profiles/r05_h2_msm_host_ranges.txt; H2_MSM_HOST_CHUNKS: sweeps, 1 = the round-4 path)
+static unsigned host_msm_chunks(size_t n) {
+    static const int env = [] { const char *e = getenv("H2_MSM_HOST_CHUNKS"); return e ? atoi(e) : 0; }();
+    if (env >= 1) return (unsigned)std::min<size_t>((size_t)std::min(env, 16), std::max<size_t>(1, n >> 14));
+    if (n < ((size_t)1 << 19)) return 1;
+    return 3;
+}
+// runs `body` (launches on `st`) either directly or into a new executable graph
+template <class Body> static int capture_graph(hipStream_t st, hipGraphExec_t *exec, Body body) {
+    H2_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+    const int rc = body();
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc != H2_OK || e != hipSuccess) {
+        if (g) (void)hipGraphDestroy(g);
+        if (rc != H2_OK) return rc;
+        set_last_hip_error(e, __FILE__, __LINE__);
+        return H2_ERR_HIP;
+    }
+    const hipError_t ei = hipGraphInstantiate(exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ei != hipSuccess) { set_last_hip_error(ei, __FILE__, __LINE__); return H2_ERR_HIP; }
+    return H2_OK;
+}
+// H2_ERR_BATCH_SHAPE: the ranges do not take the slice-sum form (nothing was enqueued): the caller falls back to the one-piece path
+static int msm_host_chunked(MsmContext &cx, int curve, const uint64_t *scalars, const uint64_t *bases_xy, size_t n, int form, int out_kind,
+                            unsigned Q) {
+    int dev = 0;
+    H2_HIP(hipGetDevice(&dev));
+    HostMsmPipe &hp = g_host_msm[dev & 15];
+    std::lock_guard<std::mutex> lk(hp.mu);
+    int rc = hp.ensure(Q);
+    if (rc != H2_OK) return rc;
+    auto range = [&](unsigned q, size_t &lo, size_t &hi) { lo = n * q / Q; hi = n * (q + 1) / Q; };
+    const int c = choose_c((n + Q - 1) / Q, false);            // ONE window width for every range: their slice sums add up
+    auto args_of = [&](unsigned q, int phase) {
+        size_t lo, hi;
+        range(q, lo, hi);
+        MsmArgs a{(const char *)cx.stage_s.ptr + 32 * lo, nullptr, (const char *)cx.stage_b.ptr + 64 * lo, nullptr, hi - lo, false,
+                  c, 0, 0xFFFFFFFFu, form, H2_OUT_JACOBIAN, nullptr};
+        a.phase = phase;
+        a.slice_sums_only = true;
+        return a;
+    };
+    auto stage = [&](unsigned q, int phase, hipStream_t st) {
+        std::lock_guard<std::mutex> lq(hp.ctx[q]->mu);
+        return msm_dispatch(*hp.ctx[q], curve, args_of(q, phase), st);
+    };
+    int slices = 0;
+    {
+        size_t lo, hi;
+        range(0, lo, hi);
+        slices = (int)make_shape(2 * (hi - lo), c, false, true).slices;
+    }
+    auto final_step = [&]() {
+        RangeSums rs;
+        memset(&rs, 0, sizeof rs);
+        for (unsigned q = 0; q < Q; ++q) rs.p[q] = hp.ctx[q]->ssums.as<u32>();
+        if (curve == H2_PALLAS) hipLaunchKernelGGL((msm_combine_ranges<FP>), dim3(1), dim3(64), 0, hp.light, rs, (int)Q, slices, c, cx.out.as<u32>(), out_kind, form == H2_FORM_MONTGOMERY);
+        else hipLaunchKernelGGL((msm_combine_ranges<FQ>), dim3(1), dim3(64), 0, hp.light, rs, (int)Q, slices, c, cx.out.as<u32>(), out_kind, form == H2_FORM_MONTGOMERY);
+        H2_HIP(hipGetLastError());
+        return (int)H2_OK;
+    };
+    // the shape probe: does a range take the slice-sum form?  (phase 1 on an EMPTY capture would be clumsy: ask the planner directly --
+    // the generic path folds on the carry-free layer from 128 buckets per slice on, with at most 16 slices)
+    {
+        size_t lo, hi;
+        range(0, lo, hi);
+        const MsmShape sh = make_shape(2 * (hi - lo), c, false, true);
+        if (!glv_applies(hi - lo) || sh.NB < 128 || sh.slices > 16 || Q > 16) return H2_ERR_BATCH_SHAPE;
+    }
+    HostMsmPipe::Shape want;
+    want.curve = curve; want.form = form; want.out_kind = out_kind; want.c = c; want.n = n; want.Q = Q;
+    want.s = cx.stage_s.ptr; want.b = cx.stage_b.ptr; want.o = cx.out.ptr;
+    want.epoch = devbuf_epoch();
+    static const bool graphs_on = [] { const char *e = getenv("H2_MSM_HOST_GRAPHS"); return !(e && atoi(e) == 0); }();
+    if (!(want == hp.shape)) {
+        hp.drop_graphs();
+        hp.shape = want;
+        hp.warm = 0;
+    }
+    const bool may_graph = graphs_on && !prof_enabled() && !timeline_on();
+    if (may_graph && hp.warm >= 1 && !hp.g_sort) {
+        // second call with this shape: every workspace exists, every attribute is set -- capture the launch sequences (nothing executes)
+        hp.g_acc.assign(Q, nullptr);
+        hp.g_fold.assign(Q, nullptr);
+        rc = capture_graph(hp.heavy, &hp.g_sort, [&] { int r = H2_OK; for (unsigned q = 0; q < Q && r == H2_OK; ++q) r = stage(q, 1, hp.heavy); return r; });
+        for (unsigned q = 0; q < Q && rc == H2_OK; ++q) {
+            rc = capture_graph(hp.heavy, &hp.g_acc[q], [&] { return stage(q, 3, hp.heavy); });
+            if (rc == H2_OK) rc = capture_graph(hp.light, &hp.g_fold[q], [&] { return stage(q, 4, hp.light); });
+        }
+        if (rc == H2_OK) rc = capture_graph(hp.light, &hp.g_final, final_step);
+        if (rc != H2_OK || devbuf_epoch() != want.epoch) {     // (a capture that had to allocate is not replayable: stay with plain launches)
+            hp.drop_graphs();
+            hp.shape.epoch = devbuf_epoch();
+            if (rc != H2_OK) return rc;
+        }
+    }
+    const bool replay = may_graph && hp.g_sort != nullptr;
+    // Who enqueues: with the captured sequences a call is ~4 + 3 Q runtime calls; a helper thread CAN make them while this thread
+    // goes from one pageable copy straight into the next (each event is recorded here, right behind its copy; the helper picks it up
+    // through an atomic counter).
+    // Measured (profiles/r05_h2_msm_host_ranges.txt, 2^20): no gain -- 3.08-3.27 ms with the helper against 3.07-3.23 without: what the
+    // copies lose to the helper's calls is what they idled before.  Off unless H2_MSM_HOST_THREAD=1.
+    static const bool thread_on = [] { const char *e = getenv("H2_MSM_HOST_THREAD"); return e && atoi(e) == 1; }();
+    const bool helper = replay && thread_on;
+    std::atomic<int> landed_n{-1};          // -1: nothing yet; 0: the scalars' event is recorded; q + 1: range q's
+    std::atomic<int> abort_flag{0};
+    int helper_rc = H2_OK;
+    auto enqueue_sorts = [&]() -> int {
+        hipError_t e = hipStreamWaitEvent(hp.heavy, hp.scalars_in, 0);
+        if (e != hipSuccess) { set_last_hip_error(e, __FILE__, __LINE__); return H2_ERR_HIP; }
+        if (replay) {
+            if ((e = hipGraphLaunch(hp.g_sort, hp.heavy)) != hipSuccess) { set_last_hip_error(e, __FILE__, __LINE__); return H2_ERR_HIP; }
+            return H2_OK;
+        }
+        int r = H2_OK;
+        for (unsigned q = 0; q < Q && r == H2_OK; ++q) r = stage(q, 1, hp.heavy);       // every range's sort: it needs the scalars only
+        return r;
+    };
+    auto enqueue_range = [&](unsigned q) -> int {      // range q's accumulate on `heavy` behind its bases, its fold on `light`
+        int r = H2_OK;
+        hipError_t e = hipStreamWaitEvent(hp.heavy, hp.landed[q], 0);
+        if (e == hipSuccess) {
+            if (replay) e = hipGraphLaunch(hp.g_acc[q], hp.heavy);
+            else r = stage(q, 3, hp.heavy);
+        }
+        if (r == H2_OK && e == hipSuccess) e = hipEventRecord(hp.acc_done[q], hp.heavy);
+        if (r == H2_OK && e == hipSuccess) e = hipStreamWaitEvent(hp.light, hp.acc_done[q], 0);
+        if (r == H2_OK && e == hipSuccess) {
+            if (replay) e = hipGraphLaunch(hp.g_fold[q], hp.light);
+            else r = stage(q, 4, hp.light);
+        }
+        if (r == H2_OK && e != hipSuccess) { set_last_hip_error(e, __FILE__, __LINE__); r = H2_ERR_HIP; }
+        return r;
+    };
+    auto enqueue_final = [&]() -> int {
+        hipError_t e = hipSuccess;
+        int r = H2_OK;
+        if (replay) {
+            if ((e = hipGraphLaunch(hp.g_final, hp.light)) != hipSuccess) { set_last_hip_error(e, __FILE__, __LINE__); return H2_ERR_HIP; }
+        } else if ((r = final_step()) != H2_OK) {
+            return r;
+        }
+        if ((e = hipEventRecord(hp.folds_done, hp.light)) != hipSuccess) { set_last_hip_error(e, __FILE__, __LINE__); return H2_ERR_HIP; }
+        return H2_OK;
+    };
+    std::thread worker;
+    if (helper)
+        worker = std::thread([&] {
+            (void)hipSetDevice(dev);
+            auto wait_for = [&](int v) {
+                while (landed_n.load(std::memory_order_acquire) < v && !abort_flag.load(std::memory_order_acquire)) std::this_thread::yield();
+                return !abort_flag.load(std::memory_order_acquire);
+            };
+            if (!wait_for(0)) return;
+            int r = enqueue_sorts();
+            for (unsigned q = 0; q < Q && r == H2_OK; ++q) {
+                if (!wait_for((int)q + 1)) return;
+                r = enqueue_range(q);
+            }
+            if (r == H2_OK) r = enqueue_final();
+            helper_rc = r;
+        });
+    hipError_t e = hipStreamSynchronize(0);                    // the staging buffers may still be read by an earlier call's kernels
+    if (e == hipSuccess) e = hipMemcpyAsync(cx.stage_s.ptr, scalars, n * 32, hipMemcpyHostToDevice, 0);
+    if (e == hipSuccess) e = hipEventRecord(hp.scalars_in, 0);
+    if (e != hipSuccess) { set_last_hip_error(e, __FILE__, __LINE__); rc = H2_ERR_HIP; }
+    if (rc == H2_OK) {
+        if (helper) landed_n.store(0, std::memory_order_release);
+        else rc = enqueue_sorts();
+    }
+    // range q's bases: the pageable copy holds this thread for its length
+    for (unsigned q = 0; q < Q && rc == H2_OK; ++q) {
+        size_t lo, hi;
+        range(q, lo, hi);
+        e = hipMemcpyAsync((char *)cx.stage_b.ptr + 64 * lo, (const char *)bases_xy + 64 * lo, 64 * (hi - lo), hipMemcpyHostToDevice, hp.copy);
+        if (e == hipSuccess && form == H2_FORM_CANONICAL) to_mont_async(curve, (u32 *)((char *)cx.stage_b.ptr + 64 * lo), (hi - lo) * 2, hp.copy);
+        if (e == hipSuccess) e = hipEventRecord(hp.landed[q], hp.copy);
+        if (e != hipSuccess) { set_last_hip_error(e, __FILE__, __LINE__); rc = H2_ERR_HIP; break; }
+        if (helper) landed_n.store((int)q + 1, std::memory_order_release);
+        else rc = enqueue_range(q);
+    }
+    if (helper) {
+        if (rc != H2_OK) abort_flag.store(1, std::memory_order_release);
+        worker.join();
+        if (rc == H2_OK) rc = helper_rc;
+    } else if (rc == H2_OK) {
+        rc = enqueue_final();
+    }
+    if (rc == H2_OK && (e = hipStreamWaitEvent(0, hp.folds_done, 0)) != hipSuccess) {
+        set_last_hip_error(e, __FILE__, __LINE__);
+        rc = H2_ERR_HIP;
+    }
+    if (rc != H2_OK) {            // drain everything that was enqueued before reporting
+        (void)hipStreamSynchronize(hp.heavy);
+        (void)hipStreamSynchronize(hp.light);
+        (void)hipStreamSynchronize(hp.copy);
+        (void)hipStreamSynchronize(0);
+        return rc;
+    }
+    hp.warm++;
+    return H2_OK;
+}
+namespace h2 {
+void msm_release_host_msm_pipe() {        // h2_trim: the ranges' workspaces and the graphs that name them
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    HostMsmPipe &hp = g_host_msm[dev & 15];
+    std::lock_guard<std::mutex> lk(hp.mu);
+    hp.drop_graphs();
+    hp.shape = HostMsmPipe::Shape();
+    hp.warm = 0;
+    for (auto &c : hp.ctx) {
+        std::lock_guard<std::mutex> lc(c->mu);
+        c->release_all();
+    }
+}
+}  // namespace h2
+
 extern "C" int h2_msm(int curve, const uint64_t *scalars, const uint64_t *bases_xy, size_t n, int form, int out_kind,
                       uint64_t *out) {
     if (bad_common(curve, form, out_kind) || !out || (n && (!scalars || !bases_xy)) || n > 0x7FFFFFF0u) return H2_ERR_ARGS;
@@ -3011,6 +3357,15 @@ extern "C" int h2_msm(int curve, const uint64_t *scalars, const uint64_t *bases_
     if ((rc = cx.stage_s.reserve(n * 32 + 32)) != H2_OK) return rc;
     if ((rc = cx.stage_b.reserve(n * 64 + 64)) != H2_OK) return rc;
     if ((rc = cx.out.reserve(128)) != H2_OK) return rc;
+    if (const unsigned Q = host_msm_chunks(n); Q > 1) {
+        rc = msm_host_chunked(cx, curve, scalars, bases_xy, n, form, out_kind, Q);
+        if (rc == H2_OK) {
+            H2_HIP(hipMemcpyAsync(out, cx.out.ptr, out_bytes, hipMemcpyDeviceToHost, 0));
+            H2_HIP(hipStreamSynchronize(0));
+            return H2_OK;
+        }
+        if (rc != H2_ERR_BATCH_SHAPE) return rc;              // (a shape the range pipeline does not take: one piece, below)
+    }
     MsmArgs a{cx.stage_s.ptr, nullptr, cx.stage_b.ptr, nullptr, n, false, choose_c(n ? n : 1, false), 0, 0xFFFFFFFFu, form,
               out_kind, cx.out.ptr};
     // Large multiexps: the scalars cross first (a third of the bytes), the sort -- which reads nothing else -- is enqueued, and only

@@ -679,3 +679,26 @@ def test_generator_collapse_edge_challenges():
     for v in (lam, sm - 1, (1 << 128) + 1):
         u = fields.scalar_limbs(v, sf, True)
         assert np.array_equal(h.parallel_generator_collapse(g_big, u, curve), co.generator_collapse(curve, g_big, u)), hex(v)
+
+
+# ------------------------------------------------------------------ h2_msm from host slices: the range pipeline (round 5)
+@pytest.mark.parametrize("curve,canonical,affine", [(h.PALLAS, False, False), (h.VESTA, True, True)])
+def test_best_multiexp_host_slices_range_pipeline(curve, canonical, affine):
+    """From 2^19 points on h2_msm cuts the multiexp into point ranges that start behind their bases' upload (csrc/msm.hip,
+    msm_host_chunked): ragged ranges (n = 2^19 + 4097 over three), both data forms, both output kinds -- and FOUR calls with fresh
+    scalars each, so that the first plain-launch call, the call that captures the launch sequences as hipGraphs and the calls that
+    replay them (same staging buffers, new bytes) are all compared with the oracle."""
+    n = (1 << 19) + 4097
+    sf, bf = co.field_of_curve(curve, "scalar"), co.field_of_curve(curve, "base")
+    bases = co.generate_bases(curve, 4242, n)
+    bases_in = np.ascontiguousarray(co.from_mont(bf, bases.reshape(2 * n, 4)).reshape(n, 8)) if canonical else bases
+    form = h.FORM_CANONICAL if canonical else h.FORM_MONTGOMERY
+    for rep in range(4):
+        scal = co.random_field(sf, 8800 + rep, n)
+        if rep == 2:
+            scal[: n // 2] = 0                     # half the scalars zero: empty digits everywhere in the first ranges
+        scal_in = co.from_mont(sf, scal) if canonical else scal
+        got = np.ascontiguousarray(h.best_multiexp(scal_in, bases_in, curve, form=form, affine=affine), dtype=np.uint64)
+        if canonical:                              # canonical coordinates out: back to Montgomery limbs for the oracle's reader
+            got = co.to_mont(bf, got.reshape(-1, 4)).reshape(-1)
+        assert affine_of(curve, got) == affine_of(curve, co.best_multiexp(curve, scal, bases)), rep
