@@ -242,19 +242,26 @@ def main():
     t0 = time.perf_counter()
     run_steps(args.steps)
     torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed_own = elapsed_local if world > 1 else elapsed          # this rank's own K steps, before the closing barrier
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
+    rank_figures = None
     if world > 1:
+        # every rank's own figures travel to rank 0 (the first real 1 -> 8 curve must be readable for stragglers: a slow GPU, a slow
+        # table build, a clock that one socket's power limit cut deeper): [its K steps alone, its table registration]
+        mine = torch.tensor([elapsed_own, register_ms], dtype=torch.float64, device=comm_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_figures = {"ms_per_step_own": [round(float(x[0]) / max(args.steps, 1) * 1e3, 4) for x in allr],
+                    "bases_register_ms": [round(float(x[1]), 1) for x in allr]}
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if world > 1:                 # setup: the slowest rank's (8 table builds share nothing but the host's memory bandwidth)
-        t = torch.tensor([register_ms], dtype=torch.float64, device=comm_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        register_ms = float(t.item())
+        register_ms = max(float(x[1]) for x in allr)     # setup: the slowest rank's (8 table builds share nothing but the host's memory bandwidth)
     prof, busy = {}, {}
     for name, slot in (("msm_accumulate", 0), ("msm_sort", 2), ("msm_reduce", 3)):
         ms, bz, cnt = C.c_double(0), C.c_double(0), C.c_uint64(0)
@@ -293,7 +300,30 @@ def main():
     # ---- shader clock and socket power under the two loads above (amdgpu hwmon, sampled from a thread): the sustained rate is the
     # accumulate's issue bound AT THE CLOCK THE POWER LIMIT LEAVES, so the line carries that clock ----
     clock = None
-    hw = _hwmon_dir(local_rank) if rank == 0 and not args.minimal else None
+    hw = _hwmon_dir(local_rank) if not args.minimal and (rank == 0 or world > 1) else None
+    if world > 1 and not args.minimal:
+        # N > 1: EVERY rank samples its own GPU for 0.3 s under the timed region's schedule, all at once (the sockets of one node draw on
+        # one power envelope and one cooling loop), and rank 0 lists the medians
+        own = [0.0, 0.0]
+        if hw:
+            sync_all()
+            with _ClockSampler(hw) as smp_r:
+                t_l = time.perf_counter()
+                while time.perf_counter() - t_l < 0.3:
+                    run_steps(max(args.steps, 1))
+                    torch.cuda.synchronize()
+            sm_ = smp_r.summary()
+            if sm_:
+                own = [float(sm_["sclk_mhz_median"]), float(sm_["power_w_median"])]
+        else:
+            sync_all()
+        mine_c = torch.tensor(own, dtype=torch.float64, device=comm_dev)
+        allc = [torch.zeros_like(mine_c) for _ in range(world)]
+        dist.all_gather(allc, mine_c)
+        if rank_figures is not None:
+            rank_figures["sclk_mhz_median_under_timed_schedule"] = [round(float(x[0])) for x in allc]
+            rank_figures["power_w_median_under_timed_schedule"] = [round(float(x[1])) for x in allc]
+        hw = hw if rank == 0 else None
     if hw:
         def load(fn, seconds=0.4):
             t_l = time.perf_counter()
@@ -496,15 +526,34 @@ def main():
             lib.h2_profile_read(1, C.byref(ms), C.byref(cnt))
             lib.h2_profile_enable(0)
             bf = (1 << (log_n - 1)) * log_n
+            # the reference recomputes its twiddles on every call (arithmetic.rs:215-221); the library caches the stage-major table per
+            # (field, omega, log n) and every `ms` above is a cache hit: the FIRST transform with an omega the process has not seen
+            # (a fresh random one, benches/fft.rs:17) pays the table build (ntt_twiddles9: 2^log_n - 1 entries of 36 B) in front of it
+            fresh = co.random_field(h.FP, 0xF5E5 + log_n + int(time.time() * 1e3) % 100000, 1)[0]
+            d_m = torch.from_numpy(a.view(np.int64)).to(dev)
+            torch.cuda.synchronize()
+            t_m = time.perf_counter()
+            h.best_fft(d_m, fresh, log_n, h.FP)
+            torch.cuda.synchronize()
+            first_ms = (time.perf_counter() - t_m) * 1e3
+            t_m = time.perf_counter()
+            h.best_fft(d_m, fresh, log_n, h.FP)
+            torch.cuda.synchronize()
+            again_ms = (time.perf_counter() - t_m) * 1e3
+            del d_m
             cpu_ntt = None
             if world == 1 and not args.no_cpu_baseline:
-                t2 = time.perf_counter()
-                ref_out = co.best_fft(h.FP, a, omega, log_n)
-                cpu_dt = time.perf_counter() - t2
+                cpu_runs = []
+                for _ in range(5):
+                    t2 = time.perf_counter()
+                    ref_out = co.best_fft(h.FP, a, omega, log_n)
+                    cpu_runs.append(time.perf_counter() - t2)
+                cpu_dt = sorted(cpu_runs)[2]
                 d_chk = torch.from_numpy(a.view(np.int64)).to(dev)
                 h.best_fft(d_chk, omega, log_n, h.FP)
                 torch.cuda.synchronize()
-                cpu_ntt = {"ms": round(cpu_dt * 1e3, 2), "Gbutterflies_per_s": round(bf / cpu_dt / 1e9, 4),
+                cpu_ntt = {"ms": round(cpu_dt * 1e3, 2), "runs_ms": [round(r * 1e3, 2) for r in cpu_runs], "sample": "median of 5 runs of the same transform",
+                           "Gbutterflies_per_s": round(bf / cpu_dt / 1e9, 4),
                            "kind": "port", "host_cores": int(co.lib().orc_get_threads()),
                            "bit_exact_vs_gpu": bool(np.array_equal(d_chk.cpu().numpy().view(np.uint64), ref_out))}
                 del d_chk
@@ -525,7 +574,7 @@ def main():
                 ms_dt = (time.perf_counter() - t3) / (reps_b * len(d_cols_ntt))
                 del d_cols_ntt
             rt_ms = None
-            if log_n == 22:   # BASELINE configs[2]: forward + inverse round trip
+            if True:          # BASELINE configs[2]: forward + inverse round trip (2^22 is the config's size; 2^20 beside it)
                 omega_inv = fields.scalar_limbs(pow(pasta.omega_for(pasta.P, log_n), -1, pasta.P), h.FP)
                 divisor = fields.scalar_limbs(pow(1 << log_n, -1, pasta.P), h.FP)
                 d_rt = torch.from_numpy(a.view(np.int64)).to(dev)
@@ -540,7 +589,11 @@ def main():
                 rt_ms = {"ms": round((time.perf_counter() - t5) / 2 * 1e3, 4),
                          "returns_input": bool(np.array_equal(d_rt.cpu().numpy().view(np.uint64), a))}
                 del d_rt
-            ntt[f"2^{log_n}"] = {"ms": round(dt * 1e3, 4), "forward_inverse_roundtrip": rt_ms, "Gbutterflies_per_s": round(bf / dt / 1e9, 3), "cpu_baseline": cpu_ntt,
+            ntt[f"2^{log_n}"] = {"ms": round(dt * 1e3, 4), "forward_inverse_roundtrip": rt_ms,
+                                 "twiddle_miss": {"first_call_fresh_omega_ms": round(first_ms, 4), "second_call_same_omega_ms": round(again_ms, 4),
+                                                  "twiddle_miss_ms": round(first_ms - again_ms, 4),
+                                                  "what": "one synchronised best_fft with an omega this process has not used (the table build, ntt_twiddles9, runs in "
+                                                          "front of the passes), then the same call again (a cache hit; a lone synchronised call, so above `ms`)"}, "Gbutterflies_per_s": round(bf / dt / 1e9, 3), "cpu_baseline": cpu_ntt,
                                  "kernel_ms": round(ms.value / reps, 4), "passes": int(cnt.value // reps),
                                  "independent_columns": None if ms_dt is None else {
                                      "streams": len(streams), "ms_per_fft": round(ms_dt * 1e3, 4), "Gbutterflies_per_s": round(bf / ms_dt / 1e9, 3)},
@@ -700,7 +753,10 @@ def main():
                        "parallelism": f"{world} GPU(s) x {len(streams)} stream(s) of independent column commits"},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 2) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
-                         "traffic": int(traffic * cols_per_launch) if traffic else traffic, "avg_kernel_ms": round(avg_ms, 4), "launches": int(acc_cnt),
+                         "traffic": int(traffic * cols_per_launch) if traffic else traffic,
+                         "traffic_source": "profiles/r04_pmc_traffic.json: the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on this workload, corrected as "
+                                           "calibrated there -- a constant read from that file, NOT measured in this run (the kernel has not changed since)",
+                         "avg_kernel_ms": round(avg_ms, 4), "launches": int(acc_cnt),
                          "columns_per_launch": round(cols_per_launch, 3),
                          "avg_kernel_ms_definition": "union of the launch intervals on the device / launches (HIP events on the launching "
                                                      "streams, timed region only); overlapped_launch_ms = plain mean of the launch durations",
@@ -729,7 +785,7 @@ def main():
                 "algorithmic_bytes_per_scalar": 244,
                 "achieved": round(244.0 * n / (ms_ * 1e-3) / 1e9, 1) if ms_ else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(244.0 * n / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_ else None,
-                "traffic": tr_, "stage_ms_isolated": ms_})(
+                "traffic": tr_, "traffic_source": "profiles/r04_pmc_traffic.json, not measured in this run", "stage_ms_isolated": ms_})(
                 iso.get("msm_sort"), (pmc or {}).get("msm_bucket_sort_2^20", {}).get("total_hbm_bytes_corrected") if args.log_n == 20 else None),
             # the second hot kernel of the path (BASELINE configs[2]): the NTT passes, priced the same way -- 64 B per element per
             # transform over the transform's wall time, against HBM; traffic = PMC bytes of the two passes
@@ -738,6 +794,7 @@ def main():
                 "bound": "hbm", "kernel": "ntt_pass9 (two passes of 10 stages at 2^20)", "achieved": e_["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(e_["algorithmic_GBps"] / HBM_PEAK_GBS, 5), "ms_per_transform": e_["ms"], "kernel_ms_per_transform": e_["kernel_ms"],
                 "traffic": (pmc or {}).get("ntt_2^20", {}).get("total_hbm_bytes_corrected"),
+                "traffic_source": "profiles/r04_pmc_traffic.json, not measured in this run",
                 "note": "VALU-bound like the MSM: 10.5 M modular multiplications per 2^20 transform at ~200 G/s are 0.052 ms before any addition, carry pass "
                         "or LDS round trip; the passes issue ~4800 instructions per lane and pass (DESIGN.md section 5.5)"})(ntt.get("2^20")),
             "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items() if v[1]},
@@ -745,6 +802,7 @@ def main():
             "clock": clock, "generic_best_multiexp": generic, "extra": extra, "skewed_columns": skew, "ntt": ntt, "cpu_baseline": cpu,
             "checks": {"split_sum_identity": None if split_ok is None else bool(split_ok), "split_msm_allgather": split_msm_ok, "split_msm_rccl_in_library": split_rccl_c},
             "config5": config5,
+            "per_rank": rank_figures,
             "setup": {"bases_register_ms_max_over_ranks": round(register_ms, 1),
                       "what": "h2_bases_register_ex per GPU, untimed by the steps: 64 MiB of `g` from pageable host memory + the precomputed table "
                               f"({255 // col_bits + (1 if 255 % col_bits else 0)} rows of {n} + 1 points, 64 B each); once per Params per device"},

@@ -48,6 +48,13 @@ def test_bench_single_gpu_contract():
     assert d["value"] > 10 * c["value"]                                   # north star: >= 10x the host CPU, bit-exact
     assert d["checks"]["split_sum_identity"] is True
     assert d["ntt"]["2^22"]["forward_inverse_roundtrip"]["returns_input"] is True
+    assert d["ntt"]["2^20"]["forward_inverse_roundtrip"]["returns_input"] is True
+    # round 5: the cold-twiddle cost beside every cached figure, the CPU transform as a median, the PMC constants labelled as constants
+    tm = d["ntt"]["2^20"]["twiddle_miss"]
+    assert tm["first_call_fresh_omega_ms"] > tm["second_call_same_omega_ms"] > 0
+    assert len(d["ntt"]["2^20"]["cpu_baseline"]["runs_ms"]) == 5 and d["ntt"]["2^20"]["cpu_baseline"]["bit_exact_vs_gpu"] is True
+    assert "NOT measured in this run" in r["traffic_source"]
+    assert d["per_rank"] is None                                          # (N = 1: nothing to compare)
 
 
 def test_bench_two_ranks_gloo():
@@ -87,6 +94,12 @@ def test_bench_eight_ranks_gloo_rehearsal():
     assert c5["columns_total"] == 64 and c5["columns_per_gpu"] == 8 and c5["columns_first_equals_timed_step"] is True
     assert c5["split_equals_whole"] is True and c5["split_commit_ms"] > 0
     assert d["setup"]["bases_register_ms_max_over_ranks"] > 0
+    # every rank's own figures (round 5): its K steps alone, its table build, its clock and power under the timed schedule -- the max
+    # over ranks is what `ms_per_step` reports, the list is what shows a straggler
+    pr = d["per_rank"]
+    assert len(pr["ms_per_step_own"]) == 8 and all(0 < x <= d["ms_per_step"] * 1.001 for x in pr["ms_per_step_own"])
+    assert len(pr["bases_register_ms"]) == 8 and max(pr["bases_register_ms"]) == d["setup"]["bases_register_ms_max_over_ranks"]
+    assert len(pr["sclk_mhz_median_under_timed_schedule"]) == 8 and len(pr["power_w_median_under_timed_schedule"]) == 8
 
 
 def test_bench_batched_steps():
