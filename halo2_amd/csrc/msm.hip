@@ -1237,11 +1237,14 @@ __global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(
         heads = H2_COLZ(heads, cs.heads);
         buckets = H2_COLZ(buckets, cs.buckets);
     }
-    const u32 M = starts[total_buckets];
+    // `starts` may be a VIEW into a longer boundary array (a group of window slices of a generic multiexp accumulated on its own,
+    // msm_launch's slice split): its first entry is then the group's offset into `entries`, not zero; the T ranges tile [base, base + M)
+    const u32 base = starts[0];
+    const u32 M = starts[total_buckets] - base;
     T = eff_lanes(M, T, div);
     if (t >= T) return;
     const u32 chunk = (M + T - 1) / T;
-    const u32 lo = min(M, t * chunk), hi = min(M, lo + chunk);
+    const u32 lo = base + min(M, t * chunk), hi = min(base + M, lo + chunk);
     if (M9) {
         xyzz9<FB> acc = xyzz9_identity<FB>();
         if (lo < hi) {
@@ -1530,10 +1533,11 @@ __global__ void __launch_bounds__(256) fold9_finish(const u32 *__restrict__ head
         buckets9 = H2_COLZ(buckets9, cs.buckets);
         heavy = H2_COLZ(heavy, cs.heavy);
     }
-    const u32 M = starts[total_buckets];
+    const u32 base = starts[0];                      // (a slice group's view: see msm_accumulate)
+    const u32 M = starts[total_buckets] - base;
     T = eff_lanes(M, T, div);
     const u32 chunk = max(1u, (M + T - 1) / T);
-    const u32 h0 = (starts[b] + chunk - 1) / chunk, h1 = (starts[b + 1] + chunk - 1) / chunk;
+    const u32 h0 = (starts[b] - base + chunk - 1) / chunk, h1 = (starts[b + 1] - base + chunk - 1) / chunk;
     if (h1 <= h0) return;
     if (h1 - h0 > kHeavy) {
         const u32 slot = atomicAdd(&heavy[1], 1u);
@@ -1614,10 +1618,11 @@ __global__ void __launch_bounds__(256, 3) fold9_finish_heavy(const u32 *__restri
     }
     if (blockIdx.y >= min(heavy[1], kMaxHeavy)) return;
     const u32 b = heavy[2 + blockIdx.y];
-    const u32 M = starts[total_buckets];
+    const u32 base = starts[0];
+    const u32 M = starts[total_buckets] - base;
     T = eff_lanes(M, T, div);
     const u32 chunk = max(1u, (M + T - 1) / T);
-    const u32 h0 = (starts[b] + chunk - 1) / chunk, h1 = (starts[b + 1] + chunk - 1) / chunk;
+    const u32 h0 = (starts[b] - base + chunk - 1) / chunk, h1 = (starts[b + 1] - base + chunk - 1) / chunk;
     const u32 share = (h1 - h0 + kHeavyBlocks - 1) / kHeavyBlocks;
     const u32 lo = h0 + blockIdx.x * share, hi = min(h1, lo + share);
     xyzz9<FB> acc = fold9_quad_gather<FB, H2_FOLD_D>(heads9, hi > lo ? hi - lo : 0u, [lo](u32 k) { return lo + k; });
@@ -1833,9 +1838,12 @@ __global__ void __launch_bounds__(256) msm_rowcol_sums(const u32 *__restrict__ b
 }
 
 // ---- combine: Horner over slices (windows), emit Jacobian / affine; one quad of lanes ---------------
+// extra_dbl / addend / out_kind == kOutSliceSum serve the slice split of a large generic multiexp (msm_launch): the UPPER group of
+// slices is summed by Horner, doubled extra_dbl = c x (slices below it) more times and left as XYZZ (32 words); the lower group's
+// call then adds that point (`addend`) to its own Horner sum and emits the result.
 template <int FB>
 __global__ void __launch_bounds__(64) msm_combine(const u32 *__restrict__ slice_sums, int slices, int c, u32 *__restrict__ out,
-                                                  int out_kind, int out_mont) {
+                                                  int out_kind, int out_mont, int extra_dbl = 0, const u32 *__restrict__ addend = nullptr) {
     H2_LATENCY_STAGE();
     if (threadIdx.x >= kGroup) return;
     // one block: Horner over the slices.  Several blocks (pair commits): block b emits slice b alone as output b.
@@ -1853,8 +1861,14 @@ __global__ void __launch_bounds__(64) msm_combine(const u32 *__restrict__ slice_
         const xyzz9<FB> s9 = xyzz9_from_r256_wide<FB>(xyzz_load<FB>(slice_sums + 32 * (size_t)w));
         xyzz9_add_wide<FB>(r9, s9);
     }
+    for (int k = 0; k < extra_dbl; ++k) r9 = xyzz9_dbl_wide<FB>(r9);
+    if (addend) xyzz9_add_wide<FB>(r9, xyzz9_from_r256_wide<FB>(xyzz_load<FB>(addend)));
     const xyzz<FB> r = xyzz9_to_r256_wide<FB>(r9);
     if (threadIdx.x != 0) return;
+    if (out_kind == kOutSliceSum) {
+        xyzz_store<FB>(out, r);
+        return;
+    }
     if (out_kind == H2_OUT_AFFINE) {
         affine<FB> a = xyzz_to_affine<FB>(r);
         if (!out_mont) { a.x = fe_from_mont<FB>(a.x); a.y = fe_from_mont<FB>(a.y); }
@@ -2254,10 +2268,20 @@ struct MsmContext {
         if (copy_done) (void)hipEventDestroy(copy_done);
         copy_stream = nullptr;
         copy_done = nullptr;
+        if (side) (void)hipStreamDestroy(side);
+        for (hipEvent_t *e : {&ev_fork, &ev_conv, &ev_acc_a, &ev_join}) {
+            if (*e) (void)hipEventDestroy(*e);
+            *e = nullptr;
+        }
+        side = nullptr;
     }
     bool attr_set = false, attr2_set = false, attr_bins_set = false;
     hipStream_t copy_stream = nullptr;      // h2_msm: the bases cross PCIe on this one while the sort runs (null-stream context only)
     hipEvent_t copy_done = nullptr;
+    // the slice split of a large generic multiexp (msm_launch): the upper slices' fold and Horner chain run on `side` beside the lower
+    // slices' accumulate; fork / conv / acc_a / join order the two streams
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_conv = nullptr, ev_acc_a = nullptr, ev_join = nullptr;
     u32 lanes[2][3] = {{0, 0, 0}, {0, 0, 0}};  // resident lanes of msm_accumulate<FP / FQ, plain / GLV> on this device
 };
 
@@ -2404,7 +2428,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     static const bool join_env = [] { const char *e = getenv("H2_BATCH_JOIN"); return !(e && e[0] == '0'); }();
     const bool joined = K > 1 && join_env;
     u32 T = (u32)std::min<size_t>(usable, std::max<size_t>(256, ((joined ? K : 1) * all_items / lane_div + 255) / 256 * 256));
-    const size_t head_slots = joined ? (size_t)T : (size_t)T * K;      // range heads parked in cx.seg9, in front of the K x tb bucket slots
+    size_t head_slots = joined ? (size_t)T : (size_t)T * K;            // range heads parked in cx.seg9, in front of the K x tb bucket slots
     const u32 max_heavy = kMaxHeavy;
     // two-pass sort (registered path): always for windows beyond 16 bits, else for large bucket counts
     Sort2 S2;
@@ -2492,6 +2516,19 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     const bool fold9 = fold9_on && sh.NB >= fold9_min_nb && sh.slices <= 16 && m9 && !a.add_into && !fold_only;      // (16: arrival counters of fold9_planes)
     if (K > 1 && !fold9) return H2_ERR_BATCH_SHAPE;
     if (a.slice_sums_only && !(fold9 && glv)) return H2_ERR_BATCH_SHAPE;
+    // Slice split (round 5; generic multiexps from 2^19 points): the sorted list is ordered by (slice, bucket), so the upper slices
+    // [split_k, slices) and the lower ones [0, split_k) are two contiguous halves of it.  They are accumulated one after the other on
+    // `st`; as soon as the UPPER group is in its buckets its fold and its Horner chain -- (slices - 1) c ~ 128 dependent doublings, 0.25 ms
+    // on one quad of lanes, which used to follow the whole accumulate -- run on a side stream beside the lower group's accumulate and
+    // fold.  What is left behind the accumulate: the lower group's fold, (split_k - 1) c doublings and one addition.  The bases'
+    // conversion to M9 form runs on the side stream beside the sort.  H2_GENERIC_SPLIT=0: off (A/B); = k: force the lower group's size.
+    static const int split_env = [] { const char *e = getenv("H2_GENERIC_SPLIT"); return e ? atoi(e) : -1; }();
+    int split_k = 0;
+    if (glv && fold9 && m9 && a.phase == 0 && !a.slice_sums_only && K == 1 && sh.slices >= 6 && split_env != 0 && !prof_enabled() && !timeline_on()) {
+        if (split_env > 0) split_k = std::min<int>(split_env, (int)sh.slices - 2);
+        else if (scalars_n >= ((size_t)1 << 19)) split_k = 3;
+    }
+    if (split_k) head_slots = 2 * (size_t)T;               // each group's T range heads
     // pass 2 of the two-pass sort in its one-launch form (a workgroup per pass-1 bin)?  Decided here, before anything is launched,
     // because a column-batched commit exists in that form only.
     bool s2_bins_form = false;
@@ -2541,8 +2578,8 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     if ((rc = cx.bsums.reserve((size_t)(nblocks + 4) * 4)) != H2_OK) return rc;
     if ((rc = cx.entries.reserve((size_t)K * all_items * 4)) != H2_OK) return rc;
     if ((rc = cx.heads.reserve((size_t)std::max<size_t>(T, (size_t)sh.slices * 32) * 128)) != H2_OK) return rc;
-    if ((rc = cx.heavy.reserve((size_t)K * (max_heavy + 2) * 4)) != H2_OK) return rc;
-    if ((rc = cx.hscratch.reserve((size_t)K * max_heavy * kHeavyBlocks * 144)) != H2_OK) return rc;
+    if ((rc = cx.heavy.reserve((size_t)(split_k ? 2 : K) * (max_heavy + 2) * 4)) != H2_OK) return rc;
+    if ((rc = cx.hscratch.reserve((size_t)(split_k ? 2 : K) * max_heavy * kHeavyBlocks * 144)) != H2_OK) return rc;
     if ((rc = cx.buckets.reserve((size_t)tb * 128)) != H2_OK) return rc;
     if ((rc = cx.partial.reserve(std::max(wide_reduce ? ((size_t)2 * wideNR / kSeg + 2 * wideNR) * 128 : (size_t)segs * 128,
                                           fold9 ? (size_t)K * sh.slices * (wideS + wideNR + 32) * 144 : (size_t)0))) != H2_OK) return rc;
@@ -2578,7 +2615,11 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         cs.planes = sh.slices * 32 * 36;
         cs.ctr = 16;
     }
-    if ((rc = cx.ssums.reserve((size_t)std::max<u32>(sh.slices, 2) * 128)) != H2_OK) return rc;
+    if ((rc = cx.ssums.reserve((size_t)(std::max<u32>(sh.slices, 2) + 1) * 128)) != H2_OK) return rc;      // (+ 1: the upper group's weighted sum of a slice split)
+    if (split_k && !cx.side) {
+        H2_HIP(hipStreamCreateWithFlags(&cx.side, hipStreamNonBlocking));
+        for (hipEvent_t *e : {&cx.ev_fork, &cx.ev_conv, &cx.ev_acc_a, &cx.ev_join}) H2_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
     const u32 m32 = (u32)m;
     u32 *grand = cx.bsums.as<u32>() + nblocks;
     const u32 tl_id = (u32)(((uintptr_t)st >> 4) & 0xFFFF) << 8;
@@ -2592,6 +2633,14 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     const u32 max_big = all_items >= ((size_t)3 << 20) ? kMaxBig : 0u;
     if (!fold_only) {
     TL_STAMP(tl_id | 1);
+    if (split_k) {          // the bases' conversion (it reads nothing the sort writes) on the side stream, beside the sort
+        if ((rc = cx.bases9.reserve((size_t)scalars_n * 128 + 64)) != H2_OK) return rc;
+        H2_HIP(hipEventRecord(cx.ev_fork, st));
+        H2_HIP(hipStreamWaitEvent(cx.side, cx.ev_fork, 0));
+        hipLaunchKernelGGL((msm_bases_to_m9_glv<FB>), dim3(((u32)scalars_n + 255) / 256), dim3(256), 0, cx.side, (const u32 *)a.d_bases,
+                           cx.bases9.as<u32>(), (u32)scalars_n);
+        H2_HIP(hipEventRecord(cx.ev_conv, cx.side));
+    }
     if (a.phase < 2) prof_begin(PROF_MSM_SORT, st);          // (phases >= 2 resume behind a sort the phase-1 call enqueued and timed)
     const u32 extra_col = a.d_extra_scalar ? (a.table ? a.extra_col : (u32)a.n_used) : 0xFFFFFFFFu;
     if (a.phase >= 2) {
@@ -2724,6 +2773,51 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
             if ((rc = cx.seg9.reserve((head_slots + (size_t)K * tb) * 144)) != H2_OK) return rc;
         }
         prof_end(PROF_MSM_SORT, st);
+        H2_HIP(hipGetLastError());
+        return H2_OK;
+    }
+    if (split_k) {
+        if ((rc = cx.seg9.reserve((head_slots + (size_t)tb) * 144)) != H2_OK) return rc;
+        u32 *heads_b = cx.seg9.as<u32>(), *heads_a = heads_b + 36 * (size_t)T, *buckets9 = cx.seg9.as<u32>() + 36 * head_slots;
+        if (!zero_in_sort) H2_HIP(hipMemsetAsync(buckets9, 0, (size_t)tb * 144, st));
+        const u32 kb = (u32)split_k * sh.NB, tb_a = tb - kb, ns_a = sh.slices - (u32)split_k;       // buckets of the lower group; buckets / slices of the upper one
+        u32 *heavy_b = cx.heavy.as<u32>(), *heavy_a = heavy_b + (max_heavy + 2);
+        u32 *hscr_b = cx.hscratch.as<u32>(), *hscr_a = hscr_b + (size_t)max_heavy * kHeavyBlocks * 36;
+        if (!use_sort2) H2_HIP(hipMemsetAsync(heavy_b, 0, 8, st));
+        H2_HIP(hipMemsetAsync(heavy_a, 0, 8, st));
+        H2_HIP(hipStreamWaitEvent(st, cx.ev_conv, 0));
+        const u32 *pts = cx.bases9.as<u32>(), *starts = cx.starts.as<u32>();
+        u32 *lines9 = cx.partial.as<u32>(), *planes9 = lines9 + 36 * (size_t)sh.slices * (wideS + wideNR), *ssums = cx.ssums.as<u32>();
+        int cb = 0;
+        while ((1u << cb) < wideS) ++cb;
+        const bool mont = a.form == H2_FORM_MONTGOMERY;
+        // the upper slices first, then the lower ones
+        hipLaunchKernelGGL((msm_accumulate<FB, false, true>), dim3(T / 256), dim3(256), 0, st, pts, (const u32 *)nullptr, 0xFFFFFFFFu, cx.entries.as<u32>(),
+                           starts + kb, heads_a, buckets9 + 36 * (size_t)kb, tb_a, T, lane_div, cs);
+        H2_HIP(hipEventRecord(cx.ev_acc_a, st));
+        hipLaunchKernelGGL((msm_accumulate<FB, false, true>), dim3(T / 256), dim3(256), 0, st, pts, (const u32 *)nullptr, 0xFFFFFFFFu, cx.entries.as<u32>(),
+                           starts, heads_b, buckets9, kb, T, lane_div, cs);
+        // a group's fold down to its slice sums: finish (range heads into their buckets), the heavy buckets, line sums, planes
+        auto fold_group = [&](hipStream_t s_, const u32 *heads9, const u32 *gstarts, u32 *gbuckets, u32 *heavy, u32 *hscr, u32 gtb, u32 slice0, u32 nslices) {
+            hipLaunchKernelGGL((fold9_finish<FB>), dim3((gtb + 255) / 256), dim3(256), 0, s_, heads9, gstarts, gbuckets, heavy, gtb, T, lane_div, cs);
+            hipLaunchKernelGGL((fold9_finish_heavy<FB>), dim3(kHeavyBlocks, max_heavy), dim3(256), 0, s_, heads9, gstarts, hscr, (const u32 *)heavy, gtb, T, lane_div, cs);
+            hipLaunchKernelGGL((fold9_finish_heavy2<FB>), dim3(max_heavy), dim3(64), 0, s_, (const u32 *)hscr, gbuckets, (const u32 *)heavy, cs);
+            hipLaunchKernelGGL((fold9_rowcol<FB>), dim3(wideS + wideNR - 1, nslices), dim3(256), 0, s_, (const u32 *)gbuckets, lines9 + 36 * (size_t)slice0 * (wideS + wideNR),
+                               wideS, wideNR, cs);
+            hipLaunchKernelGGL((fold9_planes<FB>), dim3(sh.c - 1, nslices), dim3(256), 0, s_, (const u32 *)(lines9 + 36 * (size_t)slice0 * (wideS + wideNR)),
+                               planes9 + 36 * (size_t)slice0 * 32, cx.fold_ctr.as<u32>() + slice0, wideS, wideNR, cb, ssums + 32 * (size_t)slice0, kOutSliceSum, mont, co, cs);
+        };
+        // upper group on the side stream: fold, Horner over its slices, split_k c more doublings -> one weighted point behind the slice sums
+        H2_HIP(hipStreamWaitEvent(cx.side, cx.ev_acc_a, 0));
+        fold_group(cx.side, heads_a, starts + kb, buckets9 + 36 * (size_t)kb, heavy_a, hscr_a, tb_a, (u32)split_k, ns_a);
+        hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, cx.side, (const u32 *)(ssums + 32 * (size_t)split_k), (int)ns_a, sh.c, ssums + 32 * (size_t)sh.slices,
+                           kOutSliceSum, 1, split_k * sh.c, (const u32 *)nullptr);
+        H2_HIP(hipEventRecord(cx.ev_join, cx.side));
+        // lower group behind its accumulate, then the two halves meet
+        fold_group(st, heads_b, starts, buckets9, heavy_b, hscr_b, kb, 0u, (u32)split_k);
+        H2_HIP(hipStreamWaitEvent(st, cx.ev_join, 0));
+        hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, (const u32 *)ssums, split_k, sh.c, (u32 *)a.d_out, a.out_kind, mont ? 1 : 0, 0,
+                           (const u32 *)(ssums + 32 * (size_t)sh.slices));
         H2_HIP(hipGetLastError());
         return H2_OK;
     }
