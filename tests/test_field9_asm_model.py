@@ -247,11 +247,16 @@ def _reference_network(a, omega, log_n, p):
     return a
 
 
-@pytest.mark.parametrize("field", [0, 1])
-def test_ntt_pass_limb_model_against_reference_network(field):
+@pytest.mark.parametrize("field,L", [(0, 10), (1, 10), (0, 11), (1, 11), (0, 12)])
+def test_ntt_pass_limb_model_against_reference_network(field, L):
+    """L = 10: the shipped 10-stage pass.  L = 11 / 12 (round 5): the 11- and 12-stage passes behind H2_NTT_MAXR -- an ODD stage count opens
+    with a radix-2 round on four elements per lane (the transform's first stage multiplies by omega^0 only: four loads, four additions),
+    the radix-4 rounds then start at stage 1 and have no omega^0 shortcuts; six rounds of products instead of five must still leave
+    |value| < 2^260 and |q| <= 64 for the fold.  The last step is ntt_canonical_folded9 as round 5 writes it: the folded value packed as a
+    256-bit two's-complement word, p added by an 8-word carry chain exactly when bit 255 is set."""
     p = P[field]
-    L, n = 10, 1 << 10
-    rng = random.Random(0x70A55 + field)
+    n = 1 << L
+    rng = random.Random(0x70A55 + field + 97 * L)
     mul = _statement("field9_mul.inc")
     omega = rng.randrange(2, p)                                    # any field element: the network is the contract, not the DFT
     data = [rng.randrange(0, p) for _ in range(n)]
@@ -259,6 +264,7 @@ def test_ntt_pass_limb_model_against_reference_network(field):
     want = _reference_network(data, omega, L, p)
     R9 = pow(2, 261, p)
     plimbs = [(p >> (29 * i)) & M29 for i in range(8)] + [p >> 232]
+    pwords = [(p >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
 
     def tw(e):                                                     # omega^e in M9 form, normalised limbs (ntt_twiddles9)
         v = pow(omega, e, p) * R9 % p
@@ -279,7 +285,15 @@ def test_ntt_pass_limb_model_against_reference_network(field):
     # first pass: LDS row `row` holds input element bitrev(row) (the bit reversal is folded into the gather)
     rev = lambda k: int(format(k, f"0{L}b")[::-1], 2)
     x = [[(data[rev(k)] >> (29 * i)) & M29 for i in range(8)] + [data[rev(k)] >> 232] for k in range(n)]     # fe9_unpack
-    for u in range(0, L, 2):                                       # round u: stages t = u and u + 1
+    u0 = 0
+    if L & 1:                                                      # odd stage count: stage 0 as a radix-2 round, no products (omega^0)
+        nxt = list(x)
+        for base in range(0, n, 2):
+            nxt[base], nxt[base + 1] = _i32(add(x[base], x[base + 1])), _i32(sub(x[base], x[base + 1]))
+            assert raw_ok(nxt[base]) and raw_ok(nxt[base + 1])
+        x = nxt
+        u0 = 1
+    for u in range(u0, L, 2):                                      # round u: stages t = u and u + 1
         t = u
         nxt = list(x)
         for base in range(n):
@@ -304,7 +318,7 @@ def test_ntt_pass_limb_model_against_reference_network(field):
                 assert raw_ok(o), o                                # RAW: limbs in (-2^30, 3 x 2^29)
                 max_abs_value = max(max_abs_value, abs(_value(o)))
         x = nxt
-    assert max_abs_value < 1 << 260                                # five rounds of two products each, absorbed by limb 8
+    assert max_abs_value < 1 << 260                                # two products per radix-4 round (one for the radix-2 round), absorbed by limb 8
     assert peak_all < 1 << 63
     got = []
     for k in range(n):
@@ -318,11 +332,21 @@ def test_ntt_pass_limb_model_against_reference_network(field):
             c = tq >> 29
         qp.append(q * plimbs[8] + c)
         f = _norm(_i32(sub(v, qp)))
-        assert abs(_value(f)) < (1 << 253) + (1 << 133)
-        neg = f[8] >> 31                                           # ntt_canonical_folded9: add p exactly when negative, ONE carry pass
-        g = _norm([f[i] + (plimbs[i] if neg else 0) for i in range(9)])
-        val = _value(g)
-        assert 0 <= val < p and all(0 <= y < (1 << 29) for y in g[:8]) and 0 <= g[8] < (1 << 24)
+        fv = _value(f)
+        assert abs(fv) < (1 << 253) + (1 << 133)
+        # ntt_canonical_folded9: fe9_pack of the normalised limbs IS the 256-bit two's-complement word; bit 255 selects + p, one carry chain
+        words = [((fv % (1 << 256)) >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+        packed = sum(((f[i] % (1 << 32)) << (29 * i)) for i in range(8)) + ((f[8] % (1 << 32)) << 232)        # shifts and ors of the limbs
+        assert packed % (1 << 256) == fv % (1 << 256)
+        neg = words[7] >> 31
+        assert neg == (1 if fv < 0 else 0)
+        out, carry = [], 0
+        for i in range(8):
+            t_ = words[i] + (pwords[i] if neg else 0) + carry
+            out.append(t_ & 0xFFFFFFFF)
+            carry = t_ >> 32
+        val = sum(w << (32 * i) for i, w in enumerate(out))
+        assert 0 <= val < p
         got.append(val)
     assert got == want
 

@@ -55,9 +55,10 @@ def test_accumulate_keeps_its_registers_and_its_instruction_count(listings, curv
         assert not any(op.startswith("scratch_") for op in c), (lbl, [op for op in c if op.startswith("scratch_")])
 
 
-@pytest.mark.parametrize("r,first", [(10, "true"), (10, "false"), (8, "true"), (8, "false"), (6, "false")])
+@pytest.mark.parametrize("r,first", [(10, "true"), (10, "false"), (8, "true"), (8, "false"), (6, "false"), (7, "false"), (11, "true"), (11, "false"), (12, "false")])
 def test_ntt_passes_keep_four_waves_per_simd(listings, r, first):
-    """ntt_pass9<F, R, FIRST>: 1024 lanes per tile = four waves per SIMD needs <= 128 VGPRs, and nothing may spill."""
+    """ntt_pass9<F, R, FIRST>: 1024 lanes per tile = four waves per SIMD needs <= 128 VGPRs, and nothing may spill.  (7: an odd stage count
+    of the default plans, 2^21 = 8 + 6 + 7; 11 and 12: the round-5 passes behind H2_NTT_MAXR, which open with a radix-2 round when odd.)"""
     for field in (0, 1):
         res, blocks = _kernel(listings, "ntt.hip", f"ntt_pass9<{field}, {r}, {first}>")
         assert res["NumVgprs"] <= 128 and res["ScratchSize"] == 0 and res["Occupancy"] >= 4, (field, res)
