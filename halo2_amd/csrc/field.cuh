@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "field_inv.cuh"
+
 namespace h2 {
 
 typedef uint32_t u32;
@@ -370,8 +372,9 @@ template <int F> __device__ __forceinline__ fe fe_redc(const fe &a) {
     return fe_reduce_once<F>(r);                                               // (a + (R - 1) p) / R < p + 1
 }
 
-// a^(p-2); used only for the handful of Jacobian -> affine conversions
-template <int F> __device__ fe fe_inv(const fe &a) {
+// a^(p-2) by square-and-multiply: ~256 squarings + ~80 products on the calling lane's dependent chain (~84 000 instructions).  Kept as the
+// A/B arm (-DH2_FE_INV_FERMAT=1) of fe_inv below.
+template <int F> __device__ fe fe_inv_fermat(const fe &a) {
     // exponent p - 2 = [0xffffffff, P1 - 1, P2, P3, 0, 0, 0, 2^30] (p0 = 1 borrows from P1)
     const u32 e[8] = {0xffffffffu, Mod<F>::P1 - 1, Mod<F>::P2, Mod<F>::P3, 0, 0, 0, P7};
     fe acc = fe_one<F>();
@@ -380,6 +383,26 @@ template <int F> __device__ fe fe_inv(const fe &a) {
         if ((e[i >> 5] >> (i & 31)) & 1) acc = fe_mulx<F>(acc, a);
     }
     return acc;
+}
+// 1 / a (Montgomery in, Montgomery out; 0 for 0): the divstep inversion of field_inv.cuh on the Montgomery word (a R)^-1 = a^-1 R^-1, brought
+// back to a^-1 R by two products with R^2.  ~16 000 instructions against the ladder's ~84 000, constant time, no divergence between lanes.
+#ifndef H2_FE_INV_FERMAT
+#define H2_FE_INV_FERMAT 0
+#endif
+template <int F> __device__ fe fe_inv(const fe &a) {
+#if H2_FE_INV_FERMAT
+    return fe_inv_fermat<F>(a);
+#else
+    u32 p[8], y[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = mod_limb<F>(i);
+    modinv30(a.v, p, y);
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = y[i];
+    const fe r2 = fe_r2<F>();
+    return fe_mulx<F>(fe_mulx<F>(r, r2), r2);
+#endif
 }
 
 // ---- memory access: one field element = 32 B = two 16-B vectors ------------------------------

@@ -291,3 +291,16 @@ def test_library_transcript_matches_hashlib_restatement(curve):
         tr.write_point(np.zeros(8, dtype=np.uint64))
     with pytest.raises(ValueError):
         tr.write_point(np.zeros(12, dtype=np.uint64))
+
+
+def test_divstep_inversion_on_the_host():
+    """csrc/field_inv.cuh (fe_inv on the device: Bernstein-Yang divsteps on signed 30-bit limbs) is plain __host__ __device__ integer code:
+    tests/native/modinv_check.cpp compiles the same functions for the CPU and checks x * modinv30(x) = 1 mod p for 2 x 600 values of both
+    Pasta moduli -- 0, 1, 2, p - 1, powers of two and random ones -- with the result in [0, p)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build", "modinv_check")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(root, "tests", "native", "modinv_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "1200 cases, 0 failures" in out.stdout, out.stdout + out.stderr
