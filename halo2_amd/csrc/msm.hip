@@ -1435,6 +1435,7 @@ __global__ void __launch_bounds__(256) msm_finish_buckets(const u32 *__restrict_
 // heavy buckets: kHeavyBlocks workgroups share one bucket's heads (quad-wide adds), then msm_finish_heavy2 folds
 // their partial sums and the bucket's own segment
 static constexpr u32 kHeavyBlocks = 32;
+static constexpr u32 kHeavyRows = 16;     // workgroup rows of the heavy-bucket launches: they walk the list (at most kMaxHeavy long, usually empty)
 template <int FB>
 __global__ void __launch_bounds__(256) msm_finish_heavy(const u32 *__restrict__ heads, const u32 *__restrict__ starts,
                                                         u32 *__restrict__ scratch, const u32 *__restrict__ heavy,
@@ -1616,18 +1617,24 @@ __global__ void __launch_bounds__(256, 3) fold9_finish_heavy(const u32 *__restri
         starts = H2_COLZ(starts, cs.starts);
         scratch9 = H2_COLZ(scratch9, cs.hscratch);
     }
-    if (blockIdx.y >= min(heavy[1], kMaxHeavy)) return;
-    const u32 b = heavy[2 + blockIdx.y];
+    // gridDim.y = kHeavyRows workgroup rows walk the list of heavy buckets (round 5: the launch used to carry one row per POSSIBLE heavy
+    // bucket -- 32 x 512 workgroups that found an empty list and left, ~12 us of dispatch per commit; a column has no heavy bucket
+    // unless it is degenerate, and then a handful)
+    const u32 count = min(heavy[1], kMaxHeavy);
     const u32 base = starts[0];
     const u32 M = starts[total_buckets] - base;
     T = eff_lanes(M, T, div);
     const u32 chunk = max(1u, (M + T - 1) / T);
-    const u32 h0 = (starts[b] - base + chunk - 1) / chunk, h1 = (starts[b + 1] - base + chunk - 1) / chunk;
-    const u32 share = (h1 - h0 + kHeavyBlocks - 1) / kHeavyBlocks;
-    const u32 lo = h0 + blockIdx.x * share, hi = min(h1, lo + share);
-    xyzz9<FB> acc = fold9_quad_gather<FB, H2_FOLD_D>(heads9, hi > lo ? hi - lo : 0u, [lo](u32 k) { return lo + k; });
-    acc = fold9_quads_sum<FB>(acc, sh);
-    if (fold9_root() && (threadIdx.x & (kGroup - 1)) == 0) xyzz9_store_raw<FB>(scratch9 + 36 * ((size_t)blockIdx.y * kHeavyBlocks + blockIdx.x), acc);
+    for (u32 slot = blockIdx.y; slot < count; slot += gridDim.y) {
+        const u32 b = heavy[2 + slot];
+        const u32 h0 = (starts[b] - base + chunk - 1) / chunk, h1 = (starts[b + 1] - base + chunk - 1) / chunk;
+        const u32 share = (h1 - h0 + kHeavyBlocks - 1) / kHeavyBlocks;
+        const u32 lo = h0 + blockIdx.x * share, hi = min(h1, lo + share);
+        xyzz9<FB> acc = fold9_quad_gather<FB, H2_FOLD_D>(heads9, hi > lo ? hi - lo : 0u, [lo](u32 k) { return lo + k; });
+        acc = fold9_quads_sum<FB>(acc, sh);
+        if (fold9_root() && (threadIdx.x & (kGroup - 1)) == 0) xyzz9_store_raw<FB>(scratch9 + 36 * ((size_t)slot * kHeavyBlocks + blockIdx.x), acc);
+        __syncthreads();                                 // `sh` is reused by the next bucket's tree
+    }
 }
 template <int FB>
 __global__ void __launch_bounds__(64, 3) fold9_finish_heavy2(const u32 *__restrict__ scratch9, u32 *__restrict__ buckets9, const u32 *__restrict__ heavy,
@@ -1639,15 +1646,18 @@ __global__ void __launch_bounds__(64, 3) fold9_finish_heavy2(const u32 *__restri
         scratch9 = H2_COLZ(scratch9, cs.hscratch);
         buckets9 = H2_COLZ(buckets9, cs.buckets);
     }
-    if (blockIdx.x >= min(heavy[1], kMaxHeavy)) return;
-    // 16 quads: two partials each, a 4-level tree, then the bucket's own segment (6 dependent additions)
-    const u32 b = heavy[2 + blockIdx.x];
-    const u32 *src = scratch9 + 36 * ((size_t)blockIdx.x * kHeavyBlocks);
-    xyzz9<FB> acc = fold9_quad_gather<FB, H2_FOLD_D>(src, kHeavyBlocks, [](u32 k) { return k; });
-    acc = fold9_quads_sum<FB>(acc, sh);
-    if (fold9_root()) {
-        xyzz9_add_wide<FB>(acc, xyzz9_load_raw<FB>(buckets9 + 36 * (size_t)b));
-        if ((threadIdx.x & (kGroup - 1)) == 0) xyzz9_store_raw<FB>(buckets9 + 36 * (size_t)b, acc);
+    const u32 count = min(heavy[1], kMaxHeavy);
+    for (u32 slot = blockIdx.x; slot < count; slot += gridDim.x) {          // (kHeavyRows workgroups walk the list: see fold9_finish_heavy)
+        // 16 quads: two partials each, a 4-level tree, then the bucket's own segment (6 dependent additions)
+        const u32 b = heavy[2 + slot];
+        const u32 *src = scratch9 + 36 * ((size_t)slot * kHeavyBlocks);
+        xyzz9<FB> acc = fold9_quad_gather<FB, H2_FOLD_D>(src, kHeavyBlocks, [](u32 k) { return k; });
+        acc = fold9_quads_sum<FB>(acc, sh);
+        if (fold9_root()) {
+            xyzz9_add_wide<FB>(acc, xyzz9_load_raw<FB>(buckets9 + 36 * (size_t)b));
+            if ((threadIdx.x & (kGroup - 1)) == 0) xyzz9_store_raw<FB>(buckets9 + 36 * (size_t)b, acc);
+        }
+        __syncthreads();
     }
 }
 // row / column sums of the NR x S bucket matrix (see msm_rowcol_sums for the algebra): one workgroup of 64 quads per line,
@@ -2800,8 +2810,8 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         // a group's fold down to its slice sums: finish (range heads into their buckets), the heavy buckets, line sums, planes
         auto fold_group = [&](hipStream_t s_, const u32 *heads9, const u32 *gstarts, u32 *gbuckets, u32 *heavy, u32 *hscr, u32 gtb, u32 slice0, u32 nslices) {
             hipLaunchKernelGGL((fold9_finish<FB>), dim3((gtb + 255) / 256), dim3(256), 0, s_, heads9, gstarts, gbuckets, heavy, gtb, T, lane_div, cs);
-            hipLaunchKernelGGL((fold9_finish_heavy<FB>), dim3(kHeavyBlocks, max_heavy), dim3(256), 0, s_, heads9, gstarts, hscr, (const u32 *)heavy, gtb, T, lane_div, cs);
-            hipLaunchKernelGGL((fold9_finish_heavy2<FB>), dim3(max_heavy), dim3(64), 0, s_, (const u32 *)hscr, gbuckets, (const u32 *)heavy, cs);
+            hipLaunchKernelGGL((fold9_finish_heavy<FB>), dim3(kHeavyBlocks, kHeavyRows), dim3(256), 0, s_, heads9, gstarts, hscr, (const u32 *)heavy, gtb, T, lane_div, cs);
+            hipLaunchKernelGGL((fold9_finish_heavy2<FB>), dim3(kHeavyRows), dim3(64), 0, s_, (const u32 *)hscr, gbuckets, (const u32 *)heavy, cs);
             hipLaunchKernelGGL((fold9_rowcol<FB>), dim3(wideS + wideNR - 1, nslices), dim3(256), 0, s_, (const u32 *)gbuckets, lines9 + 36 * (size_t)slice0 * (wideS + wideNR),
                                wideS, wideNR, cs);
             hipLaunchKernelGGL((fold9_planes<FB>), dim3(sh.c - 1, nslices), dim3(256), 0, s_, (const u32 *)(lines9 + 36 * (size_t)slice0 * (wideS + wideNR)),
@@ -2869,9 +2879,9 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         const u32 fz = joined ? 1 : K, ftb = joined ? K * tb : tb;       // joined columns: one pass over the K x tb buckets
         hipLaunchKernelGGL((fold9_finish<FB>), dim3((ftb + 255) / 256, 1, fz), dim3(256), 0, st, (const u32 *)heads9, cx.starts.as<u32>(), buckets9,
                            cx.heavy.as<u32>(), ftb, T, lane_div, cs);
-        hipLaunchKernelGGL((fold9_finish_heavy<FB>), dim3(kHeavyBlocks, max_heavy, fz), dim3(256), 0, st, (const u32 *)heads9, cx.starts.as<u32>(),
+        hipLaunchKernelGGL((fold9_finish_heavy<FB>), dim3(kHeavyBlocks, kHeavyRows, fz), dim3(256), 0, st, (const u32 *)heads9, cx.starts.as<u32>(),
                            cx.hscratch.as<u32>(), cx.heavy.as<u32>(), ftb, T, lane_div, cs);
-        hipLaunchKernelGGL((fold9_finish_heavy2<FB>), dim3(max_heavy, 1, fz), dim3(64), 0, st, cx.hscratch.as<u32>(), buckets9, cx.heavy.as<u32>(), cs);
+        hipLaunchKernelGGL((fold9_finish_heavy2<FB>), dim3(kHeavyRows, 1, fz), dim3(64), 0, st, cx.hscratch.as<u32>(), buckets9, cx.heavy.as<u32>(), cs);
     } else {
     hipLaunchKernelGGL((msm_finish_buckets<FB>), dim3((tb * kGroup + 255) / 256), dim3(256), 0, st, cx.heads.as<u32>(),
                        cx.starts.as<u32>(), cx.buckets.as<u32>(), cx.heavy.as<u32>(), tb, T, lane_div);
