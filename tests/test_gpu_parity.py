@@ -702,3 +702,25 @@ def test_best_multiexp_host_slices_range_pipeline(curve, canonical, affine):
         if canonical:                              # canonical coordinates out: back to Montgomery limbs for the oracle's reader
             got = co.to_mont(bf, got.reshape(-1, 4)).reshape(-1)
         assert affine_of(curve, got) == affine_of(curve, co.best_multiexp(curve, scal, bases)), rep
+
+
+@pytest.mark.parametrize("env,args", [
+    ({"H2_NTT_MAXR": "11"}, ["ntt", "5,11,13,21,22", "0", "1"]),          # 11-stage passes: 2^21 = 11 + 10, 2^22 = 11 + 11 (odd stage counts open with a radix-2 round)
+    ({"H2_NTT_MAXR": "12"}, ["ntt", "12,23,24", "1", "1"]),               # 12-stage passes on Fq: 2^24 = 12 + 12, one 4096-row column per tile
+    ({"H2_GENERIC_SPLIT": "0", "H2_MSM_HOST_CHUNKS": "1"}, ["msm", "19", "0"]),      # round 4's forms: one accumulate, one piece from host slices
+    ({"H2_GENERIC_SPLIT": "5"}, ["msm", "19", "1"]),                      # another cut of the window slices
+    ({"H2_MSM_HOST_CHUNKS": "5", "H2_MSM_HOST_GRAPHS": "0"}, ["msm", "19", "0"]),    # five ragged ranges, plain launches
+    ({"H2_MSM_HOST_CHUNKS": "2", "H2_MSM_HOST_THREAD": "1"}, ["msm", "20", "1"]),    # two ranges, captured sequences replayed from a helper thread
+])
+def test_switched_forms_keep_parity(env, args):
+    """The A/B arms this round left behind switches (read once per process, so each runs in the native driver): every one of them is the same
+    mathematics and must stay bit-exact against the C oracle -- the 11- and 12-stage NTT passes that the default plan does not use, the
+    generic multiexp without its slice split or with another cut, the host-slice multiexp in one piece, in ragged ranges with plain
+    launches, and with the runtime calls made by a helper thread."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "h2bench")
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} not built (run __graft_entry__.build())")
+    out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert out.returncode == 0 and "H2BENCH OK" in out.stdout and "FAIL" not in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
