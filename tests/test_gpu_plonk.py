@@ -162,3 +162,39 @@ def test_two_circuit_instances_in_one_proof():
     create_proof(params, pk, advice_a, inst_a, _rng(sf, 7300), single)
     assert len(proof) > len(single.finalize())
     params.close()
+
+
+@pytest.mark.parametrize("k", [16, 20])
+def test_create_proof_bytes_equal_the_restated_prover_golden(k):
+    """Whole-proof BYTES at the sizes where the opening argument switches generators (k >= 16) and at BASELINE configs[3]'s k = 20: the
+    device prover against the proof the restated prover (oracle/plonk.py, sequential, C-backed) wrote for the same seeded inputs -- minutes to
+    tens of minutes of CPU, so it was run once (oracle/make_plonk_proof_fixture.py, committed beside its output tests/golden/plonk_proof_k*.json)
+    and the test rebuilds the inputs from the same seeds.  Every commitment, evaluation and opening round of the proof is in those bytes."""
+    import hashlib
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "plonk_proof_k%d.json" % k)
+    if not os.path.exists(path):
+        pytest.skip("no golden proof at k = %d (oracle/make_plonk_proof_fixture.py %d)" % (k, k))
+    gold = json.load(open(path))
+    curve = h.VESTA
+    sf = fields.CURVE_FIELDS[curve][1]
+    m = fields.MODULUS[sf]
+    n = 1 << k
+    cs = _cs()
+    usable = n - (cs.blinding_factors + 1)
+    fixed, advice, mapping, instances = _witness(random.Random(k), m, n, usable)
+    g = co.generate_bases(curve, 970 + k, n)
+    w, u = co.generate_bases(curve, 60, 1)[0], co.generate_bases(curve, 61, 1)[0]
+    params = h.Params.from_generators(curve, k, g, None, w, u)
+    vk_repr = int(gold["vk_repr"], 16)
+    assert vk_repr == 0x1234567890ABCDEF ** 3 % m and gold["rng_seed"] == 7000
+    pk = keygen_pk(params, cs, fixed, mapping, vk_repr)
+    tr = Blake2bWrite(curve)
+    create_proof(params, pk, advice, instances, _rng(sf, gold["rng_seed"]), tr)
+    proof = tr.finalize()
+    assert hashlib.sha256(bytes.fromhex(gold["proof_hex"])).hexdigest() == gold["proof_sha256"]
+    assert proof.hex() == gold["proof_hex"]
+    dvk = hv.keygen_vk(params, pk)
+    assert hv.verify_proof(params, dvk, instances, proof)
+    params.close()
