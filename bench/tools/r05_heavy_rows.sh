@@ -1,3 +1,6 @@
+#!/bin/bash
+# Round 5: after the heavy-bucket launches were cut to 16 workgroup rows -- the degenerate-column / parity / proof-byte tests, the opening argument at k = 20
+# (bench/tools/opening_probe.py) and two small-commit timings (profiles/r05_opening_k20.txt).
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out/r05_heavy
 {
 timeout 900 python -m pytest tests/test_gpu_column_tables.py tests/test_gpu_parity.py tests/test_gpu_opening.py -x -q 2>&1 | tail -3

@@ -1,3 +1,6 @@
+#!/bin/bash
+# Round 5: rocprofv3 kernel + memory-copy trace of build/h2bench msm 20 with four ranges (H2_MSM_HOST_CHUNKS=4): the timeline of one h2_msm call from host slices
+# (profiles/r05_h2_msm_host_ranges.txt prints it).  No --pmc beside the trace domains.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/r05_host/trace
