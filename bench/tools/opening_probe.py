@@ -24,8 +24,8 @@ def main():
     dev = torch.device("cuda:0")
     g = co.generate_bases(curve, 1, n)
     w, u = co.generate_bases(curve, 2, 1)[0], co.generate_bases(curve, 3, 1)[0]
-    res = {"k": k}
-    for m in (12, 13, 15, 17):
+    res = {"k": k, "form": "h2_open_device (one call)" if os.environ.get("NATIVE", "1") != "0" else "step by step from Python + h2_ipa_rounds_device"}
+    for m in ((12, 13, 15, 17) if os.environ.get("TABLES", "1") != "0" else ()):
         if m > k:
             continue
         t0 = time.perf_counter()
@@ -71,7 +71,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         create_proof(params, rng, tr, d_px, blind, x, schedule=os.environ.get("SCHEDULE") or None,
-                     hybrid_rounds=int(os.environ["HYBRID"]) if "HYBRID" in os.environ else None)
+                     hybrid_rounds=int(os.environ["HYBRID"]) if "HYBRID" in os.environ else None, native=os.environ.get("NATIVE", "1") != "0")
         torch.cuda.synchronize()
         t1 = time.perf_counter()
     res["total_ms"] = round((t1 - t0) * 1e3, 3)

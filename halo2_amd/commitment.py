@@ -68,6 +68,34 @@ def hash_to_curve(curve: int, domain_prefix: str, messages, form: int = FORM_MON
     return out
 
 
+def _transcript_callbacks(transcript):
+    """write_point / squeeze of the opening argument's native calls over `transcript`: (cb_w, cb_s, user, failures).  A transcript of
+    the library (halo2_amd.transcript, a `handle` attribute) is called natively, no Python in between; any other object through
+    ctypes callbacks whose exceptions are parked in `failures` (an exception must not unwind through the C frames)."""
+    from ._lib import IPA_SQUEEZE_FN, IPA_WRITE_POINT_FN
+    failure = []
+    if getattr(transcript, "handle", 0):
+        return (C.cast(lib().h2_transcript_cb_write_point, IPA_WRITE_POINT_FN), C.cast(lib().h2_transcript_cb_squeeze, IPA_SQUEEZE_FN),
+                C.c_void_p(transcript.handle), failure)
+
+    def write_point(_user, xy):
+        try:
+            transcript.write_point(np.ctypeslib.as_array(xy, shape=(8,)).copy())
+            return 0
+        except Exception as e:
+            failure.append(e)
+            return 1
+
+    def squeeze(_user, out):
+        try:
+            np.ctypeslib.as_array(out, shape=(4,))[:] = np.asarray(transcript.squeeze_challenge_scalar(), dtype=np.uint64).reshape(4)
+            return 0
+        except Exception as e:
+            failure.append(e)
+            return 1
+    return IPA_WRITE_POINT_FN(write_point), IPA_SQUEEZE_FN(squeeze), None, failure
+
+
 class Params:
     def __init__(self, curve: int, k: int, g, g_lagrange, w, u):
         self.curve, self.k, self.n = curve, k, 1 << k
@@ -271,7 +299,7 @@ class Params:
         hybrid_rounds = J > 0: the first J rounds run over the original generators, then the library reads G'_J off the
         registered table and runs the remaining k - J rounds over it (None: the library's choice)."""
         import torch
-        from ._lib import IPA_SQUEEZE_FN, IPA_SWITCH_DEFAULT, IPA_WRITE_POINT_FN
+        from ._lib import IPA_SWITCH_DEFAULT
         n, k = self.n, self.k
         if d_p.shape[0] != n or d_b.shape[0] != n or not d_p.is_contiguous() or not d_b.is_contiguous():
             raise ValueError("opening_rounds: p' and b must hold n scalars")
@@ -281,29 +309,7 @@ class Params:
         J = IPA_SWITCH_DEFAULT if hybrid_rounds is None else int(hybrid_rounds)
         if J != IPA_SWITCH_DEFAULT and (J < 0 or J >= k or J > 12 or (J and not paired)):
             raise ValueError("opening_rounds: hybrid_rounds must be in [0, min(k - 1, 12)] and needs the paired schedule")
-        failure = []
-        if getattr(transcript, "handle", 0):
-            # a transcript of the library (halo2_amd.transcript): the loop calls it natively, no Python in between
-            cb_w = C.cast(lib().h2_transcript_cb_write_point, IPA_WRITE_POINT_FN)
-            cb_s = C.cast(lib().h2_transcript_cb_squeeze, IPA_SQUEEZE_FN)
-            user = C.c_void_p(transcript.handle)
-        else:
-            def write_point(_user, xy):
-                try:
-                    transcript.write_point(np.ctypeslib.as_array(xy, shape=(8,)).copy())
-                    return 0
-                except Exception as e:                      # an exception must not unwind through the C frames
-                    failure.append(e)
-                    return 1
-
-            def squeeze(_user, out):
-                try:
-                    np.ctypeslib.as_array(out, shape=(4,))[:] = np.asarray(transcript.squeeze_challenge_scalar(), dtype=np.uint64).reshape(4)
-                    return 0
-                except Exception as e:
-                    failure.append(e)
-                    return 1
-            cb_w, cb_s, user = IPA_WRITE_POINT_FN(write_point), IPA_SQUEEZE_FN(squeeze), None
+        cb_w, cb_s, user, failure = _transcript_callbacks(transcript)
         col_l = torch.empty((n + (4 if paired else 2), 4), dtype=torch.int64, device=dev)
         col_r = None if paired else torch.empty((n + 2, 4), dtype=torch.int64, device=dev)
         c = np.zeros(4, dtype=np.uint64)
@@ -315,6 +321,47 @@ class Params:
         if failure:
             raise failure[0]
         check(rc, "h2_ipa_rounds_device")
+        return c, f
+
+    def open(self, p_poly, p_blind: Blind, x_3, s_poly, s_blind: Blind, rands, transcript, paired: bool, hybrid_rounds: int | None = None):
+        """`commitment::create_proof` (poly/commitment/prover.rs:26-151) between its rng and its transcript as ONE native call
+        (h2_open_device / h2_open): the commitment to s_poly, xi and z, P', b, v and the whole round loop.  p_poly, s_poly: both
+        (n, 4) CUDA tensors (s_poly is consumed: it becomes p' and is folded in place) or both host arrays; s_poly, s_blind, rands
+        (2k scalars): the randomness in the reference's order.  Returns (c, f), the two scalars the caller writes last (:146-148)."""
+        from ._lib import IPA_SWITCH_DEFAULT
+        n, k = self.n, self.k
+        rands = np.ascontiguousarray(rands, dtype=np.uint64).reshape(2 * k, 4)
+        x3 = np.ascontiguousarray(x_3, dtype=np.uint64).reshape(4)
+        pb = np.ascontiguousarray(p_blind.value, dtype=np.uint64).reshape(4)
+        sb = np.ascontiguousarray(s_blind.value, dtype=np.uint64).reshape(4)
+        J = IPA_SWITCH_DEFAULT if hybrid_rounds is None else int(hybrid_rounds)
+        if J != IPA_SWITCH_DEFAULT and (J < 0 or J >= k or J > 12 or (J and not paired)):
+            raise ValueError("open: hybrid_rounds must be in [0, min(k - 1, 12)] and needs the paired schedule")
+        if p_poly.shape[0] != n or s_poly.shape[0] != n:
+            raise ValueError("open: p_poly and s_poly must hold n scalars")
+        cb_w, cb_s, user, failure = _transcript_callbacks(transcript)
+        c = np.zeros(4, dtype=np.uint64)
+        f = np.zeros(4, dtype=np.uint64)
+        uw = np.ascontiguousarray(np.stack([self.u, self.w]), dtype=np.uint64)
+        basis = self._opening_basis(paired)
+        if _is_torch(p_poly) != _is_torch(s_poly):
+            raise ValueError("open: p_poly and s_poly must both be device tensors or both host arrays")
+        if _is_torch(p_poly):
+            self._check_device(p_poly)
+            self._check_device(s_poly)
+            if not p_poly.is_contiguous() or not s_poly.is_contiguous():
+                raise ValueError("open: contiguous tensors, please")
+            rc = lib().h2_open_device(self.curve, k, self._h_g, basis, 1 if paired else 0, J, _p(uw), p_poly.data_ptr(), _p(pb), _p(x3),
+                                      s_poly.data_ptr(), _p(sb), _p(rands), cb_w, cb_s, user, _p(c), _p(f), _stream_ptr())
+            name = "h2_open_device"
+        else:
+            pp, sp = _np(p_poly, 4), _np(s_poly, 4)
+            rc = lib().h2_open(self.curve, k, self._h_g, basis, 1 if paired else 0, J, _p(uw), _p(pp), _p(pb), _p(x3), _p(sp), _p(sb), _p(rands),
+                               cb_w, cb_s, user, _p(c), _p(f))
+            name = "h2_open"
+        if failure:
+            raise failure[0]
+        check(rc, name)
         return c, f
 
     def commit_unblinded(self, scalars):

@@ -133,6 +133,13 @@ struct IpaContext {
     h2_bases_t gp_handle = 0;          // the table of the collapsed generators, kept between arguments (rebuilt in place while its shape repeats)
     size_t gp_n = 0;
     int gp_curve = -1;
+    // the whole argument (h2_open_device / h2_open): b, the round loop's column(s), the landing places of host vectors, a few words
+    // { s(x_3), p(x_3), the S commitment, its blind }, a pinned landing pad, and a side stream for what does not wait for xi
+    std::mutex open_mu;
+    DevBuf open_b, open_col, open_s, open_p, open_small;
+    void *open_host = nullptr;
+    hipStream_t open_side = nullptr;
+    hipEvent_t open_ev = nullptr, open_ev2 = nullptr;
     void release_all() {
         naf.release();
         stage.release();
@@ -148,6 +155,20 @@ struct IpaContext {
         gp_handle = 0;
         if (rounds_host) (void)hipHostFree(rounds_host);
         rounds_host = nullptr;
+        std::unique_lock<std::mutex> ol(open_mu, std::try_to_lock);      // (as above: never under a running argument)
+        if (!ol.owns_lock()) return;
+        open_b.release();
+        open_col.release();
+        open_s.release();
+        open_p.release();
+        open_small.release();
+        if (open_host) (void)hipHostFree(open_host);
+        open_host = nullptr;
+        if (open_ev) (void)hipEventDestroy(open_ev);
+        if (open_ev2) (void)hipEventDestroy(open_ev2);
+        open_ev = open_ev2 = nullptr;
+        if (open_side) (void)hipStreamDestroy(open_side);
+        open_side = nullptr;
     }
 };
 static StreamContexts<IpaContext> g_ipa_ctxs;
@@ -405,6 +426,11 @@ __global__ void __launch_bounds__(256) ipa_round_fold(u32 *__restrict__ p, u32 *
     if (h >= s_count) return;
     const fe v = fe_load(s_old + 8 * (size_t)(h >> 1));
     fe_store(s_new + 8 * (size_t)h, (h & 1) ? fe_mulx<F>(v, u) : v);
+}
+
+// a[0] -= *v: the constant coefficient of s_poly / p' after their evaluation at x_3 (prover.rs:51, :72), without a host round trip
+template <int F> __global__ void __launch_bounds__(64) ipa_sub_at0(u32 *__restrict__ a, const u32 *__restrict__ v) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) fe_store(a, fe_sub<F>(fe_load(a), fe_load(v)));
 }
 
 }  // namespace h2
@@ -704,4 +730,136 @@ extern "C" int h2_ipa_rounds(int curve, unsigned k, unsigned switch_rounds, h2_b
     (void)hipFree(d);
     if (e != hipSuccess) { set_last_hip_error(e, __FILE__, __LINE__); return H2_ERR_HIP; }
     return rc;
+}
+
+// ---- the whole opening argument: poly::commitment::prover::create_proof (prover.rs:26-151) as ONE call -----------------------------
+// What a Rust shim replaces is the function, not its loop: the caller draws the randomness (n + 1 + 2k scalars in the reference's
+// order, :45-47, :53, :111-112) and owns the transcript; everything between is here.  With the round loop alone native
+// (h2_ipa_rounds) the C++ host mirror spent 68-71 ms on a k = 20 argument whose device work is 18: two host Horner evaluations
+// of 2^20 coefficients and five 32 MiB vectors across PCIe between host-pointer calls.  Here the vectors cross once (h2_open) or
+// not at all (h2_open_device), the constant-coefficient corrections (:51, :72) are one-lane kernels instead of host round trips,
+// and what does not depend on xi -- b = powers of x_3 (:86-97) and v -- runs while the host normalises and hashes the S
+// commitment.  v: P'(x_3) = xi s(x_3) + p(x_3) with s(x_3) = 0 EXACTLY after :51 (field arithmetic), so v = p(x_3) is
+// evaluated before xi exists and p' is never read a second time.  Same bytes as the reference for the same randomness
+// (tests/test_gpu_opening.py).
+static int open_impl(IpaContext &cx, int curve, unsigned k, h2_bases_t g_basis, h2_bases_t opening_basis, int paired, unsigned switch_rounds,
+                     const uint64_t *uw_xy, const void *d_p, const uint64_t *host_p, const uint64_t *p_blind, const uint64_t *x3, void *d_s,
+                     const uint64_t *s_blind, const uint64_t *rands, h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze, void *user,
+                     uint64_t *c_out, uint64_t *f_out, hipStream_t st) {
+    const int sf = curve == H2_PALLAS ? H2_FQ : H2_FP, bf = curve == H2_PALLAS ? H2_FP : H2_FQ;
+    const size_t n = (size_t)1 << k;
+    int rc;
+    if ((rc = cx.open_b.reserve(n * 32)) != H2_OK || (rc = cx.open_col.reserve((2 * n + 8) * 32)) != H2_OK || (rc = cx.open_small.reserve(256)) != H2_OK) return rc;
+    if (!cx.open_host) H2_HIP(hipHostMalloc(&cx.open_host, 256, hipHostMallocDefault));
+    if (!cx.open_ev) H2_HIP(hipEventCreateWithFlags(&cx.open_ev, hipEventDisableTiming));
+    if (!cx.open_ev2) H2_HIP(hipEventCreateWithFlags(&cx.open_ev2, hipEventDisableTiming));
+    if (!cx.open_side) H2_HIP(hipStreamCreateWithFlags(&cx.open_side, hipStreamNonBlocking));
+    u32 *small = cx.open_small.as<u32>(), *d_s_at = small, *d_v = small + 8, *d_commit = small + 16, *d_blind = small + 40;
+    void *d_b = cx.open_b.ptr;
+    // s_poly gets its root at x_3 (:49-51) and is committed to (:56)
+    if ((rc = h2_eval_polynomial_device(sf, d_s, n, x3, H2_FORM_MONTGOMERY, d_s_at, st)) != H2_OK) return rc;
+    if (sf == H2_FP) hipLaunchKernelGGL((ipa_sub_at0<FP>), dim3(1), dim3(64), 0, st, (u32 *)d_s, (const u32 *)d_s_at);
+    else hipLaunchKernelGGL((ipa_sub_at0<FQ>), dim3(1), dim3(64), 0, st, (u32 *)d_s, (const u32 *)d_s_at);
+    H2_HIP(hipGetLastError());
+    H2_HIP(hipMemcpyAsync(d_blind, s_blind, 32, hipMemcpyHostToDevice, st));
+    if ((rc = h2_commit_device(g_basis, d_s, n, nullptr, d_blind, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_commit, st)) != H2_OK) return rc;
+    u64 *land = (u64 *)cx.open_host;
+    H2_HIP(hipMemcpyAsync(land, d_commit, 96, hipMemcpyDeviceToHost, st));
+    H2_HIP(hipEventRecord(cx.open_ev, st));
+    // beside the commit and the host's part: p_poly's way in (host vectors), b and v on the side stream
+    hipStream_t side = cx.open_side;
+    if (host_p) {
+        if ((rc = cx.open_p.reserve(n * 32)) != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(cx.open_p.ptr, host_p, n * 32, hipMemcpyHostToDevice, side));
+        d_p = cx.open_p.ptr;
+    } else {
+        H2_HIP(hipEventRecord(cx.open_ev2, st));          // a resident p_poly may have been produced on the caller's stream
+        H2_HIP(hipStreamWaitEvent(side, cx.open_ev2, 0));
+    }
+    if ((rc = h2_powers_device(sf, x3, n, H2_FORM_MONTGOMERY, d_b, side)) != H2_OK) return rc;
+    if ((rc = h2_eval_polynomial_device(sf, d_p, n, x3, H2_FORM_MONTGOMERY, d_v, side)) != H2_OK) return rc;
+    H2_HIP(hipEventRecord(cx.open_ev2, side));
+    H2_HIP(hipEventSynchronize(cx.open_ev));
+    {   // .to_affine() (:56), the transcript (:57), xi (:62) and z (:66)
+        const u64 *Z = land + 8;
+        if (host_is_zero(Z)) {
+            (void)hipStreamSynchronize(side);
+            set_last_error_msg("h2_open: the commitment to s_poly is the point at infinity, which a transcript cannot absorb");
+            return H2_ERR_ARGS;
+        }
+        u64 zi[4], i2[4], i3[4], xy[8];
+        host_inv(bf, zi, Z);
+        host_mul(bf, i2, zi, zi);
+        host_mul(bf, i3, i2, zi);
+        host_mul(bf, xy, land, i2);
+        host_mul(bf, xy + 4, land + 4, i3);
+        if ((rc = write_point(user, xy)) != H2_OK) { (void)hipStreamSynchronize(side); return rc; }
+    }
+    u64 xi[4], z[4];
+    if ((rc = squeeze(user, xi)) != H2_OK || (rc = squeeze(user, z)) != H2_OK) { (void)hipStreamSynchronize(side); return rc; }
+    // P' = P - [v] G_0 + [xi] S (:70-73), in place on s_poly
+    H2_HIP(hipStreamWaitEvent(st, cx.open_ev2, 0));
+    if ((rc = h2_scale_add_device(sf, d_s, xi, d_p, n, H2_FORM_MONTGOMERY, st)) != H2_OK) return rc;
+    if (sf == H2_FP) hipLaunchKernelGGL((ipa_sub_at0<FP>), dim3(1), dim3(64), 0, st, (u32 *)d_s, (const u32 *)d_v);
+    else hipLaunchKernelGGL((ipa_sub_at0<FQ>), dim3(1), dim3(64), 0, st, (u32 *)d_s, (const u32 *)d_v);
+    H2_HIP(hipGetLastError());
+    u64 f0[4], t[4], f_delta[4];
+    host_mul(sf, t, s_blind, xi);                                                                      // :74-78
+    host_add(sf, f0, t, p_blind);
+    char *col = cx.open_col.as<char>();
+    rc = h2_ipa_rounds_device(curve, k, switch_rounds, opening_basis, paired, d_s, d_b, z, rands, uw_xy, col, paired ? nullptr : col + (n + 4) * 32,
+                              write_point, squeeze, user, c_out, f_delta, st);
+    if (rc != H2_OK) { (void)hipStreamSynchronize(side); return rc; }
+    host_add(sf, f_out, f0, f_delta);
+    return H2_OK;
+}
+
+static bool open_bad_args(int curve, unsigned k, const uint64_t *p_blind, const uint64_t *x3, const uint64_t *s_blind, const uint64_t *rands,
+                          h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze, uint64_t *c_out, uint64_t *f_out) {
+    return (curve != H2_PALLAS && curve != H2_VESTA) || k < 1 || k > 30 || !p_blind || !x3 || !s_blind || !rands || !write_point || !squeeze ||
+           !c_out || !f_out;
+}
+
+// what can be refused is refused before the S commitment reaches the caller's transcript
+static int open_check_bases(int curve, unsigned k, h2_bases_t g_basis, h2_bases_t opening_basis, int paired) {
+    size_t gn = 0, on = 0;
+    int gc = -1, oc = -1;
+    if (h2_bases_info(g_basis, &gn, nullptr, &gc) != H2_OK || h2_bases_info(opening_basis, &on, nullptr, &oc) != H2_OK) return H2_ERR_HANDLE;
+    const size_t n = (size_t)1 << k;
+    if (gc != curve || oc != curve || gn != n || on != n + (paired ? 4 : 2)) return H2_ERR_ARGS;
+    if (h2_bases_blind_base_set(g_basis) != 1) return H2_ERR_ARGS;             // Params::w must be installed (h2_bases_set_blind_base)
+    return H2_OK;
+}
+
+extern "C" int h2_open_device(int curve, unsigned k, h2_bases_t g_basis, h2_bases_t opening_basis, int paired, unsigned switch_rounds,
+                              const uint64_t *uw_xy, const void *d_p_poly, const uint64_t *p_blind, const uint64_t *x3, void *d_s_poly,
+                              const uint64_t *s_blind, const uint64_t *rands, h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze,
+                              void *user, uint64_t *c_out, uint64_t *f_out, void *stream) {
+    if (open_bad_args(curve, k, p_blind, x3, s_blind, rands, write_point, squeeze, c_out, f_out) || !d_p_poly || !d_s_poly) return H2_ERR_ARGS;
+    int rc = open_check_bases(curve, k, g_basis, opening_basis, paired);
+    if (rc != H2_OK) return rc;
+    if ((rc = ensure_device()) != H2_OK) return rc;
+    IpaContext &cx = g_ipa_ctxs.get((hipStream_t)stream);
+    std::lock_guard<std::mutex> lk(cx.open_mu);
+    return open_impl(cx, curve, k, g_basis, opening_basis, paired, switch_rounds, uw_xy, d_p_poly, nullptr, p_blind, x3, d_s_poly, s_blind, rands,
+                     write_point, squeeze, user, c_out, f_out, (hipStream_t)stream);
+}
+
+// the same from host vectors (what `&Polynomial<C::Scalar, Coeff>` and a Vec of fresh randomness are): both cross PCIe once, p_poly
+// beside the commitment to s_poly; nothing is copied back
+extern "C" int h2_open(int curve, unsigned k, h2_bases_t g_basis, h2_bases_t opening_basis, int paired, unsigned switch_rounds,
+                       const uint64_t *uw_xy, const uint64_t *p_poly, const uint64_t *p_blind, const uint64_t *x3, const uint64_t *s_poly,
+                       const uint64_t *s_blind, const uint64_t *rands, h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze, void *user,
+                       uint64_t *c_out, uint64_t *f_out) {
+    if (open_bad_args(curve, k, p_blind, x3, s_blind, rands, write_point, squeeze, c_out, f_out) || !p_poly || !s_poly) return H2_ERR_ARGS;
+    int rc = open_check_bases(curve, k, g_basis, opening_basis, paired);
+    if (rc != H2_OK) return rc;
+    if ((rc = ensure_device()) != H2_OK) return rc;
+    IpaContext &cx = g_ipa_ctxs.get(nullptr);
+    std::lock_guard<std::mutex> lk(cx.open_mu);
+    const size_t n = (size_t)1 << k;
+    if ((rc = cx.open_s.reserve(n * 32)) != H2_OK) return rc;
+    H2_HIP(hipMemcpyAsync(cx.open_s.ptr, s_poly, n * 32, hipMemcpyHostToDevice, nullptr));
+    return open_impl(cx, curve, k, g_basis, opening_basis, paired, switch_rounds, uw_xy, nullptr, p_poly, p_blind, x3, cx.open_s.ptr, s_blind, rands,
+                     write_point, squeeze, user, c_out, f_out, nullptr);
 }

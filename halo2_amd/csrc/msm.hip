@@ -2990,17 +2990,19 @@ struct Bases {
     bool blind_set = false, blind_host_known = false;
     int blind_form = 0;
     unsigned char blind_host[64] = {0};
+    DevBuf fill_tmp;           // table_fill's staging, kept only by handles that are refilled (bases_refill_device: the opening argument's G' table)
     // The table is owned here: it goes back to the allocator when the LAST reference drops -- h2_bases_free only removes
     // the handle, so a commit another host thread is still enqueueing (it holds the shared_ptr from find_bases) keeps the
     // memory alive, and every error path of h2_bases_register releases what it had allocated.
     ~Bases() {
-        if (!d_table && !d_blind_tmp) return;
+        if (!d_table && !d_blind_tmp && !fill_tmp.ptr) return;
         int cur = 0;
         (void)hipGetDevice(&cur);
         if (cur != device) (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
         if (d_table) (void)hipFree(d_table);
         if (d_blind_tmp) (void)hipFree(d_blind_tmp);
+        fill_tmp.release();
         if (cur != device) (void)hipSetDevice(cur);
     }
 };
@@ -3020,12 +3022,21 @@ static bool bad_common(int curve, int form, int out_kind) {
 }
 
 // fills rows 1..W-1 of the table for columns [first, first + count) from row 0
-static int table_fill(Bases &b, u32 first, u32 count, hipStream_t st) {
+// keep_tmp: the staging stays with the handle (a refilled table pays hipMalloc / hipFree -- ~0.3 ms, and a device synchronisation each -- once)
+static int table_fill(Bases &b, u32 first, u32 count, hipStream_t st, bool keep_tmp = false) {
     if (!count || b.W <= 1) return H2_OK;
     void *tmp = nullptr;
     // worked in slabs so the XYZZ staging stays modest
     const u32 slab = 1u << 18;
-    H2_HIP(hipMalloc(&tmp, (size_t)std::min(count, slab) * (b.W - 1) * 160));      // XYZZ staging + the running products
+    const size_t tmp_bytes = (size_t)std::min(count, slab) * (b.W - 1) * 160;      // XYZZ staging + the running products
+    keep_tmp = keep_tmp && tmp_bytes <= ((size_t)256 << 20);
+    if (keep_tmp) {
+        int rc = b.fill_tmp.reserve(tmp_bytes);
+        if (rc != H2_OK) return rc;
+        tmp = b.fill_tmp.ptr;
+    } else {
+        H2_HIP(hipMalloc(&tmp, tmp_bytes));
+    }
     for (u32 off = 0; off < count; off += slab) {
         u32 cnt = std::min(slab, count - off);
         dim3 g1((cnt + 255) / 256), blk(256);
@@ -3049,7 +3060,7 @@ static int table_fill(Bases &b, u32 first, u32 count, hipStream_t st) {
         else hipLaunchKernelGGL((msm_table_row0_to_m9<FQ>), g0, blk, 0, st, (u32 *)b.d_table, count, first);
     }
     hipError_t e = hipStreamSynchronize(st);
-    (void)hipFree(tmp);
+    if (!keep_tmp) (void)hipFree(tmp);
     if (e != hipSuccess) { set_last_hip_error(e, __FILE__, __LINE__); return H2_ERR_HIP; }
     H2_HIP(hipGetLastError());
     return H2_OK;
@@ -3591,7 +3602,7 @@ int bases_refill_device(h2_bases_t handle, const void *d_bases_xy, size_t n, int
     H2_HIP(hipMemcpyAsync(b->d_table, d_bases_xy, n * 64, hipMemcpyDeviceToDevice, 0));
     if (form == H2_FORM_CANONICAL) to_mont_async(b->curve, (u32 *)b->d_table, n * 2, 0);
     b->blind_set = b->blind_host_known = false;
-    if ((rc = table_fill(*b, 0, (u32)n, 0)) != H2_OK) return rc;
+    if ((rc = table_fill(*b, 0, (u32)n, 0, true)) != H2_OK) return rc;
     H2_HIP(hipStreamSynchronize(0));
     return H2_OK;
 }

@@ -403,11 +403,38 @@ template <int CURVE> inline Affine to_affine(const Jacobian &p) {
 // ---- poly/commitment/prover.rs:26-151 ------------------------------------------------------------------------------
 // create_proof: the opening argument for `p_poly` at `x_3`, written to `transcript`.  rng() -> one uniformly random scalar
 // (C::Scalar::random); it is drawn n + 1 + 2k times in the reference's order (s_poly coefficients, s_poly_blind, then l_j, r_j
-// per round).  The O(n) steps and the round loop run on the GPU through the host-pointer entry points; the proof bytes are the
-// reference's for the same randomness (tests/test_gpu_parity.py::test_native_drivers compares them with the Python mirror's).
+// per round).  Between the rng and the transcript the function is ONE library call (h2_open): the two host vectors cross PCIe
+// once each and nothing comes back but c and f.  (Through round 4 only the round loop was native, h2_ipa_rounds, with host-pointer
+// calls and two host Horner evaluations around it: 68-71 ms at k = 20 against ~19 now; `create_proof_stepwise` keeps that form.)
+// The proof bytes are the reference's for the same randomness (tests/test_gpu_parity.py::test_native_drivers compares them with
+// the Python mirror's).
 template <int CURVE, class Rng>
 inline void create_proof(const Params<CURVE> &params, Rng &&rng, Blake2bWrite<CURVE> &transcript, const std::vector<Fe> &p_poly,
                          const Blind<CURVE> &p_blind, const Fe &x_3) {
+    const size_t n = params.n;
+    const uint32_t k = params.k;
+    if (p_poly.size() != n) throw std::invalid_argument("create_proof: p_poly.len() != params.n");                      // :41
+    std::vector<Fe> s_poly(n);                                                                                         // :44-47
+    for (Fe &c : s_poly) c = rng();
+    const Blind<CURVE> s_poly_blind{rng()};                                                                            // :53
+    std::vector<Fe> rands(2 * (size_t)k);                                                                              // :111-112
+    for (Fe &r : rands) r = rng();
+    bool paired = false;
+    const h2_bases_t basis = params.opening_basis(&paired);
+    const Affine uw[2] = {params.u, params.w};
+    Fe c_final{}, f_final{};
+    check(h2_open(CURVE, k, params.handle_g(), basis, paired ? 1 : 0, H2_IPA_SWITCH_DEFAULT, uw[0].data(), p_poly[0].data(), p_blind.value.data(),
+                  x_3.data(), s_poly[0].data(), s_poly_blind.value.data(), rands[0].data(), h2_transcript_cb_write_point, h2_transcript_cb_squeeze,
+                  (void *)(uintptr_t)transcript.handle(), c_final.data(), f_final.data()), "h2_open");                  // :49-142
+    transcript.write_scalar(c_final);                                                                                  // :146-148
+    transcript.write_scalar(f_final);
+}
+
+// the same argument step by step through the host-pointer entry points, the round loop alone native (the form before h2_open; kept
+// as the A/B arm of `host_mirror_check opening-time` and as a second path to the same bytes)
+template <int CURVE, class Rng>
+inline void create_proof_stepwise(const Params<CURVE> &params, Rng &&rng, Blake2bWrite<CURVE> &transcript, const std::vector<Fe> &p_poly,
+                                  const Blind<CURVE> &p_blind, const Fe &x_3) {
     constexpr int SF = CURVE == H2_PALLAS ? H2_FQ : H2_FP;
     const size_t n = params.n;
     const uint32_t k = params.k;

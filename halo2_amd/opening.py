@@ -13,9 +13,11 @@ Three schedules produce the same L_j, R_j (and so the same proof bytes):
 * "paired" (the default where it applies, n >= 8192): the same scalars, but L_j and R_j have disjoint supports in g (the low /
   high half of every 2^(k-j) block), so they share ONE column and leave ONE sort, ONE bucket accumulation (two bucket slices)
   and one fold per round (`h2_commit_pair_device` over g || u || u || w || w).
-For the last two the whole round loop is one C-ABI call (`h2_ipa_rounds_device`, reached through `Params.opening_rounds`) that
-calls back into the transcript; from k = 16 on it moves to the collapsed generators, read off the registered table, after
-min(k - 14, 5) rounds (`hybrid_rounds`; k = 20: 0.020 s against 0.037 s with every round on the original generators).
+For the last two the whole ARGUMENT is one C-ABI call (`h2_open_device` / `h2_open`, reached through `Params.open`: the commitment
+to s_poly, xi and z, P', b, v and the round loop between the caller's rng and the caller's transcript); `native=False` keeps the
+earlier form for A/B -- the steps before the loop from here, the loop alone native (`h2_ipa_rounds_device`, `Params.opening_rounds`).
+From k = 16 on the loop moves to the collapsed generators, read off the registered table, after min(k - 14, 5) rounds
+(`hybrid_rounds`; k = 20: 0.020 s against 0.037 s with every round on the original generators).
 
 torch is plumbing (device buffers, slicing); all arithmetic goes through the C ABI."""
 from __future__ import annotations
@@ -34,7 +36,7 @@ def _host(t) -> np.ndarray:
 
 
 def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, device=None, schedule: str | None = None,
-                 hybrid_rounds: int | None = None) -> None:
+                 hybrid_rounds: int | None = None, native: bool = True) -> None:
     """Writes the opening proof of `p_poly` at `x_3` to `transcript`.
 
     rng(count) -> (count, 4) uniformly random scalars, Montgomery limbs (the reference draws `C::Scalar::random`
@@ -51,8 +53,28 @@ def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, d
     to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64)).to(dev)
     as_int = lambda limbs: fields.from_limbs(limbs, sf, True)[0]
     as_limbs = lambda v: fields.scalar_limbs(v % m, sf, True)
-    d_p = p_poly if not isinstance(p_poly, np.ndarray) else to_dev(p_poly)
     x3 = np.ascontiguousarray(x_3, dtype=np.uint64).reshape(4)
+    if schedule is None:
+        schedule = "paired" if n >= 8192 else "original"
+    if schedule not in ("original", "collapse", "paired"):
+        raise ValueError("create_proof: schedule must be 'paired', 'original' or 'collapse'")
+    if schedule == "paired" and (n < 8192 or not params.pair_commit_supported()):
+        schedule = "original"          # small tables use narrower windows, which the paired sort does not take
+    if native and schedule != "collapse":
+        # the whole argument as one C-ABI call; the randomness is drawn here, in the reference's order (:45-47, :53, :111-112)
+        s_raw = rng(n)                         # host limbs, or a CUDA tensor from an rng that draws its large vectors on the device
+        s_blind = Blind(np.ascontiguousarray(rng(1)[0]))
+        rands = np.ascontiguousarray(np.concatenate([np.asarray(rng(2), dtype=np.uint64).reshape(2, 4) for _ in range(k)]))
+        if isinstance(p_poly, np.ndarray) and isinstance(s_raw, np.ndarray):
+            c, f_final = params.open(p_poly, p_blind, x3, s_raw, s_blind, rands, transcript, paired=schedule == "paired", hybrid_rounds=hybrid_rounds)
+        else:
+            d_p = p_poly.contiguous() if not isinstance(p_poly, np.ndarray) else to_dev(p_poly)
+            c, f_final = params.open(d_p, p_blind, x3, fields.to_device_limbs(s_raw, dev).contiguous(), s_blind, rands, transcript,
+                                     paired=schedule == "paired", hybrid_rounds=hybrid_rounds)
+        transcript.write_scalar(c)                                                        # prover.rs:146-148
+        transcript.write_scalar(f_final)
+        return
+    d_p = p_poly if not isinstance(p_poly, np.ndarray) else to_dev(p_poly)
 
     # random polynomial with a root at x_3 (prover.rs:43-53)
     d_s = fields.to_device_limbs(rng(n), dev)
@@ -71,12 +93,6 @@ def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, d
     z_i = as_int(z)
 
     d_b = powers(x3, n, sf, device=dev)                                                   # prover.rs:86-97
-    if schedule is None:
-        schedule = "paired" if n >= 8192 else "original"
-    if schedule not in ("original", "collapse", "paired"):
-        raise ValueError("create_proof: schedule must be 'paired', 'original' or 'collapse'")
-    if schedule == "paired" and (n < 8192 or not params.pair_commit_supported()):
-        schedule = "original"          # small tables use narrower windows, which the paired sort does not take
     if schedule != "collapse":
         # the round loop as one C-ABI call (h2_ipa_rounds_device): the host sees L_j, R_j once per round and answers with the challenge
         rands = np.ascontiguousarray(np.concatenate([np.asarray(rng(2), dtype=np.uint64).reshape(2, 4) for _ in range(k)]))

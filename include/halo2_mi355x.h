@@ -302,6 +302,32 @@ int h2_ipa_rounds_device(int curve, unsigned k, unsigned switch_rounds, h2_bases
 int h2_ipa_rounds(int curve, unsigned k, unsigned switch_rounds, h2_bases_t basis, int paired, const uint64_t *p, const uint64_t *b,
                   const uint64_t *z, const uint64_t *rands, const uint64_t *uw_xy, h2_ipa_write_point_fn write_point,
                   h2_ipa_squeeze_fn squeeze, void *user, uint64_t *c_out, uint64_t *f_out);
+/* replaces poly::commitment::prover::create_proof (halo2_proofs/src/poly/commitment/prover.rs:26-151) -- the whole opening
+ * argument for p_poly at x_3 -- as ONE call: the function a Rust shim swaps, with the caller keeping what is the caller's (its rng
+ * and its transcript).  Everything is Montgomery form.
+ *   g_basis        Params::g registered with Params::w installed (h2_bases_set_blind_base): the commitment to s_poly (:56)
+ *   opening_basis  g || u || u || w || w (paired != 0) or g || u || w (paired == 0), as for h2_ipa_rounds_device; switch_rounds,
+ *                  uw_xy: as there
+ *   p_poly         the 2^k coefficients (:41), read only;  p_blind (:38), x3 (:39): one scalar each (host)
+ *   s_poly         2^k fresh random scalars, s_blind one more, rands the 2k blinds l_0, r_0, l_1, ... -- C::Scalar::random in the
+ *                  order the reference draws them (:45-47, :53, :111-112).  h2_open_device overwrites d_s_poly (it becomes p' and is
+ *                  folded in place); h2_open reads s_poly and p_poly from host memory, once each, and writes nothing back
+ *   write_point    receives the commitment to s_poly (:57), then L_j, R_j per round (:121-122); squeeze yields xi (:62), z (:66),
+ *                  then u_j per round (:124) -- the TranscriptWrite calls of the function, in its order
+ *   c_out, f_out   the two scalars the caller writes last (:146-148): the final p'[0] and the synthetic blinding factor
+ * The constant-coefficient corrections (:51, :72) happen on the device; b (:86-97) and v run beside the commitment to s_poly
+ * (v = p_poly(x_3): s_poly(x_3) is exactly zero after :51).  Scratch (b, the round column, landing places for host vectors)
+ * belongs to the (device, stream) context and goes back with h2_trim.  Same proof bytes as the reference for the same
+ * randomness.  Errors: as h2_ipa_rounds_device; H2_ERR_ARGS also when g_basis has no blind base or a table has the wrong size --
+ * all of that before anything reaches the transcript. */
+int h2_open_device(int curve, unsigned k, h2_bases_t g_basis, h2_bases_t opening_basis, int paired, unsigned switch_rounds,
+                   const uint64_t *uw_xy, const void *d_p_poly, const uint64_t *p_blind, const uint64_t *x3, void *d_s_poly,
+                   const uint64_t *s_blind, const uint64_t *rands, h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze,
+                   void *user, uint64_t *c_out, uint64_t *f_out, void *stream);
+int h2_open(int curve, unsigned k, h2_bases_t g_basis, h2_bases_t opening_basis, int paired, unsigned switch_rounds,
+            const uint64_t *uw_xy, const uint64_t *p_poly, const uint64_t *p_blind, const uint64_t *x3, const uint64_t *s_poly,
+            const uint64_t *s_blind, const uint64_t *rands, h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze, void *user,
+            uint64_t *c_out, uint64_t *f_out);
 /* The generators after `rounds` collapses, without collapsing: G'[i] = sum_{h < 2^rounds} s(h) * G[i + h * 2^(k-rounds)] for
  * i < 2^(k-rounds), s(h) the challenge products of h2_ipa_round_scalars_device, read off the registered table of `basis` (its
  * first 2^k points are G; the table must use 16-bit windows, h2_commit_window_bits) as 2^(k-rounds) multiexps that share their

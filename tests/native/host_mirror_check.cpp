@@ -53,15 +53,26 @@ static int opening_mode(uint32_t k) {
     const Fe x = tr.squeeze_challenge_scalar();
     tr.write_scalar(eval_polynomial<SF>(px, x));
     create_proof<CURVE>(params, rng, tr, px, blind, x);
-    for (uint8_t b : tr.finalize()) printf("%02x", b);
+    // the step-by-step form (host-pointer calls around h2_ipa_rounds) must write the same bytes as the one-call form (h2_open)
+    ctr = 0;
+    Blake2bWrite<CURVE> tr2;
+    tr2.write_point(to_affine<CURVE>(params.commit(px, blind)));
+    const Fe x2 = tr2.squeeze_challenge_scalar();
+    tr2.write_scalar(eval_polynomial<SF>(px, x2));
+    create_proof_stepwise<CURVE>(params, rng, tr2, px, blind, x2);
+    const std::vector<uint8_t> bytes = tr.finalize();
+    if (bytes != tr2.finalize()) { printf("FAIL: h2_open and the step-by-step argument wrote different bytes\n"); return 1; }
+    for (uint8_t b : bytes) printf("%02x", b);
     printf("\n");
     return 0;
 }
 
-// `host_mirror_check opening-time <k> [reps]`: the same opening argument timed natively (no Python in the process: a fresh GPU box is
-// measuring within a second) -- Params::new(k) once, then `reps` arguments over the same polynomial; prints the wall time of each and
-// whether every repetition wrote the same bytes.  A measurement aid for the round loop of csrc/ipa.hip; not run by the test suite.
-static int opening_time_mode(uint32_t k, int reps) {
+// `host_mirror_check opening-time <k> [reps] [stepwise]`: the same opening argument timed natively (no Python in the process: a fresh GPU
+// box is measuring within a second) -- Params::new(k) once, then `reps` arguments over the same polynomial; prints the wall time of each and
+// whether every repetition wrote the same bytes.  The n + 1 + 2k random scalars are drawn into a pool BEFORE the clock starts (the rng
+// is the caller's in the reference too; this counter rng costs ~35 ns a draw, 37 ms at k = 20, which round 4's 68-71 ms included): the
+// timed region is create_proof with host vectors in and the transcript out.  `stepwise`: the form before h2_open.  Not run by the test suite.
+static int opening_time_mode(uint32_t k, int reps, bool stepwise) {
     constexpr int CURVE = H2_VESTA, SF = H2_FP;
     const auto t_p = std::chrono::steady_clock::now();
     Params<CURVE> params = Params<CURVE>::new_params(k);
@@ -71,15 +82,30 @@ static int opening_time_mode(uint32_t k, int reps) {
     const Blind<CURVE> blind{field::from_u64(SF, 7)};
     std::vector<uint8_t> first;
     bool same = true;
+    const auto t_r = std::chrono::steady_clock::now();
+    std::vector<Fe> pool(params.n + 1 + 2 * (size_t)k);
+    for (size_t i = 0; i < pool.size(); i++) pool[i] = field::from_u64(SF, (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ULL + 1);
+    printf("%zu random scalars drawn in %.1f ms (outside the timed region); %s\n", pool.size(),
+           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_r).count(),
+           stepwise ? "step-by-step form (host-pointer calls around h2_ipa_rounds)" : "one-call form (h2_open)");
+    {   // the mirror's own share of the timed region: a fresh Vec of n scalars filled from the rng, as create_proof does (:44-47)
+        const auto t_f = std::chrono::steady_clock::now();
+        size_t c0 = 0;
+        std::vector<Fe> s_poly(params.n);
+        for (Fe &c : s_poly) c = pool[c0++];
+        printf("of which the mirror's allocation and fill of s_poly (host): %.3f ms (checksum %llu)\n",
+               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f).count(), (unsigned long long)s_poly[params.n - 1][0]);
+    }
     for (int rep = 0; rep < reps; ++rep) {
-        uint64_t ctr = 0;
-        auto rng = [&]() { ++ctr; return field::from_u64(SF, ctr * 0x9E3779B97F4A7C15ULL + 1); };
+        size_t ctr = 0;
+        auto rng = [&]() { return pool[ctr++]; };
         Blake2bWrite<CURVE> tr;
         tr.write_point(to_affine<CURVE>(params.commit(px, blind)));
         const Fe x = tr.squeeze_challenge_scalar();
         tr.write_scalar(eval_polynomial<SF>(px, x));
         const auto t0 = std::chrono::steady_clock::now();
-        create_proof<CURVE>(params, rng, tr, px, blind, x);
+        if (stepwise) create_proof_stepwise<CURVE>(params, rng, tr, px, blind, x);
+        else create_proof<CURVE>(params, rng, tr, px, blind, x);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         const std::vector<uint8_t> bytes = tr.finalize();
         if (rep == 0) first = bytes;
@@ -93,7 +119,7 @@ static int opening_time_mode(uint32_t k, int reps) {
 int main(int argc, char **argv) {
     if (h2_device_count() <= 0) { printf("no GPU: host mirror check needs an MI355X\n"); return 2; }
     if (argc == 3 && std::string(argv[1]) == "opening") return opening_mode((uint32_t)atoi(argv[2]));
-    if (argc >= 3 && std::string(argv[1]) == "opening-time") return opening_time_mode((uint32_t)atoi(argv[2]), argc > 3 ? atoi(argv[3]) : 5);
+    if (argc >= 3 && std::string(argv[1]) == "opening-time") return opening_time_mode((uint32_t)atoi(argv[2]), argc > 3 ? atoi(argv[3]) : 5, argc > 4 && std::string(argv[4]) == "stepwise");
     constexpr int CURVE = H2_VESTA, FIELD = H2_FP;   // every proof in the reference runs on Vesta / Fp
     const uint32_t k = 8;
     const size_t n = (size_t)1 << k;

@@ -323,3 +323,70 @@ def test_native_host_mirror_opening_same_bytes(k):
     create_proof(params, rng, tr, px, blind, x)
     assert tr.finalize() == native
     params.close()
+
+
+@pytest.mark.parametrize("curve,k", [(h.PALLAS, 1), (h.VESTA, 6), (h.PALLAS, 13), (h.VESTA, 16)])
+def test_whole_argument_entry_points_write_the_oracles_bytes(curve, k):
+    """`commitment::create_proof` as ONE native call (h2_open from host vectors, h2_open_device from resident ones) against the
+    sequential restatement of the reference prover, and against the step-by-step form it replaces (native=False: the steps before
+    the loop from Python, h2_ipa_rounds_device for the loop) -- four routes, one byte string.  k = 1: a single round, no table
+    pair; 6: the two-commit rounds; 13: the paired rounds; 16: the switch to the collapsed generators inside the call."""
+    import torch
+    n = 1 << k
+    sf = fields.CURVE_FIELDS[curve][1]
+    g = co.generate_bases(curve, 150 + k, n)
+    w, u = co.generate_bases(curve, 60, 1)[0], co.generate_bases(curve, 61, 1)[0]
+    params = h.Params.from_generators(curve, k, g, None, w, u)
+    px = co.random_field(sf, 170 + k, n)
+    blind = h.Blind(co.random_field(sf, 171, 1)[0])
+    x = co.random_field(sf, 172, 1)[0]
+    d_px = torch.from_numpy(px.view(np.int64)).to("cuda:0")
+    proofs = []
+    for resident in (False, True):
+        for native in (True, False):
+            tr = Blake2bWrite(curve)
+            create_proof(params, _rng(sf, 9000), tr, d_px.clone() if resident else px.copy(), blind, x, native=native)
+            proofs.append(tr.finalize())
+    assert torch.equal(d_px.cpu(), torch.from_numpy(px.view(np.int64)))          # p_poly is read only
+    assert proofs[0] == proofs[1] == proofs[2] == proofs[3]
+    ot = ipa.Transcript(curve)
+    ipa.create_proof(curve, k, g, w, u, _rng(sf, 9000), ot, px, blind.value, x)
+    assert bytes(ot.out) == proofs[0]
+    params.close()
+
+
+def test_whole_argument_refuses_before_touching_the_transcript():
+    """What h2_open can refuse it refuses before the commitment to s_poly reaches the caller's transcript: a g table without
+    Params::w installed, tables of the wrong size, a missing argument."""
+    import ctypes as C
+    from halo2_amd._lib import IPA_SQUEEZE_FN, IPA_WRITE_POINT_FN, IPA_SWITCH_DEFAULT, lib
+    from halo2_amd.arithmetic import _p
+    curve, k = h.VESTA, 6
+    n = 1 << k
+    sf = fields.CURVE_FIELDS[curve][1]
+    g = co.generate_bases(curve, 180, n)
+    w, u = co.generate_bases(curve, 60, 1)[0], co.generate_bases(curve, 61, 1)[0]
+    params = h.Params.from_generators(curve, k, g, None, w, u)
+    calls = []
+    cb_w = IPA_WRITE_POINT_FN(lambda _u, _xy: calls.append("w") or 0)
+    cb_s = IPA_SQUEEZE_FN(lambda _u, _out: calls.append("s") or 0)
+    px, s = co.random_field(sf, 181, n), co.random_field(sf, 182, n)
+    one = co.random_field(sf, 183, 1)[0]
+    rands = co.random_field(sf, 184, 2 * k)
+    uw = np.ascontiguousarray(np.stack([params.u, params.w]))
+    c, f = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    bare = C.c_uint64(0)                                     # the same generators, no blind base installed
+    assert lib().h2_bases_register(curve, _p(np.ascontiguousarray(g)), n, 1, C.byref(bare)) == 0
+    basis = params._opening_basis(False)
+
+    def call(g_handle, open_handle, paired, p_ptr=_p(px)):
+        return lib().h2_open(curve, k, g_handle, open_handle, paired, IPA_SWITCH_DEFAULT, _p(uw), p_ptr, _p(one), _p(one), _p(s), _p(one), _p(rands),
+                             cb_w, cb_s, None, _p(c), _p(f))
+    assert call(bare, basis, 0) != 0                         # no Params::w on the g table
+    assert call(params._h_g, params._h_g, 0) != 0            # the opening basis must be g || u || w
+    assert call(params._h_g, basis, 1) != 0                  # ... or g || u || u || w || w when paired
+    assert call(params._h_g, basis, 0, None) != 0            # p_poly missing
+    assert call(C.c_uint64(0xDEAD), basis, 0) != 0           # not a handle
+    assert calls == []
+    lib().h2_bases_free(bare)
+    params.close()
