@@ -376,6 +376,23 @@ def main():
                            "registered (no precomputed table; endomorphism split), one call at a time on one stream",
                    "ms": round(g_ms, 4), "Mscalar_mults_per_s": round((n + 1) / g_ms / 1e3, 1),
                    "equals_registered_path": bool(co.jac_to_affine_ints(curve, d_gen.cpu().numpy().view(np.uint64)) == co.jac_to_affine_ints(curve, first))}
+        # the same call as INDEPENDENT multiexps round-robin over the headline's streams (the shape of a prover phase without a
+        # registered table): one call's sort and fold run beside another's accumulate, as for the headline's commits
+        if len(sps) > 1:
+            d_gens = [torch.zeros(12, dtype=torch.int64, device=dev) for _ in sps]
+            reps_s = 6 * len(sps)
+            for rep_ in range(reps_s + len(sps)):
+                if rep_ == len(sps):
+                    torch.cuda.synchronize()
+                    t6 = time.perf_counter()
+                j_ = rep_ % len(sps)
+                check(lib.h2_msm_device(curve, d_sc.data_ptr(), d_bases.data_ptr(), n + 1, h.FORM_MONTGOMERY, 0, d_gens[j_].data_ptr(), sps[j_]),
+                      "h2_msm_device")
+            torch.cuda.synchronize()
+            gs_ms = (time.perf_counter() - t6) / reps_s * 1e3
+            generic["independent_calls"] = {"streams": len(sps), "ms_per_call": round(gs_ms, 4), "Mscalar_mults_per_s": round((n + 1) / gs_ms / 1e3, 1),
+                                            "all_equal": bool(all(torch.equal(g_, d_gen) for g_ in d_gens))}
+            del d_gens
         del d_bases, d_sc
 
     # ---- skewed columns: 90 % zeros, and every scalar < 2^16 -- same kernels, same partition ----
@@ -704,6 +721,39 @@ def main():
             torch.cuda.synchronize()
             params_s = time.perf_counter() - t9
             res = mod.prove_and_verify(prm, quiet=True)
+            # (3b) the opening argument alone (poly/commitment/prover.rs:26-151) through its one-call entry points, the randomness drawn
+            # beforehand (the rng is the caller's): p_poly resident (h2_open_device; the n random coefficients of s_poly still cross PCIe
+            # inside, as they come from a host rng) and p_poly + s_poly as host vectors (h2_open: what a Rust caller holds)
+            from halo2_amd.opening import create_proof as _open
+            from halo2_amd.transcript import Blake2bWrite as _Tr
+            o_px = co.random_field(vs, 0x09E1, n)
+            o_pool = co.random_field(vs, 0x09E2, n + 1 + 2 * args.log_n)
+            o_blind, o_x = h.Blind(co.random_field(vs, 0x09E3, 1)[0]), co.random_field(vs, 0x09E4, 1)[0]
+            d_opx = torch.from_numpy(o_px.view(np.int64)).to(dev)
+
+            def _opening(p_):
+                pos = [0]
+
+                def rng_(count):
+                    pos[0] += count
+                    return o_pool[pos[0] - count: pos[0]]
+                tr_ = _Tr(h.VESTA)
+                _open(prm, rng_, tr_, p_, o_blind, o_x)
+                torch.cuda.synchronize()
+                return tr_.finalize()
+            o_bytes = [None, None]
+
+            def _timed_opening(slot, p_):
+                o_bytes[slot] = _opening(p_)
+            open_res_ms = _med(lambda: _timed_opening(0, d_opx), reps=3)
+            open_host_ms = _med(lambda: _timed_opening(1, o_px), reps=3)
+            extra["opening_argument_k20"] = {
+                "what": "commitment::create_proof (poly/commitment/prover.rs:26-151) for one 2^20-coefficient polynomial on Vesta as ONE library call, median of 3 "
+                        "after a warm-up: the S commitment, 20 rounds (5 over the registered generators, the read-out and registration of G'_5, 15 over its table), "
+                        "40 points and 2 scalars to a BLAKE2b transcript",
+                "resident_p_poly_ms": round(open_res_ms, 3), "host_vectors_ms": round(open_host_ms, 3), "same_proof_bytes": bool(o_bytes[0] == o_bytes[1]),
+                "proof_bytes": len(o_bytes[0])}
+            del d_opx
             prm.close()
             extra["create_proof_simple_example_k20"] = {
                 "accepted_and_wrong_instance_rejected": res["ok"], "create_proof_s": round(res["create_proof_s"], 4),

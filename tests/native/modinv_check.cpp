@@ -5,6 +5,7 @@
 #include <cstring>
 #include <random>
 #include "../../halo2_amd/csrc/field_inv.cuh"
+#include "../../halo2_amd/csrc/host_field.h"      // host_inv (the divsteps above, Montgomery in and out) and the binary Euclid it replaced
 
 typedef unsigned __int128 u128;
 struct U256 { uint64_t w[4]; };
@@ -60,5 +61,30 @@ int main() {
         }
     }
     printf("modinv30: %d cases, %d failures\n", done, bad);
-    return bad ? 1 : 0;
+    // the library's host inversion (csrc/host_field.h: what the opening argument's round loop and the transcript call twice per round) against
+    // the binary extended Euclid it replaced and against a * a^-1 = 1 in Montgomery form; raw limbs at or above p (up to 2^256 - 1) included
+    int hbad = 0, hdone = 0;
+    for (int field = 0; field < 2; ++field) {
+        for (int it = 0; it < 4000; ++it) {
+            uint64_t a[4], r1[4], r2[4], prod[4];
+            for (int k = 0; k < 4; ++k) a[k] = rng();
+            if (it % 3) a[3] &= 0x3FFFFFFFFFFFFFFFULL;
+            if (it == 0) memset(a, 0, 32);
+            if (it == 1) memcpy(a, h2::kHostField[field].p, 32);                          // p itself: zero
+            if (it == 2) memcpy(a, h2::kHostField[field].one, 32);
+            h2::host_inv(field, r1, a);
+            h2::host_inv_euclid(field, r2, a);
+            bool ok = memcmp(r1, r2, 32) == 0;
+            h2::host_mul(field, prod, a, r1);
+            uint64_t red[4];
+            memcpy(red, a, 32);
+            while (h2::host_ge(red, h2::kHostField[field].p)) h2::host_sub_raw(red, red, h2::kHostField[field].p);
+            const bool zero = !(red[0] | red[1] | red[2] | red[3]);
+            ok = ok && (zero ? !(r1[0] | r1[1] | r1[2] | r1[3]) : memcmp(prod, h2::kHostField[field].one, 32) == 0);
+            if (!ok) { if (hbad < 5) printf("FAIL host_inv field %d case %d\n", field, it); ++hbad; }
+            ++hdone;
+        }
+    }
+    printf("host_inv: %d cases, %d failures\n", hdone, hbad);
+    return bad || hbad ? 1 : 0;
 }

@@ -296,11 +296,13 @@ def test_library_transcript_matches_hashlib_restatement(curve):
 def test_divstep_inversion_on_the_host():
     """csrc/field_inv.cuh (fe_inv on the device: Bernstein-Yang divsteps on signed 30-bit limbs) is plain __host__ __device__ integer code:
     tests/native/modinv_check.cpp compiles the same functions for the CPU and checks x * modinv30(x) = 1 mod p for 2 x 600 values of both
-    Pasta moduli -- 0, 1, 2, p - 1, powers of two and random ones -- with the result in [0, p)."""
+    Pasta moduli -- 0, 1, 2, p - 1, powers of two and random ones -- with the result in [0, p).  The library's HOST inversion (host_inv of
+    csrc/host_field.h: the same divsteps, Montgomery in and out -- two per round of the opening argument) is checked there too, against the
+    binary Euclid it replaced and against a * a^-1 = 1, for 2 x 4000 values including raw limbs at or above p."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "build", "modinv_check")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(root, "tests", "native", "modinv_check.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "1200 cases, 0 failures" in out.stdout, out.stdout + out.stderr
+    assert out.returncode == 0 and "1200 cases, 0 failures" in out.stdout and "host_inv: 8000 cases, 0 failures" in out.stdout, out.stdout + out.stderr
