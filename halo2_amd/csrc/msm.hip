@@ -3814,6 +3814,212 @@ extern "C" int h2_bases_set_blind_base(h2_bases_t g, const uint64_t *w_xy, int f
 // 2^(k-j) block), so their scalars share one column, and the basis g || u || u || w || w carries the [value z] U and
 // [rand] W terms of each.  One sort, one bucket accumulation into two slices, one fold: ~1.5 ms per round at k = 20 against
 // 2.0 ms for two half-empty commits.  d_out receives output 0 then output 1.
+// ---- the paired commit over a SMALL 16-bit table: 8-bit sub-digits, 512 buckets, no bucket fold to speak of ----------------------
+// The opening argument's rounds over the collapsed generators are paired commits of 2^14 .. 2^15 points, fifteen of them in a row at
+// k = 20, each a chain of ~13 short launches through the machinery above: a two-pass sort into 2 x 2^15 buckets that hold eight
+// entries each, an accumulate of four entries per lane, and a fold over 2^16 buckets (finish, two heavy-bucket launches that find
+// nothing, 383 line sums per slice, 15 bit planes with a 15-doubling chain) -- 0.24 ms of which 0.05 is bucket arithmetic.  For a small
+// table the same commit is cheaper with FEWER buckets: every signed 16-bit table digit d is cut once more, |d| = e_0 + 256 e_1 with e_0
+// in [-127, 128] and e_1 in [0, 128] (the read-out of the collapsed generators does the same, ipa_readout_*), so that
+//     sum_m c_m G_m = P_0 + 2^8 P_1,     P_pos = sum_{b < 128} (b + 1) * (sum of +-T[w][m] over the (m, w) whose sub-digit at `pos` is +-(b + 1))
+// per output: 2 sides x 2 positions x 128 = 512 buckets in all, two entries per digit (2^20 entries for 2^15 + 4 scalars: the
+// accumulate doubles, to the 50 us the chip needs for 2^20 mixed additions), a sort by a 9-bit key (three short launches, LDS
+// histograms), a finisher in which EVERY bucket is a tree over ~256 range heads, 8 bit planes straight over each slice's 128 bucket sums
+// (a slice is ONE line of the bucket matrix: no line sums) with a 7-doubling chain, and 8 doublings to join the positions.  The
+// accumulate and the planes are the kernels above.  Bucket SLOTS lie 129 apart per slice (slot = key + key / 128: a slice's sums, then one
+// slot that stays empty) -- the layout fold9_planes reads S column sums and NR - 1 row sums in, with S = 128 and NR = 1.
+static constexpr u32 kSubKeys = 512;     // side (2) x position (2) x (|e| - 1 < 128)
+static constexpr u32 kSubSlots = 516;    // 4 x 129
+template <typename Fn> __device__ __forceinline__ void for_each_subdigit(const fe &s, u32 side, Fn f) {       // s: canonical, below 2^255
+    u32 carry = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const u32 raw = ((s.v[w >> 1] >> (16 * (w & 1))) & 0xFFFFu) + carry;      // signed 16-bit digits, as msm_recode cuts them
+        const bool neg = raw > 0x8000u;
+        carry = neg ? 1u : 0u;
+        const u32 mag = neg ? 0x10000u - raw : raw;                             // |d| <= 2^15 (raw = 2^16: digit 0, carry out)
+        u32 e0 = mag & 255u, c8 = 0;
+        bool e0neg = false;
+        if (e0 > 128u) {
+            e0 = 256u - e0;
+            e0neg = true;
+            c8 = 1;
+        }
+        const u32 e1 = (mag >> 8) + c8;                                         // <= 128: |d| <= 2^15, and |d| = 2^15 has e_0 = 0
+        if (e0) f(side * 256u + e0 - 1u, (u32)w, (neg != e0neg) ? 0x80000000u : 0u);
+        if (e1) f(side * 256u + 128u + e1 - 1u, (u32)w, neg ? 0x80000000u : 0u);
+    }
+    // (carry is 0 here: the scalar is below 2^255, the top window takes it)
+}
+__device__ __forceinline__ u32 pair_side(u32 i, u32 pair_n, int pair_shift) { return i < pair_n ? (i >> pair_shift) & 1u : (i - pair_n) & 1u; }
+// pass A: a workgroup's 1024 scalars -> its 512 counters (1024 lanes: a quarter of the workgroups for pass B to walk)
+static constexpr u32 kSubBlock = 1024;
+template <int FS>
+__global__ void __launch_bounds__(kSubBlock) sub_count(const u32 *__restrict__ scalars, u32 n, u32 pair_n, int pair_shift, int mont, u32 *__restrict__ wg_hist) {
+    H2_LATENCY_STAGE();
+    __shared__ u32 sh[kSubKeys];
+    for (u32 k = threadIdx.x; k < kSubKeys; k += blockDim.x) sh[k] = 0;
+    __syncthreads();
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        fe s = fe_load(scalars + 8 * (size_t)i);
+        if (mont) s = fe_redc<FS>(s);
+        for_each_subdigit(s, pair_side(i, pair_n, pair_shift), [&](u32 key, u32, u32) { atomicAdd(&sh[key], 1u); });
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < kSubKeys; k += blockDim.x) wg_hist[(size_t)blockIdx.x * kSubKeys + k] = sh[k];
+}
+// pass B (one workgroup, a lane per key): the workgroups' offsets inside each key's run, every key's start (`kstart`, for pass C), the boundary
+// array over the 516 SLOTS (+ total + the sentinel msm_accumulate reads; a gap slot is an empty bucket), and the raw bucket slots cleared for the
+// accumulate (36 words each: a lane clears its own, lanes 0 .. 3 the gaps too)
+__global__ void __launch_bounds__(kSubKeys) sub_scan(const u32 *__restrict__ wg_hist, u32 nblk, u32 *__restrict__ wg_off, u32 *__restrict__ kstart,
+                                                     u32 *__restrict__ starts, u32 *__restrict__ buckets9) {
+    H2_LATENCY_STAGE();
+    __shared__ u32 tot[kSubKeys];
+    const u32 k = threadIdx.x;
+    u32 run = 0;
+    for (u32 b0 = 0; b0 < nblk; b0 += 8) {               // eight loads in flight: the walk is a chain of memory round trips otherwise
+        u32 c[8];
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) c[j] = b0 + j < nblk ? wg_hist[(size_t)(b0 + j) * kSubKeys + k] : 0u;
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) {
+            if (b0 + j < nblk) wg_off[(size_t)(b0 + j) * kSubKeys + k] = run;
+            run += c[j];
+        }
+    }
+    const u32 slot = k + (k >> 7);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) buckets9[36 * (size_t)slot + i] = 0u;
+    if (k < 4)
+        for (int i = 0; i < 36; ++i) buckets9[36 * (size_t)(129 * k + 128) + i] = 0u;
+    tot[k] = run;
+    __syncthreads();
+    for (u32 off = 1; off < kSubKeys; off <<= 1) {
+        const u32 t = k >= off ? tot[k - off] : 0u;
+        __syncthreads();
+        tot[k] += t;
+        __syncthreads();
+    }
+    kstart[k] = tot[k] - run;
+    starts[slot] = tot[k] - run;
+    if ((k & 127u) == 127u) starts[slot + 1] = tot[k];          // the gap behind a slice: starts where the next slice starts
+    if (k == kSubKeys - 1) {
+        starts[kSubSlots] = tot[k];
+        starts[kSubSlots + 1] = 0xFFFFFFFFu;
+    }
+}
+// pass C: the same digits again, each to its place (entry = table index | sign << 31; the order inside a bucket is immaterial)
+template <int FS>
+__global__ void __launch_bounds__(kSubBlock) sub_scatter(const u32 *__restrict__ scalars, u32 n, u32 pair_n, int pair_shift, int mont, u32 stride,
+                                                   const u32 *__restrict__ wg_off, const u32 *__restrict__ kstart, u32 *__restrict__ entries) {
+    H2_LATENCY_STAGE();
+    __shared__ u32 cur[kSubKeys];
+    for (u32 k = threadIdx.x; k < kSubKeys; k += blockDim.x) cur[k] = kstart[k] + wg_off[(size_t)blockIdx.x * kSubKeys + k];
+    __syncthreads();
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe s = fe_load(scalars + 8 * (size_t)i);
+    if (mont) s = fe_redc<FS>(s);
+    for_each_subdigit(s, pair_side(i, pair_n, pair_shift), [&](u32 key, u32 w, u32 sign) {
+        const u32 pos = atomicAdd(&cur[key], 1u);
+        entries[pos] = (w * stride + i) | sign;
+    });
+}
+// the finisher when EVERY bucket owns hundreds of range heads: a workgroup per bucket, a tree over its heads, then the bucket's own segment
+template <int FB>
+__global__ void __launch_bounds__(256, 3) fold9_finish_dense(const u32 *__restrict__ heads9, const u32 *__restrict__ starts, u32 *__restrict__ buckets9,
+                                                           u32 total_buckets, u32 T, u32 div) {
+    H2_LATENCY_STAGE();
+    __shared__ __attribute__((aligned(16))) u32 sh[32 * 36];
+    const u32 b = blockIdx.x, base = starts[0];
+    const u32 M = starts[total_buckets] - base;
+    T = eff_lanes(M, T, div);
+    const u32 chunk = max(1u, (M + T - 1) / T);
+    const u32 h0 = (starts[b] - base + chunk - 1) / chunk, h1 = (starts[b + 1] - base + chunk - 1) / chunk;
+    xyzz9<FB> acc = fold9_quad_gather<FB, H2_FOLD_D>(heads9, h1 > h0 ? h1 - h0 : 0u, [h0](u32 k) { return h0 + k; });
+    acc = fold9_quads_sum<FB>(acc, sh);
+    if (!fold9_root()) return;
+    xyzz9_add_wide<FB>(acc, xyzz9_load_raw<FB>(buckets9 + 36 * (size_t)b));
+    if ((threadIdx.x & (kGroup - 1)) == 0) xyzz9_store_raw<FB>(buckets9 + 36 * (size_t)b, acc);
+}
+// output `side` = P_0 + 2^8 P_1 from the four slice sums (side-major, XYZZ in the reference's form): 8 doublings and one addition on a quad
+template <int FB>
+__global__ void __launch_bounds__(64) sub_combine(const u32 *__restrict__ slice_sums, u32 *__restrict__ out, int out_kind, int out_mont) {
+    H2_LATENCY_STAGE();
+    if (threadIdx.x >= kGroup) return;
+    slice_sums += 64 * (size_t)blockIdx.x;
+    out += (out_kind == H2_OUT_AFFINE ? 16 : 24) * (size_t)blockIdx.x;
+    xyzz9<FB> r9 = xyzz9_from_r256_wide<FB>(xyzz_load<FB>(slice_sums + 32));
+    for (int k = 0; k < 8; ++k) r9 = xyzz9_dbl_wide<FB>(r9);
+    xyzz9_add_wide<FB>(r9, xyzz9_from_r256_wide<FB>(xyzz_load<FB>(slice_sums)));
+    const xyzz<FB> r = xyzz9_to_r256_wide<FB>(r9);
+    if (threadIdx.x != 0) return;
+    if (out_kind == H2_OUT_AFFINE) {
+        affine<FB> a = xyzz_to_affine<FB>(r);
+        if (!out_mont) { a.x = fe_from_mont<FB>(a.x); a.y = fe_from_mont<FB>(a.y); }
+        fe_store(out, a.x);
+        fe_store(out + 8, a.y);
+    } else {
+        fe X, Y, Z;
+        xyzz_to_jacobian<FB>(r, X, Y, Z);
+        if (!out_mont) { X = fe_from_mont<FB>(X); Y = fe_from_mont<FB>(Y); Z = fe_from_mont<FB>(Z); }
+        fe_store(out, X);
+        fe_store(out + 8, Y);
+        fe_store(out + 16, Z);
+    }
+}
+
+template <int FB, int FS>
+static int pair_subdigit_launch(MsmContext &cx, const Bases &b, const void *d_scalars, size_t n, unsigned pair_shift, int form, int out_kind,
+                                void *d_out, hipStream_t st) {
+    int rc;
+    const u32 nblk = (u32)((n + kSubBlock - 1) / kSubBlock), tb = kSubSlots, S = 128, NR = 1, nsl = 4;
+    const size_t max_entries = n * 32;
+    u32 &lanes = cx.lanes[FB][2];
+    if (!lanes) {            // how many lanes of the M9 accumulate the chip holds at once (as msm_launch sizes it)
+        int dev = 0, cus = 0, per_cu = 0;
+        H2_HIP(hipGetDevice(&dev));
+        H2_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        H2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)msm_accumulate<FB, false, true>, 256, 0));
+        per_cu = std::min(per_cu, (int)H2_ACC9_WAVES);
+        lanes = (u32)cus * (u32)std::max(per_cu, 1) * 256u;
+    }
+    const u32 lane_div = 8;
+    const u32 T = (u32)std::min<size_t>(lanes, std::max<size_t>(256, (max_entries / lane_div + 255) / 256 * 256));
+    if ((rc = cx.hist.reserve(((size_t)2 * nblk + 1) * kSubKeys * 4)) != H2_OK || (rc = cx.starts.reserve((tb + 2) * 4)) != H2_OK ||
+        (rc = cx.entries.reserve(max_entries * 4)) != H2_OK || (rc = cx.seg9.reserve(((size_t)T + tb) * 144)) != H2_OK ||
+        (rc = cx.partial.reserve((size_t)nsl * 32 * 144)) != H2_OK || (rc = cx.ssums.reserve((size_t)nsl * 128)) != H2_OK)
+        return rc;
+    if (cx.fold_ctr.cap < 64) {          // fold9_planes' arrival counters: zero once, every launch leaves them at zero
+        if ((rc = cx.fold_ctr.reserve((size_t)kMaxCols * 64)) != H2_OK) return rc;
+        H2_HIP(hipMemsetAsync(cx.fold_ctr.ptr, 0, (size_t)kMaxCols * 64, st));
+    }
+    u32 *wg_hist = cx.hist.as<u32>(), *wg_off = wg_hist + (size_t)nblk * kSubKeys, *kstart = wg_off + (size_t)nblk * kSubKeys;
+    u32 *starts = cx.starts.as<u32>(), *entries = cx.entries.as<u32>();
+    u32 *heads9 = cx.seg9.as<u32>(), *buckets9 = heads9 + 36 * (size_t)T;
+    u32 *planes9 = cx.partial.as<u32>(), *ssums = cx.ssums.as<u32>();
+    const int mont = form == H2_FORM_MONTGOMERY ? 1 : 0;
+    const u32 pair_n = (u32)(n - 4);
+    ColStride cs;
+    ColOut co;
+    memset(&cs, 0, sizeof cs);
+    memset(&co, 0, sizeof co);
+    hipLaunchKernelGGL((sub_count<FS>), dim3(nblk), dim3(kSubBlock), 0, st, (const u32 *)d_scalars, (u32)n, pair_n, (int)pair_shift, mont, wg_hist);
+    hipLaunchKernelGGL(sub_scan, dim3(1), dim3(kSubKeys), 0, st, (const u32 *)wg_hist, nblk, wg_off, kstart, starts, buckets9);
+    hipLaunchKernelGGL((sub_scatter<FS>), dim3(nblk), dim3(kSubBlock), 0, st, (const u32 *)d_scalars, (u32)n, pair_n, (int)pair_shift, mont, b.stride,
+                       (const u32 *)wg_off, (const u32 *)kstart, entries);
+    hipLaunchKernelGGL((msm_accumulate<FB, false, true>), dim3(T / 256), dim3(256), 0, st, (const u32 *)b.d_table, (const u32 *)nullptr, 0xFFFFFFFFu,
+                       (const u32 *)entries, (const u32 *)starts, heads9, buckets9, tb, T, lane_div, cs);
+    hipLaunchKernelGGL((fold9_finish_dense<FB>), dim3(tb), dim3(256), 0, st, (const u32 *)heads9, (const u32 *)starts, buckets9, tb, T, lane_div);
+    // the finished bucket slots ARE the planes' line sums: S = 128 columns, no rows; plane t < 7 = the 64 buckets with bit t of b + 1 set, plane 7 = bucket 127
+    hipLaunchKernelGGL((fold9_planes<FB>), dim3(8, nsl), dim3(256), 0, st, (const u32 *)buckets9, planes9, cx.fold_ctr.as<u32>(), S, NR, 7, ssums,
+                       kOutSliceSum, 1, co, cs);
+    hipLaunchKernelGGL((sub_combine<FB>), dim3(2), dim3(64), 0, st, (const u32 *)ssums, (u32 *)d_out, out_kind, mont);
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
 extern "C" int h2_commit_pair_device(h2_bases_t g, const void *d_scalars, size_t n, unsigned pair_shift, int form, int out_kind,
                                      void *d_out, void *stream) {
     auto b = find_bases(g);
@@ -3824,6 +4030,13 @@ extern "C" int h2_commit_pair_device(h2_bases_t g, const void *d_scalars, size_t
     hipStream_t st = (hipStream_t)stream;
     MsmContext &cx = msm_ctx(st);
     std::lock_guard<std::mutex> lk(cx.mu);
+    // small 16-bit tables (the opening argument's rounds over the collapsed generators): the 8-bit sub-digit form above.
+    // H2_PAIR_SUBDIGITS=0: the general form for every size (A/B); = n: the largest table (points) that takes the sub-digit form.
+    static const long sub_max = [] { const char *e = getenv("H2_PAIR_SUBDIGITS"); return e ? atol(e) : (long)((1 << 16) + 4); }();
+    if (sub_max > 0 && b->c == 16 && b->W == 16 && n <= (size_t)sub_max && !prof_enabled() && !timeline_on()) {
+        if (b->curve == H2_PALLAS) return pair_subdigit_launch<FP, FQ>(cx, *b, d_scalars, n, pair_shift, form, out_kind, d_out, st);
+        return pair_subdigit_launch<FQ, FP>(cx, *b, d_scalars, n, pair_shift, form, out_kind, d_out, st);
+    }
     MsmArgs a{d_scalars, nullptr, b->d_table, nullptr, n, true, b->c, b->stride, (u32)b->n, form, out_kind, d_out};
     a.pair_shift = (int)pair_shift;
     a.pair_n = (u32)(n - 4);
