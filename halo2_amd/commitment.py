@@ -287,7 +287,7 @@ class Params:
 
     def default_hybrid_rounds(self, paired: bool) -> int:
         """After how many rounds the opening argument moves to the collapsed generators (0 = never): the library's choice,
-        min(k - 14, 5) from k = 16 on (h2_ipa_default_switch_rounds)."""
+        k - 14 rounds from k = 16 to 20 (a table of 2^14 points is left), 6 at k = 21, 5 beyond (h2_ipa_default_switch_rounds)."""
         return int(lib().h2_ipa_default_switch_rounds(self.k, 1 if paired else 0))
 
     def opening_rounds(self, d_p, d_b, z, rands, transcript, paired: bool, hybrid_rounds: int | None = None):

@@ -635,9 +635,12 @@ static int ipa_rounds_impl(int curve, unsigned k, unsigned rounds, h2_bases_t ba
 // Measured (profiles/r04_opening_switch_sweep.txt, ms per argument): k = 16: J = 2 8.8 / 1 9.3; k = 18: J = 4 10.7 / 3 11.6; k = 19: 5 13.4 / 4 13.6;
 // k = 20: 5 19.5 / 6 20.0 / 4 21.2; k = 21: 6 31.8 / 5 32.2; k = 22: 5 58.2 / 6 59.8 / 4 61.5 / 8 66.1 -- a table of 2^14 points up to k = 19, then
 // five rounds: every further round over the original generators costs a full 2^k commit, a larger G' only its registration.
+// Round 5: rounds over a table of up to 2^16 points are paired commits with 8-bit sub-digits (msm.hip, pair_subdigit_launch: 0.20 ms at 2^14
+// points against 0.245 at 2^15 and 0.26 for the general form at either), which moves k = 20 to a 2^14-point table as well: J = 6 16.8 ms, J = 5
+// 16.9-17.4, the general form 17.6-17.7 either way (profiles/r05_pair_subdigits.txt).  k = 21 keeps 6 rounds, k >= 22 five.
 extern "C" unsigned h2_ipa_default_switch_rounds(unsigned k, int paired) {
     if (!paired || k < 16 || k > 26 || h2_commit_window_bits(((size_t)1 << k) + 4) != 16) return 0;
-    return k - 14 < 5 ? k - 14 : 5;
+    return k <= 20 ? k - 14 : k == 21 ? 6 : 5;
 }
 
 extern "C" int h2_ipa_rounds_device(int curve, unsigned k, unsigned switch_rounds, h2_bases_t basis, int paired, void *d_p, void *d_b,

@@ -16,7 +16,7 @@ Three schedules produce the same L_j, R_j (and so the same proof bytes):
 For the last two the whole ARGUMENT is one C-ABI call (`h2_open_device` / `h2_open`, reached through `Params.open`: the commitment
 to s_poly, xi and z, P', b, v and the round loop between the caller's rng and the caller's transcript); `native=False` keeps the
 earlier form for A/B -- the steps before the loop from here, the loop alone native (`h2_ipa_rounds_device`, `Params.opening_rounds`).
-From k = 16 on the loop moves to the collapsed generators, read off the registered table, after min(k - 14, 5) rounds
+From k = 16 on the loop moves to the collapsed generators, read off the registered table, after the rounds that leave a table of 2^14 points (k - 14, up to k = 20; 6 at k = 21, 5 beyond)
 (`hybrid_rounds`; k = 20: 0.020 s against 0.037 s with every round on the original generators).
 
 torch is plumbing (device buffers, slicing); all arithmetic goes through the C ABI."""

@@ -288,7 +288,8 @@ int h2_ipa_round_scalars_device(int field, const void *d_p, unsigned k, unsigned
  *   generators -- G'_J is read off the table (h2_ipa_collapsed_generators_device), registered next to u and w (uw_xy: u then w,
  *   host, affine Montgomery) as a table of 2^(k-J) points, and the remaining rounds run over it: a round over the original
  *   generators costs a full-size commit whatever j, a round over G'_J a small one.  0 = never; H2_IPA_SWITCH_DEFAULT = the
- *   library's choice (h2_ipa_default_switch_rounds: min(k - 14, 5) from k = 16 on).  Same L_j, R_j, so the same proof bytes.
+ *   library's choice (h2_ipa_default_switch_rounds: from k = 16 on the rounds that leave a table of 2^14 points up to k = 20, six rounds at
+ *   k = 21, five beyond).  Same L_j, R_j, so the same proof bytes.
  * Returns H2_ERR_ARGS if an L_j / R_j is the point at infinity or a challenge is zero (the reference errors / panics).
  * h2_ipa_rounds: the same with p' and b in host memory (copied in; only c and f leave the argument). */
 #define H2_IPA_SWITCH_DEFAULT 0xFFFFFFFFu

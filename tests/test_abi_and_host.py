@@ -56,7 +56,8 @@ def test_argument_validation_without_gpu():
     assert lib.h2_ntt(3, p(z4), 2, p(z4[0]), 1) == _lib.H2_ERR_ARGS                  # bad field
     assert lib.h2_bases_free(123456) == _lib.H2_ERR_HANDLE
     # round-2 entries: the opening argument's policies are host logic; bad handles / curves are refused before any device work
-    assert lib.h2_ipa_default_switch_rounds(20, 1) == 5 and lib.h2_ipa_default_switch_rounds(16, 1) == 2 and lib.h2_ipa_default_switch_rounds(24, 1) == 5
+    assert lib.h2_ipa_default_switch_rounds(20, 1) == 6 and lib.h2_ipa_default_switch_rounds(16, 1) == 2 and lib.h2_ipa_default_switch_rounds(24, 1) == 5
+    assert lib.h2_ipa_default_switch_rounds(19, 1) == 5 and lib.h2_ipa_default_switch_rounds(21, 1) == 6 and lib.h2_ipa_default_switch_rounds(22, 1) == 5
     assert lib.h2_ipa_default_switch_rounds(15, 1) == 0 and lib.h2_ipa_default_switch_rounds(20, 0) == 0
     assert lib.h2_commit_pair_supported(8192 + 4) == 1 and lib.h2_commit_pair_supported(4096 + 4) == 0
     assert [lib.h2_commit_window_bits(1 << k) for k in (4, 10, 12, 13, 14, 20)] == [8, 13, 13, 16, 16, 16]

@@ -139,6 +139,58 @@ def test_paired_commit_matches_two_commits(curve, k):
     params.close()
 
 
+@pytest.mark.parametrize("curve,k", [(h.VESTA, 13), (h.PALLAS, 15)])
+def test_paired_commit_sub_digit_boundaries_and_skew(curve, k):
+    """Small 16-bit tables take the paired commit with 8-bit sub-digits (msm.hip, pair_subdigit_launch: every signed table digit d is
+    cut again, |d| = e_0 + 256 e_1 with e_0 in [-127, 128], e_1 in [0, 128]).  Columns made of the boundary cases of that cut -- 16-bit
+    windows 0x0000, 0x0001, 0x007f .. 0x0081, 0x00ff .. 0x0101, 0x7f80 / 0x7f81 (e_1 = 128 through the carry of e_0), 0x8000 (|d| = 2^15),
+    0x8001 (the first digit that recodes negative and carries into the next window), 0xff7f .. 0xff81, 0xffff, in every window
+    position and all at once -- and of the skewed shapes that pile entries into few of the 512 buckets (one scalar repeated, zeros,
+    16-bit scalars): both outputs against the oracle's multiexp over g || u || u || w || w with the other side's scalars zeroed."""
+    import random
+    import torch
+    n = 1 << k
+    sf = fields.CURVE_FIELDS[curve][1]
+    m = fields.MODULUS[sf]
+    g = co.generate_bases(curve, 93, n)
+    w, u = co.generate_bases(curve, 60, 1)[0], co.generate_bases(curve, 61, 1)[0]
+    params = h.Params(curve, k, g, g, w, u)
+    basis = np.ascontiguousarray(np.concatenate([g, np.stack([u, u, w, w])]))
+    rng = random.Random(k)
+    windows = [0x0000, 0x0001, 0x007F, 0x0080, 0x0081, 0x00FF, 0x0100, 0x0101, 0x7F80, 0x7F81, 0x7FFF, 0x8000, 0x8001, 0x80FF, 0xFF7F, 0xFF80,
+               0xFF81, 0xFFFF]
+    vals = []
+    for v in windows:
+        vals += [(v << (16 * pos)) % m for pos in range(16)]                                  # one window set, fifteen zero
+        vals.append(sum(v << (16 * pos) for pos in range(16)) % m)                             # every window the same
+        vals.append(sum((v if (pos + i_) % 2 else windows[(i_ + pos) % len(windows)]) << (16 * pos) for i_, pos in enumerate(range(16))) % m)
+    vals += [0, 1, m - 1, m - 2, (m - 1) // 2, (m + 1) // 2]
+    idx = np.arange(n + 4)
+
+    def check(col, shifts):
+        d_col = torch.from_numpy(np.ascontiguousarray(col).view(np.int64)).cuda()
+        for shift in shifts:
+            side = np.where(idx < n, (idx >> shift) & 1, (idx - n) & 1)
+            got = params.opening_pair_commit(d_col, shift, affine=False).cpu().numpy().view(np.uint64)
+            for s_ in (0, 1):
+                part = col.copy()
+                part[side != s_] = 0
+                assert co.jac_to_affine_ints(curve, got[s_]) == co.jac_to_affine_ints(curve, co.best_multiexp(curve, part, basis)), (shift, s_)
+    col = co.random_field(sf, 94, n + 4)
+    where = rng.sample(range(n + 4), len(vals))
+    col[where] = fields.to_limbs(vals, sf, True)
+    check(col, (0, 3, k - 1))
+    alone = np.zeros_like(col)
+    alone[where] = col[where]
+    check(alone, (0, k - 1))                                                                    # the boundary scalars alone: no cancellation can hide a weight
+    same = np.tile(co.random_field(sf, 95, 1), (n + 4, 1))                                     # one scalar everywhere: 32 buckets hold everything
+    check(same, (1,))
+    small = fields.to_limbs([(i * 2654435761) & 0xFFFF for i in range(n + 4)], sf, True)       # one window in use
+    check(small, (2,))
+    check(np.zeros_like(col), (0,))                                                             # nothing at all: two identities
+    params.close()
+
+
 def test_opening_proof_full_size_schedules_agree_and_verify():
     """k = 20 (BASELINE's size): the two schedules -- independent device algorithms for L_j, R_j -- write identical proof
     bytes, and the oracle's restatement of the reference verifier (one 2^20 multiexp on the host) accepts them."""
@@ -152,9 +204,9 @@ def test_opening_proof_full_size_schedules_agree_and_verify():
     blind = h.Blind(co.random_field(sf, 70, 1)[0])
     p = params.commit(px, blind, affine=True)
     proofs = []
-    assert params.default_hybrid_rounds(True) == 5
-    # "paired" alone moves to the collapsed generators after 5 rounds (the default); 0 keeps every round on the original ones
-    for schedule, hybrid in (("original", None), ("collapse", None), ("paired", 0), ("paired", None), ("paired", 9)):
+    assert params.default_hybrid_rounds(True) == 6
+    # "paired" alone moves to the collapsed generators after 6 rounds (the default at k = 20); 0 keeps every round on the original ones
+    for schedule, hybrid in (("original", None), ("collapse", None), ("paired", 0), ("paired", None), ("paired", 5), ("paired", 9)):
         tr = Blake2bWrite(curve)
         tr.write_point(p)
         x = tr.squeeze_challenge_scalar()
