@@ -1594,8 +1594,8 @@ template <int FB, int D = 4, class Index> __device__ __forceinline__ xyzz9<FB> f
 // line sums got 5 us SLOWER.)
 __device__ __forceinline__ u32 fold9_vquad() { return threadIdx.x / kGroup; }
 __device__ __forceinline__ bool fold9_root() { return threadIdx.x < kGroup; }
-template <int FB> __device__ __forceinline__ xyzz9<FB> fold9_quads_sum(xyzz9<FB> acc, u32 *sh) {
-    const u32 q = fold9_vquad(), nq = blockDim.x / kGroup;
+template <int FB> __device__ __forceinline__ xyzz9<FB> fold9_quads_sum(xyzz9<FB> acc, u32 *sh, u32 first_quads = 0) {      // first_quads (a power of two): only those hold a summand
+    const u32 q = fold9_vquad(), nq = first_quads ? first_quads : blockDim.x / kGroup;
     const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
     for (u32 off = nq / 2; off > 0; off >>= 1) {
         if (q >= off && q < 2 * off && lead) xyzz9_store_raw<FB>(sh + 36 * (size_t)(q - off), acc);
@@ -3943,18 +3943,57 @@ __global__ void __launch_bounds__(256, 3) fold9_finish_dense(const u32 *__restri
     xyzz9_add_wide<FB>(acc, xyzz9_load_raw<FB>(buckets9 + 36 * (size_t)b));
     if ((threadIdx.x & (kGroup - 1)) == 0) xyzz9_store_raw<FB>(buckets9 + 36 * (size_t)b, acc);
 }
-// output `side` = P_0 + 2^8 P_1 from the four slice sums (side-major, XYZZ in the reference's form): 8 doublings and one addition on a quad
+// The rest of the fold of the four 128-bucket slices in ONE launch (fold9_planes' scheme, without line sums and with the join of the two
+// positions inside): workgroup (t, y) sums plane t of slice y = side * 2 + pos -- the 64 finished buckets with bit t of b + 1 set (plane 7:
+// bucket 127 alone) -- and doubles it t times; the workgroup that arrives LAST at its slice adds the eight planes (three tree levels), doubles
+// the sum eight more times when the slice is a position 1 (its buckets count in units of 2^8), and of the two slices of a side the one that
+// arrives last adds the other's sum and writes output `side`.  Arrival counters behind fences, left at zero: counter[0..3] the slices',
+// counter[4..5] the sides'.
 template <int FB>
-__global__ void __launch_bounds__(64) sub_combine(const u32 *__restrict__ slice_sums, u32 *__restrict__ out, int out_kind, int out_mont) {
+__global__ void __launch_bounds__(256, 3) sub_planes(const u32 *__restrict__ buckets9, u32 *__restrict__ planes9, u32 *__restrict__ sums9,
+                                                   u32 *__restrict__ counter, u32 *__restrict__ out, int out_kind, int out_mont) {
     H2_LATENCY_STAGE();
-    if (threadIdx.x >= kGroup) return;
-    slice_sums += 64 * (size_t)blockIdx.x;
-    out += (out_kind == H2_OUT_AFFINE ? 16 : 24) * (size_t)blockIdx.x;
-    xyzz9<FB> r9 = xyzz9_from_r256_wide<FB>(xyzz_load<FB>(slice_sums + 32));
-    for (int k = 0; k < 8; ++k) r9 = xyzz9_dbl_wide<FB>(r9);
-    xyzz9_add_wide<FB>(r9, xyzz9_from_r256_wide<FB>(xyzz_load<FB>(slice_sums)));
-    const xyzz<FB> r = xyzz9_to_r256_wide<FB>(r9);
-    if (threadIdx.x != 0) return;
+    __shared__ __attribute__((aligned(16))) u32 sh[32 * 36];
+    __shared__ u32 s_last;
+    const u32 t = blockIdx.x, y = blockIdx.y;
+    const bool lead = (threadIdx.x & (kGroup - 1)) == 0;
+    const u32 *src = buckets9 + 36 * (size_t)129 * y;
+    planes9 += 36 * (size_t)8 * y;
+    xyzz9<FB> acc = fold9_quad_gather<FB, H2_FOLD_D>(src, t < 7 ? 64u : 1u, [t](u32 k) {
+        return t < 7 ? ((((k >> t) << (t + 1)) | (1u << t) | (k & ((1u << t) - 1u))) - 1u) : 127u;      // the k-th b with bit t of b + 1 set
+    });
+    acc = fold9_quads_sum<FB>(acc, sh);
+    if (fold9_root()) {
+        for (u32 k = 0; k < t; ++k) acc = xyzz9_dbl_wide<FB>(acc);
+        if (lead) {
+            xyzz9_store_raw<FB>(planes9 + 36 * (size_t)t, acc);
+            __threadfence();
+            s_last = atomicAdd(counter + y, 1u) == 7u ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    acc = fold9_quad_gather<FB, H2_FOLD_D>(planes9, 8u, [](u32 k) { return k; });
+    acc = fold9_quads_sum<FB>(acc, sh, 8u);
+    if (!fold9_root()) return;
+    if (y & 1u)
+        for (int k = 0; k < 8; ++k) acc = xyzz9_dbl_wide<FB>(acc);
+    u32 ticket = 0;
+    if (lead) {
+        counter[y] = 0;
+        xyzz9_store_raw<FB>(sums9 + 36 * (size_t)y, acc);
+        __threadfence();
+        ticket = atomicAdd(counter + 4 + (y >> 1), 1u);
+    }
+    ticket = (u32)__builtin_amdgcn_mov_dpp((int)ticket, 0, 0xf, 0xf, false);      // quad lane 0's ticket
+    if (ticket == 0) return;                                                       // the side's other slice finishes the output
+    __threadfence();
+    xyzz9_add_wide<FB>(acc, xyzz9_load_raw<FB>(sums9 + 36 * (size_t)(y ^ 1u)));
+    const xyzz<FB> r = xyzz9_to_r256_wide<FB>(acc);
+    if (!lead) return;
+    counter[4 + (y >> 1)] = 0;
+    out += (out_kind == H2_OUT_AFFINE ? 16 : 24) * (size_t)(y >> 1);
     if (out_kind == H2_OUT_AFFINE) {
         affine<FB> a = xyzz_to_affine<FB>(r);
         if (!out_mont) { a.x = fe_from_mont<FB>(a.x); a.y = fe_from_mont<FB>(a.y); }
@@ -3974,7 +4013,7 @@ template <int FB, int FS>
 static int pair_subdigit_launch(MsmContext &cx, const Bases &b, const void *d_scalars, size_t n, unsigned pair_shift, int form, int out_kind,
                                 void *d_out, hipStream_t st) {
     int rc;
-    const u32 nblk = (u32)((n + kSubBlock - 1) / kSubBlock), tb = kSubSlots, S = 128, NR = 1, nsl = 4;
+    const u32 nblk = (u32)((n + kSubBlock - 1) / kSubBlock), tb = kSubSlots, nsl = 4;
     const size_t max_entries = n * 32;
     u32 &lanes = cx.lanes[FB][2];
     if (!lanes) {            // how many lanes of the M9 accumulate the chip holds at once (as msm_launch sizes it)
@@ -3989,7 +4028,7 @@ static int pair_subdigit_launch(MsmContext &cx, const Bases &b, const void *d_sc
     const u32 T = (u32)std::min<size_t>(lanes, std::max<size_t>(256, (max_entries / lane_div + 255) / 256 * 256));
     if ((rc = cx.hist.reserve(((size_t)2 * nblk + 1) * kSubKeys * 4)) != H2_OK || (rc = cx.starts.reserve((tb + 2) * 4)) != H2_OK ||
         (rc = cx.entries.reserve(max_entries * 4)) != H2_OK || (rc = cx.seg9.reserve(((size_t)T + tb) * 144)) != H2_OK ||
-        (rc = cx.partial.reserve((size_t)nsl * 32 * 144)) != H2_OK || (rc = cx.ssums.reserve((size_t)nsl * 128)) != H2_OK)
+        (rc = cx.partial.reserve((size_t)nsl * (8 + 1) * 144)) != H2_OK)
         return rc;
     if (cx.fold_ctr.cap < 64) {          // fold9_planes' arrival counters: zero once, every launch leaves them at zero
         if ((rc = cx.fold_ctr.reserve((size_t)kMaxCols * 64)) != H2_OK) return rc;
@@ -3998,13 +4037,11 @@ static int pair_subdigit_launch(MsmContext &cx, const Bases &b, const void *d_sc
     u32 *wg_hist = cx.hist.as<u32>(), *wg_off = wg_hist + (size_t)nblk * kSubKeys, *kstart = wg_off + (size_t)nblk * kSubKeys;
     u32 *starts = cx.starts.as<u32>(), *entries = cx.entries.as<u32>();
     u32 *heads9 = cx.seg9.as<u32>(), *buckets9 = heads9 + 36 * (size_t)T;
-    u32 *planes9 = cx.partial.as<u32>(), *ssums = cx.ssums.as<u32>();
+    u32 *planes9 = cx.partial.as<u32>(), *sums9 = planes9 + 36 * (size_t)nsl * 8;
     const int mont = form == H2_FORM_MONTGOMERY ? 1 : 0;
     const u32 pair_n = (u32)(n - 4);
     ColStride cs;
-    ColOut co;
     memset(&cs, 0, sizeof cs);
-    memset(&co, 0, sizeof co);
     hipLaunchKernelGGL((sub_count<FS>), dim3(nblk), dim3(kSubBlock), 0, st, (const u32 *)d_scalars, (u32)n, pair_n, (int)pair_shift, mont, wg_hist);
     hipLaunchKernelGGL(sub_scan, dim3(1), dim3(kSubKeys), 0, st, (const u32 *)wg_hist, nblk, wg_off, kstart, starts, buckets9);
     hipLaunchKernelGGL((sub_scatter<FS>), dim3(nblk), dim3(kSubBlock), 0, st, (const u32 *)d_scalars, (u32)n, pair_n, (int)pair_shift, mont, b.stride,
@@ -4012,10 +4049,8 @@ static int pair_subdigit_launch(MsmContext &cx, const Bases &b, const void *d_sc
     hipLaunchKernelGGL((msm_accumulate<FB, false, true>), dim3(T / 256), dim3(256), 0, st, (const u32 *)b.d_table, (const u32 *)nullptr, 0xFFFFFFFFu,
                        (const u32 *)entries, (const u32 *)starts, heads9, buckets9, tb, T, lane_div, cs);
     hipLaunchKernelGGL((fold9_finish_dense<FB>), dim3(tb), dim3(256), 0, st, (const u32 *)heads9, (const u32 *)starts, buckets9, tb, T, lane_div);
-    // the finished bucket slots ARE the planes' line sums: S = 128 columns, no rows; plane t < 7 = the 64 buckets with bit t of b + 1 set, plane 7 = bucket 127
-    hipLaunchKernelGGL((fold9_planes<FB>), dim3(8, nsl), dim3(256), 0, st, (const u32 *)buckets9, planes9, cx.fold_ctr.as<u32>(), S, NR, 7, ssums,
-                       kOutSliceSum, 1, co, cs);
-    hipLaunchKernelGGL((sub_combine<FB>), dim3(2), dim3(64), 0, st, (const u32 *)ssums, (u32 *)d_out, out_kind, mont);
+    hipLaunchKernelGGL((sub_planes<FB>), dim3(8, nsl), dim3(256), 0, st, (const u32 *)buckets9, planes9, sums9, cx.fold_ctr.as<u32>(), (u32 *)d_out, out_kind,
+                       mont);
     H2_HIP(hipGetLastError());
     return H2_OK;
 }
