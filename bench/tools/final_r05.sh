@@ -23,6 +23,10 @@ timeout 120 build/h2bench ntt 16,18,20,21,22,24 0 1 > $O/h2bench_ntt.txt 2>&1
 timeout 120 build/h2bench msm 20 0 > $O/h2bench_msm.txt 2>&1
 timeout 120 build/h2bench host 20 > $O/h2bench_host.txt 2>&1
 el "h2bench legs done"
+# the opening argument (commitment::create_proof as one native call): resident from the Python mirror, with per-round stamps; from host Vecs through the C++ mirror
+TABLES=0 timeout 200 python bench/tools/opening_probe.py 2>/dev/null | tail -1 > $O/opening_k20.json
+timeout 200 build/host_mirror_check opening-time 20 4 > $O/opening_host_mirror.txt 2>&1
+el "opening legs done"
 PORT=$(python - <<'PY'
 import socket
 s = socket.socket(); s.bind(("127.0.0.1", 0)); print(s.getsockname()[1])

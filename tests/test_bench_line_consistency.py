@@ -36,6 +36,13 @@ def test_committed_bench_line_is_self_consistent():
     assert abs(rn["frac"] - rn["achieved"] / rn["peak"]) < 1e-4
     assert d["checks"]["split_sum_identity"] is True
     assert d["extra"]["create_proof_simple_example_k20"]["accepted_and_wrong_instance_rejected"] is True
+    # round 5, second half: the opening argument as one native call (resident and from host vectors: the same bytes), the generic multiexp as
+    # independent calls (the same point from every stream)
+    oa = d["extra"]["opening_argument_k20"]
+    assert oa["same_proof_bytes"] is True and oa["proof_bytes"] == 32 + 64 * 20 + 64 and 5 < oa["resident_p_poly_ms"] < 40 and 5 < oa["host_vectors_ms"] < 60
+    ic = d["generic_best_multiexp"]["independent_calls"]
+    assert ic["all_equal_affine"] is True and ic["ms_per_call"] <= d["generic_best_multiexp"]["ms"] * 1.05
+    assert abs(ic["Mscalar_mults_per_s"] - (n + 1) / ic["ms_per_call"] / 1e3) / ic["Mscalar_mults_per_s"] < 2e-3
     # round 5: the PMC constants say that they are constants; the cold-twiddle cost stands beside the cached NTT figures
     assert "NOT measured in this run" in r["traffic_source"] and "not measured in this run" in rn["traffic_source"]
     for key in ("2^20", "2^22"):
