@@ -750,7 +750,7 @@ def main():
             open_host_ms = _med(lambda: _timed_opening(1, o_px), reps=3)
             extra["opening_argument_k20"] = {
                 "what": "commitment::create_proof (poly/commitment/prover.rs:26-151) for one 2^20-coefficient polynomial on Vesta as ONE library call, median of 3 "
-                        "after a warm-up: the S commitment, 20 rounds (5 over the registered generators, the read-out and registration of G'_5, 15 over its table), "
+                        "after a warm-up: the S commitment, 20 rounds (6 over the registered generators, the read-out and registration of G'_6, 14 over its table as paired commits with 8-bit sub-digits), "
                         "40 points and 2 scalars to a BLAKE2b transcript",
                 "resident_p_poly_ms": round(open_res_ms, 3), "host_vectors_ms": round(open_host_ms, 3), "same_proof_bytes": bool(o_bytes[0] == o_bytes[1]),
                 "proof_bytes": len(o_bytes[0])}
