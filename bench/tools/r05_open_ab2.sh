@@ -1,12 +1,11 @@
 #!/bin/bash
-# Round 5: opening argument k = 20 after the host divstep inversion; A/B of the table chain's quad-lane threshold at the switch (2^15 + 4 points)
+# Round 5: the opening argument at k = 20 from the resident Python mirror (twice) and from host Vecs through the C++ mirror (h2_open), with the
+# parity tests of the whole-argument entry points.  (The run kept in profiles/r05_open_entry.txt also alternated H2_TABLE_WIDE_MAX=16384 -- the table's
+# doubling chain on one lane per point at 2^15 points -- which lost to the quad-lane chain and was removed with its switch.)
 mkdir -p gpurun_out
 {
   for rep in 1 2; do
-    echo "== default (chain on quads of lanes up to 65536 points)"
     TABLES=0 python bench/tools/opening_probe.py 2>&1 | tail -1
-    echo "== H2_TABLE_WIDE_MAX=16384 (one lane per point at 2^15)"
-    H2_TABLE_WIDE_MAX=16384 TABLES=0 python bench/tools/opening_probe.py 2>&1 | tail -1
   done
   echo "== host vectors, C++ mirror, one call (h2_open)"
   build/host_mirror_check opening-time 20 5
