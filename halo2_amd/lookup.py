@@ -21,6 +21,7 @@ from .arithmetic import batch_invert, eval_polynomial, grand_product, permute_ex
 from .commitment import Blind, Params
 from .evaluator import LAGRANGE, Ast, Evaluator
 from .multiopen import ProverQuery
+from .transcript import write_evaluation
 
 
 def _host(t) -> np.ndarray:
@@ -148,7 +149,7 @@ class Constructed:
         x_inv, x_next = domain.rotate_omega(x, -1), domain.rotate_omega(x, 1)
         for poly, pt in ((self.product_poly, x), (self.product_poly, x_next), (self.permuted_input_poly, x),
                          (self.permuted_input_poly, x_inv), (self.permuted_table_poly, x)):
-            transcript.write_scalar(_host(eval_polynomial(poly, lim(pt), sf)))
+            write_evaluation(transcript, eval_polynomial(poly, lim(pt), sf))
         return Evaluated(self)
 
 

@@ -16,6 +16,7 @@ from . import fields
 from .arithmetic import eval_polynomial, kate_division, scale_add
 from .commitment import Blind, Params
 from .opening import create_proof as commitment_create_proof
+from .transcript import DeferredScalars, write_evaluation
 
 
 @dataclass
@@ -107,8 +108,10 @@ def create_proof(params: Params, rng, transcript, queries, schedule: str | None 
     q_prime_blind = Blind(np.ascontiguousarray(rng(1)[0]))                                # prover.rs:99-102
     transcript.write_point(host(params.commit(q_prime, q_prime_blind)))
     x_3 = transcript.squeeze_challenge_scalar()                                           # prover.rs:104
+    evals = DeferredScalars(transcript)             # the evaluations cross PCIe together (transcript.py)
     for q in q_polys:                                                                     # prover.rs:108-110
-        transcript.write_scalar(host(eval_polynomial(q, x_3, sf)))
+        write_evaluation(evals, eval_polynomial(q, x_3, sf))
+    evals.flush()
     x_4 = transcript.squeeze_challenge_scalar()                                           # prover.rs:112
 
     p_poly, p_blind = q_prime, as_int(q_prime_blind.value)                                # prover.rs:114-122

@@ -20,6 +20,7 @@ from .arithmetic import batch_invert, eval_polynomial, grand_product
 from .commitment import Blind, Params
 from .evaluator import LAGRANGE, Ast, Evaluator
 from .multiopen import ProverQuery
+from .transcript import write_evaluation
 
 
 def _host(t) -> np.ndarray:
@@ -38,7 +39,7 @@ class ProvingKey:
 
     def evaluate(self, x, field: int, transcript) -> None:                                # prover.rs:321-333
         for poly in self.polys:
-            transcript.write_scalar(_host(eval_polynomial(poly, x, field)))
+            write_evaluation(transcript, eval_polynomial(poly, x, field))
 
 
 class Argument:
@@ -143,11 +144,10 @@ class Constructed:
         sf = domain.field
         lim = lambda v: fields.scalar_limbs(v % domain.m, sf, True)
         for i, s in enumerate(self.sets):
-            transcript.write_scalar(_host(eval_polynomial(s.permutation_product_poly, lim(x), sf)))
-            transcript.write_scalar(_host(eval_polynomial(s.permutation_product_poly, lim(domain.rotate_omega(x, 1)), sf)))
+            write_evaluation(transcript, eval_polynomial(s.permutation_product_poly, lim(x), sf))
+            write_evaluation(transcript, eval_polynomial(s.permutation_product_poly, lim(domain.rotate_omega(x, 1)), sf))
             if i + 1 < len(self.sets):                                                     # chain to the next set (:366-373)
-                transcript.write_scalar(_host(eval_polynomial(s.permutation_product_poly,
-                                                              lim(domain.rotate_omega(x, -(blinding_factors + 1))), sf)))
+                write_evaluation(transcript, eval_polynomial(s.permutation_product_poly, lim(domain.rotate_omega(x, -(blinding_factors + 1))), sf))
         return Evaluated(self)
 
 

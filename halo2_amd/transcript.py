@@ -93,3 +93,42 @@ class Blake2bWrite(_Blake2bTranscript):
         buf = (C.c_uint8 * max(n.value, 1))()
         check(lib().h2_transcript_bytes(self._h, buf, n.value, C.byref(n)), "h2_transcript_bytes")
         return bytes(buf[:n.value])
+
+
+class DeferredScalars:
+    """A transcript seen through a queue of scalars that are still in HBM.  The prover writes runs of evaluations to the transcript with no
+    challenge between them (plonk/prover.rs:602-675: instance, advice, fixed, vanishing, permutation and lookup evaluations; multiopen/prover.rs:108-110);
+    read back one by one, every evaluation is a launch, a 32-byte copy and a stream synchronisation -- 27 of them in the simple-example proof.
+    Through this wrapper `write_scalar` accepts the (4,) device tensor itself and queues it; everything queued crosses in ONE copy at `flush()`,
+    which any other use of the transcript (a point, a challenge, its handle, its bytes) triggers first -- the bytes written are the same, in the
+    same order.  Host scalars may be queued too (they keep their place)."""
+    defers = True
+
+    def __init__(self, inner):
+        self.inner, self.queue = inner, []
+
+    def write_scalar(self, scalar) -> None:
+        self.queue.append(scalar)
+
+    def flush(self) -> None:
+        if not self.queue:
+            return
+        import torch
+        dev = [t.reshape(4) for t in self.queue if isinstance(t, torch.Tensor)]
+        landed = iter(torch.stack(dev).cpu().numpy().view(np.uint64)) if dev else iter(())
+        queue, self.queue = self.queue, []
+        for t in queue:
+            self.inner.write_scalar(next(landed) if isinstance(t, torch.Tensor) else t)
+
+    def __getattr__(self, name):                   # whatever else the transcript offers, after what is queued
+        self.flush()
+        return getattr(self.inner, name)
+
+
+def write_evaluation(transcript, value) -> None:
+    """`transcript.write_scalar(eval)` for an evaluation that is a (4,) device tensor: queued when the transcript defers (DeferredScalars),
+    read back now otherwise."""
+    if getattr(transcript, "defers", False) or isinstance(value, np.ndarray):
+        transcript.write_scalar(value)
+    else:
+        transcript.write_scalar(value.cpu().numpy().view(np.uint64))

@@ -14,6 +14,7 @@ from .arithmetic import eval_polynomial, scale_add
 from .commitment import Blind, Params
 from .evaluator import Ast
 from .multiopen import ProverQuery
+from .transcript import write_evaluation
 
 
 def _host(t) -> np.ndarray:
@@ -63,7 +64,7 @@ class Constructed:
         for piece, blind in zip(reversed(self.h_pieces), reversed(self.h_blinds)):                    # :134-144
             h_poly = piece.clone() if h_poly is None else scale_add(h_poly, xn_l, piece, sf)
             h_blind = (h_blind * xn + fields.from_limbs(blind.value.reshape(1, 4), sf, True)[0]) % m
-        transcript.write_scalar(_host(eval_polynomial(self.committed.random_poly, x, sf)))           # :146-147
+        write_evaluation(transcript, eval_polynomial(self.committed.random_poly, x, sf))           # :146-147
         return Evaluated(h_poly, Blind(fields.scalar_limbs(h_blind, sf, True)), self.committed)
 
 
