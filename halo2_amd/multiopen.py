@@ -74,8 +74,8 @@ def create_proof(params: Params, rng, transcript, queries, schedule: str | None 
     as_limbs = lambda v: fields.scalar_limbs(v % m, sf, True)
     host = lambda t: t.cpu().numpy().view(np.uint64)
 
-    x_1 = transcript.squeeze_challenge_scalar()                                           # prover.rs:38-39
-    x_2 = transcript.squeeze_challenge_scalar()
+    # (the grouping of the queries is host work that asks the transcript nothing: done BEFORE the challenges, so that a transcript that still has
+    # evaluations queued in HBM -- transcript.DeferredScalars, plonk.create_proof -- is flushed after it, while the GPU finishes them)
     by_id = {id(q.poly): q for q in queries}
     for q in queries:
         if q.poly.shape[0] != n:
@@ -84,6 +84,8 @@ def create_proof(params: Params, rng, transcript, queries, schedule: str | None 
     if sets is None:
         raise ValueError("queries iterator contains mismatching evaluations")             # prover.rs:41-46
     poly_map, point_sets = sets
+    x_1 = transcript.squeeze_challenge_scalar()                                           # prover.rs:38-39
+    x_2 = transcript.squeeze_challenge_scalar()
 
     # openings at the same point set collapse into one polynomial with x_1 (prover.rs:50-72)
     x1_i = as_int(x_1)
@@ -108,7 +110,7 @@ def create_proof(params: Params, rng, transcript, queries, schedule: str | None 
     q_prime_blind = Blind(np.ascontiguousarray(rng(1)[0]))                                # prover.rs:99-102
     transcript.write_point(host(params.commit(q_prime, q_prime_blind)))
     x_3 = transcript.squeeze_challenge_scalar()                                           # prover.rs:104
-    evals = DeferredScalars(transcript)             # the evaluations cross PCIe together (transcript.py)
+    evals = transcript if getattr(transcript, "defers", False) else DeferredScalars(transcript)      # the evaluations cross PCIe together (transcript.py)
     for q in q_polys:                                                                     # prover.rs:108-110
         write_evaluation(evals, eval_polynomial(q, x_3, sf))
     evals.flush()

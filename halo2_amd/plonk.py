@@ -291,9 +291,8 @@ def create_proof_many(params: Params, pk: ProvingKey, circuits, rng, transcript,
                               if cs.permutation_columns else permutation.Committed([]))
     lookups = [[p.commit_product(params, domain, bf, beta, gamma, cosets, rng, transcript) for p in ls] for ls in lookups]      # :483-502
 
-    vanishing = vanishing_arg.Argument.commit(params, domain, rng, transcript, device=dev)                      # :505
-    y = transcript.squeeze_challenge()                                                    # :508
-
+    # the expression trees of the quotient (:511-586) ask for beta and gamma, not for y, and draw no randomness: built HERE, while the GPU still
+    # works off the transforms the permutation / lookup products left queued, instead of behind the read-back of the next commitment
     perm_pairs = [pc.construct(domain, cs.degree, bf, pkey, leaves, l0, l_blind, l_last, beta, gamma)
                   for pc, leaves in zip(perm_committed, perm_leaves_all)]                 # :511-531
     lookup_pairs = [[p.construct(beta, gamma, l0, l_blind, l_last) for p in ls] for ls in lookups]             # :533-543
@@ -301,6 +300,9 @@ def create_proof_many(params: Params, pk: ProvingKey, circuits, rng, transcript,
     for cc, (_, perm_exprs), lps in zip(cells_c, perm_pairs, lookup_pairs):               # :545-586
         expressions += [g(cc) for g in cs.gates] + perm_exprs + [e for _, es in lps for e in es]
     expressions = [e if isinstance(e, Ast) else Ast.constant(int(e)) for e in expressions]
+
+    vanishing = vanishing_arg.Argument.commit(params, domain, rng, transcript, device=dev)                      # :505
+    y = transcript.squeeze_challenge()                                                    # :508
     vanishing = vanishing.construct(params, domain, cosets, expressions, y, rng, transcript)                    # :589-597
 
     x_l = transcript.squeeze_challenge_scalar()                                           # :598
@@ -322,7 +324,6 @@ def create_proof_many(params: Params, pk: ProvingKey, circuits, rng, transcript,
     pkey.evaluate(x_l, sf, evals)                                                         # :658
     perm_evaluated = [pc.evaluate(domain, bf, x, evals) for pc, _ in perm_pairs]          # :661-664
     lookups_evaluated = [[c.evaluate(domain, x, evals) for c, _ in lps] for lps in lookup_pairs]               # :667-675
-    evals.flush()
 
     queries = []                                                                          # :677-722
     for inst, adv, advice_blinds, pe, les in zip(inst_all, adv_all, blinds_all, perm_evaluated, lookups_evaluated):
@@ -334,4 +335,6 @@ def create_proof_many(params: Params, pk: ProvingKey, circuits, rng, transcript,
     queries += [ProverQuery(at(rot), pk.fixed_polys[col], Blind(field=sf)) for col, rot in cs.fixed_queries]
     queries += pkey.open(x_l, sf)
     queries += vanishing.open(x_l)
-    multiopen.create_proof(params, rng, transcript, queries, schedule=schedule)           # :724
+    # (still through `evals`: the multi-point opening groups its queries on the host before it asks for its first challenge, which flushes)
+    multiopen.create_proof(params, rng, evals, queries, schedule=schedule)                # :724
+    evals.flush()

@@ -95,6 +95,10 @@ class Blake2bWrite(_Blake2bTranscript):
         return bytes(buf[:n.value])
 
 
+import os as _os
+_DEFER_OFF = _os.environ.get("H2_PLONK_DEFER", "1") == "0"
+
+
 class DeferredScalars:
     """A transcript seen through a queue of scalars that are still in HBM.  The prover writes runs of evaluations to the transcript with no
     challenge between them (plonk/prover.rs:602-675: instance, advice, fixed, vanishing, permutation and lookup evaluations; multiopen/prover.rs:108-110);
@@ -109,6 +113,8 @@ class DeferredScalars:
 
     def write_scalar(self, scalar) -> None:
         self.queue.append(scalar)
+        if _DEFER_OFF:                              # H2_PLONK_DEFER=0: every scalar is read back where it is written (the A/B arm)
+            self.flush()
 
     def flush(self) -> None:
         if not self.queue:
