@@ -838,7 +838,9 @@ extern "C" int h2_open_device(int curve, unsigned k, h2_bases_t g_basis, h2_base
                               const uint64_t *uw_xy, const void *d_p_poly, const uint64_t *p_blind, const uint64_t *x3, void *d_s_poly,
                               const uint64_t *s_blind, const uint64_t *rands, h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze,
                               void *user, uint64_t *c_out, uint64_t *f_out, void *stream) {
-    if (open_bad_args(curve, k, p_blind, x3, s_blind, rands, write_point, squeeze, c_out, f_out) || !d_p_poly || !d_s_poly) return H2_ERR_ARGS;
+    if (open_bad_args(curve, k, p_blind, x3, s_blind, rands, write_point, squeeze, c_out, f_out) || !d_p_poly || !d_s_poly ||
+        d_p_poly == d_s_poly)                          // (s_poly is overwritten with P' while p_poly is still being read)
+        return H2_ERR_ARGS;
     int rc = open_check_bases(curve, k, g_basis, opening_basis, paired);
     if (rc != H2_OK) return rc;
     if ((rc = ensure_device()) != H2_OK) return rc;

@@ -439,6 +439,10 @@ def test_whole_argument_refuses_before_touching_the_transcript():
     assert call(params._h_g, basis, 1) != 0                  # ... or g || u || u || w || w when paired
     assert call(params._h_g, basis, 0, None) != 0            # p_poly missing
     assert call(C.c_uint64(0xDEAD), basis, 0) != 0           # not a handle
+    import torch
+    d_same = torch.from_numpy(px.view(np.int64)).cuda()
+    assert lib().h2_open_device(curve, k, params._h_g, basis, 0, IPA_SWITCH_DEFAULT, _p(uw), d_same.data_ptr(), _p(one), _p(one), d_same.data_ptr(), _p(one),
+                                _p(rands), cb_w, cb_s, None, _p(c), _p(f), None) != 0       # p_poly and s_poly must not be one buffer
     assert calls == []
     lib().h2_bases_free(bare)
     params.close()
