@@ -23,6 +23,8 @@
 namespace h2 {
 
 int bases_refill_device(h2_bases_t handle, const void *d_bases_xy, size_t n, int form);      // msm.hip
+int bases_register_device_internal(int curve, const void *d_bases_xy, size_t n, int form, h2_bases_t *handle, bool glv);
+bool pair_subdigits_apply(size_t n);
 
 // naf1 / naf2: signed digits in {-1, 0, 1} of k1 and k2 (signs folded in), little-endian, uniform across lanes;
 // g[i] <- g[i] + [k1] g[half + i] + [k2] phi(g[half + i])
@@ -694,7 +696,11 @@ extern "C" int h2_ipa_rounds_device(int curve, unsigned k, unsigned switch_round
     if (cx.gp_handle) {
         if ((rc = bases_refill_device(cx.gp_handle, d_g, nj + tail, H2_FORM_MONTGOMERY)) != H2_OK) return rc;
     } else {
-        if ((rc = h2_bases_register_device(curve, d_g, nj + tail, H2_FORM_MONTGOMERY, &cx.gp_handle)) != H2_OK) return rc;
+        // rounds over a small table are sub-digit paired commits, which read an ENDOMORPHISM table as well: 8 x 16 doublings in its chain instead
+        // of 15 x 16 -- the chain is what the table costs (0.77 ms of 240 dependent doublings at 2^14 points).  H2_IPA_GLV_TABLE=0: the plain table (A/B).
+        static const bool glv_env = [] { const char *e = getenv("H2_IPA_GLV_TABLE"); return !(e && e[0] == '0'); }();
+        const bool glv = glv_env && pair2 && pair_subdigits_apply(nj + tail);
+        if ((rc = bases_register_device_internal(curve, d_g, nj + tail, H2_FORM_MONTGOMERY, &cx.gp_handle, glv)) != H2_OK) return rc;
         cx.gp_curve = curve;
         cx.gp_n = nj + tail;
     }

@@ -2014,9 +2014,10 @@ __global__ void __launch_bounds__(64) msm_blind_install(u32 *__restrict__ table,
 // rows 1 .. W-1 of the table from the chains' XYZZ results, affine and in M9 form, with ONE inversion per point: the W - 1
 // multiples of a point are normalised together (Montgomery's trick over
 // d_w = ZZ_w ZZZ_w; the running products wait in `pre`), ~8 multiplications per entry instead of a 255-step inversion each
+// phi_rows != 0 (endomorphism tables): row phi_rows + w receives phi of what row w receives -- one more product per entry
 template <int FB>
 __global__ void __launch_bounds__(256) msm_table_normalise_batch(const u32 *__restrict__ tmp, u32 *__restrict__ pre, u32 *__restrict__ table,
-                                                                 u32 count, u32 first, u32 stride, int W) {
+                                                                 u32 count, u32 first, u32 stride, int W, int phi_rows = 0) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     fe acc = fe_one<FB>();
@@ -2038,20 +2039,33 @@ __global__ void __launch_bounds__(256) msm_table_normalise_batch(const u32 *__re
         }
         const fe di = fe_mulx<FB>(inv, fe_load(pre + 8 * t));                      // 1 / (ZZ ZZZ)
         inv = fe_mulx<FB>(inv, fe_mulx<FB>(r.zz, r.zzz));
-        const affine<FB> a = aff_to_m9<FB>(affine<FB>{fe_mulx<FB>(r.x, fe_mulx<FB>(di, r.zzz)), fe_mulx<FB>(r.y, fe_mulx<FB>(di, r.zz))});
+        const affine<FB> am = affine<FB>{fe_mulx<FB>(r.x, fe_mulx<FB>(di, r.zzz)), fe_mulx<FB>(r.y, fe_mulx<FB>(di, r.zz))};
+        const affine<FB> a = aff_to_m9<FB>(am);
         fe_store(dst, a.x);
         fe_store(dst + 8, a.y);
+        if (phi_rows) {
+            const affine<FB> ph = aff_to_m9<FB>(affine<FB>{fe_mulx<FB>(am.x, glv_zeta<FB>()), am.y});
+            u32 *dph = dst + 16 * (size_t)phi_rows * stride;
+            fe_store(dph, ph.x);
+            fe_store(dph + 8, ph.y);
+        }
     }
 }
 // row 0 (the caller's points, reference Montgomery form) -> M9 form, once the chains have read it
 template <int FB>
-__global__ void __launch_bounds__(256) msm_table_row0_to_m9(u32 *__restrict__ table, u32 count, u32 first) {
+__global__ void __launch_bounds__(256) msm_table_row0_to_m9(u32 *__restrict__ table, u32 count, u32 first, u32 phi_row_words = 0) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     u32 *dst = table + 16 * (size_t)(first + i);
-    const affine<FB> a = aff_to_m9<FB>(aff_load<FB>(dst));
+    const affine<FB> am = aff_load<FB>(dst);
+    const affine<FB> a = aff_to_m9<FB>(am);
     fe_store(dst, a.x);
     fe_store(dst + 8, a.y);
+    if (phi_row_words && !aff_is_identity(am)) {       // (endomorphism tables: row `glv` = phi(row 0); the identity stays all-zero)
+        const affine<FB> ph = aff_to_m9<FB>(affine<FB>{fe_mulx<FB>(am.x, glv_zeta<FB>()), am.y});
+        fe_store(dst + phi_row_words, ph.x);
+        fe_store(dst + phi_row_words + 8, ph.y);
+    }
 }
 
 // ---- the collapsed generators of the opening argument, straight from a registered table ------------------------------------
@@ -2991,6 +3005,8 @@ struct Bases {
     int blind_form = 0;
     unsigned char blind_host[64] = {0};
     DevBuf fill_tmp;           // table_fill's staging, kept only by handles that are refilled (bases_refill_device: the opening argument's G' table)
+    int glv = 0;               // != 0: an ENDOMORPHISM table (the opening argument's G', served by pair_subdigit_launch only): rows 0 .. glv - 1 are
+                               // 2^(16 w) P, rows glv .. 2 glv - 1 their images phi(2^(16 w) P) = (zeta x, y) = [lambda] 2^(16 w) P; W = 2 glv
     // The table is owned here: it goes back to the allocator when the LAST reference drops -- h2_bases_free only removes
     // the handle, so a commit another host thread is still enqueueing (it holds the shared_ptr from find_bases) keeps the
     // memory alive, and every error path of h2_bases_register releases what it had allocated.
@@ -3028,7 +3044,8 @@ static int table_fill(Bases &b, u32 first, u32 count, hipStream_t st, bool keep_
     void *tmp = nullptr;
     // worked in slabs so the XYZZ staging stays modest
     const u32 slab = 1u << 18;
-    const size_t tmp_bytes = (size_t)std::min(count, slab) * (b.W - 1) * 160;      // XYZZ staging + the running products
+    const int Wd = b.glv ? b.glv : b.W;              // rows that come from the doubling chain (an endomorphism table: half of them, 8 x 16 doublings)
+    const size_t tmp_bytes = (size_t)std::min(count, slab) * (Wd - 1) * 160;      // XYZZ staging + the running products
     keep_tmp = keep_tmp && tmp_bytes <= ((size_t)256 << 20);
     if (keep_tmp) {
         int rc = b.fill_tmp.reserve(tmp_bytes);
@@ -3040,24 +3057,25 @@ static int table_fill(Bases &b, u32 first, u32 count, hipStream_t st, bool keep_
     for (u32 off = 0; off < count; off += slab) {
         u32 cnt = std::min(slab, count - off);
         dim3 g1((cnt + 255) / 256), blk(256);
-        size_t tot = (size_t)cnt * (b.W - 1);
+        size_t tot = (size_t)cnt * (Wd - 1);
         u32 *pre = (u32 *)tmp + 32 * tot;
         const bool wide = count <= 65536;           // few points: the doubling chain is pure latency
         dim3 g1w((cnt * kGroup + 255) / 256);
         if (b.curve == H2_PALLAS) {
-            if (wide) hipLaunchKernelGGL((msm_table_chain_wide<FP>), g1w, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.c, b.W);
-            else hipLaunchKernelGGL((msm_table_chain<FP>), g1, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.stride, b.c, b.W);
-            hipLaunchKernelGGL((msm_table_normalise_batch<FP>), g1, blk, 0, st, (const u32 *)tmp, pre, (u32 *)b.d_table, cnt, first + off, b.stride, b.W);
+            if (wide) hipLaunchKernelGGL((msm_table_chain_wide<FP>), g1w, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.c, Wd);
+            else hipLaunchKernelGGL((msm_table_chain<FP>), g1, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.stride, b.c, Wd);
+            hipLaunchKernelGGL((msm_table_normalise_batch<FP>), g1, blk, 0, st, (const u32 *)tmp, pre, (u32 *)b.d_table, cnt, first + off, b.stride, Wd, b.glv);
         } else {
-            if (wide) hipLaunchKernelGGL((msm_table_chain_wide<FQ>), g1w, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.c, b.W);
-            else hipLaunchKernelGGL((msm_table_chain<FQ>), g1, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.stride, b.c, b.W);
-            hipLaunchKernelGGL((msm_table_normalise_batch<FQ>), g1, blk, 0, st, (const u32 *)tmp, pre, (u32 *)b.d_table, cnt, first + off, b.stride, b.W);
+            if (wide) hipLaunchKernelGGL((msm_table_chain_wide<FQ>), g1w, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.c, Wd);
+            else hipLaunchKernelGGL((msm_table_chain<FQ>), g1, blk, 0, st, (const u32 *)b.d_table, (u32 *)tmp, cnt, first + off, b.stride, b.c, Wd);
+            hipLaunchKernelGGL((msm_table_normalise_batch<FQ>), g1, blk, 0, st, (const u32 *)tmp, pre, (u32 *)b.d_table, cnt, first + off, b.stride, Wd, b.glv);
         }
     }
     {
         dim3 g0((count + 255) / 256), blk(256);
-        if (b.curve == H2_PALLAS) hipLaunchKernelGGL((msm_table_row0_to_m9<FP>), g0, blk, 0, st, (u32 *)b.d_table, count, first);
-        else hipLaunchKernelGGL((msm_table_row0_to_m9<FQ>), g0, blk, 0, st, (u32 *)b.d_table, count, first);
+        const u32 phi_words = b.glv ? 16u * (u32)b.glv * b.stride : 0u;
+        if (b.curve == H2_PALLAS) hipLaunchKernelGGL((msm_table_row0_to_m9<FP>), g0, blk, 0, st, (u32 *)b.d_table, count, first, phi_words);
+        else hipLaunchKernelGGL((msm_table_row0_to_m9<FQ>), g0, blk, 0, st, (u32 *)b.d_table, count, first, phi_words);
     }
     hipError_t e = hipStreamSynchronize(st);
     if (!keep_tmp) (void)hipFree(tmp);
@@ -3522,7 +3540,7 @@ extern "C" int h2_msm(int curve, const uint64_t *scalars, const uint64_t *bases_
     return H2_OK;
 }
 
-static int bases_register_impl(int curve, const void *bases_xy, bool on_device, size_t n, int form, h2_bases_t *handle, int want_c = 0) {
+static int bases_register_impl(int curve, const void *bases_xy, bool on_device, size_t n, int form, h2_bases_t *handle, int want_c = 0, bool glv = false) {
     if ((curve != H2_PALLAS && curve != H2_VESTA) || (form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY) ||
         !handle || (n && !bases_xy) || n > (1u << 26))
         return H2_ERR_ARGS;
@@ -3533,6 +3551,11 @@ static int bases_register_impl(int curve, const void *bases_xy, bool on_device, 
     b->n = n;
     b->c = want_c ? want_c : choose_c(n ? n : 1, true);
     b->W = 255 / b->c + 1;
+    if (glv) {                 // the halves of a split scalar have 129 bits: nine 16-bit windows each, the second set of rows through phi
+        b->c = 16;
+        b->glv = 9;
+        b->W = 18;
+    }
     b->stride = (u32)n + 1;
     H2_HIP(hipGetDevice(&b->device));
     H2_HIP(hipMalloc(&b->d_table, (size_t)b->W * b->stride * 64));
@@ -3592,6 +3615,18 @@ extern "C" int h2_bases_register_device(int curve, const void *d_bases_xy, size_
 // saves the allocation and the release (~0.35 ms of hipMalloc / hipFree, which also synchronise the device).  The handle's blind
 // column is cleared with the table.  Nothing else may be using the handle (the caller owns it).
 namespace h2 {
+// Does h2_commit_pair_device take the sub-digit form for a table of n points (16-bit windows)?  (H2_PAIR_SUBDIGITS: 0 = never; n = the largest table.)
+static long pair_subdigit_max() {
+    static const long v = [] { const char *e = getenv("H2_PAIR_SUBDIGITS"); return e ? atol(e) : (long)((1 << 16) + 4); }();
+    return v;
+}
+bool pair_subdigits_apply(size_t n) { return pair_subdigit_max() > 0 && n >= 8 && n <= (size_t)pair_subdigit_max(); }
+// Internal (ipa.hip): the table of the opening argument's collapsed generators.  glv: an ENDOMORPHISM table (Bases::glv) -- nine rows by the doubling
+// chain instead of sixteen (128 dependent doublings instead of 240: the chain is the latency of the switch), nine more through phi; only the
+// sub-digit paired commit reads such a table.
+int bases_register_device_internal(int curve, const void *d_bases_xy, size_t n, int form, h2_bases_t *handle, bool glv) {
+    return bases_register_impl(curve, d_bases_xy, true, n, form, handle, 0, glv);
+}
 int bases_refill_device(h2_bases_t handle, const void *d_bases_xy, size_t n, int form) {
     auto b = find_bases(handle);
     if (!b || b->n != n || !d_bases_xy || (form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY)) return H2_ERR_ARGS;
@@ -3851,11 +3886,74 @@ template <typename Fn> __device__ __forceinline__ void for_each_subdigit(const f
     }
     // (carry is 0 here: the scalar is below 2^255, the top window takes it)
 }
+// the same over an ENDOMORPHISM table (Bases::glv = 9): the scalar is split k = k1 + k2 lambda (glv.cuh, |k1|, |k2| < 2^129), each half cut into nine
+// signed 16-bit digits -- the ninth holds bit 128 and the last carry -- and every digit into its two sub-digits; the digits of k1 read rows 0 .. 8,
+// those of k2 rows 9 .. 17 (the images under phi); a negative half flips the sign of all its entries.  f(key, ROW, sign).
+template <int FS, typename Fn> __device__ __forceinline__ void for_each_subdigit_glv(const fe &s, u32 side, Fn f) {
+    u32 mag[2][5], hneg[2];
+    glv_split<FS>(s, mag[0], hneg[0], mag[1], hneg[1]);
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const bool hn = hneg[part] != 0;
+        u32 carry = 0;
+#pragma unroll
+        for (int w = 0; w < 7; ++w) {                                                // windows 0 .. 6: signed, as in for_each_subdigit
+            const u32 raw = ((mag[part][w >> 1] >> (16 * (w & 1))) & 0xFFFFu) + carry;
+            const bool neg = raw > 0x8000u;
+            carry = neg ? 1u : 0u;
+            const u32 m = neg ? 0x10000u - raw : raw;
+            u32 e0 = m & 255u, c8 = 0;
+            bool e0neg = false;
+            if (e0 > 128u) {
+                e0 = 256u - e0;
+                e0neg = true;
+                c8 = 1;
+            }
+            const u32 e1 = (m >> 8) + c8;
+            const bool dn = neg != hn;                                                // the digit's sign times the half's
+            if (e0) f(side * 256u + e0 - 1u, (u32)(part * 9 + w), (dn != e0neg) ? 0x80000000u : 0u);
+            if (e1) f(side * 256u + 128u + e1 - 1u, (u32)(part * 9 + w), dn ? 0x80000000u : 0u);
+        }
+        // Window 7 is cut UNSIGNED (0 .. 2^16 with the carry): recoded like the others it would send a carry into window 8 for a quarter of
+        // the halves, every one of those entries into the SAME bucket (position 0, magnitude 1) -- four times the average bucket, and the
+        // finisher's launch is as long as its longest tree.  Its high sub-digit may then exceed 128 (up to 257): it leaves as two or three
+        // entries of at most 128 each, cut evenly so that they spread over the buckets of position 1.
+        {
+            const u32 raw = (mag[part][3] >> 16) + carry;
+            u32 e0 = raw & 255u, c8 = 0;
+            bool e0neg = false;
+            if (e0 > 128u) {
+                e0 = 256u - e0;
+                e0neg = true;
+                c8 = 1;
+            }
+            u32 e1 = (raw >> 8) + c8;
+            if (e0) f(side * 256u + e0 - 1u, (u32)(part * 9 + 7), (hn != e0neg) ? 0x80000000u : 0u);
+            // (split EVENLY: "128 and the rest" would pile a quarter of the halves into the one bucket of magnitude 128)
+            const u32 pieces = (e1 + 127u) / 128u;                  // 0 .. 3
+            for (u32 j = 0; j < pieces; ++j) {
+                const u32 d = (e1 + j) / pieces;                    // floor((e1 + j) / pieces), j < pieces: sums to e1, each <= 128
+                f(side * 256u + 128u + d - 1u, (u32)(part * 9 + 7), hn ? 0x80000000u : 0u);
+            }
+        }
+        // window 8: bit 128 and beyond (glv_split promises < 2^129; nothing has been seen above 2^128) -- unsigned too, almost always nothing
+        {
+            u32 rest = min(mag[part][4], 256u);        // (<= 1 by glv_split's bound, which tests/test_glv_constants.py holds the constants to; the clamp keeps a
+                                                       // broken promise from running past the entry list: two entries per half are reserved for this window)
+            while (rest) {
+                const u32 d = rest > 128u ? 128u : rest;
+                rest -= d;
+                f(side * 256u + d - 1u, (u32)(part * 9 + 8), hn ? 0x80000000u : 0u);
+            }
+        }
+    }
+}
 __device__ __forceinline__ u32 pair_side(u32 i, u32 pair_n, int pair_shift) { return i < pair_n ? (i >> pair_shift) & 1u : (i - pair_n) & 1u; }
 // pass A: a workgroup's 1024 scalars -> its 512 counters (1024 lanes: a quarter of the workgroups for pass B to walk)
 static constexpr u32 kSubBlock = 1024;
 template <int FS>
-__global__ void __launch_bounds__(kSubBlock) sub_count(const u32 *__restrict__ scalars, u32 n, u32 pair_n, int pair_shift, int mont, u32 *__restrict__ wg_hist) {
+__global__ void __launch_bounds__(kSubBlock) sub_count(const u32 *__restrict__ scalars, u32 n, u32 pair_n, int pair_shift, int mont, int glv,
+                                                       u32 *__restrict__ wg_hist) {
     H2_LATENCY_STAGE();
     __shared__ u32 sh[kSubKeys];
     for (u32 k = threadIdx.x; k < kSubKeys; k += blockDim.x) sh[k] = 0;
@@ -3864,7 +3962,8 @@ __global__ void __launch_bounds__(kSubBlock) sub_count(const u32 *__restrict__ s
     if (i < n) {
         fe s = fe_load(scalars + 8 * (size_t)i);
         if (mont) s = fe_redc<FS>(s);
-        for_each_subdigit(s, pair_side(i, pair_n, pair_shift), [&](u32 key, u32, u32) { atomicAdd(&sh[key], 1u); });
+        if (glv) for_each_subdigit_glv<FS>(s, pair_side(i, pair_n, pair_shift), [&](u32 key, u32, u32) { atomicAdd(&sh[key], 1u); });
+        else for_each_subdigit(s, pair_side(i, pair_n, pair_shift), [&](u32 key, u32, u32) { atomicAdd(&sh[key], 1u); });
     }
     __syncthreads();
     for (u32 k = threadIdx.x; k < kSubKeys; k += blockDim.x) wg_hist[(size_t)blockIdx.x * kSubKeys + k] = sh[k];
@@ -3911,7 +4010,7 @@ __global__ void __launch_bounds__(kSubKeys) sub_scan(const u32 *__restrict__ wg_
 }
 // pass C: the same digits again, each to its place (entry = table index | sign << 31; the order inside a bucket is immaterial)
 template <int FS>
-__global__ void __launch_bounds__(kSubBlock) sub_scatter(const u32 *__restrict__ scalars, u32 n, u32 pair_n, int pair_shift, int mont, u32 stride,
+__global__ void __launch_bounds__(kSubBlock) sub_scatter(const u32 *__restrict__ scalars, u32 n, u32 pair_n, int pair_shift, int mont, int glv, u32 stride,
                                                    const u32 *__restrict__ wg_off, const u32 *__restrict__ kstart, u32 *__restrict__ entries) {
     H2_LATENCY_STAGE();
     __shared__ u32 cur[kSubKeys];
@@ -3921,10 +4020,12 @@ __global__ void __launch_bounds__(kSubBlock) sub_scatter(const u32 *__restrict__
     if (i >= n) return;
     fe s = fe_load(scalars + 8 * (size_t)i);
     if (mont) s = fe_redc<FS>(s);
-    for_each_subdigit(s, pair_side(i, pair_n, pair_shift), [&](u32 key, u32 w, u32 sign) {
+    auto place = [&](u32 key, u32 row, u32 sign) {
         const u32 pos = atomicAdd(&cur[key], 1u);
-        entries[pos] = (w * stride + i) | sign;
-    });
+        entries[pos] = (row * stride + i) | sign;
+    };
+    if (glv) for_each_subdigit_glv<FS>(s, pair_side(i, pair_n, pair_shift), place);
+    else for_each_subdigit(s, pair_side(i, pair_n, pair_shift), place);
 }
 // the finisher when EVERY bucket owns hundreds of range heads: a workgroup per bucket, a tree over its heads, then the bucket's own segment
 template <int FB>
@@ -4014,7 +4115,8 @@ static int pair_subdigit_launch(MsmContext &cx, const Bases &b, const void *d_sc
                                 void *d_out, hipStream_t st) {
     int rc;
     const u32 nblk = (u32)((n + kSubBlock - 1) / kSubBlock), tb = kSubSlots, nsl = 4;
-    const size_t max_entries = n * 32;
+    const int glv = b.glv ? 1 : 0;
+    const size_t max_entries = n * (glv ? 40 : 32);             // two sub-digits per table digit: 16 digits; over an endomorphism table 2 x (7 x 2 + 4 + 2) at most
     u32 &lanes = cx.lanes[FB][2];
     if (!lanes) {            // how many lanes of the M9 accumulate the chip holds at once (as msm_launch sizes it)
         int dev = 0, cus = 0, per_cu = 0;
@@ -4024,7 +4126,10 @@ static int pair_subdigit_launch(MsmContext &cx, const Bases &b, const void *d_sc
         per_cu = std::min(per_cu, (int)H2_ACC9_WAVES);
         lanes = (u32)cus * (u32)std::max(per_cu, 1) * 256u;
     }
-    const u32 lane_div = 8;
+    // entries per lane: 8 over a plain table (2^14 + 4 scalars: 2^19 entries, 128 range heads per bucket -- exactly what the finisher's 64 quads take in
+    // ONE round of two gathers each); an endomorphism table leaves ~33 entries per scalar, which at 8 per lane is 131 heads per bucket and a second
+    // round for three of them (finisher 35 -> 54 us): 9 per lane there
+    const u32 lane_div = glv ? 9 : 8;
     const u32 T = (u32)std::min<size_t>(lanes, std::max<size_t>(256, (max_entries / lane_div + 255) / 256 * 256));
     if ((rc = cx.hist.reserve(((size_t)2 * nblk + 1) * kSubKeys * 4)) != H2_OK || (rc = cx.starts.reserve((tb + 2) * 4)) != H2_OK ||
         (rc = cx.entries.reserve(max_entries * 4)) != H2_OK || (rc = cx.seg9.reserve(((size_t)T + tb) * 144)) != H2_OK ||
@@ -4042,9 +4147,9 @@ static int pair_subdigit_launch(MsmContext &cx, const Bases &b, const void *d_sc
     const u32 pair_n = (u32)(n - 4);
     ColStride cs;
     memset(&cs, 0, sizeof cs);
-    hipLaunchKernelGGL((sub_count<FS>), dim3(nblk), dim3(kSubBlock), 0, st, (const u32 *)d_scalars, (u32)n, pair_n, (int)pair_shift, mont, wg_hist);
+    hipLaunchKernelGGL((sub_count<FS>), dim3(nblk), dim3(kSubBlock), 0, st, (const u32 *)d_scalars, (u32)n, pair_n, (int)pair_shift, mont, glv, wg_hist);
     hipLaunchKernelGGL(sub_scan, dim3(1), dim3(kSubKeys), 0, st, (const u32 *)wg_hist, nblk, wg_off, kstart, starts, buckets9);
-    hipLaunchKernelGGL((sub_scatter<FS>), dim3(nblk), dim3(kSubBlock), 0, st, (const u32 *)d_scalars, (u32)n, pair_n, (int)pair_shift, mont, b.stride,
+    hipLaunchKernelGGL((sub_scatter<FS>), dim3(nblk), dim3(kSubBlock), 0, st, (const u32 *)d_scalars, (u32)n, pair_n, (int)pair_shift, mont, glv, b.stride,
                        (const u32 *)wg_off, (const u32 *)kstart, entries);
     hipLaunchKernelGGL((msm_accumulate<FB, false, true>), dim3(T / 256), dim3(256), 0, st, (const u32 *)b.d_table, (const u32 *)nullptr, 0xFFFFFFFFu,
                        (const u32 *)entries, (const u32 *)starts, heads9, buckets9, tb, T, lane_div, cs);
@@ -4067,8 +4172,7 @@ extern "C" int h2_commit_pair_device(h2_bases_t g, const void *d_scalars, size_t
     std::lock_guard<std::mutex> lk(cx.mu);
     // small 16-bit tables (the opening argument's rounds over the collapsed generators): the 8-bit sub-digit form above.
     // H2_PAIR_SUBDIGITS=0: the general form for every size (A/B); = n: the largest table (points) that takes the sub-digit form.
-    static const long sub_max = [] { const char *e = getenv("H2_PAIR_SUBDIGITS"); return e ? atol(e) : (long)((1 << 16) + 4); }();
-    if (sub_max > 0 && b->c == 16 && b->W == 16 && n <= (size_t)sub_max && !prof_enabled() && !timeline_on()) {
+    if (b->glv || (pair_subdigits_apply(n) && b->c == 16 && b->W == 16 && !prof_enabled() && !timeline_on())) {      // (an endomorphism table has no other reader)
         if (b->curve == H2_PALLAS) return pair_subdigit_launch<FP, FQ>(cx, *b, d_scalars, n, pair_shift, form, out_kind, d_out, st);
         return pair_subdigit_launch<FQ, FP>(cx, *b, d_scalars, n, pair_shift, form, out_kind, d_out, st);
     }

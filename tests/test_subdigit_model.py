@@ -101,3 +101,85 @@ def test_bit_planes_weigh_bucket_b_by_b_plus_one():
     weight[127] += 1 << 7
     assert weight == [b + 1 for b in range(128)]
     assert [w << 8 for w in weight] == [256 * (b + 1) for b in range(128)]
+
+
+def _halves(k, curve):
+    """glv.cuh's split of a canonical scalar, with the constants tests/test_glv_constants.py holds the kernel to."""
+    import test_glv_constants as t
+    base, q, fs_is_fq = (t.FP, t.FQ, True) if curve == "pallas" else (t.FQ, t.FP, False)
+    a1, b1m, a2, b2 = (t._array(n, fs_is_fq) for n in ("a1", "b1", "a2", "b2"))
+    g1, g2 = t._array("g1", fs_is_fq), t._array("g2", fs_is_fq)
+    c1, c2 = (k * g1) >> 256, (k * g2) >> 256
+    k1, k2 = k - c1 * a1 - c2 * a2, c1 * b1m - c2 * b2
+    lam = a1 * pow(b1m, -1, q) % q
+    assert (k1 + k2 * lam - k) % q == 0
+    return k1, k2, lam, q
+
+
+def for_each_subdigit_glv(k1, k2, side):
+    """(key, ROW, negative) triples over an endomorphism table (rows 0 .. 8: 2^(16 w) P, rows 9 .. 17: their images under phi), as the device
+    function emits them: windows 0 .. 6 of each half signed, window 7 unsigned with its high sub-digit cut evenly into pieces of at most 128,
+    window 8 (bit 128 on) unsigned."""
+    out = []
+    for part, half in enumerate((k1, k2)):
+        mag, hn, carry = abs(half), half < 0, 0
+        for w in range(7):
+            raw = ((mag >> (16 * w)) & 0xFFFF) + carry
+            neg = raw > 0x8000
+            carry = 1 if neg else 0
+            m = 0x10000 - raw if neg else raw
+            e0, c8, e0neg = m & 255, 0, False
+            if e0 > 128:
+                e0, e0neg, c8 = 256 - e0, True, 1
+            e1 = (m >> 8) + c8
+            dn = neg != hn
+            if e0:
+                out.append((side * 256 + e0 - 1, part * 9 + w, dn != e0neg))
+            if e1:
+                out.append((side * 256 + 128 + e1 - 1, part * 9 + w, dn))
+        raw = ((mag >> 112) & 0xFFFF) + carry
+        e0, c8, e0neg = raw & 255, 0, False
+        if e0 > 128:
+            e0, e0neg, c8 = 256 - e0, True, 1
+        e1 = (raw >> 8) + c8
+        if e0:
+            out.append((side * 256 + e0 - 1, part * 9 + 7, hn != e0neg))
+        pieces = (e1 + 127) // 128
+        for j in range(pieces):
+            d = (e1 + j) // pieces
+            assert 1 <= d <= 128
+            out.append((side * 256 + 128 + d - 1, part * 9 + 7, hn))
+        rest = min(mag >> 128, 256)
+        while rest:
+            d = min(rest, 128)
+            rest -= d
+            out.append((side * 256 + d - 1, part * 9 + 8, hn))
+    return out
+
+
+def test_sub_digits_over_the_endomorphism_table_add_up():
+    """sum of (+-)(b + 1) 256^pos 2^(16 (row mod 9)) lambda^(row div 9) over the entries = the scalar, for both curves; at most 40 entries per scalar
+    (what the entry list is sized for); no bucket far above the average (the two cuts that WOULD pile entries up -- a carry window, "128 and the
+    rest" -- are the ones the kernel avoids: profiles/r05_glv_table.txt)."""
+    import collections
+    rng = random.Random(0x61)
+    for curve in ("pallas", "vesta"):
+        hist = collections.Counter()
+        n_scalars = 3000
+        _, _, lam, q = _halves(1, curve)
+        cases = [0, 1, q - 1, lam, q - lam, (q - 1) // 2] + [rng.randrange(q) for _ in range(n_scalars)]
+        for k in cases:
+            k1, k2, lam, q = _halves(k, curve)
+            assert abs(k1) < 1 << 129 and abs(k2) < 1 << 129
+            e = for_each_subdigit_glv(k1, k2, 1)
+            assert len(e) <= 40
+            total = 0
+            for key, row, negative in e:
+                assert key // 256 == 1 and 0 <= row < 18
+                pos, b = (key >> 7) & 1, key & 127
+                v = (b + 1) * (256 ** pos) * (1 << (16 * (row % 9))) * (lam if row >= 9 else 1)
+                total += -v if negative else v
+                hist[key & 255] += 1
+            assert (total - k) % q == 0, hex(k)
+        avg = sum(hist.values()) / 256
+        assert max(hist.values()) < 1.6 * avg, (curve, max(hist.values()), avg)
