@@ -2178,34 +2178,36 @@ __global__ void __launch_bounds__(256, 2) ipa_readout_groups(const u32 *__restri
     xyzz_store<FB>(sums + 32 * ((size_t)(2 * y) * nJ + i), xyzz9_is_identity(tot) ? xyzz_identity<FB>() : xyzz9_to_r256<FB>(tot));
     xyzz_store<FB>(sums + 32 * ((size_t)(2 * y + 1) * nJ + i), xyzz9_is_identity(run) ? xyzz_identity<FB>() : xyzz9_to_r256<FB>(run));
 }
-// lane (i, position): sums[32 + position][i] <- sum_g tot_g + 16 * sum_g g * run_g
+// quad (i, position): sums[32 + position][i] <- sum_g tot_g + 16 * sum_g g * run_g.  27 dependent point operations per output and position,
+// 2 nJ chains: the chip is nearly idle in them, so each runs on a QUAD of lanes (curve_wide.cuh; round 5: 0.22 -> ~0.08 ms at 2^14 outputs)
 template <int FB>
 __global__ void __launch_bounds__(256) ipa_readout_combine(u32 *__restrict__ sums, u32 nJ) {
     H2_LATENCY_STAGE();
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 t = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
     if (t >= 2 * nJ) return;
     const u32 pos = t / nJ, i = t % nJ;
     xyzz<FB> P = xyzz_identity<FB>(), rr = xyzz_identity<FB>(), tt = xyzz_identity<FB>();
     for (int g = 7; g >= 0; --g) {
         const u32 y = pos * 8 + g;
-        xyzz_add<FB>(P, xyzz_load<FB>(sums + 32 * ((size_t)(2 * y) * nJ + i)));
+        xyzz_add_wide<FB>(P, xyzz_load<FB>(sums + 32 * ((size_t)(2 * y) * nJ + i)));
         if (g) {
-            xyzz_add<FB>(rr, xyzz_load<FB>(sums + 32 * ((size_t)(2 * y + 1) * nJ + i)));
-            xyzz_add<FB>(tt, rr);
+            xyzz_add_wide<FB>(rr, xyzz_load<FB>(sums + 32 * ((size_t)(2 * y + 1) * nJ + i)));
+            xyzz_add_wide<FB>(tt, rr);
         }
     }
-    for (int d = 0; d < 4; ++d) tt = xyzz_dbl<FB>(tt);
-    xyzz_add<FB>(P, tt);
-    xyzz_store<FB>(sums + 32 * ((size_t)(32 + pos) * nJ + i), P);
+    for (int d = 0; d < 4; ++d) tt = xyzz_dbl_wide<FB>(tt);
+    xyzz_add_wide<FB>(P, tt);
+    if ((threadIdx.x & (kGroup - 1)) == 0) xyzz_store<FB>(sums + 32 * ((size_t)(32 + pos) * nJ + i), P);
 }
 template <int FB>
 __global__ void __launch_bounds__(256) ipa_readout_finish(const u32 *__restrict__ sums, u32 nJ, u32 *__restrict__ out_xy) {
     H2_LATENCY_STAGE();
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
     if (i >= nJ) return;
     xyzz<FB> acc = xyzz_load<FB>(sums + 32 * ((size_t)33 * nJ + i));
-    for (int d = 0; d < 8; ++d) acc = xyzz_dbl<FB>(acc);
-    xyzz_add<FB>(acc, xyzz_load<FB>(sums + 32 * ((size_t)32 * nJ + i)));
+    for (int d = 0; d < 8; ++d) acc = xyzz_dbl_wide<FB>(acc);
+    xyzz_add_wide<FB>(acc, xyzz_load<FB>(sums + 32 * ((size_t)32 * nJ + i)));
+    if ((threadIdx.x & (kGroup - 1)) != 0) return;
     const affine<FB> a = xyzz_to_affine<FB>(acc);
     fe_store(out_xy + 16 * (size_t)i, a.x);
     fe_store(out_xy + 16 * (size_t)i + 8, a.y);
@@ -3721,7 +3723,8 @@ extern "C" int h2_ipa_collapsed_generators_device(h2_bases_t basis, unsigned k, 
         dim3 blk(256), g1((nJ + 255) / 256, 32), g2((4 * nJ + 255) / 256), g3((nJ + 255) / 256);
         u32 *sums = cx.collapse.as<u32>();
         if (!nibbles) {
-            dim3 r1((nJ + 255) / 256, 16), r2((2 * nJ + 255) / 256);
+            dim3 r1((nJ + 255) / 256, 16), r2((2 * nJ * kGroup + 255) / 256);
+            g3 = dim3((nJ * kGroup + 255) / 256);            // combine and finish run one chain per QUAD of lanes
             if (b->curve == H2_PALLAS) {
                 hipLaunchKernelGGL((ipa_readout_groups<FP>), r1, blk, 0, st, (const u32 *)b->d_table, d_list, d_start, nJ, sums);
                 hipLaunchKernelGGL((ipa_readout_combine<FP>), r2, blk, 0, st, sums, nJ);
