@@ -3952,10 +3952,11 @@ template <int FS, typename Fn> __device__ __forceinline__ void for_each_subdigit
     }
 }
 __device__ __forceinline__ u32 pair_side(u32 i, u32 pair_n, int pair_shift) { return i < pair_n ? (i >> pair_shift) & 1u : (i - pair_n) & 1u; }
-// pass A: a workgroup's 1024 scalars -> its 512 counters (1024 lanes: a quarter of the workgroups for pass B to walk)
-static constexpr u32 kSubBlock = 1024;
+// pass A: a workgroup's 512 scalars -> its 512 counters (H2_SUB_BLOCK = 256 / 512 / 1024, late round of the k = 20 argument: 0.220 / 0.219 / 0.227 ms --
+// fewer workgroups shorten pass B's walk, more of them pass C's scattered stores)
+static constexpr u32 kSubBlock = 512;
 template <int FS>
-__global__ void __launch_bounds__(kSubBlock) sub_count(const u32 *__restrict__ scalars, u32 n, u32 pair_n, int pair_shift, int mont, int glv,
+__global__ void __launch_bounds__(1024) sub_count(const u32 *__restrict__ scalars, u32 n, u32 pair_n, int pair_shift, int mont, int glv,
                                                        u32 *__restrict__ wg_hist) {
     H2_LATENCY_STAGE();
     __shared__ u32 sh[kSubKeys];
@@ -4013,7 +4014,7 @@ __global__ void __launch_bounds__(kSubKeys) sub_scan(const u32 *__restrict__ wg_
 }
 // pass C: the same digits again, each to its place (entry = table index | sign << 31; the order inside a bucket is immaterial)
 template <int FS>
-__global__ void __launch_bounds__(kSubBlock) sub_scatter(const u32 *__restrict__ scalars, u32 n, u32 pair_n, int pair_shift, int mont, int glv, u32 stride,
+__global__ void __launch_bounds__(1024) sub_scatter(const u32 *__restrict__ scalars, u32 n, u32 pair_n, int pair_shift, int mont, int glv, u32 stride,
                                                    const u32 *__restrict__ wg_off, const u32 *__restrict__ kstart, u32 *__restrict__ entries) {
     H2_LATENCY_STAGE();
     __shared__ u32 cur[kSubKeys];
@@ -4117,7 +4118,8 @@ template <int FB, int FS>
 static int pair_subdigit_launch(MsmContext &cx, const Bases &b, const void *d_scalars, size_t n, unsigned pair_shift, int form, int out_kind,
                                 void *d_out, hipStream_t st) {
     int rc;
-    const u32 nblk = (u32)((n + kSubBlock - 1) / kSubBlock), tb = kSubSlots, nsl = 4;
+    static const u32 sub_block = [] { const char *e = getenv("H2_SUB_BLOCK"); int v = e ? atoi(e) : 0; return (u32)(v == 256 || v == 512 || v == 1024 ? v : kSubBlock); }();   // A/B
+    const u32 nblk = (u32)((n + sub_block - 1) / sub_block), tb = kSubSlots, nsl = 4;
     const int glv = b.glv ? 1 : 0;
     const size_t max_entries = n * (glv ? 40 : 32);             // two sub-digits per table digit: 16 digits; over an endomorphism table 2 x (7 x 2 + 4 + 2) at most
     u32 &lanes = cx.lanes[FB][2];
@@ -4150,9 +4152,9 @@ static int pair_subdigit_launch(MsmContext &cx, const Bases &b, const void *d_sc
     const u32 pair_n = (u32)(n - 4);
     ColStride cs;
     memset(&cs, 0, sizeof cs);
-    hipLaunchKernelGGL((sub_count<FS>), dim3(nblk), dim3(kSubBlock), 0, st, (const u32 *)d_scalars, (u32)n, pair_n, (int)pair_shift, mont, glv, wg_hist);
+    hipLaunchKernelGGL((sub_count<FS>), dim3(nblk), dim3(sub_block), 0, st, (const u32 *)d_scalars, (u32)n, pair_n, (int)pair_shift, mont, glv, wg_hist);
     hipLaunchKernelGGL(sub_scan, dim3(1), dim3(kSubKeys), 0, st, (const u32 *)wg_hist, nblk, wg_off, kstart, starts, buckets9);
-    hipLaunchKernelGGL((sub_scatter<FS>), dim3(nblk), dim3(kSubBlock), 0, st, (const u32 *)d_scalars, (u32)n, pair_n, (int)pair_shift, mont, glv, b.stride,
+    hipLaunchKernelGGL((sub_scatter<FS>), dim3(nblk), dim3(sub_block), 0, st, (const u32 *)d_scalars, (u32)n, pair_n, (int)pair_shift, mont, glv, b.stride,
                        (const u32 *)wg_off, (const u32 *)kstart, entries);
     hipLaunchKernelGGL((msm_accumulate<FB, false, true>), dim3(T / 256), dim3(256), 0, st, (const u32 *)b.d_table, (const u32 *)nullptr, 0xFFFFFFFFu,
                        (const u32 *)entries, (const u32 *)starts, heads9, buckets9, tb, T, lane_div, cs);
