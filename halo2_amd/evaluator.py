@@ -31,6 +31,23 @@ class AstLeaf:
         return AstLeaf(self.evaluator, self.index, rotation)
 
 
+class LateConstant:
+    """The base of a `distribute_powers` whose value is not known yet: the quotient's expressions are folded with powers of the challenge y
+    (plonk/vanishing/prover.rs:84), which exists only after a commitment has crossed PCIe and been hashed -- while the tree, its flattening into the
+    evaluation kernel's program and the table of its other constants ask for nothing of the kind.  Evaluator.compile takes the tree with a
+    LateConstant in y's place, Evaluator.run takes the value."""
+
+    def __init__(self):
+        self.index = None            # its slot in the compiled program's constant table
+
+
+class Compiled:
+    """A flattened expression tree: the program words and constant table h2_evaluate_device takes (Evaluator.compile)."""
+
+    def __init__(self, prog, n_words, consts, n_consts):
+        self.prog, self.n_words, self.consts, self.n_consts = prog, n_words, consts, n_consts
+
+
 class Ast:
     """evaluator.rs:236-258.  kind in {poly, add, mul, scale, distribute, linear, constant}."""
 
@@ -54,8 +71,9 @@ class Ast:
         return Ast.constant(1)
 
     @staticmethod
-    def distribute_powers(terms, base: int) -> "Ast":     # :260-264, terms from the highest power down
-        return Ast("distribute", list(terms), int(base))
+    def distribute_powers(terms, base) -> "Ast":          # :260-264, terms from the highest power down
+        """base: a canonical integer, or a LateConstant whose value arrives after the tree has been compiled (Evaluator.compile / run)."""
+        return Ast("distribute", list(terms), base if isinstance(base, LateConstant) else int(base))
 
     def __add__(self, other):                             # :318-340
         return Ast("add", self, _as_ast(other))
@@ -118,7 +136,11 @@ class Evaluator:
     def _compile(self, ast: Ast, domain, words: list, consts: list):
         m = domain.m
 
-        def const_index(v: int) -> int:
+        def const_index(v) -> int:
+            if isinstance(v, LateConstant):            # filled in by run()
+                consts.append(0)
+                v.index = len(consts) - 1
+                return v.index
             consts.append(int(v) % m)
             return len(consts) - 1
         k = ast.kind
@@ -171,16 +193,32 @@ class Evaluator:
         want = domain.extended_len() if self.basis == EXTENDED else domain.n
         if n != want:
             raise ValueError("evaluate: polynomial length does not match the domain")
-        log_len = n.bit_length() - 1
+        return self.run(self.compile(ast, domain), domain)
+
+    def compile(self, ast: Ast, domain) -> Compiled:
+        """The host half of `evaluate`: the tree flattened into program words and a constant table (Montgomery limbs).  A LateConstant in the tree
+        leaves its slot open for `run`."""
         words, consts = [], []
         self._compile(_as_ast(ast), domain, words, consts)
         prog = (C.c_uint32 * len(words))(*words)
         cst = fields.to_limbs(consts, domain.field, True) if consts else np.zeros((1, 4), dtype=np.uint64)
+        return Compiled(prog, len(words), np.ascontiguousarray(cst), len(consts))
+
+    def run(self, compiled: Compiled, domain, late=None):
+        """The device half: one launch of the evaluation kernel over the registered polynomials.  late: {LateConstant: canonical integer}."""
+        import torch
+        n = self.polys[0].shape[0]
+        want = domain.extended_len() if self.basis == EXTENDED else domain.n
+        if n != want:
+            raise ValueError("evaluate: polynomial length does not match the domain")
+        for slot, value in (late or {}).items():
+            compiled.consts[slot.index] = fields.scalar_limbs(int(value) % domain.m, domain.field, True)
+        log_len = n.bit_length() - 1
         ptrs = (C.c_void_p * len(self.polys))(*[p.data_ptr() for p in self.polys])
         omega = fields.scalar_limbs(domain.extended_omega if self.basis == EXTENDED else domain.omega, domain.field, True)
         out = torch.empty_like(self.polys[0])
-        check(lib().h2_evaluate_device(domain.field, self.basis, prog, len(words), _p(cst), len(consts), ptrs, len(self.polys), log_len,
-                                       _p(omega), out.data_ptr(), _stream_ptr()), "h2_evaluate_device")
+        check(lib().h2_evaluate_device(domain.field, self.basis, compiled.prog, compiled.n_words, _p(compiled.consts), compiled.n_consts, ptrs, len(self.polys),
+                                       log_len, _p(omega), out.data_ptr(), _stream_ptr()), "h2_evaluate_device")
         return out
 
 

@@ -24,7 +24,7 @@ from . import multiopen, permutation
 from . import vanishing as vanishing_arg
 from .arithmetic import eval_polynomial
 from .commitment import Blind, Params
-from .evaluator import EXTENDED, LAGRANGE, Ast, Evaluator
+from .evaluator import EXTENDED, LAGRANGE, Ast, Evaluator, LateConstant
 from .multiopen import ProverQuery
 from .transcript import DeferredScalars, write_evaluation
 
@@ -300,6 +300,10 @@ def create_proof_many(params: Params, pk: ProvingKey, circuits, rng, transcript,
     for cc, (_, perm_exprs), lps in zip(cells_c, perm_pairs, lookup_pairs):               # :545-586
         expressions += [g(cc) for g in cs.gates] + perm_exprs + [e for _, es in lps for e in es]
     expressions = [e if isinstance(e, Ast) else Ast.constant(int(e)) for e in expressions]
+    # ... and flattened into the evaluation kernel's program with y's slot left open (evaluator.LateConstant): behind the commitment's read-back
+    # only the challenge, one constant and the launch remain
+    y_slot = LateConstant()
+    expressions = (cosets.compile(Ast.distribute_powers(expressions, y_slot), domain), y_slot)
 
     vanishing = vanishing_arg.Argument.commit(params, domain, rng, transcript, device=dev)                      # :505
     y = transcript.squeeze_challenge()                                                    # :508

@@ -41,7 +41,11 @@ class Committed:
         """prover.rs:65-123.  `evaluator`: a halo2_amd.evaluator.Evaluator over the extended basis; `expressions`: its Asts,
         folded with powers of y (highest first, :84); y a canonical integer."""
         n = params.n
-        h_ext = evaluator.evaluate(Ast.distribute_powers(list(expressions), y), domain)              # :84-85
+        if isinstance(expressions, tuple):          # (Compiled, LateConstant): the tree was flattened before y existed (plonk.create_proof)
+            compiled, y_slot = expressions
+            h_ext = evaluator.run(compiled, domain, {y_slot: y})                                      # :84-85
+        else:
+            h_ext = evaluator.evaluate(Ast.distribute_powers(list(expressions), y), domain)          # :84-85
         h_coeff = domain.extended_to_coeff(domain.divide_by_vanishing_poly(h_ext))                    # :88-91
         h_pieces = [h_coeff[i * n:(i + 1) * n] for i in range(h_coeff.shape[0] // n)]                 # chunks_exact, :94-97
         h_blinds = [Blind(np.ascontiguousarray(b)) for b in rng(len(h_pieces))]                       # :99-102
