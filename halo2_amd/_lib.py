@@ -72,6 +72,8 @@ SIGNATURES = {
     "h2_ipa_default_switch_rounds": ([C.c_uint, C.c_int], C.c_uint),
     "h2_open_device": ([C.c_int, C.c_uint, C.c_uint64, C.c_uint64, C.c_int, C.c_uint, u64p, vp, u64p, u64p, vp, u64p, u64p, IPA_WRITE_POINT_FN,
                        IPA_SQUEEZE_FN, vp, u64p, u64p, vp], C.c_int),
+    "h2_open_device_host_s": ([C.c_int, C.c_uint, C.c_uint64, C.c_uint64, C.c_int, C.c_uint, u64p, vp, u64p, u64p, u64p, u64p, u64p, IPA_WRITE_POINT_FN,
+                              IPA_SQUEEZE_FN, vp, u64p, u64p, vp], C.c_int),
     "h2_open": ([C.c_int, C.c_uint, C.c_uint64, C.c_uint64, C.c_int, C.c_uint, u64p, u64p, u64p, u64p, u64p, u64p, u64p, IPA_WRITE_POINT_FN,
                 IPA_SQUEEZE_FN, vp, u64p, u64p], C.c_int),
     "h2_transcript_new": ([C.c_int, C.POINTER(C.c_uint64)], C.c_int),

@@ -325,8 +325,8 @@ class Params:
 
     def open(self, p_poly, p_blind: Blind, x_3, s_poly, s_blind: Blind, rands, transcript, paired: bool, hybrid_rounds: int | None = None):
         """`commitment::create_proof` (poly/commitment/prover.rs:26-151) between its rng and its transcript as ONE native call
-        (h2_open_device / h2_open): the commitment to s_poly, xi and z, P', b, v and the whole round loop.  p_poly, s_poly: both
-        (n, 4) CUDA tensors (s_poly is consumed: it becomes p' and is folded in place) or both host arrays; s_poly, s_blind, rands
+        (h2_open_device / h2_open_device_host_s / h2_open): the commitment to s_poly, xi and z, P', b, v and the whole round loop.  p_poly, s_poly: both
+        (n, 4) CUDA tensors (s_poly is consumed: it becomes p' and is folded in place), both host arrays, or p_poly on the device and s_poly a host array; s_poly, s_blind, rands
         (2k scalars): the randomness in the reference's order.  Returns (c, f), the two scalars the caller writes last (:146-148)."""
         from ._lib import IPA_SWITCH_DEFAULT
         n, k = self.n, self.k
@@ -344,8 +344,20 @@ class Params:
         f = np.zeros(4, dtype=np.uint64)
         uw = np.ascontiguousarray(np.stack([self.u, self.w]), dtype=np.uint64)
         basis = self._opening_basis(paired)
+        if _is_torch(p_poly) and not _is_torch(s_poly):
+            # p_poly resident, s_poly from a host rng: its quarters cross PCIe inside the call and are committed as they land
+            self._check_device(p_poly)
+            if not p_poly.is_contiguous():
+                raise ValueError("open: contiguous tensors, please")
+            sp = _np(s_poly, 4)
+            rc = lib().h2_open_device_host_s(self.curve, k, self._h_g, basis, 1 if paired else 0, J, _p(uw), p_poly.data_ptr(), _p(pb), _p(x3), _p(sp),
+                                             _p(sb), _p(rands), cb_w, cb_s, user, _p(c), _p(f), _stream_ptr())
+            if failure:
+                raise failure[0]
+            check(rc, "h2_open_device_host_s")
+            return c, f
         if _is_torch(p_poly) != _is_torch(s_poly):
-            raise ValueError("open: p_poly and s_poly must both be device tensors or both host arrays")
+            raise ValueError("open: a host p_poly needs a host s_poly")
         if _is_torch(p_poly):
             self._check_device(p_poly)
             self._check_device(s_poly)

@@ -140,8 +140,9 @@ struct IpaContext {
     std::mutex open_mu;
     DevBuf open_b, open_col, open_s, open_p, open_small;
     void *open_host = nullptr;
-    hipStream_t open_side = nullptr;
+    hipStream_t open_side = nullptr, open_side2 = nullptr;
     hipEvent_t open_ev = nullptr, open_ev2 = nullptr;
+    hipEvent_t open_land[4] = {nullptr, nullptr, nullptr, nullptr}, open_fixed = nullptr, open_parts = nullptr;     // the S commitment by ranges (open_impl)
     void release_all() {
         naf.release();
         stage.release();
@@ -170,7 +171,12 @@ struct IpaContext {
         if (open_ev2) (void)hipEventDestroy(open_ev2);
         open_ev = open_ev2 = nullptr;
         if (open_side) (void)hipStreamDestroy(open_side);
-        open_side = nullptr;
+        if (open_side2) (void)hipStreamDestroy(open_side2);
+        open_side = open_side2 = nullptr;
+        for (hipEvent_t *e : {&open_land[0], &open_land[1], &open_land[2], &open_land[3], &open_fixed, &open_parts}) {
+            if (*e) (void)hipEventDestroy(*e);
+            *e = nullptr;
+        }
     }
 };
 static StreamContexts<IpaContext> g_ipa_ctxs;
@@ -433,6 +439,17 @@ __global__ void __launch_bounds__(256) ipa_round_fold(u32 *__restrict__ p, u32 *
 // a[0] -= *v: the constant coefficient of s_poly / p' after their evaluation at x_3 (prover.rs:51, :72), without a host round trip
 template <int F> __global__ void __launch_bounds__(64) ipa_sub_at0(u32 *__restrict__ a, const u32 *__restrict__ v) {
     if (blockIdx.x == 0 && threadIdx.x == 0) fe_store(a, fe_sub<F>(fe_load(a), fe_load(v)));
+}
+
+// s[0] -= ev[0] + xp1 ev[1] + xp2 ev[2] + xp3 ev[3]: the evaluation of s_poly at x_3 from the evaluations of its four quarters (each a polynomial in the
+// quarter's own index; xp_r = x_3^(r n / 4)), subtracted from the constant coefficient (prover.rs:49-51) -- one lane
+template <int F> __global__ void __launch_bounds__(64) ipa_fix_s0(u32 *__restrict__ s0, const u32 *__restrict__ ev, fe xp1, fe xp2, fe xp3) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    fe t = fe_load(ev);
+    t = fe_add<F>(t, fe_mulx<F>(fe_load(ev + 8), xp1));
+    t = fe_add<F>(t, fe_mulx<F>(fe_load(ev + 16), xp2));
+    t = fe_add<F>(t, fe_mulx<F>(fe_load(ev + 24), xp3));
+    fe_store(s0, fe_sub<F>(fe_load(s0), t));
 }
 
 }  // namespace h2
@@ -753,35 +770,89 @@ extern "C" int h2_ipa_rounds(int curve, unsigned k, unsigned switch_rounds, h2_b
 // (tests/test_gpu_opening.py).
 static int open_impl(IpaContext &cx, int curve, unsigned k, h2_bases_t g_basis, h2_bases_t opening_basis, int paired, unsigned switch_rounds,
                      const uint64_t *uw_xy, const void *d_p, const uint64_t *host_p, const uint64_t *p_blind, const uint64_t *x3, void *d_s,
-                     const uint64_t *s_blind, const uint64_t *rands, h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze, void *user,
-                     uint64_t *c_out, uint64_t *f_out, hipStream_t st) {
+                     const uint64_t *host_s, const uint64_t *s_blind, const uint64_t *rands, h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze,
+                     void *user, uint64_t *c_out, uint64_t *f_out, hipStream_t st) {
     const int sf = curve == H2_PALLAS ? H2_FQ : H2_FP, bf = curve == H2_PALLAS ? H2_FP : H2_FQ;
     const size_t n = (size_t)1 << k;
     int rc;
-    if ((rc = cx.open_b.reserve(n * 32)) != H2_OK || (rc = cx.open_col.reserve((2 * n + 8) * 32)) != H2_OK || (rc = cx.open_small.reserve(256)) != H2_OK) return rc;
+    if ((rc = cx.open_b.reserve(n * 32)) != H2_OK || (rc = cx.open_col.reserve((2 * n + 8) * 32)) != H2_OK || (rc = cx.open_small.reserve(1024)) != H2_OK) return rc;
     if (!cx.open_host) H2_HIP(hipHostMalloc(&cx.open_host, 256, hipHostMallocDefault));
     if (!cx.open_ev) H2_HIP(hipEventCreateWithFlags(&cx.open_ev, hipEventDisableTiming));
     if (!cx.open_ev2) H2_HIP(hipEventCreateWithFlags(&cx.open_ev2, hipEventDisableTiming));
     if (!cx.open_side) H2_HIP(hipStreamCreateWithFlags(&cx.open_side, hipStreamNonBlocking));
     u32 *small = cx.open_small.as<u32>(), *d_s_at = small, *d_v = small + 8, *d_commit = small + 16, *d_blind = small + 40;
+    u32 *d_ev = small + 64, *d_part = small + 128;              // (ranges) the quarters' evaluations, 4 x 8 words; their partial commitments, 4 x 24 words
     void *d_b = cx.open_b.ptr;
-    // s_poly gets its root at x_3 (:49-51) and is committed to (:56)
-    if ((rc = h2_eval_polynomial_device(sf, d_s, n, x3, H2_FORM_MONTGOMERY, d_s_at, st)) != H2_OK) return rc;
-    if (sf == H2_FP) hipLaunchKernelGGL((ipa_sub_at0<FP>), dim3(1), dim3(64), 0, st, (u32 *)d_s, (const u32 *)d_s_at);
-    else hipLaunchKernelGGL((ipa_sub_at0<FQ>), dim3(1), dim3(64), 0, st, (u32 *)d_s, (const u32 *)d_s_at);
-    H2_HIP(hipGetLastError());
-    H2_HIP(hipMemcpyAsync(d_blind, s_blind, 32, hipMemcpyHostToDevice, st));
-    if ((rc = h2_commit_device(g_basis, d_s, n, nullptr, d_blind, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_commit, st)) != H2_OK) return rc;
     u64 *land = (u64 *)cx.open_host;
-    H2_HIP(hipMemcpyAsync(land, d_commit, 96, hipMemcpyDeviceToHost, st));
-    H2_HIP(hipEventRecord(cx.open_ev, st));
-    // beside the commit and the host's part: p_poly's way in (host vectors), b and v on the side stream
-    hipStream_t side = cx.open_side;
+    // s_poly gets its root at x_3 (:49-51) and is committed to (:56)
+    static const bool ranges_env = [] { const char *e = getenv("H2_OPEN_S_RANGES"); return !(e && e[0] == '0'); }();      // 0: one upload, one commit (A/B)
+    // (with p_poly in host memory too -- h2_open -- the calling thread is the bottleneck either way: 96 MiB of pageable copies through one thread, and every launch
+    // between two of them is PCIe idle time; measured there the quarters LOSE a millisecond to one upload + one commit, so they serve the resident p_poly only)
+    const bool by_ranges = host_s && !host_p && ranges_env && k >= 16;
+    if (by_ranges) {
+        // The fresh coefficients come from the caller's rng, i.e. from HOST memory: 32 MiB across PCIe at k = 20 (0.9 ms) in front of a 1.1 ms commit.
+        // Cut into four quarters that cross from the top down: quarter r's share of the commitment (h2_commit_range_device over its columns of the
+        // table) starts as soon as it has landed, on one of two side streams, while the next quarter crosses; every quarter is evaluated at x_3 on the
+        // way (as a polynomial in its own index).  The quarter with the constant coefficient crosses LAST: s(x_3) = sum_r x_3^(r n / 4) ev_r is known a
+        // kernel later, the coefficient is fixed, that quarter is committed with the blind, and the four shares are added.  Behind the last byte: one
+        // quarter-size commit instead of a whole one.
+        const size_t q = n / 4;
+        if (!cx.open_side2) H2_HIP(hipStreamCreateWithFlags(&cx.open_side2, hipStreamNonBlocking));
+        for (hipEvent_t *e : {&cx.open_land[0], &cx.open_land[1], &cx.open_land[2], &cx.open_land[3], &cx.open_fixed, &cx.open_parts})
+            if (!*e) H2_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        H2_HIP(hipMemcpyAsync(d_blind, s_blind, 32, hipMemcpyHostToDevice, st));
+        u64 xq[4], xp[4][4];                                    // x_3^(n / 4) by squaring, then its first three powers
+        memcpy(xq, x3, 32);
+        for (unsigned i = 0; i + 2 < k; ++i) host_mul(sf, xq, xq, xq);
+        memcpy(xp[1], xq, 32);
+        host_mul(sf, xp[2], xq, xq);
+        host_mul(sf, xp[3], xp[2], xq);
+        hipStream_t sides[2] = {cx.open_side, cx.open_side2};
+        for (int r = 3; r >= 0; --r) {
+            char *dst = (char *)d_s + (size_t)r * q * 32;
+            H2_HIP(hipMemcpyAsync(dst, (const char *)host_s + (size_t)r * q * 32, q * 32, hipMemcpyHostToDevice, st));
+            if ((rc = h2_eval_polynomial_device(sf, dst, q, x3, H2_FORM_MONTGOMERY, d_ev + 8 * r, st)) != H2_OK) return rc;
+            if (r == 0) {
+                fe f1, f2, f3;
+                memcpy(f1.v, xp[1], 32);
+                memcpy(f2.v, xp[2], 32);
+                memcpy(f3.v, xp[3], 32);
+                if (sf == H2_FP) hipLaunchKernelGGL((ipa_fix_s0<FP>), dim3(1), dim3(64), 0, st, (u32 *)d_s, (const u32 *)d_ev, f1, f2, f3);
+                else hipLaunchKernelGGL((ipa_fix_s0<FQ>), dim3(1), dim3(64), 0, st, (u32 *)d_s, (const u32 *)d_ev, f1, f2, f3);
+                H2_HIP(hipGetLastError());
+            }
+            H2_HIP(hipEventRecord(cx.open_land[r], st));
+            hipStream_t sd = sides[r & 1];
+            H2_HIP(hipStreamWaitEvent(sd, cx.open_land[r], 0));
+            if ((rc = h2_commit_range_device(g_basis, dst, (size_t)r * q, q, r == 0 ? d_blind : nullptr, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_part + 24 * r,
+                                             sd)) != H2_OK)
+                return rc;
+        }
+        // the four shares meet on the first side stream (quarter 0 ran on it last; the other stream's two are awaited)
+        H2_HIP(hipEventRecord(cx.open_parts, sides[1]));
+        H2_HIP(hipStreamWaitEvent(sides[0], cx.open_parts, 0));
+        if ((rc = h2_points_sum_device(curve, d_part, 4, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_commit, sides[0])) != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(land, d_commit, 96, hipMemcpyDeviceToHost, sides[0]));
+        H2_HIP(hipEventRecord(cx.open_ev, sides[0]));
+    } else {
+        if (host_s) H2_HIP(hipMemcpyAsync(d_s, host_s, n * 32, hipMemcpyHostToDevice, st));
+        if ((rc = h2_eval_polynomial_device(sf, d_s, n, x3, H2_FORM_MONTGOMERY, d_s_at, st)) != H2_OK) return rc;
+        if (sf == H2_FP) hipLaunchKernelGGL((ipa_sub_at0<FP>), dim3(1), dim3(64), 0, st, (u32 *)d_s, (const u32 *)d_s_at);
+        else hipLaunchKernelGGL((ipa_sub_at0<FQ>), dim3(1), dim3(64), 0, st, (u32 *)d_s, (const u32 *)d_s_at);
+        H2_HIP(hipGetLastError());
+        H2_HIP(hipMemcpyAsync(d_blind, s_blind, 32, hipMemcpyHostToDevice, st));
+        if ((rc = h2_commit_device(g_basis, d_s, n, nullptr, d_blind, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_commit, st)) != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(land, d_commit, 96, hipMemcpyDeviceToHost, st));
+        H2_HIP(hipEventRecord(cx.open_ev, st));
+    }
+    // beside the commit and the host's part: p_poly's way in (host vectors), b and v -- on the side stream, or (S commitment by ranges: the side streams
+    // carry its shares) on `st` itself, which has only moved and evaluated the quarters so far
+    hipStream_t side = by_ranges ? st : cx.open_side;
     if (host_p) {
         if ((rc = cx.open_p.reserve(n * 32)) != H2_OK) return rc;
         H2_HIP(hipMemcpyAsync(cx.open_p.ptr, host_p, n * 32, hipMemcpyHostToDevice, side));
         d_p = cx.open_p.ptr;
-    } else {
+    } else if (!by_ranges) {
         H2_HIP(hipEventRecord(cx.open_ev2, st));          // a resident p_poly may have been produced on the caller's stream
         H2_HIP(hipStreamWaitEvent(side, cx.open_ev2, 0));
     }
@@ -852,7 +923,23 @@ extern "C" int h2_open_device(int curve, unsigned k, h2_bases_t g_basis, h2_base
     if ((rc = ensure_device()) != H2_OK) return rc;
     IpaContext &cx = g_ipa_ctxs.get((hipStream_t)stream);
     std::lock_guard<std::mutex> lk(cx.open_mu);
-    return open_impl(cx, curve, k, g_basis, opening_basis, paired, switch_rounds, uw_xy, d_p_poly, nullptr, p_blind, x3, d_s_poly, s_blind, rands,
+    return open_impl(cx, curve, k, g_basis, opening_basis, paired, switch_rounds, uw_xy, d_p_poly, nullptr, p_blind, x3, d_s_poly, nullptr, s_blind, rands,
+                     write_point, squeeze, user, c_out, f_out, (hipStream_t)stream);
+}
+
+// p_poly resident, the fresh s_poly where a host rng leaves it: its quarters cross PCIe inside the call and are committed as they land (open_impl)
+extern "C" int h2_open_device_host_s(int curve, unsigned k, h2_bases_t g_basis, h2_bases_t opening_basis, int paired, unsigned switch_rounds,
+                                     const uint64_t *uw_xy, const void *d_p_poly, const uint64_t *p_blind, const uint64_t *x3, const uint64_t *s_poly,
+                                     const uint64_t *s_blind, const uint64_t *rands, h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze,
+                                     void *user, uint64_t *c_out, uint64_t *f_out, void *stream) {
+    if (open_bad_args(curve, k, p_blind, x3, s_blind, rands, write_point, squeeze, c_out, f_out) || !d_p_poly || !s_poly) return H2_ERR_ARGS;
+    int rc = open_check_bases(curve, k, g_basis, opening_basis, paired);
+    if (rc != H2_OK) return rc;
+    if ((rc = ensure_device()) != H2_OK) return rc;
+    IpaContext &cx = g_ipa_ctxs.get((hipStream_t)stream);
+    std::lock_guard<std::mutex> lk(cx.open_mu);
+    if ((rc = cx.open_s.reserve(((size_t)1 << k) * 32)) != H2_OK) return rc;
+    return open_impl(cx, curve, k, g_basis, opening_basis, paired, switch_rounds, uw_xy, d_p_poly, nullptr, p_blind, x3, cx.open_s.ptr, s_poly, s_blind, rands,
                      write_point, squeeze, user, c_out, f_out, (hipStream_t)stream);
 }
 
@@ -870,7 +957,6 @@ extern "C" int h2_open(int curve, unsigned k, h2_bases_t g_basis, h2_bases_t ope
     std::lock_guard<std::mutex> lk(cx.open_mu);
     const size_t n = (size_t)1 << k;
     if ((rc = cx.open_s.reserve(n * 32)) != H2_OK) return rc;
-    H2_HIP(hipMemcpyAsync(cx.open_s.ptr, s_poly, n * 32, hipMemcpyHostToDevice, nullptr));
-    return open_impl(cx, curve, k, g_basis, opening_basis, paired, switch_rounds, uw_xy, nullptr, p_poly, p_blind, x3, cx.open_s.ptr, s_blind, rands,
+    return open_impl(cx, curve, k, g_basis, opening_basis, paired, switch_rounds, uw_xy, nullptr, p_poly, p_blind, x3, cx.open_s.ptr, s_poly, s_blind, rands,
                      write_point, squeeze, user, c_out, f_out, nullptr);
 }

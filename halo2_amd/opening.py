@@ -65,8 +65,9 @@ def create_proof(params: Params, rng, transcript, p_poly, p_blind: Blind, x_3, d
         s_raw = rng(n)                         # host limbs, or a CUDA tensor from an rng that draws its large vectors on the device
         s_blind = Blind(np.ascontiguousarray(rng(1)[0]))
         rands = np.ascontiguousarray(np.concatenate([np.asarray(rng(2), dtype=np.uint64).reshape(2, 4) for _ in range(k)]))
-        if isinstance(p_poly, np.ndarray) and isinstance(s_raw, np.ndarray):
-            c, f_final = params.open(p_poly, p_blind, x3, s_raw, s_blind, rands, transcript, paired=schedule == "paired", hybrid_rounds=hybrid_rounds)
+        if isinstance(s_raw, np.ndarray):          # host randomness: it crosses PCIe inside the call, committed quarter by quarter as it lands
+            c, f_final = params.open(p_poly if isinstance(p_poly, np.ndarray) else p_poly.contiguous(), p_blind, x3, s_raw, s_blind, rands, transcript,
+                                     paired=schedule == "paired", hybrid_rounds=hybrid_rounds)
         else:
             d_p = p_poly.contiguous() if not isinstance(p_poly, np.ndarray) else to_dev(p_poly)
             c, f_final = params.open(d_p, p_blind, x3, fields.to_device_limbs(s_raw, dev).contiguous(), s_blind, rands, transcript,

@@ -325,6 +325,12 @@ int h2_open_device(int curve, unsigned k, h2_bases_t g_basis, h2_bases_t opening
                    const uint64_t *uw_xy, const void *d_p_poly, const uint64_t *p_blind, const uint64_t *x3, void *d_s_poly,
                    const uint64_t *s_blind, const uint64_t *rands, h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze,
                    void *user, uint64_t *c_out, uint64_t *f_out, void *stream);
+/* p_poly resident in HBM, the fresh s_poly where a host rng leaves it (what a prover that keeps its polynomials on the device has at this point):
+ * s_poly crosses PCIe inside the call, in quarters, each committed as it lands (from k = 16 on). */
+int h2_open_device_host_s(int curve, unsigned k, h2_bases_t g_basis, h2_bases_t opening_basis, int paired, unsigned switch_rounds,
+                          const uint64_t *uw_xy, const void *d_p_poly, const uint64_t *p_blind, const uint64_t *x3, const uint64_t *s_poly,
+                          const uint64_t *s_blind, const uint64_t *rands, h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze,
+                          void *user, uint64_t *c_out, uint64_t *f_out, void *stream);
 int h2_open(int curve, unsigned k, h2_bases_t g_basis, h2_bases_t opening_basis, int paired, unsigned switch_rounds,
             const uint64_t *uw_xy, const uint64_t *p_poly, const uint64_t *p_blind, const uint64_t *x3, const uint64_t *s_poly,
             const uint64_t *s_blind, const uint64_t *rands, h2_ipa_write_point_fn write_point, h2_ipa_squeeze_fn squeeze, void *user,

@@ -379,7 +379,8 @@ def test_native_host_mirror_opening_same_bytes(k):
 
 @pytest.mark.parametrize("curve,k", [(h.PALLAS, 1), (h.VESTA, 6), (h.PALLAS, 13), (h.VESTA, 16)])
 def test_whole_argument_entry_points_write_the_oracles_bytes(curve, k):
-    """`commitment::create_proof` as ONE native call (h2_open from host vectors, h2_open_device from resident ones) against the
+    """`commitment::create_proof` as ONE native call (h2_open from host vectors; with p_poly resident h2_open_device_host_s, which moves the host rng's
+    s_poly across in quarters and commits each as it lands from k = 16 on -- the k = 16 case here --, or h2_open_device when the rng draws on the device) against the
     sequential restatement of the reference prover, and against the step-by-step form it replaces (native=False: the steps before
     the loop from Python, h2_ipa_rounds_device for the loop) -- four routes, one byte string.  k = 1: a single round, no table
     pair; 6: the two-commit rounds; 13: the paired rounds; 16: the switch to the collapsed generators inside the call."""
@@ -443,6 +444,10 @@ def test_whole_argument_refuses_before_touching_the_transcript():
     d_same = torch.from_numpy(px.view(np.int64)).cuda()
     assert lib().h2_open_device(curve, k, params._h_g, basis, 0, IPA_SWITCH_DEFAULT, _p(uw), d_same.data_ptr(), _p(one), _p(one), d_same.data_ptr(), _p(one),
                                 _p(rands), cb_w, cb_s, None, _p(c), _p(f), None) != 0       # p_poly and s_poly must not be one buffer
+    assert lib().h2_open_device_host_s(curve, k, bare, basis, 0, IPA_SWITCH_DEFAULT, _p(uw), d_same.data_ptr(), _p(one), _p(one), _p(s), _p(one), _p(rands),
+                                       cb_w, cb_s, None, _p(c), _p(f), None) != 0                 # resident p_poly, host s_poly: the same refusals
+    assert lib().h2_open_device_host_s(curve, k, params._h_g, basis, 0, IPA_SWITCH_DEFAULT, _p(uw), d_same.data_ptr(), _p(one), _p(one), None, _p(one), _p(rands),
+                                       cb_w, cb_s, None, _p(c), _p(f), None) != 0
     assert calls == []
     lib().h2_bases_free(bare)
     params.close()
