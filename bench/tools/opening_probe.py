@@ -24,7 +24,7 @@ def main():
     dev = torch.device("cuda:0")
     g = co.generate_bases(curve, 1, n)
     w, u = co.generate_bases(curve, 2, 1)[0], co.generate_bases(curve, 3, 1)[0]
-    res = {"k": k, "form": "h2_open_device (one call)" if os.environ.get("NATIVE", "1") != "0" else "step by step from Python + h2_ipa_rounds_device"}
+    res = {"k": k, "form": "one call (h2_open_device_host_s: p_poly resident, s_poly from the host rng)" if os.environ.get("NATIVE", "1") != "0" else "step by step from Python + h2_ipa_rounds_device"}
     for m in ((12, 13, 15, 17) if os.environ.get("TABLES", "1") != "0" else ()):
         if m > k:
             continue
