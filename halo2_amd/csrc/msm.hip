@@ -3028,10 +3028,13 @@ static std::mutex g_bases_mu;
 static std::map<h2_bases_t, std::shared_ptr<Bases>> g_bases;
 static h2_bases_t g_next_handle = 1;
 
-static std::shared_ptr<Bases> find_bases(h2_bases_t h) {
+// endomorphism: may the handle be an ENDOMORPHISM table (Bases::glv)?  Such a table belongs to the opening argument's round loop and never leaves the
+// library; only the sub-digit paired commit, its refill and the bookkeeping entry points read it -- to everything else it is not a handle.
+static std::shared_ptr<Bases> find_bases(h2_bases_t h, bool endomorphism = false) {
     std::lock_guard<std::mutex> lk(g_bases_mu);
     auto it = g_bases.find(h);
-    return it == g_bases.end() ? nullptr : it->second;
+    if (it == g_bases.end() || (it->second->glv && !endomorphism)) return nullptr;
+    return it->second;
 }
 
 static bool bad_common(int curve, int form, int out_kind) {
@@ -3630,7 +3633,7 @@ int bases_register_device_internal(int curve, const void *d_bases_xy, size_t n, 
     return bases_register_impl(curve, d_bases_xy, true, n, form, handle, 0, glv);
 }
 int bases_refill_device(h2_bases_t handle, const void *d_bases_xy, size_t n, int form) {
-    auto b = find_bases(handle);
+    auto b = find_bases(handle, true);
     if (!b || b->n != n || !d_bases_xy || (form != H2_FORM_CANONICAL && form != H2_FORM_MONTGOMERY)) return H2_ERR_ARGS;
     int rc = ensure_device();
     if (rc != H2_OK) return rc;
@@ -3749,7 +3752,7 @@ extern "C" int h2_ipa_collapsed_generators_device(h2_bases_t basis, unsigned k, 
 }
 
 extern "C" int h2_bases_info(h2_bases_t handle, size_t *n, int *window_bits, int *curve) {
-    auto b = find_bases(handle);
+    auto b = find_bases(handle, true);
     if (!b) return H2_ERR_HANDLE;
     if (n) *n = b->n;
     if (window_bits) *window_bits = b->c;
@@ -4167,7 +4170,7 @@ static int pair_subdigit_launch(MsmContext &cx, const Bases &b, const void *d_sc
 
 extern "C" int h2_commit_pair_device(h2_bases_t g, const void *d_scalars, size_t n, unsigned pair_shift, int form, int out_kind,
                                      void *d_out, void *stream) {
-    auto b = find_bases(g);
+    auto b = find_bases(g, true);
     if (!b) return H2_ERR_HANDLE;
     if (bad_common(b->curve, form, out_kind) || !d_out || !d_scalars || n != b->n || n < 8 || pair_shift > 31) return H2_ERR_ARGS;
     int rc = ensure_device();
