@@ -376,6 +376,54 @@ static void mode_msm_n(size_t n, int curve, bool timing) {
         for (int i = 0; i < R; ++i) CHECK_RC(p_h2_msm_device(curve, d_s, d_b, n, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_o, nullptr));
         HIPCK(hipDeviceSynchronize());
         const double dev_ms = (now_ms() - t0) / R;
+        if (getenv("H2BENCH_CLOCK")) {      // shader clock / socket power with calls back to back for ~0.4 s, then as independent calls on 3 streams
+            ClockWatch cw;
+            cw.start();
+            t0 = now_ms();
+            int done = 0;
+            while (now_ms() - t0 < 400.0) {
+                for (int i = 0; i < 8; ++i) CHECK_RC(p_h2_msm_device(curve, d_s, d_b, n, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_o, nullptr));
+                HIPCK(hipDeviceSynchronize());
+                done += 8;
+            }
+            const double per = (now_ms() - t0) / done;
+            printf("    one stream, back to back for 0.4 s: %.4f ms per call; %s\n", per, cw.finish().c_str());
+        }
+        {
+            const int NS = 3;
+            hipStream_t ss[NS];
+            void *d_os[NS];
+            for (int j = 0; j < NS; ++j) { HIPCK(hipStreamCreateWithFlags(&ss[j], hipStreamNonBlocking)); HIPCK(hipMalloc(&d_os[j], 96)); }
+            for (int i = 0; i < 2 * NS; ++i) CHECK_RC(p_h2_msm_device(curve, d_s, d_b, n, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_os[i % NS], ss[i % NS]));
+            HIPCK(hipDeviceSynchronize());
+            const int RS = 6 * NS;
+            ClockWatch cw;
+            const bool watch = getenv("H2BENCH_CLOCK") != nullptr;
+            double best = 1e30;
+            for (int rep = 0; rep < (watch ? 12 : 2); ++rep) {
+                if (watch && rep == 2) cw.start();
+                t0 = now_ms();
+                for (int i = 0; i < RS; ++i) CHECK_RC(p_h2_msm_device(curve, d_s, d_b, n, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_os[i % NS], ss[i % NS]));
+                HIPCK(hipDeviceSynchronize());
+                best = std::min(best, (now_ms() - t0) / RS);
+            }
+            bool all_ok = true;
+            for (int j = 0; j < NS; ++j) {
+                uint64_t g3[12];
+                HIPCK(hipMemcpy(g3, d_os[j], 96, hipMemcpyDeviceToHost));
+                all_ok = all_ok && same_point(curve, g3, want);
+            }
+            snprintf(msg, sizeof msg, "h2_msm_device n = %zu as independent calls on %d streams == oracle best_multiexp", n, NS);
+            expect(all_ok, msg);
+            printf("    independent calls round-robin on %d streams: %.4f ms per call (%.1f M scalar-mults/s)%s%s\n", NS, best, n / best / 1e3, watch ? "; " : "",
+                   watch ? cw.finish().c_str() : "");
+            for (int j = 0; j < NS; ++j) { (void)hipStreamDestroy(ss[j]); (void)hipFree(d_os[j]); }
+        }
+        if (getenv("H2BENCH_MSM_DEVICE_ONLY")) {
+            printf("generic best_multiexp n = %zu: %.4f ms device-resident (%.1f M scalar-mults/s)\n", n, dev_ms, n / dev_ms / 1e3);
+            (void)hipFree(d_b); (void)hipFree(d_s); (void)hipFree(d_o);
+            return;
+        }
         for (int i = 0; i < 3; ++i) CHECK_RC(p_h2_msm(curve, sc.data(), bases.data(), n, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, got_h));    // (workspaces, captured launch sequences)
         std::vector<double> hm;
         for (int i = 0; i < 9; ++i) {

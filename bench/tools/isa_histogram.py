@@ -23,14 +23,14 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # (source file, demangled-name substring, what it is)
 KERNELS = [
-    ("msm.hip", "msm_accumulate<0, false, true>", "registered-table accumulate, Pallas (the roofline kernel)"),
-    ("msm.hip", "msm_accumulate<1, false, true>", "the same, Vesta"),
-    ("msm.hip", "msm_s1_count<1, false>", "bucket sort pass 1: count (Pallas scalars = Fq)"),
-    ("msm.hip", "msm_s1_scatter<1, false>", "bucket sort pass 1: scatter"),
-    ("msm.hip", "msm_s2_bins", "bucket sort pass 2 (a workgroup per bin)"),
-    ("msm.hip", "fold9_finish<0>", "fold: range heads into their buckets"),
-    ("msm.hip", "fold9_rowcol<0>", "fold: row / column sums"),
-    ("msm.hip", "fold9_planes<0>", "fold: bit planes + final point"),
+    ("msm_accumulate.hip", "msm_accumulate<0, false, true>", "registered-table accumulate, Pallas (the roofline kernel)"),
+    ("msm_accumulate.hip", "msm_accumulate<1, false, true>", "the same, Vesta"),
+    ("msm_sort.hip", "msm_s1_count<1, false>", "bucket sort pass 1: count (Pallas scalars = Fq)"),
+    ("msm_sort.hip", "msm_s1_scatter<1, false>", "bucket sort pass 1: scatter"),
+    ("msm_sort.hip", "msm_s2_bins", "bucket sort pass 2 (a workgroup per bin)"),
+    ("msm_fold.hip", "fold9_finish<0>", "fold: range heads into their buckets"),
+    ("msm_fold.hip", "fold9_rowcol<0>", "fold: row / column sums"),
+    ("msm_fold.hip", "fold9_planes<0>", "fold: bit planes + final point"),
     ("ntt.hip", "ntt_pass9<0, 10, true>", "NTT first pass of a 2^20 transform (10 stages, bit-reversed gather)"),
     ("ntt.hip", "ntt_pass9<0, 10, false>", "NTT second pass of a 2^20 transform"),
     ("ntt.hip", "ntt_pass9<0, 8, true>", "NTT first pass of the batched / 2^22 plans (8 stages)"),

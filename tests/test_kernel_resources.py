@@ -21,9 +21,9 @@ def listings():
         pytest.skip("hipcc not installed")
     with tempfile.TemporaryDirectory() as td:
         with concurrent.futures.ThreadPoolExecutor(2) as ex:
-            got = list(ex.map(lambda src: ih.compile_s(src, td), ["msm.hip", "ntt.hip"]))
+            got = list(ex.map(lambda src: ih.compile_s(src, td), ["msm_accumulate.hip", "ntt.hip"]))
     out = {}
-    for src, lines in zip(["msm.hip", "ntt.hip"], got):
+    for src, lines in zip(["msm_accumulate.hip", "ntt.hip"], got):
         fn = ih.functions(lines)
         names = list(fn)
         out[src] = (lines, fn, dict(zip(ih.demangle(names), names)))
@@ -42,7 +42,7 @@ def test_accumulate_keeps_its_registers_and_its_instruction_count(listings, curv
     """msm_accumulate<FB, false, true>: sized so that the sort / fold kernels of other streams fit beside two of its waves per SIMD
     (<= 168 VGPRs, three waves by the register file); the mixed addition's common path carries no scratch traffic (the only spills
     belong to the out-of-line P = +-Q path); 1151 multiply-adds per addition (8 products, 2 squares, one fused pair)."""
-    res, blocks = _kernel(listings, "msm.hip", f"msm_accumulate<{curve}, false, true>")
+    res, blocks = _kernel(listings, "msm_accumulate.hip", f"msm_accumulate<{curve}, false, true>")
     assert res["NumVgprs"] <= 168 and res["NumAgprs"] == 0 and res["Occupancy"] >= 3, res
     assert res["ScratchSize"] <= 512, res
     big = [(lbl, c) for lbl, in_loop, c in blocks if in_loop and sum(c.values()) >= 200]
