@@ -1,5 +1,7 @@
 #!/bin/bash
 # A second build of the library for a same-box A/B:  bench/tools/build_variant.sh NAME [hipcc flags, e.g. -DH2_ACC9_WAVES=4]
+# (-DH2_AB=1 makes the environment switches live in it: the shipped library reads none -- csrc/common.h; `make -C halo2_amd/csrc ab`
+#  builds exactly that as build/ab/libhalo2_mi355x_ab.so)
 #   -> build/ab/lib_NAME.so   (objects under build/ab/obj_NAME/; the shipped library and build/obj are not touched)
 # With SRC_REV=<git rev> the sources of halo2_amd/csrc and include/ are taken from that revision instead of the working tree
 # (e.g. SRC_REV=HEAD~1 bench/tools/build_variant.sh before).  Then, on the GPU box (seconds per run, no Python):
@@ -15,7 +17,7 @@ if [ -n "$SRC_REV" ]; then
   (cd $ROOT && git archive "$SRC_REV" halo2_amd/csrc include | tar -x -C $OUT/src_$NAME)
   SRC=$OUT/src_$NAME/halo2_amd/csrc
 fi
-FILES="api transcript multi h2c msm ntt ipa ecfft poly points evaluator lookup"
+FILES=$(cd $SRC && ls *.hip | sed "s/\.hip$//" | tr "\n" " ")      # every unit of that revision (round 6 split msm.hip)
 for f in $FILES; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function "$@" -c $SRC/$f.hip -o $OUT/obj_$NAME/$f.o &
 done

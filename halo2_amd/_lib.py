@@ -14,7 +14,9 @@ FORM_CANONICAL, FORM_MONTGOMERY = 0, 1
 OUT_JACOBIAN, OUT_AFFINE = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhalo2_mi355x.so")
+# H2_LIB_PATH: another build of the same sources -- the laboratory build with its A/B switches live (build/ab/libhalo2_mi355x_ab.so,
+# `make -C halo2_amd/csrc ab`), which the A/B parity tests and bench/tools load in child processes.  The product path never sets it.
+LIB_PATH = os.environ.get("H2_LIB_PATH") or os.path.join(_HERE, "libhalo2_mi355x.so")
 _lib = None
 
 u64p = C.POINTER(C.c_uint64)

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <map>
 #include <memory>
@@ -25,6 +26,17 @@ namespace h2 {
 
 void set_last_hip_error(hipError_t e, const char *file, int line);
 void set_last_error_msg(const char *msg);   // what h2_last_error() returns on this thread
+
+// The laboratory is not in the product.  Every A/B arm and sweep knob of the experiments behind DESIGN_LOG.md (window widths, sort
+// geometries, plan depths, pipeline shapes ...) is read through ab_env(): in the shipped library it is a constant null -- each arm folds
+// to its default at compile time and NO environment variable changes what the prover computes or how.  `make ab` builds the same sources
+// with -DH2_AB=1 into build/ab/libhalo2_mi355x_ab.so, where the switches are live; the A/B parity tests and bench/tools point at that
+// build (H2_LIB_PATH / H2BENCH_LIB).  The only variable the shipped library reads is the diagnostic H2_TIMELINE (include/halo2_mi355x.h).
+#ifdef H2_AB
+inline const char *ab_env(const char *name) { return getenv(name); }
+#else
+inline const char *ab_env(const char *) { return nullptr; }
+#endif
 
 // Grow-only device buffer.  One instance per use site, guarded by the owning context's mutex.
 // counts every (re)allocation and release of a DevBuf in the process: a captured hipGraph names device pointers, and is replayed

@@ -705,7 +705,7 @@ extern "C" int h2_ipa_rounds_device(int curve, unsigned k, unsigned switch_round
     for (size_t t = 0; t < tail; ++t) memcpy(tails + 8 * t, uw_xy + 8 * (pair2 ? t / 2 : t), 64);
     H2_HIP(hipMemcpyAsync(d_g + nj * 64, tails, tail * 64, hipMemcpyHostToDevice, st));
     H2_HIP(hipStreamSynchronize(st));                                // the registration reads the points on the null stream
-    static const bool keep_table = [] { const char *e = getenv("H2_IPA_KEEP_TABLE"); return !(e && e[0] == '0'); }();      // 0: register / free per argument (A/B)
+    static const bool keep_table = [] { const char *e = ab_env("H2_IPA_KEEP_TABLE"); return !(e && e[0] == '0'); }();      // 0: register / free per argument (A/B)
     if (cx.gp_handle && (!keep_table || cx.gp_curve != curve || cx.gp_n != nj + tail)) {
         (void)h2_bases_free(cx.gp_handle);
         cx.gp_handle = 0;
@@ -715,7 +715,7 @@ extern "C" int h2_ipa_rounds_device(int curve, unsigned k, unsigned switch_round
     } else {
         // rounds over a small table are sub-digit paired commits, which read an ENDOMORPHISM table as well: 8 x 16 doublings in its chain instead
         // of 15 x 16 -- the chain is what the table costs (0.77 ms of 240 dependent doublings at 2^14 points).  H2_IPA_GLV_TABLE=0: the plain table (A/B).
-        static const bool glv_env = [] { const char *e = getenv("H2_IPA_GLV_TABLE"); return !(e && e[0] == '0'); }();
+        static const bool glv_env = [] { const char *e = ab_env("H2_IPA_GLV_TABLE"); return !(e && e[0] == '0'); }();
         const bool glv = glv_env && pair2 && pair_subdigits_apply(nj + tail);
         if ((rc = bases_register_device_internal(curve, d_g, nj + tail, H2_FORM_MONTGOMERY, &cx.gp_handle, glv)) != H2_OK) return rc;
         cx.gp_curve = curve;
@@ -785,7 +785,7 @@ static int open_impl(IpaContext &cx, int curve, unsigned k, h2_bases_t g_basis, 
     void *d_b = cx.open_b.ptr;
     u64 *land = (u64 *)cx.open_host;
     // s_poly gets its root at x_3 (:49-51) and is committed to (:56)
-    static const bool ranges_env = [] { const char *e = getenv("H2_OPEN_S_RANGES"); return !(e && e[0] == '0'); }();      // 0: one upload, one commit (A/B)
+    static const bool ranges_env = [] { const char *e = ab_env("H2_OPEN_S_RANGES"); return !(e && e[0] == '0'); }();      // 0: one upload, one commit (A/B)
     // (with p_poly in host memory too -- h2_open -- the calling thread is the bottleneck either way: 96 MiB of pageable copies through one thread, and every launch
     // between two of them is PCIe idle time; measured there the quarters LOSE a millisecond to one upload + one commit, so they serve the resident p_poly only)
     const bool by_ranges = host_s && !host_p && ranges_env && k >= 16;

@@ -72,7 +72,7 @@ HostMsmPipe g_host_msm[16];      // per device
 // 3.11-3.26 / 3.63 ms against 3.44-3.46 in one piece: finer ranges lose more to the per-copy cost of pageable memory and to narrower
 // windows than their shorter tail wins -- profiles/r05_h2_msm_host_ranges.txt; H2_MSM_HOST_CHUNKS: sweeps, 1 = the round-4 path)
 static unsigned host_msm_chunks(size_t n) {
-    static const int env = [] { const char *e = getenv("H2_MSM_HOST_CHUNKS"); return e ? atoi(e) : 0; }();
+    static const int env = [] { const char *e = ab_env("H2_MSM_HOST_CHUNKS"); return e ? atoi(e) : 0; }();
     if (env >= 1) return (unsigned)std::min<size_t>((size_t)std::min(env, 16), std::max<size_t>(1, n >> 14));
     if (n < ((size_t)1 << 19)) return 1;
     return 3;
@@ -145,7 +145,7 @@ static int msm_host_chunked(MsmContext &cx, int curve, const uint64_t *scalars, 
     want.curve = curve; want.form = form; want.out_kind = out_kind; want.c = c; want.n = n; want.Q = Q;
     want.s = cx.stage_s.ptr; want.b = cx.stage_b.ptr; want.o = cx.out.ptr;
     want.epoch = devbuf_epoch();
-    static const bool graphs_on = [] { const char *e = getenv("H2_MSM_HOST_GRAPHS"); return !(e && atoi(e) == 0); }();
+    static const bool graphs_on = [] { const char *e = ab_env("H2_MSM_HOST_GRAPHS"); return !(e && atoi(e) == 0); }();
     if (!(want == hp.shape)) {
         hp.drop_graphs();
         hp.shape = want;
@@ -174,7 +174,7 @@ static int msm_host_chunked(MsmContext &cx, int curve, const uint64_t *scalars, 
     // through an atomic counter).
     // Measured (profiles/r05_h2_msm_host_ranges.txt, 2^20): no gain -- 3.08-3.27 ms with the helper against 3.07-3.23 without: what the
     // copies lose to the helper's calls is what they idled before.  Off unless H2_MSM_HOST_THREAD=1.
-    static const bool thread_on = [] { const char *e = getenv("H2_MSM_HOST_THREAD"); return e && atoi(e) == 1; }();
+    static const bool thread_on = [] { const char *e = ab_env("H2_MSM_HOST_THREAD"); return e && atoi(e) == 1; }();
     const bool helper = replay && thread_on;
     std::atomic<int> landed_n{-1};          // -1: nothing yet; 0: the scalars' event is recorded; q + 1: range q's
     std::atomic<int> abort_flag{0};
@@ -315,7 +315,7 @@ extern "C" int h2_msm(int curve, const uint64_t *scalars, const uint64_t *bases_
     // Large multiexps: the scalars cross first (a third of the bytes), the sort -- which reads nothing else -- is enqueued, and only
     // then does the host enter the copy of the bases, on a second stream: the sort runs while the bases are on the bus (2^20 points:
     // 0.25 ms of a 3.6 ms call).  H2_MSM_HOST_OVERLAP=0: copy, copy, compute (A/B).
-    static const bool overlap_on = [] { const char *e = getenv("H2_MSM_HOST_OVERLAP"); return !(e && atoi(e) == 0); }();
+    static const bool overlap_on = [] { const char *e = ab_env("H2_MSM_HOST_OVERLAP"); return !(e && atoi(e) == 0); }();
     if (n >= ((size_t)1 << 16) && overlap_on) {
         if (!cx.copy_stream) {
             H2_HIP(hipStreamCreateWithFlags(&cx.copy_stream, hipStreamNonBlocking));

@@ -167,7 +167,7 @@ extern "C" int h2_ipa_collapsed_generators_device(h2_bases_t basis, unsigned k, 
     const u32 J = rounds, nJ = 1u << (k - J);
     u64 um[12 * 4];
     for (u32 r = 0; r < J; ++r) host_to_mont(sf, um + 4 * r, challenges + 4 * r, form);
-    static const bool nibbles = [] { const char *e = getenv("H2_READOUT_NIBBLES"); return e && e[0] == '1'; }();
+    static const bool nibbles = [] { const char *e = ab_env("H2_READOUT_NIBBLES"); return e && e[0] == '1'; }();
     const int nlists = nibbles ? 32 : 256;
     std::vector<std::vector<u32>> lists(nlists);
     for (u32 h = 0; h < (1u << J); ++h) {

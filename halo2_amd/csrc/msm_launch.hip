@@ -51,7 +51,7 @@ bool sort2_geometry(u32 stride, int c, int *lowb_out, int *lb_out, int *side_out
     // -- windows of 18 bits and more at 2^20 points, where those are too few -- in a 16-bit SIDE array next to the tagged list
     // (pass 1 writes 6 bytes per entry instead of 4; without it c = 20 meant 4096 bins and 6-entry runs)
     int lowb = std::min(31 - lb, bucket_bits - 9), side = 0;
-    static const bool side_ok = [] { const char *e = getenv("H2_SORT_SIDE"); return !(e && atoi(e) == 0); }();      // A/B switch
+    static const bool side_ok = [] { const char *e = ab_env("H2_SORT_SIDE"); return !(e && atoi(e) == 0); }();      // A/B switch
     // ... only where the entry's own spare bits would leave more than 1024 bins: at 17-bit windows over 2^20 points (1024 bins
     // without it) the side array buys nothing and costs 50 % more tagged traffic (measured: 1027 against 1026-1038 M/s)
     if (side_ok && bucket_bits - lowb > 10 && bucket_bits - 9 <= 14 && W <= 64) {
@@ -62,7 +62,7 @@ bool sort2_geometry(u32 stride, int c, int *lowb_out, int *lb_out, int *side_out
     const size_t nh = (size_t)1 << (bucket_bits - lowb);
     // pass-1 stage in LDS: 2048 scalars' digits per workgroup, 1024 where narrower windows mean more digits per scalar (13-bit tables:
     // 20 digits) -- only for callers that ask (s1_out); the others keep the fixed 2048 they were measured with
-    static const u32 s1_env = [] { const char *e = getenv("H2_S1_SCALARS"); int v = e ? atoi(e) : 0; return (u32)(v == 512 || v == 1024 || v == 2048 ? v : 0); }();   // sweeps only
+    static const u32 s1_env = [] { const char *e = ab_env("H2_S1_SCALARS"); int v = e ? atoi(e) : 0; return (u32)(v == 512 || v == 1024 || v == 2048 ? v : 0); }();   // sweeps only
     u32 s1 = s1_out && s1_env ? s1_env : kS1Scalars;
     if (s1_out && (nh * 3 + 1 + (size_t)s1 * W) * 4 > kLdsCap) s1 = 1024;
     if ((nh * 3 + 1 + (size_t)s1 * W) * 4 > kLdsCap) return false;
@@ -108,7 +108,7 @@ int choose_c(size_t n, bool shared_buckets) {
         int lowb, lb;
         return shared_buckets && n + 1 < ((size_t)1 << 31) && sort2_geometry((u32)n + 1, c, &lowb, &lb);
     };
-    if (const char *e = getenv("H2_MSM_C")) {   // tuning sweeps only; the only way to windows beyond 16 bits (see below)
+    if (const char *e = ab_env("H2_MSM_C")) {   // tuning sweeps only; the only way to windows beyond 16 bits (see below)
         int v = atoi(e);
         if (v >= 4 && v <= kMaxCShared && feasible(v)) return v;
     }
@@ -294,7 +294,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         cx.attr_set = true;
     }
     // registered tables are stored in M9 form (h2_bases_register); the generic path converts its bases per call (below)
-    static const bool glv_on_fe9 = [] { const char *e = getenv("H2_GENERIC_FE9"); return !(e && atoi(e) == 0); }();
+    static const bool glv_on_fe9 = [] { const char *e = ab_env("H2_GENERIC_FE9"); return !(e && atoi(e) == 0); }();
     const bool m9 = (a.table && !glv) || (glv && glv_on_fe9);
     u32 &lanes = cx.lanes[FB][m9 ? 2 : glv ? 1 : 0];
     if (!lanes) {  // how many lanes of the accumulate kernel the chip holds at once
@@ -308,7 +308,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         // the M9 accumulate is sized for H2_ACC9_WAVES workgroups per CU even where its register count would let a third one in:
         // the wave slots and registers left over are what the sort / fold kernels of commits on OTHER streams run in
         // (H2_ACC_WAVES: sweeps only)
-        static const int acc_waves = [] { const char *e = getenv("H2_ACC_WAVES"); int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? v : H2_ACC9_WAVES; }();
+        static const int acc_waves = [] { const char *e = ab_env("H2_ACC_WAVES"); int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? v : H2_ACC9_WAVES; }();
         if (m9) per_cu = std::min(per_cu, acc_waves);
         lanes = (u32)cus * (u32)std::max(per_cu, 1) * 256u;
     }
@@ -319,17 +319,17 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     // H2_ACC_OVERSUB = k (sweeps only): k times as many, k times shorter lanes than the chip holds at once -- workgroups then enter as
     // slots free up, which evens out a launch that found some CUs half taken by other streams' sort / fold kernels, at the price of
     // k times the range heads for the finisher
-    static const u32 oversub = [] { const char *e = getenv("H2_ACC_OVERSUB"); int v = e ? atoi(e) : 0; return (u32)(v >= 1 && v <= 8 ? v : 1); }();
+    static const u32 oversub = [] { const char *e = ab_env("H2_ACC_OVERSUB"); int v = e ? atoi(e) : 0; return (u32)(v >= 1 && v <= 8 ? v : 1); }();
     const u32 usable = std::max(256u, (u32)(lanes * fraction) / 256u * 256u) * (a.table ? oversub : 1u);
     // entries per lane of the accumulate: 16 for full-size columns; small commits are chains of latency-bound kernels and run
     // shorter with more, shorter lanes (one registered commit at 2^11 .. 2^15 points: 3-7 % faster at 8; H2_MSM_DIV: sweeps only)
-    static const u32 env_div = [] { const char *e = getenv("H2_MSM_DIV"); int v = e ? atoi(e) : 0; return (u32)(v >= 1 && v <= 64 ? v : 0); }();
+    static const u32 env_div = [] { const char *e = ab_env("H2_MSM_DIV"); int v = e ? atoi(e) : 0; return (u32)(v >= 1 && v <= 64 ? v : 0); }();
     const u32 lane_div = env_div ? env_div : (all_items < ((size_t)1 << 20) ? 8u : 16u);
     // Column-batched commits are JOINED (ColStride::joined) unless H2_BATCH_JOIN=0: the K sorted lists form one, which ONE launch of
     // msm_accumulate cuts into equal ranges -- the chip is tiled exactly as by a single commit (a launch per column leaves its last
     // round of workgroups ragged, and K of them next to each other share CUs unevenly), and the finisher meets T range heads per
     // batch instead of per column.
-    static const bool join_env = [] { const char *e = getenv("H2_BATCH_JOIN"); return !(e && e[0] == '0'); }();
+    static const bool join_env = [] { const char *e = ab_env("H2_BATCH_JOIN"); return !(e && e[0] == '0'); }();
     const bool joined = K > 1 && join_env;
     u32 T = (u32)std::min<size_t>(usable, std::max<size_t>(256, ((joined ? K : 1) * all_items / lane_div + 255) / 256 * 256));
     size_t head_slots = joined ? (size_t)T : (size_t)T * K;            // range heads parked in cx.seg9, in front of the K x tb bucket slots
@@ -338,7 +338,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     Sort2 S2;
     memset(&S2, 0, sizeof S2);
     S2.pair_shift = -1;
-    static const u32 run_lanes_env = [] { const char *e = getenv("H2_S1_RUN_LANES"); int v = e ? atoi(e) : 0; return (u32)(v == 8 || v == 16 || v == 32 || v == 64 ? v : 16); }();
+    static const u32 run_lanes_env = [] { const char *e = ab_env("H2_S1_RUN_LANES"); int v = e ? atoi(e) : 0; return (u32)(v == 8 || v == 16 || v == 32 || v == 64 ? v : 16); }();
     S2.run_lanes = run_lanes_env;
     bool use_sort2 = false;
     if (pair) {
@@ -361,7 +361,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     } else if (a.table && (sh.c > kMaxC || (sh.NB >= 4096 && (m >= 8192 || K > 1)))) {
         // (a column-batched commit exists in the two-pass form only, so it takes it from 13-bit tables on whatever the column length:
         // eight 2^12-point columns in one launch set are 0.3 ms against 0.9 ms for eight chains of one-pass sorts)
-        static const int force_old = [] { const char *e = getenv("H2_MSM_SORT"); return e && atoi(e) == 1 ? 1 : 0; }();
+        static const int force_old = [] { const char *e = ab_env("H2_MSM_SORT"); return e && atoi(e) == 1 ? 1 : 0; }();
         int lowb = 0, lb = 0, side = 0;
         u32 s1 = kS1Scalars;
         if (sort2_geometry(a.stride, sh.c, &lowb, &lb, &side, &s1) && (sh.c > kMaxC || !force_old)) {
@@ -380,7 +380,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         }
     } else if (glv && scalars_n >= 65536) {
         // generic path, large: sort key = window * NB + bucket over all slices, entry = digit column (< 2 * scalars)
-        static const int force_old = [] { const char *e = getenv("H2_MSM_SORT"); return e && atoi(e) == 1 ? 1 : 0; }();
+        static const int force_old = [] { const char *e = ab_env("H2_MSM_SORT"); return e && atoi(e) == 1 ? 1 : 0; }();
         int lb = 0, kb = 0;
         while (((u64)(m - 1) >> lb) != 0) ++lb;
         while (((u64)(tb - 1) >> kb) != 0) ++kb;
@@ -390,7 +390,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         // into ONE bucket, and a bin that large was scattered by a single workgroup (2^19: sort 0.28 -> 0.16 ms; 2^20: 0.30 -> 0.61).
         // With the oversized-bin kernels (msm_s2_big_*) that bin is chunked over 64 workgroups: 2^20 takes the one-launch form with
         // 10 bits (1.83 -> 1.71 ms on one box; 11 bits 1.80, 12 bits 1.83); from 2^21 the forms are equal within 1 %.
-        static const int glv_bin_bits = [] { const char *e = getenv("H2_GLV_BIN_BITS"); int v = e ? atoi(e) : 0; return v >= 8 && v <= 12 ? v : 0; }();
+        static const int glv_bin_bits = [] { const char *e = ab_env("H2_GLV_BIN_BITS"); int v = e ? atoi(e) : 0; return v >= 8 && v <= 12 ? v : 0; }();
         const int bin_bits = glv_bin_bits ? glv_bin_bits : (scalars_n <= ((size_t)1 << 19) ? 11 : scalars_n <= ((size_t)1 << 20) ? 10 : 9);
         const int lowb = std::min(31 - lb, std::max(1, kb - bin_bits));
         const u32 nh = (tb + (1u << lowb) - 1) >> lowb;
@@ -412,11 +412,11 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     if (sh.c > kMaxC && !use_sort2) return H2_ERR_ARGS;   // choose_c only picks wide windows the two-pass sort can take
     if (K > 1 && !use_sort2) return H2_ERR_BATCH_SHAPE;
     const bool wide_reduce = sh.NB > 32768u;              // implies the registered path (one slice)
-    static const bool fold9_on = [] { const char *e = getenv("H2_FOLD9"); return !(e && atoi(e) == 0); }();     // A/B switch
+    static const bool fold9_on = [] { const char *e = ab_env("H2_FOLD9"); return !(e && atoi(e) == 0); }();     // A/B switch
     // the fold on the carry-free layer (fold9_* kernels: registered tables from 16-bit windows, paired commits, and the window
     // slices of a large generic multiexp); a range of a chunked commit hands finished buckets on in the reference's form
     // (add_into), so it keeps the 8 x 32 finisher
-    static const u32 fold9_min_nb = [] { const char *e = getenv("H2_FOLD9_MIN_NB"); int v = e ? atoi(e) : 0; return (u32)(v >= 64 ? v : 128); }();
+    static const u32 fold9_min_nb = [] { const char *e = ab_env("H2_FOLD9_MIN_NB"); int v = e ? atoi(e) : 0; return (u32)(v >= 64 ? v : 128); }();
     const bool fold9 = fold9_on && sh.NB >= fold9_min_nb && sh.slices <= 16 && m9 && !a.add_into && !fold_only;      // (16: arrival counters of fold9_planes)
     if (K > 1 && !fold9) return H2_ERR_BATCH_SHAPE;
     if (a.slice_sums_only && !(fold9 && glv)) return H2_ERR_BATCH_SHAPE;
@@ -426,7 +426,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     // on one quad of lanes, which used to follow the whole accumulate -- run on a side stream beside the lower group's accumulate and
     // fold.  What is left behind the accumulate: the lower group's fold, (split_k - 1) c doublings and one addition.  The bases'
     // conversion to M9 form runs on the side stream beside the sort.  H2_GENERIC_SPLIT=0: off (A/B); = k: force the lower group's size.
-    static const int split_env = [] { const char *e = getenv("H2_GENERIC_SPLIT"); return e ? atoi(e) : -1; }();
+    static const int split_env = [] { const char *e = ab_env("H2_GENERIC_SPLIT"); return e ? atoi(e) : -1; }();
     int split_k = 0;
     if (glv && fold9 && m9 && a.phase == 0 && !a.slice_sums_only && K == 1 && sh.slices >= 6 && split_env != 0 && !prof_enabled() && !timeline_on()) {
         if (split_env > 0) split_k = std::min<int>(split_env, (int)sh.slices - 2);
@@ -438,12 +438,12 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     bool s2_bins_form = false;
     size_t s2_cap_entries = 0;
     if (use_sort2) {
-        static const bool bins_on = [] { const char *e = getenv("H2_S2_BINS"); return !(e && atoi(e) == 0); }();
+        static const bool bins_on = [] { const char *e = ab_env("H2_S2_BINS"); return !(e && atoi(e) == 0); }();
         const size_t nbk = (size_t)1 << S2.lowb;
         // LDS stage: the average bin + 25 % (two workgroups per CU where that fits: 2^20 scalars at 17 bits, 15 K-entry bins), at
         // most what one workgroup can have; a bin beyond its stage takes the direct-scatter branch.  H2_S2_CAP: sweeps only.
         const size_t cap_max = nbk * 8 + 64 < kLdsCap ? (kLdsCap - nbk * 8) / 4 : 0;
-        static const size_t cap_env = [] { const char *e = getenv("H2_S2_CAP"); return e ? (size_t)atol(e) : (size_t)0; }();
+        static const size_t cap_env = [] { const char *e = ab_env("H2_S2_CAP"); return e ? (size_t)atol(e) : (size_t)0; }();
         s2_cap_entries = std::min(cap_max, cap_env ? cap_env : std::max<size_t>(4096, all_items / S2.nh * 5 / 4 + 1024));
         const size_t nbins = ((size_t)tb + nbk - 1) >> S2.lowb;
         s2_bins_form = bins_on && S2.lowb <= 12 && nbins == S2.nh && s2_cap_entries && all_items / S2.nh <= s2_cap_entries * 9 / 10;
@@ -557,7 +557,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
         // msm_accumulate waves a SIMD already holds (2 x 168 of 512 registers) -- with 1024 lanes the sort of the NEXT commit on
         // another stream sat out the whole accumulate (416 us on average in a 3-stream trace against 57 us alone); LDS is free
         // there, the accumulate uses none.  H2_S1_THREADS: sweeps only.
-        static const u32 s1_threads = [] { const char *e = getenv("H2_S1_THREADS"); int v = e ? atoi(e) : 0; return (u32)(v == 256 || v == 512 || v == 1024 ? v : 512); }();
+        static const u32 s1_threads = [] { const char *e = ab_env("H2_S1_THREADS"); int v = e ? atoi(e) : 0; return (u32)(v == 256 || v == 512 || v == 1024 ? v : 512); }();
         if (glv) {
             hipLaunchKernelGGL((msm_s1_count<FS, true>), dim3(S2.B1), dim3(s1_threads), S2.nh * 4, st, (const u32 *)a.d_scalars,
                                (const u32 *)nullptr, S2, hist1, ci, cs);
@@ -587,7 +587,7 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
             // the oversized-bin kernels return at once when the list is empty (the common case).  256-lane workgroups: a 1024-lane
             // workgroup of an EMPTY launch still needs four wave slots on every SIMD of one CU, and sat behind other streams'
             // accumulate for 10-160 us (profiles/r03_kernel_stats_3streams.csv) before it could find out that it had nothing to do
-            static const u32 big_threads = [] { const char *e = getenv("H2_S2_BIG_THREADS"); int v = e ? atoi(e) : 0; return (u32)(v == 256 || v == 512 || v == 1024 ? v : 256); }();
+            static const u32 big_threads = [] { const char *e = ab_env("H2_S2_BIG_THREADS"); int v = e ? atoi(e) : 0; return (u32)(v == 256 || v == 512 || v == 1024 ? v : 256); }();
             hipLaunchKernelGGL(msm_s2_bins, dim3(S2.nh, 1, K), dim3(1024), (nbk * 2 + cap_entries) * 4, st, cx.tagged.as<u32>(),
                                (const uint16_t *)cx.tagged_low.as<uint16_t>(), bin_start, S2, tb, (u32)cap_entries, cx.starts.as<u32>(), cx.entries.as<u32>(), big, max_big,
                                zero_in_sort ? cx.seg9.as<u32>() + 36 * head_slots : (u32 *)nullptr, cs);
@@ -1061,7 +1061,7 @@ extern "C" int h2_commit_batch_device(h2_bases_t g, const void *const *d_scalars
     // streams, so that one group's sort and fold run beside the other's accumulate.  Shapes the batched form does not take
     // (narrow windows, small columns: msm_launch says so before launching anything) fall through to one commit per column
     // on three streams, as before.  H2_BATCH_COLS: sweeps only (1 = the per-column form).
-    static const int batch_env = [] { const char *e = getenv("H2_BATCH_COLS"); int v = e ? atoi(e) : 0; return v >= 1 && v <= kMaxCols ? v : 0; }();
+    static const int batch_env = [] { const char *e = ab_env("H2_BATCH_COLS"); int v = e ? atoi(e) : 0; return v >= 1 && v <= kMaxCols ? v : 0; }();
     const size_t batch_cols = batch_env ? (size_t)batch_env : (size_t)kMaxCols;
     // Which form (measured on one MI355X, bench/tools/batch_vs_fork.py, profiles/r04_batch_vs_fork.txt; ms per column, batched / forked):
     //   2^13 x 8: 0.059 / 0.116    2^14 x 8: 0.065 / 0.115    2^16 x 8: 0.102 / 0.143    2^18 x 2, 3, 8: 0.353 / 0.386, 0.302 / 0.323, 0.287 / 0.290

@@ -268,7 +268,7 @@ template <int FB, int FS>
 static int pair_subdigit_launch(MsmContext &cx, const Bases &b, const void *d_scalars, size_t n, unsigned pair_shift, int form, int out_kind,
                                 void *d_out, hipStream_t st) {
     int rc;
-    static const u32 sub_block = [] { const char *e = getenv("H2_SUB_BLOCK"); int v = e ? atoi(e) : 0; return (u32)(v == 256 || v == 512 || v == 1024 ? v : kSubBlock); }();   // A/B
+    static const u32 sub_block = [] { const char *e = ab_env("H2_SUB_BLOCK"); int v = e ? atoi(e) : 0; return (u32)(v == 256 || v == 512 || v == 1024 ? v : kSubBlock); }();   // A/B
     const u32 nblk = (u32)((n + sub_block - 1) / sub_block), tb = kSubSlots, nsl = 4;
     const int glv = b.glv ? 1 : 0;
     const size_t max_entries = n * (glv ? 40 : 32);             // two sub-digits per table digit: 16 digits; over an endomorphism table 2 x (7 x 2 + 4 + 2) at most

@@ -303,7 +303,7 @@ extern "C" int h2_bases_register(int curve, const uint64_t *bases_xy, size_t n, 
 extern "C" int h2_commit_column_window_bits(size_t n) {
     const int c = choose_c(n ? n : 1, true);
     int lowb, lb;
-    if (const char *e = getenv("H2_COLUMN_C")) {          // sweeps only (bench.py, bench/tools): the width column tables are built with
+    if (const char *e = ab_env("H2_COLUMN_C")) {          // sweeps only (bench.py, bench/tools): the width column tables are built with
         const int v = atoi(e);
         if (v >= 4 && v <= kMaxCShared && (v <= kMaxC || (n + 1 < ((size_t)1 << 31) && sort2_geometry((u32)n + 1, v, &lowb, &lb)))) return v;
     }
@@ -333,7 +333,7 @@ extern "C" int h2_bases_register_device(int curve, const void *d_bases_xy, size_
 namespace h2 {
 // Does h2_commit_pair_device take the sub-digit form for a table of n points (16-bit windows)?  (H2_PAIR_SUBDIGITS: 0 = never; n = the largest table.)
 static long pair_subdigit_max() {
-    static const long v = [] { const char *e = getenv("H2_PAIR_SUBDIGITS"); return e ? atol(e) : (long)((1 << 16) + 4); }();
+    static const long v = [] { const char *e = ab_env("H2_PAIR_SUBDIGITS"); return e ? atol(e) : (long)((1 << 16) + 4); }();
     return v;
 }
 bool pair_subdigits_apply(size_t n) { return pair_subdigit_max() > 0 && n >= 8 && n <= (size_t)pair_subdigit_max(); }

@@ -276,7 +276,9 @@ int rccl_exchange_and_sum(int curve, int local_rc, int form, int out_kind, void 
     char *buf = (char *)R.d_buf, *mine = buf + (size_t)R.world * Rccl::kSlot;
     const u32 status = local_rc == H2_OK ? 0u : 1u;
     if (status) (void)hipMemsetAsync(mine, 0, 96, st);
-    hipError_t he = hipMemcpyAsync(mine + 96, &status, 4, hipMemcpyHostToDevice, st);        // (pageable source: staged before the call returns)
+    // the status word is SET ON THE DEVICE (a memset node carries its value): no host source that would have to outlive this call --
+    // on the failure path the function returns right after the collective is enqueued
+    hipError_t he = hipMemsetAsync(mine + 96, status ? 0xFF : 0, 4, st);
     int e = R.AllGather(mine, buf, Rccl::kSlot, /*ncclChar*/ 0, R.comm, st);
     if (local_rc != H2_OK) return local_rc;                 // the peers learn of it from the status word
     if (he != hipSuccess) { set_last_hip_error(he, __FILE__, __LINE__); return H2_ERR_HIP; }
@@ -343,8 +345,9 @@ extern "C" int h2_commit_split_rccl_device(h2_bases_t g, const void *d_scalars, 
     rc = h2_commit_range_device(g, (const char *)d_scalars + 32 * lo, lo, hi - lo, rank == world - 1 ? d_blind : nullptr, form, H2_OUT_JACOBIAN,
                                 mine, st);
     // fault injection for the tests (H2_TEST_FAIL_RANK=r: rank r reports a local failure after its range commit): every rank must
-    // come back with an error and nobody may hang
-    static const int fail_rank = [] { const char *e = getenv("H2_TEST_FAIL_RANK"); return e ? atoi(e) : -1; }();
+    // come back with an error and nobody may hang.  Read through ab_env(): compiled OUT of the shipped library (common.h), live in the
+    // laboratory build the test loads
+    static const int fail_rank = [] { const char *e = ab_env("H2_TEST_FAIL_RANK"); return e ? atoi(e) : -1; }();
     if (rc == H2_OK && fail_rank == rank) {
         set_last_error_msg("H2_TEST_FAIL_RANK: injected local failure");
         rc = H2_ERR_HIP;

@@ -762,7 +762,7 @@ static int get_twiddles(NttContext &cx, int field, int L, const u64 omega_m[4], 
 }
 
 static bool ntt_on_fe9() {
-    static const bool on = [] { const char *e = getenv("H2_NTT_FE9"); return !(e && atoi(e) == 0); }();
+    static const bool on = [] { const char *e = ab_env("H2_NTT_FE9"); return !(e && atoi(e) == 0); }();
     return on;
 }
 // the carry-free passes keep in-stage twiddle indices in 32-bit lane offsets (tw9_load32): transforms up to 2^28; beyond that
@@ -880,9 +880,9 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
     // against 1.45.  The passes are issue-bound, not byte-bound: two passes carry ~10 800 instructions per lane-quadruple against
     // ~11 170 for three (3 % fewer), while their 64- / 32-byte rows and one-workgroup-per-CU tiles lose more than that to the
     // memory phases no second workgroup covers.  The default stays at 10 stages; H2_NTT_MAXR=11 / 12 reproduces the A/B.
-    static const int env_maxr = [] { const char *e = getenv("H2_NTT_MAXR"); int v = e ? atoi(e) : 0; return v >= 1 && v <= 12 ? v : 0; }();
-    static const int want_logT = [] { const char *e = getenv("H2_NTT_LOGT"); int v = e ? atoi(e) : 3; return v >= 0 && v <= 5 ? v : 3; }();
-    static const u32 env_lds = [] { const char *e = getenv("H2_NTT_LDS"); int v = e ? atoi(e) : 131072; return (u32)(v >= 32768 && v <= 131072 ? v : 131072); }();
+    static const int env_maxr = [] { const char *e = ab_env("H2_NTT_MAXR"); int v = e ? atoi(e) : 0; return v >= 1 && v <= 12 ? v : 0; }();
+    static const int want_logT = [] { const char *e = ab_env("H2_NTT_LOGT"); int v = e ? atoi(e) : 3; return v >= 0 && v <= 5 ? v : 3; }();
+    static const u32 env_lds = [] { const char *e = ab_env("H2_NTT_LDS"); int v = e ? atoi(e) : 131072; return (u32)(v >= 32768 && v <= 131072 ? v : 131072); }();
     const int dflt_maxr = env_maxr ? env_maxr : 10;
     const int maxr = J.plan == 1 ? std::min(dflt_maxr, 8) : dflt_maxr;
     const u32 lds_cap = J.plan == 1 ? std::min<u32>(env_lds, 65536u) : env_lds;
@@ -920,7 +920,7 @@ static int ntt_run(const NttJob &J, hipStream_t st) {
         const bool last = i == P - 1;
         A.last = last;
         int colbits = A.first ? (L - A.r) : s0;
-        static const int first_logT = [] { const char *e = getenv("H2_NTT_LOGT_FIRST"); int v = e ? atoi(e) : -1; return v >= 0 && v <= 5 ? v : -1; }();   // sweeps only
+        static const int first_logT = [] { const char *e = ab_env("H2_NTT_LOGT_FIRST"); int v = e ? atoi(e) : -1; return v >= 0 && v <= 5 ? v : -1; }();   // sweeps only
         A.logT = std::min(A.first && first_logT >= 0 ? first_logT : want_logT, colbits);
         while (A.logT > 0 && ((32u << A.r) << A.logT) > lds_cap) A.logT--;
         // a transform alone on the chip, below 2^20: wide tiles are FEW tiles (2^18 as 10 + 8 stages at four columns = 64 workgroups

@@ -479,7 +479,12 @@ int h2_profile_read(int slot, double *total_ms, uint64_t *launches);
  * issued on several streams overlapping on the device, total_ms counts shared time once per launch; busy_ms is the time
  * the device spent on the kernel, so busy_ms / launches never exceeds the wall time per launch. */
 int h2_profile_read_busy(int slot, double *total_ms, double *busy_ms, uint64_t *launches);
-/* With H2_TIMELINE=1 in the environment every commit stamps the device clock (100 MHz) as its sort, accumulate
+/* ENVIRONMENT.  libhalo2_mi355x.so reads ONE environment variable, the diagnostic H2_TIMELINE below; it never changes a result or an
+ * algorithm.  Every A/B switch and sweep knob of the experiments behind DESIGN_LOG.md is compiled out of this library (csrc/common.h,
+ * ab_env()) and lives only in the laboratory build of the same sources (`make -C halo2_amd/csrc ab` -> build/ab/libhalo2_mi355x_ab.so)
+ * that the A/B parity tests and bench/tools load; tests/test_abi_and_host.py holds the shipped binary to that.
+ *
+ * With H2_TIMELINE=1 in the environment every commit stamps the device clock (100 MHz) as its sort, accumulate
  * and reduce stages become runnable; this drains up to `cap` {clock, (stream id << 8) | stage} pairs, stage
  * 1 = sort, 2 = accumulate, 3 = reduce, 4 = done.  Returns the pair count, or -1 when the timeline is off. */
 int h2_debug_timeline(unsigned long long *out, unsigned cap);

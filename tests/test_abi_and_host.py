@@ -90,6 +90,32 @@ def test_product_never_imports_oracle():
                 assert "oracle" not in src.replace("the oracle", "").replace("Python oracle", "").replace("inject the oracle", ""), f
 
 
+def test_shipped_library_reads_no_algorithm_switch():
+    """The laboratory is not in the product (round-5 review, item 4): every A/B arm and sweep knob is read through ab_env()
+    (csrc/common.h), a constant null in the shipped build -- so the sources call getenv("H2_...") for the diagnostic H2_TIMELINE only, no
+    switch name survives as a string in halo2_amd/libhalo2_mi355x.so, every one of them is live in the laboratory build
+    (build/ab/libhalo2_mi355x_ab.so, which only tests and bench/tools load), and no source file is a catch-all again (<= 1500 lines)."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "halo2_amd", "csrc")
+    names, direct = set(), []
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cuh")) + glob.glob(os.path.join(csrc, "*.h")):
+        src = open(f).read()
+        assert src.count("\n") <= 1500 or not f.endswith(".hip"), (f, src.count("\n"))
+        names |= set(re.findall(r'ab_env\("(H2_\w+)"\)', src))
+        direct += re.findall(r'[^_]getenv\("(H2_\w+)"\)', src)
+    assert direct == ["H2_TIMELINE"], direct
+    assert len(names) >= 30 and "H2_TIMELINE" not in names, sorted(names)
+    blob = open(os.path.join(ROOT, "halo2_amd", "libhalo2_mi355x.so"), "rb").read()
+    leaked = [n for n in sorted(names) if (n + "\0").encode() in blob]
+    assert not leaked, leaked
+    ab = os.path.join(ROOT, "build", "ab", "libhalo2_mi355x_ab.so")
+    if os.path.exists(ab):
+        ab_blob = open(ab, "rb").read()
+        missing = [n for n in sorted(names) if (n + "\0").encode() not in ab_blob]
+        assert not missing, missing
+
+
 def test_domain_constants_match_reference_pins(golden_dir):
     vks = json.load(open(os.path.join(golden_dir, "pinned_vk.json")))
     for v in vks:

@@ -323,10 +323,7 @@ def test_column_batched_commit_matches_oracle(curve, k, bits):
 
 
 def test_column_batched_commit_one_launch_per_column_form():
-    """H2_BATCH_JOIN=0 keeps the form that launches msm_accumulate once per column (blockIdx.z); the switch is read once per process,
-    so the same parity test runs in a child process with it set."""
-    import subprocess, sys
-    env = dict(os.environ, H2_BATCH_JOIN="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_column_batched_commit_matches_oracle and 16-16"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    """H2_BATCH_JOIN=0 (laboratory build only) keeps the form that launches msm_accumulate once per column (blockIdx.z); the switch is read
+    once per process, so the same parity test runs in a child process that loads that build with it set."""
+    from conftest import run_test_in_ab_child
+    run_test_in_ab_child(__file__, "test_column_batched_commit_matches_oracle and 16-16", H2_BATCH_JOIN="0")

@@ -150,7 +150,8 @@ except H2Error as e:
 finally:
     parallel.rccl_finalize()
 """ % ROOT
-    env = dict(os.environ, H2_TEST_FAIL_RANK="0")
+    from conftest import ab_env
+    env = ab_env(H2_TEST_FAIL_RANK="0")           # the hook is compiled out of the shipped library (csrc/common.h ab_env): the child loads the laboratory build
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "H2ERROR" in out.stdout and "injected local failure" in out.stdout and "RETURNED" not in out.stdout, out.stdout + out.stderr
 

@@ -1,6 +1,8 @@
 """Parity of the HIP path (through the C ABI) against the oracle on seeded inputs.  Bit-exact bar:
 identical canonical affine (x, y) for MSM results, identical field elements at every index for NTTs.
 Runs only on a real MI355X (`-m gpu`)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -556,6 +558,10 @@ def test_registered_wide_windows_c20(monkeypatch):
     codes, the two-pass sort with 4096 bins, HBM-counted giant windows for sparse columns, row / column-sum fold."""
     import ctypes as C
     from halo2_amd.arithmetic import _p
+    if not os.environ.get("H2_AB_CHILD"):       # the knob lives in the laboratory build only: the body runs in a child that loads it
+        from conftest import run_test_in_ab_child
+        run_test_in_ab_child(__file__, "test_registered_wide_windows_c20")
+        return
     monkeypatch.setenv("H2_MSM_C", "20")
     curve, n = h.VESTA, 1 << 15
     sf = fields.CURVE_FIELDS[curve][1]
@@ -747,7 +753,8 @@ def test_best_multiexp_host_slices_range_pipeline(curve, canonical, affine):
     ({"H2_MSM_HOST_CHUNKS": "2", "H2_MSM_HOST_THREAD": "1"}, ["msm", "20", "1"]),    # two ranges, captured sequences replayed from a helper thread
 ])
 def test_switched_forms_keep_parity(env, args):
-    """The A/B arms this round left behind switches (read once per process, so each runs in the native driver): every one of them is the same
+    """The A/B arms left behind switches (live only in the laboratory build, build/ab/libhalo2_mi355x_ab.so, which the native driver loads here;
+    read once per process): every one of them is the same
     mathematics and must stay bit-exact against the C oracle -- the 11- and 12-stage NTT passes that the default plan does not use, the
     generic multiexp without its slice split or with another cut, the host-slice multiexp in one piece, in ragged ranges with plain
     launches, and with the runtime calls made by a helper thread."""
@@ -756,5 +763,6 @@ def test_switched_forms_keep_parity(env, args):
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "h2bench")
     if not os.path.exists(exe):
         pytest.skip(f"{exe} not built (run __graft_entry__.build())")
-    out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    from conftest import ab_env
+    out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=ab_env(**env))
     assert out.returncode == 0 and "H2BENCH OK" in out.stdout and "FAIL" not in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
