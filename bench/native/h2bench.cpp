@@ -374,8 +374,10 @@ static void mode_msm_n(size_t n, int curve, bool timing) {
         const int R = 12;
         double t0 = now_ms();
         for (int i = 0; i < R; ++i) CHECK_RC(p_h2_msm_device(curve, d_s, d_b, n, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_o, nullptr));
+        const double enq_ms = (now_ms() - t0) / R;
         HIPCK(hipDeviceSynchronize());
         const double dev_ms = (now_ms() - t0) / R;
+        printf("    host time to enqueue one call: %.4f ms\n", enq_ms);
         if (getenv("H2BENCH_CLOCK")) {      // shader clock / socket power with calls back to back for ~0.4 s, then as independent calls on 3 streams
             ClockWatch cw;
             cw.start();

@@ -65,8 +65,8 @@ __device__ __forceinline__ u32 load_u32_waited(const u32 *p) {
 #ifndef H2_ACC_GATHER_MASK
 #define H2_ACC_GATHER_MASK 0x7FFFFFFFu
 #endif
-template <int FB, bool GLV, bool M9>
-__global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
+template <int FB, bool GLV, bool M9, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, (M9 ? H2_ACC9_WAVES * 256 / BLOCK : 4)) msm_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
                                                       u32 extra_index, const u32 *__restrict__ entries,
                                                       const u32 *__restrict__ starts, u32 *__restrict__ heads,
                                                       u32 *__restrict__ buckets, u32 total_buckets, u32 T, u32 div, ColStride cs) {
@@ -257,6 +257,14 @@ template __global__ void msm_accumulate<FQ, true, false>(const u32 *__restrict__
                                                       const u32 *__restrict__ starts, u32 *__restrict__ heads,
                                                       u32 *__restrict__ buckets, u32 total_buckets, u32 T, u32 div, ColStride cs);
 template __global__ void msm_accumulate<FQ, false, true>(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
+                                                      u32 extra_index, const u32 *__restrict__ entries,
+                                                      const u32 *__restrict__ starts, u32 *__restrict__ heads,
+                                                      u32 *__restrict__ buckets, u32 total_buckets, u32 T, u32 div, ColStride cs);
+template __global__ void msm_accumulate<FP, false, true, 512>(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
+                                                      u32 extra_index, const u32 *__restrict__ entries,
+                                                      const u32 *__restrict__ starts, u32 *__restrict__ heads,
+                                                      u32 *__restrict__ buckets, u32 total_buckets, u32 T, u32 div, ColStride cs);
+template __global__ void msm_accumulate<FQ, false, true, 512>(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
                                                       u32 extra_index, const u32 *__restrict__ entries,
                                                       const u32 *__restrict__ starts, u32 *__restrict__ heads,
                                                       u32 *__restrict__ buckets, u32 total_buckets, u32 T, u32 div, ColStride cs);

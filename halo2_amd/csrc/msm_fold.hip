@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) msm_bucket_add(u32 *__restrict__ total, c
 template <int FB>
 __global__ void __launch_bounds__(256) fold9_finish(const u32 *__restrict__ heads9, const u32 *__restrict__ starts, u32 *__restrict__ buckets9,
                                                     u32 *__restrict__ heavy, u32 total_buckets, u32 T, u32 div, ColStride cs) {
-    H2_LATENCY_STAGE();
+    if (!cs.lowprio) H2_LATENCY_STAGE();        // (a fold with slack -- a group of a generic multiexp folded beside the next group's accumulate -- keeps priority 0)
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= total_buckets) return;
     if (gridDim.z > 1) {
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) fold9_finish(const u32 *__restrict__ head
 template <int FB>
 __global__ void __launch_bounds__(256, 3) fold9_finish_heavy(const u32 *__restrict__ heads9, const u32 *__restrict__ starts, u32 *__restrict__ scratch9,
                                                           const u32 *__restrict__ heavy, u32 total_buckets, u32 T, u32 div, ColStride cs) {
-    H2_LATENCY_STAGE();
+    if (!cs.lowprio) H2_LATENCY_STAGE();        // (a fold with slack -- a group of a generic multiexp folded beside the next group's accumulate -- keeps priority 0)
     __shared__ __attribute__((aligned(16))) u32 sh[32 * 36];
     if (gridDim.z > 1) {
         heavy = H2_COLZ(heavy, cs.heavy);
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256, 3) fold9_finish_heavy(const u32 *__restri
 template <int FB>
 __global__ void __launch_bounds__(64, 3) fold9_finish_heavy2(const u32 *__restrict__ scratch9, u32 *__restrict__ buckets9, const u32 *__restrict__ heavy,
                                                              ColStride cs) {
-    H2_LATENCY_STAGE();
+    if (!cs.lowprio) H2_LATENCY_STAGE();        // (a fold with slack -- a group of a generic multiexp folded beside the next group's accumulate -- keeps priority 0)
     __shared__ __attribute__((aligned(16))) u32 sh[8 * 36];
     if (gridDim.z > 1) {
         heavy = H2_COLZ(heavy, cs.heavy);
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(64, 3) fold9_finish_heavy2(const u32 *__restri
 // lines9[lo] = C_lo (lo < S), lines9[S + hi] = R_hi (1 <= hi < NR; row 0 carries weight 0 and is never formed), raw M9.
 template <int FB>
 __global__ void __launch_bounds__(256, 3) fold9_rowcol(const u32 *__restrict__ buckets9, u32 *__restrict__ lines9, u32 S, u32 NR, ColStride cs) {
-    H2_LATENCY_STAGE();
+    if (!cs.lowprio) H2_LATENCY_STAGE();        // (a fold with slack -- a group of a generic multiexp folded beside the next group's accumulate -- keeps priority 0)
     __shared__ __attribute__((aligned(16))) u32 sh[32 * 36];
     if (gridDim.z > 1) {
         buckets9 = H2_COLZ(buckets9, cs.buckets);
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256, 3) fold9_rowcol(const u32 *__restrict__ b
 template <int FB>
 __global__ void __launch_bounds__(256, 3) fold9_planes(const u32 *__restrict__ lines9, u32 *__restrict__ planes9, u32 *__restrict__ counter, u32 S, u32 NR,
                                                     int cb, u32 *__restrict__ out, int out_kind, int out_mont, ColOut co, ColStride cs) {
-    H2_LATENCY_STAGE();
+    if (!cs.lowprio) H2_LATENCY_STAGE();        // (a fold with slack -- a group of a generic multiexp folded beside the next group's accumulate -- keeps priority 0)
     __shared__ __attribute__((aligned(16))) u32 sh[32 * 36];
     __shared__ u32 s_last;
     if (gridDim.z > 1) {
@@ -402,10 +402,12 @@ __global__ void __launch_bounds__(256) msm_rowcol_sums(const u32 *__restrict__ b
 // ---- combine: Horner over slices (windows), emit Jacobian / affine; one quad of lanes ---------------
 // extra_dbl / addend / out_kind == kOutSliceSum serve the slice split of a large generic multiexp (msm_launch): the UPPER group of
 // slices is summed by Horner, doubled extra_dbl = c x (slices below it) more times and left as XYZZ (32 words); the lower group's
-// call then adds that point (`addend`) to its own Horner sum and emits the result.
+// call then adds that point (`addend`) to its own Horner sum and emits the result.  addend_first (the grouped form, msm_generic.hip): the
+// addend -- the chain of the groups above, already doubled down to the weight of this group's LOWEST slice -- is added BEFORE the extra
+// doublings that carry the sum on to the next group: A_g = R_g + D_(g-1), D_g = 2^(extra) A_g.
 template <int FB>
 __global__ void __launch_bounds__(64) msm_combine(const u32 *__restrict__ slice_sums, int slices, int c, u32 *__restrict__ out,
-                                                  int out_kind, int out_mont, int extra_dbl, const u32 *__restrict__ addend) {
+                                                  int out_kind, int out_mont, int extra_dbl, const u32 *__restrict__ addend, int addend_first) {
     H2_LATENCY_STAGE();
     if (threadIdx.x >= kGroup) return;
     // one block: Horner over the slices.  Several blocks (pair commits): block b emits slice b alone as output b.
@@ -423,8 +425,9 @@ __global__ void __launch_bounds__(64) msm_combine(const u32 *__restrict__ slice_
         const xyzz9<FB> s9 = xyzz9_from_r256_wide<FB>(xyzz_load<FB>(slice_sums + 32 * (size_t)w));
         xyzz9_add_wide<FB>(r9, s9);
     }
+    if (addend && addend_first) xyzz9_add_wide<FB>(r9, xyzz9_from_r256_wide<FB>(xyzz_load<FB>(addend)));
     for (int k = 0; k < extra_dbl; ++k) r9 = xyzz9_dbl_wide<FB>(r9);
-    if (addend) xyzz9_add_wide<FB>(r9, xyzz9_from_r256_wide<FB>(xyzz_load<FB>(addend)));
+    if (addend && !addend_first) xyzz9_add_wide<FB>(r9, xyzz9_from_r256_wide<FB>(xyzz_load<FB>(addend)));
     const xyzz<FB> r = xyzz9_to_r256_wide<FB>(r9);
     if (threadIdx.x != 0) return;
     if (out_kind == kOutSliceSum) {
@@ -531,9 +534,9 @@ template __global__ void msm_sum_slice<FQ>(const u32 *__restrict__ partial, u32 
 template __global__ void msm_rowcol_sums<FP>(const u32 *__restrict__ buckets, u32 *__restrict__ wide, u32 S, u32 NR);
 template __global__ void msm_rowcol_sums<FQ>(const u32 *__restrict__ buckets, u32 *__restrict__ wide, u32 S, u32 NR);
 template __global__ void msm_combine<FP>(const u32 *__restrict__ slice_sums, int slices, int c, u32 *__restrict__ out,
-                                                  int out_kind, int out_mont, int extra_dbl, const u32 *__restrict__ addend);
+                                                  int out_kind, int out_mont, int extra_dbl, const u32 *__restrict__ addend, int addend_first);
 template __global__ void msm_combine<FQ>(const u32 *__restrict__ slice_sums, int slices, int c, u32 *__restrict__ out,
-                                                  int out_kind, int out_mont, int extra_dbl, const u32 *__restrict__ addend);
+                                                  int out_kind, int out_mont, int extra_dbl, const u32 *__restrict__ addend, int addend_first);
 template __global__ void msm_combine_ranges<FP>(RangeSums rs, int ranges, int slices, int c, u32 *__restrict__ out, int out_kind, int out_mont);
 template __global__ void msm_combine_ranges<FQ>(RangeSums rs, int ranges, int slices, int c, u32 *__restrict__ out, int out_kind, int out_mont);
 

@@ -97,6 +97,18 @@ struct Sort2 {
     u32 pair_n;       //       i >= pair_n feeds output (i - pair_n) & 1; sort key = side * nb + bucket (two bucket slices)
 };
 
+// one GROUP of window slices of a large generic multiexp, sorted on its own (msm_generic.hip; kernels msm_d1_* in msm_sort.hip)
+struct GroupSort {
+    u32 cols;         // digit columns = 2 x scalars (column i: k1 / P_i, column m + i: k2 / phi(P_i))
+    u32 row;          // digit row stride: cols rounded up to 8
+    u32 w0, ns;       // the group's window slices [w0, w0 + ns)
+    u32 nb;           // buckets per slice; sort key = (w - w0) nb + bucket
+    int lowb, lb;     // the low `lowb` key bits ride in the tagged entry at bit `lb` (above the column index)
+    u32 nh;           // pass-1 bins = ceil(ns nb >> lowb)
+    u32 S;            // digit columns per pass-1 workgroup (a multiple of 8)
+    u32 run_lanes;    // lanes that copy one bin's run out of the pass-1 stage
+};
+
 // ---- column-batched launches ------------------------------------------------------------------------------------------------------
 // The column commits of a prover phase are independent multiexps over ONE registered table (plonk/prover.rs:93-101, 301-313;
 // vanishing/prover.rs:96-108).  A batched commit (h2_commit_batch_device) runs every stage ONCE for K columns: blockIdx.z is the
@@ -114,6 +126,7 @@ struct ColOut {                     // fold9_planes
 struct ColStride {                  // 32-bit words between the areas of consecutive columns (all zero for a single column)
     u32 hist, plan, items, starts, heavy, hscratch, heads, buckets, lines, planes, ctr;
     u32 entries;      // sorted entries: `items` apart, or 0 when the columns are JOINED (below)
+    u32 lowprio;      // != 0: the fold kernels keep wave priority 0 (they have slack and must not stretch an accumulate that shares their SIMDs)
     u32 joined;       // != 0: the pass-1 bin count nh.  The columns' sorted entries then form ONE list (column z's behind those of the
                       // columns before it) with ONE boundary array over K x total_buckets buckets (bucket b of column z at
                       // z * total_buckets + b), which msm_accumulate and fold9_finish walk as if it were a single commit
@@ -222,7 +235,6 @@ template <int FB> __device__ __forceinline__ xyzz9<FB> fold9_quads_sum(xyzz9<FB>
     }
     return acc;
 }
-// heavy buckets (more than kHeavy heads): kHeavyBlocks workgroups share the heads, fold9_finish_heavy2 adds their sums to the bucket
 // The Horner step over the window slices of SEVERAL ranges of one multiexp (h2_msm's range pipeline): slice sums are linear in the
 // points, so sum_q Horner(S_q) = Horner(sum_q S_q) -- quad w adds slice w's sums over the ranges (side by side), then quad 0 runs ONE
 // chain of (slices - 1) c doublings instead of one chain per range.
@@ -249,8 +261,28 @@ struct MsmContext {
             *e = nullptr;
         }
         side = nullptr;
+        for (hipStream_t &s : gstream) {
+            if (s) (void)hipStreamDestroy(s);
+            s = nullptr;
+        }
+        for (hipEvent_t &e : gev) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
+        gpending = false;
+        if (gdone) (void)hipEventDestroy(gdone);
+        gdone = nullptr;
     }
-    bool attr_set = false, attr2_set = false, attr_bins_set = false;
+    bool attr_set = false, attr2_set = false, attr_bins_set = false, attr_grouped_set = false;
+    // the grouped form of a large generic multiexp (msm_generic.hip): gstream[0] sorts the groups after the first, gstream[1 + g] folds
+    // group g and carries its link of the Horner chain; gev: fork, conversion done, then per group sorted / accumulated / chained
+    static constexpr int kMaxGroups = 4;
+    hipStream_t gstream[1 + kMaxGroups] = {};
+    hipEvent_t gev[2 + 3 * kMaxGroups] = {};
+    // recorded behind every grouped multiexp of this context; other contexts ask it whether a generic multiexp is in flight on ANOTHER stream
+    // (msm_other_generic_in_flight): independent calls side by side take the throughput form, a lone call the latency form
+    hipEvent_t gdone = nullptr;
+    std::atomic<bool> gpending{false};
     hipStream_t copy_stream = nullptr;      // h2_msm: the bases cross PCIe on this one while the sort runs (null-stream context only)
     hipEvent_t copy_done = nullptr;
     // the slice split of a large generic multiexp (msm_launch): the upper slices' fold and Horner chain run on `side` beside the lower
@@ -303,6 +335,12 @@ struct MsmArgs {
 static constexpr int H2_ERR_BATCH_SHAPE = -1000;     // internal: never leaves the library
 
 
+// msm_generic.hip: the grouped form of a large generic multiexp (unregistered bases, endomorphism split, window slices sorted and
+// accumulated in groups); H2_ERR_BATCH_SHAPE, before anything is enqueued, when the shape does not take it (msm_launch then runs its own form)
+template <int FB, int FS> int msm_generic_grouped(MsmContext &cx, const MsmArgs &a, const MsmShape &sh, size_t scalars_n, u32 lanes, hipStream_t st);
+extern template int msm_generic_grouped<FP, FQ>(MsmContext &cx, const MsmArgs &a, const MsmShape &sh, size_t scalars_n, u32 lanes, hipStream_t st);
+extern template int msm_generic_grouped<FQ, FP>(MsmContext &cx, const MsmArgs &a, const MsmShape &sh, size_t scalars_n, u32 lanes, hipStream_t st);
+bool msm_other_generic_in_flight(const MsmContext *self);                            // msm_launch.hip: a grouped multiexp of another stream of this device has not completed
 int msm_dispatch(MsmContext &cx, int curve, const MsmArgs &a, hipStream_t st);      // msm_launch.hip: the whole multiexp (or one phase of it) on `st`
 void to_mont_async(int curve, u32 *d, size_t field_elems, hipStream_t st);           // canonical -> Montgomery in place
 bool timeline_on();                                                                  // H2_TIMELINE=1 (diagnostic; never changes a result)
@@ -442,14 +480,25 @@ __global__ void __launch_bounds__(1024) msm_s2_big_scatter(const u32 *__restrict
                                                            ColStride cs);
 __global__ void __launch_bounds__(256) msm_s2_prefix(u32 *__restrict__ hist2, const u32 *__restrict__ bin_start, const u32 *__restrict__ hlo,
                                                      const u32 *__restrict__ woff, Sort2 P, u32 *__restrict__ counts, u32 NB);
+template <int FS>
+__global__ void __launch_bounds__(256) msm_glv_digits(const u32 *__restrict__ scalars, uint16_t *__restrict__ digits, u32 m, u32 row, int c, int W, int mont);
+extern template __global__ void msm_glv_digits<FP>(const u32 *__restrict__ scalars, uint16_t *__restrict__ digits, u32 m, u32 row, int c, int W, int mont);
+extern template __global__ void msm_glv_digits<FQ>(const u32 *__restrict__ scalars, uint16_t *__restrict__ digits, u32 m, u32 row, int c, int W, int mont);
+__global__ void __launch_bounds__(512) msm_d1_count(const uint16_t *__restrict__ digits, GroupSort P, u32 *__restrict__ hist1);
+__global__ void __launch_bounds__(512) msm_d1_scatter(const uint16_t *__restrict__ digits, GroupSort P, const u32 *__restrict__ hist1,
+                                                      const u32 *__restrict__ bin_count, u32 *__restrict__ bin_start, u32 *__restrict__ tagged);
 
 // ---- kernels defined in msm_accumulate.hip -------------------------------------------------------------------------------------
 template <int FB>
 __global__ void __launch_bounds__(256) msm_bases_to_m9_glv(const u32 *__restrict__ bases, u32 *__restrict__ out, u32 n);
 extern template __global__ void msm_bases_to_m9_glv<FP>(const u32 *__restrict__ bases, u32 *__restrict__ out, u32 n);
 extern template __global__ void msm_bases_to_m9_glv<FQ>(const u32 *__restrict__ bases, u32 *__restrict__ out, u32 n);
-template <int FB, bool GLV, bool M9 = false>
-__global__ void __launch_bounds__(256, (M9 ? H2_ACC9_WAVES : 4)) msm_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
+// BLOCK: lanes per workgroup.  256 everywhere (two workgroups per CU) except the grouped generic multiexp (msm_generic.hip), whose accumulates
+// are launched while the previous group's fold kernels hold wave slots on some CUs: with 256-lane workgroups the dispatcher then puts THREE
+// accumulate workgroups on the free CUs (168 registers allow three waves per SIMD), those run at two thirds of the speed for the whole launch
+// and the launch ends when they do (331 -> 477 us measured: profiles/r06_generic_grouped.txt).  One 512-lane workgroup per CU cannot double up.
+template <int FB, bool GLV, bool M9 = false, int BLOCK = 256>
+__global__ void __launch_bounds__(BLOCK, (M9 ? H2_ACC9_WAVES * 256 / BLOCK : 4)) msm_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
                                                       u32 extra_index, const u32 *__restrict__ entries,
                                                       const u32 *__restrict__ starts, u32 *__restrict__ heads,
                                                       u32 *__restrict__ buckets, u32 total_buckets, u32 T, u32 div, ColStride cs);
@@ -474,6 +523,14 @@ extern template __global__ void msm_accumulate<FQ, true, false>(const u32 *__res
                                                       const u32 *__restrict__ starts, u32 *__restrict__ heads,
                                                       u32 *__restrict__ buckets, u32 total_buckets, u32 T, u32 div, ColStride cs);
 extern template __global__ void msm_accumulate<FQ, false, true>(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
+                                                      u32 extra_index, const u32 *__restrict__ entries,
+                                                      const u32 *__restrict__ starts, u32 *__restrict__ heads,
+                                                      u32 *__restrict__ buckets, u32 total_buckets, u32 T, u32 div, ColStride cs);
+extern template __global__ void msm_accumulate<FP, false, true, 512>(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
+                                                      u32 extra_index, const u32 *__restrict__ entries,
+                                                      const u32 *__restrict__ starts, u32 *__restrict__ heads,
+                                                      u32 *__restrict__ buckets, u32 total_buckets, u32 T, u32 div, ColStride cs);
+extern template __global__ void msm_accumulate<FQ, false, true, 512>(const u32 *__restrict__ bases, const u32 *__restrict__ extra_base,
                                                       u32 extra_index, const u32 *__restrict__ entries,
                                                       const u32 *__restrict__ starts, u32 *__restrict__ heads,
                                                       u32 *__restrict__ buckets, u32 total_buckets, u32 T, u32 div, ColStride cs);
@@ -569,11 +626,11 @@ extern template __global__ void msm_rowcol_sums<FP>(const u32 *__restrict__ buck
 extern template __global__ void msm_rowcol_sums<FQ>(const u32 *__restrict__ buckets, u32 *__restrict__ wide, u32 S, u32 NR);
 template <int FB>
 __global__ void __launch_bounds__(64) msm_combine(const u32 *__restrict__ slice_sums, int slices, int c, u32 *__restrict__ out,
-                                                  int out_kind, int out_mont, int extra_dbl = 0, const u32 *__restrict__ addend = nullptr);
+                                                  int out_kind, int out_mont, int extra_dbl = 0, const u32 *__restrict__ addend = nullptr, int addend_first = 0);
 extern template __global__ void msm_combine<FP>(const u32 *__restrict__ slice_sums, int slices, int c, u32 *__restrict__ out,
-                                                  int out_kind, int out_mont, int extra_dbl, const u32 *__restrict__ addend);
+                                                  int out_kind, int out_mont, int extra_dbl, const u32 *__restrict__ addend, int addend_first);
 extern template __global__ void msm_combine<FQ>(const u32 *__restrict__ slice_sums, int slices, int c, u32 *__restrict__ out,
-                                                  int out_kind, int out_mont, int extra_dbl, const u32 *__restrict__ addend);
+                                                  int out_kind, int out_mont, int extra_dbl, const u32 *__restrict__ addend, int addend_first);
 template <int FB>
 __global__ void __launch_bounds__(64) msm_combine_ranges(RangeSums rs, int ranges, int slices, int c, u32 *__restrict__ out, int out_kind, int out_mont);
 extern template __global__ void msm_combine_ranges<FP>(RangeSums rs, int ranges, int slices, int c, u32 *__restrict__ out, int out_kind, int out_mont);

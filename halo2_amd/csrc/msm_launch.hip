@@ -242,6 +242,20 @@ MsmContext &msm_ctx(hipStream_t st) {
     if (!slot) slot.reset(new MsmContext());
     return *slot;
 }
+// Is a grouped generic multiexp (msm_generic.hip) of ANOTHER stream of this device still in flight?  hipEventQuery on the event each context
+// records behind its last one: a few microseconds, no synchronisation.
+bool msm_other_generic_in_flight(const MsmContext *self) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    for (auto &kv : g_ctxs) {
+        MsmContext *c = kv.second.get();
+        if (kv.first.first != dev || c == self || !c->gpending.load()) continue;
+        if (c->gdone && hipEventQuery(c->gdone) == hipErrorNotReady) return true;
+        c->gpending = false;
+    }
+    return false;
+}
 // h2_trim: the per-(device, stream) scratch of this device goes back to the allocator (the device is idle by then)
 void msm_release_workspaces() {
     msm_release_host_pipe();
@@ -427,6 +441,13 @@ template <int FB, int FS> static int msm_launch(MsmContext &cx, const MsmArgs &a
     // fold.  What is left behind the accumulate: the lower group's fold, (split_k - 1) c doublings and one addition.  The bases'
     // conversion to M9 form runs on the side stream beside the sort.  H2_GENERIC_SPLIT=0: off (A/B); = k: force the lower group's size.
     static const int split_env = [] { const char *e = ab_env("H2_GENERIC_SPLIT"); return e ? atoi(e) : -1; }();
+    // The grouped form (round 6, msm_generic.hip; generic multiexps beyond 2^18 points): the endomorphism split once, the window slices
+    // sorted / accumulated / folded in groups, upper slices first.  It answers H2_ERR_BATCH_SHAPE before enqueueing anything when the shape
+    // is not its own; round 5's slice split below then still applies (and is the A/B arm, H2_GENERIC_GROUPED=0 in the laboratory build).
+    if (glv && fold9 && m9 && a.phase == 0 && !a.slice_sums_only && K == 1 && !prof_enabled() && !timeline_on()) {
+        rc = msm_generic_grouped<FB, FS>(cx, a, sh, scalars_n, lanes, st);
+        if (rc != H2_ERR_BATCH_SHAPE) return rc;
+    }
     int split_k = 0;
     if (glv && fold9 && m9 && a.phase == 0 && !a.slice_sums_only && K == 1 && sh.slices >= 6 && split_env != 0 && !prof_enabled() && !timeline_on()) {
         if (split_env > 0) split_k = std::min<int>(split_env, (int)sh.slices - 2);

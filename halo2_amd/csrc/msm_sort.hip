@@ -852,6 +852,130 @@ __global__ void __launch_bounds__(256) msm_s2_prefix(u32 *__restrict__ hist2, co
 }
 
 
+// ---- the GROUPED sort of a large generic multiexp (msm_generic.hip) -----------------------------------------------------------------
+// best_multiexp without a registered table (arithmetic.rs:143-180): every scalar is split by the endomorphism into two half-length
+// digit columns.  The sort of round 5 ran over all window slices at once and did that split in BOTH of its passes (count and scatter),
+// in 72-register kernels that do not fit beside the accumulate of another call; at 2^21 / 2^22 points its bins outgrew LDS and pass 2
+// fell back to the chunked seven-launch form (sort 0.59 / 1.37 ms of a 2.8 / 5.6 ms call).  Now the split happens ONCE
+// (msm_glv_digits: a row of 16-bit digit codes per window), and the window slices are sorted in GROUPS, upper slices first: a group's
+// pass 1 reads only its rows (2 bytes per entry, coalesced), its bins fit LDS at every size, and the groups after the first are sorted
+// on a side stream while the first is being accumulated -- the sort in front of the first addition is a third of what it was.
+//
+// digits[w * row + col]: col = i for k1 / P_i, m + i for k2 / phi(P_i); row = 2 m rounded up to 8 (pass 1 reads eight codes a load).
+template <int FS>
+__global__ void __launch_bounds__(256) msm_glv_digits(const u32 *__restrict__ scalars, uint16_t *__restrict__ digits, u32 m, u32 row, int c, int W,
+                                                      int mont) {
+    H2_LATENCY_STAGE();
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    fe s = fe_load(scalars + 8 * (size_t)i);
+    if (mont) s = fe_redc<FS>(s);
+    u32 mag[2][5], neg[2];
+    glv_split<FS>(s, mag[0], neg[0], mag[1], neg[1]);
+    const u32 mask = (1u << c) - 1, half = 1u << (c - 1);
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        u32 carry = 0;
+        for (int w = 0; w < W; ++w) {
+            const int bit = w * c, word = bit >> 5, sh = bit & 31;
+            u32 lo = 0, hi = 0;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                lo = (word == q) ? mag[part][q] : lo;
+                hi = (word + 1 == q) ? mag[part][q] : hi;
+            }
+            const u32 raw = ((u32)(((u64)lo | ((u64)hi << 32)) >> sh) & mask) + carry;
+            const bool up = neg[part] ? raw >= half : raw > half;      // same digit set as msm_recode_glv / emit_entries
+            carry = up;
+            const u32 digit_mag = up ? (1u << c) - raw : raw;
+            const u32 negative = (up ? 1u : 0u) ^ neg[part];
+            digits[(size_t)w * row + (size_t)part * m + i] = (uint16_t)(digit_mag ? ((digit_mag - 1) | (negative ? 0x8000u : 0u)) : kZeroCode);
+        }
+    }
+}
+
+// pass 1 of a group, COUNT: workgroup `blk` owns digit columns [blk S, (blk + 1) S) of the group's ns rows; hist1[blk][h] = its entries per bin
+// (key = (w - w0) nb + bucket over the group's buckets, bin = key >> lowb)
+__global__ void __launch_bounds__(512) msm_d1_count(const uint16_t *__restrict__ digits, GroupSort P, u32 *__restrict__ hist1) {
+    H2_LATENCY_STAGE();
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [nh] counters
+    const u32 nh = P.nh, blk = blockIdx.x;
+    for (u32 h = threadIdx.x; h < nh; h += blockDim.x) sh[h] = 0;
+    __syncthreads();
+    const u32 c0 = blk * P.S, c1 = min(P.cols, c0 + P.S), vecs = (c1 - c0 + 7) / 8;
+    for (u32 v = threadIdx.x; v < vecs * P.ns; v += blockDim.x) {
+        const u32 s = v / vecs, col = c0 + 8 * (v - s * vecs);
+        const uint4 d = *reinterpret_cast<const uint4 *>(digits + (size_t)(P.w0 + s) * P.row + col);
+        const u32 wd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const u32 code = (wd[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+            if (col + j < c1 && code != kZeroCode) atomicAdd(&sh[(s * P.nb + (code & 0x7FFFu)) >> P.lowb], 1u);
+        }
+    }
+    __syncthreads();
+    for (u32 h = threadIdx.x; h < nh; h += blockDim.x) hist1[(size_t)blk * nh + h] = sh[h];
+}
+
+// pass 1 of a group, SCATTER: as msm_s1_scatter -- the workgroup's entries are grouped by bin in LDS, every bin's run leaves as one
+// contiguous copy -- with the entries read from the digit rows.  tagged word = column | low bucket bits << lb | sign << 31.
+__global__ void __launch_bounds__(512) msm_d1_scatter(const uint16_t *__restrict__ digits, GroupSort P, const u32 *__restrict__ hist1,
+                                                      const u32 *__restrict__ bin_count, u32 *__restrict__ bin_start, u32 *__restrict__ tagged) {
+    H2_LATENCY_STAGE();
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    const u32 nh = P.nh, blk = blockIdx.x, B1 = gridDim.x;
+    u32 *gstart = sh;                 // [nh] bin_start, then bin_start + this workgroup's offset inside the bin
+    u32 *lstart = sh + nh;            // [nh + 1] where the bin's run begins in the stage
+    u32 *cursor = lstart + nh + 1;    // [nh]
+    u32 *stage = cursor + nh;         // [S * ns] entries
+    for (u32 h = threadIdx.x; h < nh; h += blockDim.x) {
+        const u32 mine = hist1[(size_t)blk * nh + h];
+        const u32 next = blk + 1 < B1 ? hist1[(size_t)(blk + 1) * nh + h] : bin_count[h];
+        gstart[h] = bin_count[h];
+        lstart[h] = next - mine;      // this workgroup's entries in bin h
+        cursor[h] = mine;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const u32 M = wave0_excl_scan(gstart, nh);
+        const u32 L = wave0_excl_scan(lstart, nh);
+        if (threadIdx.x == 0) {
+            lstart[nh] = L;
+            if (blk == 0) bin_start[nh] = M;
+        }
+    }
+    __syncthreads();
+    for (u32 h = threadIdx.x; h < nh; h += blockDim.x) {
+        if (blk == 0) bin_start[h] = gstart[h];
+        gstart[h] += cursor[h];
+        cursor[h] = lstart[h];
+    }
+    __syncthreads();
+    const u32 lowmask = (1u << P.lowb) - 1;
+    const u32 c0 = blk * P.S, c1 = min(P.cols, c0 + P.S), vecs = (c1 - c0 + 7) / 8;
+    for (u32 v = threadIdx.x; v < vecs * P.ns; v += blockDim.x) {
+        const u32 s = v / vecs, col = c0 + 8 * (v - s * vecs);
+        const uint4 d = *reinterpret_cast<const uint4 *>(digits + (size_t)(P.w0 + s) * P.row + col);
+        const u32 wd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const u32 code = (wd[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+            if (col + j < c1 && code != kZeroCode) {
+                const u32 key = s * P.nb + (code & 0x7FFFu);
+                const u32 pos = atomicAdd(&cursor[key >> P.lowb], 1u);
+                stage[pos] = (col + j) | ((key & lowmask) << P.lb) | ((code & 0x8000u) << 16);
+            }
+        }
+    }
+    __syncthreads();
+    const u32 kRunLanes = P.run_lanes, grp = threadIdx.x / kRunLanes, lane = threadIdx.x & (kRunLanes - 1), ngrp = blockDim.x / kRunLanes;
+    for (u32 h = grp; h < nh; h += ngrp) {
+        const u32 l0 = lstart[h], l1 = lstart[h + 1];
+        u32 *dst = tagged + gstart[h];
+        for (u32 q = l0 + lane; q < l1; q += kRunLanes) dst[q - l0] = stage[q];
+    }
+}
+
 // ---- explicit instantiations (both curves): the host side lives in msm_launch.hip / msm_generic.hip ----
 template __global__ void msm_recode<FP>(const u32 *__restrict__ scalars, const u32 *__restrict__ extra_scalar,
                                                   uint16_t *__restrict__ digits, u32 m, int c, int W, int mont);
@@ -885,5 +1009,8 @@ template __global__ void msm_s1_scatter<FQ, true>(const u32 *__restrict__ scalar
                                                        const u32 *__restrict__ hist1, const u32 *__restrict__ bin_count,
                                                        u32 *__restrict__ bin_start, u32 *__restrict__ tagged, uint16_t *__restrict__ tagged_low,
                                                        ColIn ci, ColStride cs);
+
+template __global__ void msm_glv_digits<FP>(const u32 *__restrict__ scalars, uint16_t *__restrict__ digits, u32 m, u32 row, int c, int W, int mont);
+template __global__ void msm_glv_digits<FQ>(const u32 *__restrict__ scalars, uint16_t *__restrict__ digits, u32 m, u32 row, int c, int W, int mont);
 
 }  // namespace h2
