@@ -835,6 +835,12 @@ static int open_impl(IpaContext &cx, int curve, unsigned k, h2_bases_t g_basis, 
         H2_HIP(hipMemcpyAsync(land, d_commit, 96, hipMemcpyDeviceToHost, sides[0]));
         H2_HIP(hipEventRecord(cx.open_ev, sides[0]));
     } else {
+        if (!host_p) {
+            // a resident p_poly may have been produced on the caller's stream: the side stream (b and v, below) waits for what is on `st` NOW --
+            // recorded before the evaluation and the commitment of s_poly are enqueued, so that it runs beside them, not behind them
+            H2_HIP(hipEventRecord(cx.open_ev2, st));
+            H2_HIP(hipStreamWaitEvent(cx.open_side, cx.open_ev2, 0));
+        }
         if (host_s) H2_HIP(hipMemcpyAsync(d_s, host_s, n * 32, hipMemcpyHostToDevice, st));
         if ((rc = h2_eval_polynomial_device(sf, d_s, n, x3, H2_FORM_MONTGOMERY, d_s_at, st)) != H2_OK) return rc;
         if (sf == H2_FP) hipLaunchKernelGGL((ipa_sub_at0<FP>), dim3(1), dim3(64), 0, st, (u32 *)d_s, (const u32 *)d_s_at);
@@ -852,9 +858,6 @@ static int open_impl(IpaContext &cx, int curve, unsigned k, h2_bases_t g_basis, 
         if ((rc = cx.open_p.reserve(n * 32)) != H2_OK) return rc;
         H2_HIP(hipMemcpyAsync(cx.open_p.ptr, host_p, n * 32, hipMemcpyHostToDevice, side));
         d_p = cx.open_p.ptr;
-    } else if (!by_ranges) {
-        H2_HIP(hipEventRecord(cx.open_ev2, st));          // a resident p_poly may have been produced on the caller's stream
-        H2_HIP(hipStreamWaitEvent(side, cx.open_ev2, 0));
     }
     if ((rc = h2_powers_device(sf, x3, n, H2_FORM_MONTGOMERY, d_b, side)) != H2_OK) return rc;
     if ((rc = h2_eval_polynomial_device(sf, d_p, n, x3, H2_FORM_MONTGOMERY, d_v, side)) != H2_OK) return rc;

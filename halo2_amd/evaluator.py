@@ -212,6 +212,10 @@ class Evaluator:
         if n != want:
             raise ValueError("evaluate: polynomial length does not match the domain")
         for slot, value in (late or {}).items():
+            if slot.index is None:
+                # the tree that was compiled never mentioned this slot (an empty expression list folds to the constant 0): nothing to fill.
+                # Writing through consts[None] would broadcast the value over the WHOLE constant table and turn that 0 into `value`.
+                continue
             compiled.consts[slot.index] = fields.scalar_limbs(int(value) % domain.m, domain.field, True)
         log_len = n.bit_length() - 1
         ptrs = (C.c_void_p * len(self.polys))(*[p.data_ptr() for p in self.polys])

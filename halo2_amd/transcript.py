@@ -121,12 +121,26 @@ class DeferredScalars:
             return
         import torch
         dev = [t.reshape(4) for t in self.queue if isinstance(t, torch.Tensor)]
-        landed = iter(torch.stack(dev).cpu().numpy().view(np.uint64)) if dev else iter(())
-        queue, self.queue = self.queue, []
-        for t in queue:
-            self.inner.write_scalar(next(landed) if isinstance(t, torch.Tensor) else t)
+        landed = iter(torch.stack(dev).cpu().numpy().view(np.uint64)) if dev else iter(())      # (a failed read-back leaves the queue as it was)
+        host = [next(landed) if isinstance(t, torch.Tensor) else t for t in self.queue]
+        self.queue = []
+        for i, v in enumerate(host):
+            try:
+                self.inner.write_scalar(v)
+            except BaseException:
+                # what was not written stays queued -- as host values, in order, in front of anything queued since: the transcript is never
+                # left silently truncated, and a retry (or the caller's error path) sees exactly the missing tail
+                self.queue = host[i:] + self.queue
+                raise
+
+    @property
+    def handle(self):                              # an explicit probe: a failure inside flush() must not look like "no native handle"
+        self.flush()
+        return getattr(self.inner, "handle", 0)
 
     def __getattr__(self, name):                   # whatever else the transcript offers, after what is queued
+        if name in ("inner", "queue"):             # (not yet constructed: never recurse through flush)
+            raise AttributeError(name)
         self.flush()
         return getattr(self.inner, name)
 

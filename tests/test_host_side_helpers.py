@@ -57,6 +57,32 @@ def test_deferred_scalars_keep_the_order_and_flush_before_anything_else():
     assert plain.log == [("scalar", (1, 2, 3, 4)), ("scalar", (9, 10, 11, 12))]
 
 
+def test_deferred_scalars_keep_the_unwritten_tail_when_a_write_fails():
+    """Advisor (round 5): a write that raises inside flush() must not drop the scalars behind it, and probing `handle` must surface the error
+    instead of reading as "no native handle"."""
+    torch = pytest.importorskip("torch")
+
+    class _Failing(_Recorder):
+        fail_at = 1
+
+        def write_scalar(self, s):
+            if len(self.log) == self.fail_at:
+                self.fail_at = -1
+                raise RuntimeError("transcript write failed")
+            super().write_scalar(s)
+
+    inner = _Failing()
+    d = DeferredScalars(inner)
+    for v in (1, 2, 3):
+        write_evaluation(d, torch.tensor([v, 0, 0, 0], dtype=torch.int64))
+    with pytest.raises(RuntimeError):
+        d.handle                                                   # the probe flushes: the failure is reported, not turned into a default
+    assert [e[1][0] for e in inner.log] == [1] and len(d.queue) == 2           # the failing scalar and the one behind it are still queued
+    write_evaluation(d, np.array([4, 0, 0, 0], dtype=np.uint64))
+    d.flush()                                                      # the retry writes the missing tail, in order
+    assert [e[1][0] for e in inner.log] == [1, 2, 3, 4] and d.queue == []
+
+
 def test_evaluation_from_the_quarters():
     """ipa_fix_s0: s(x) = sum_r x^(r n / 4) ev_r with ev_r the evaluation of quarter r as a polynomial in its own index, and x^(n / 4) by k - 2 squarings;
     after s[0] -= s(x) the polynomial has its root at x (prover.rs:49-51)."""
