@@ -63,6 +63,17 @@ def _hwmon_dir(dev_index):
     return cands[0] if len(cands) == 1 else None
 
 
+def _newest_pmc():
+    """The newest profiles/r*_pmc_traffic.json (rocprofv3 --pmc passes of bench/tools/r06_pmc.sh and its predecessors) and its name: the HBM
+    bytes per launch the roofline objects quote as `traffic` -- constants from that file, never measured in this run."""
+    import glob
+    try:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+        return json.load(open(path)), "profiles/" + os.path.basename(path)
+    except Exception:
+        return None, None
+
+
 class _ClockSampler:
     """Samples the shader clock and the socket power from sysfs every ~2 ms on a thread while a load runs."""
 
@@ -394,6 +405,45 @@ def main():
                                             "all_equal_affine": bool(all(co.jac_to_affine_ints(curve, g_.cpu().numpy().view(np.uint64)) == co.jac_to_affine_ints(curve, first)
                                                                          for g_ in d_gens))}      # (Jacobian triples differ with the order of a bucket's additions)
             del d_gens
+        # ---- roofline of the generic path (review item 1): additions per call, the rate they are done at over the WHOLE call (sort, folds and the
+        # Horner chain included), and that rate against the accumulate's issue bound at the clock sampled under the same load ----
+        pmc_all, pmc_gen_name = _newest_pmc()
+        pmc_gen = (pmc_all or {}).get(f"generic_2^{args.log_n}")
+        split_carry = 0.053 if curve == h.PALLAS else 0.228      # halves whose top window carries into the ninth slice (measured)
+        entries = int(2 * (n + 1) * (8 * (1 - 2.0 ** -16) + split_carry))
+        rg = {"kernel": "msm_accumulate<.., 512> over the window-slice groups of one call (csrc/msm_generic.hip)", "bound": "valu",
+              "entries_per_call_model": entries,
+              "entries_model": "2 (n + 1) half-scalars x (8 sixteen-bit windows, zero digits excepted, + the share of halves whose top window carries into the ninth slice)",
+              "issue_bound_definition": "1024 SIMDs x 64 lanes x sampled shader clock / ~7400 issue cycles per mixed addition and wave (roofline.valu.issue_bound_source)",
+              "G_add_per_s_over_the_call": round(entries / (g_ms * 1e-3) / 1e9, 2),
+              "G_add_per_s_independent_calls": round(entries / (generic["independent_calls"]["ms_per_call"] * 1e-3) / 1e9, 2) if "independent_calls" in generic else None,
+              "algorithmic_GBps_over_the_call": round(ALGO_BYTES_PER_PAIR * (n + 1) / (g_ms * 1e-3) / 1e9, 1),
+              "traffic": ((pmc_gen or {}).get("accumulate_latency_form") or {}).get("hbm_bytes_per_call"),
+              "traffic_independent_calls": ((pmc_gen or {}).get("accumulate_throughput_form") or {}).get("hbm_bytes_per_call"),
+              "traffic_source": f"{pmc_gen_name}: the accumulate launches of one call (FETCH_SIZE x calibration + WRITE_SIZE), not measured in this run"}
+        hw_g = _hwmon_dir(local_rank)
+        if hw_g:
+            def _one():
+                for _ in range(8):
+                    check(lib.h2_msm_device(curve, d_sc.data_ptr(), d_bases.data_ptr(), n + 1, h.FORM_MONTGOMERY, 0, d_gen.data_ptr(), sps[0]), "h2_msm_device")
+                return 8
+
+            def _three():
+                for i_ in range(4 * len(sps)):
+                    check(lib.h2_msm_device(curve, d_sc.data_ptr(), d_bases.data_ptr(), n + 1, h.FORM_MONTGOMERY, 0, d_gen.data_ptr(), sps[i_ % len(sps)]), "h2_msm_device")
+                return 4 * len(sps)
+            for key_, fn_, rate_ in (("one_call_at_a_time", _one, "G_add_per_s_over_the_call"), ("independent_calls", _three, "G_add_per_s_independent_calls")):
+                t_l, cnt_ = time.perf_counter(), 0
+                with _ClockSampler(hw_g) as smp_g:
+                    while time.perf_counter() - t_l < 0.3:
+                        cnt_ += fn_()
+                        torch.cuda.synchronize()
+                sm_g = smp_g.summary()
+                if sm_g and rg.get(rate_):
+                    bound_ = 1024 * 64 * float(sm_g["sclk_mhz_median"]) * 1e6 / 7400.0 / 1e9
+                    rg[key_] = {"sclk_mhz_median": sm_g["sclk_mhz_median"], "power_w_median": sm_g["power_w_median"], "issue_bound_G_add_per_s": round(bound_, 2),
+                                "frac_of_issue_bound": round(rg[rate_] / bound_, 3)}
+        generic["roofline_generic"] = rg
         del d_bases, d_sc
 
     # ---- skewed columns: 90 % zeros, and every scalar < 2^16 -- same kernels, same partition ----
@@ -773,12 +823,12 @@ def main():
         # collected separately, corrected as MI355X_MICROARCH.md prescribes); null when the workload differs
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+            pmc, pmc_name = _newest_pmc()                                                                    # newest round wins
             if args.log_n == 20:
                 t_ = pmc["msm_accumulate_2^20"]
                 traffic = int(t_.get("fetch_bytes_corrected", t_["fetch_bytes_reported_max"]) + t_["write_bytes_max"])
         except Exception:
-            pmc = None
+            pmc, pmc_name = None, None
         total_mults = float(n) * args.steps * world
         value = total_mults / elapsed / 1e6
         acc_ms, acc_cnt = prof["msm_accumulate"]
@@ -805,8 +855,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 2) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
                          "traffic": int(traffic * cols_per_launch) if traffic else traffic,
-                         "traffic_source": "profiles/r04_pmc_traffic.json: the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on this workload, corrected as "
-                                           "calibrated there -- a constant read from that file, NOT measured in this run (the kernel has not changed since)",
+                         "traffic_source": f"{pmc_name}: the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on this workload (bench/tools/r06_pmc.sh on the "
+                                           "benchmarked tree), corrected by the calibration measured in the same session -- a constant read from that file, NOT measured in this run",
                          "avg_kernel_ms": round(avg_ms, 4), "launches": int(acc_cnt),
                          "columns_per_launch": round(cols_per_launch, 3),
                          "avg_kernel_ms_definition": "union of the launch intervals on the device / launches (HIP events on the launching "
@@ -826,7 +876,7 @@ def main():
                                                         "the timed region is the issue bound at that clock (DESIGN.md section 4.3)"},
                          "note": "VALU integer-multiply bound, not HBM bound (DESIGN.md section 4.3): the HBM fraction is reported as the contract "
                                  "asks, the VALU figures are what track kernel quality; traffic = PMC bytes of the registered-bases path (FETCH_SIZE calibrated on 64-byte random gathers, "
-                                 "profiles/r04_pmc_traffic.json), which gathers 15 precomputed multiples per point from a 1 GiB table by design: a 64-byte point "
+                                 "the PMC file named in traffic_source), which gathers 15 precomputed multiples per point from a 1 GiB table by design: a 64-byte point "
                                  "is half a 128-byte line, and the line is what moves"},
             # the HBM-bound part of the path (north star: "bucket-scan kernel"): the two-pass bucket sort streams 244 B per scalar
             # (32 B read twice by pass 1; 15 entries x 4 B written by pass 1, read once and written once by the one-launch pass 2);
@@ -836,16 +886,16 @@ def main():
                 "algorithmic_bytes_per_scalar": 244,
                 "achieved": round(244.0 * n / (ms_ * 1e-3) / 1e9, 1) if ms_ else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(244.0 * n / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_ else None,
-                "traffic": tr_, "traffic_source": "profiles/r04_pmc_traffic.json, not measured in this run", "stage_ms_isolated": ms_})(
+                "traffic": tr_, "traffic_source": f"{pmc_name}, not measured in this run", "stage_ms_isolated": ms_})(
                 iso.get("msm_sort"), (pmc or {}).get("msm_bucket_sort_2^20", {}).get("total_hbm_bytes_corrected") if args.log_n == 20 else None),
             # the second hot kernel of the path (BASELINE configs[2]): the NTT passes, priced the same way -- 64 B per element per
             # transform over the transform's wall time, against HBM; traffic = PMC bytes of the two passes
-            # (FETCH_SIZE calibrated on the passes' own access patterns, profiles/r04_pmc_traffic.json)
+            # (FETCH_SIZE calibrated on the passes' own access patterns, in the PMC file's own session)
             "roofline_ntt": (lambda e_: None if not e_ else {
                 "bound": "hbm", "kernel": "ntt_pass9 (two passes of 10 stages at 2^20)", "achieved": e_["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(e_["algorithmic_GBps"] / HBM_PEAK_GBS, 5), "ms_per_transform": e_["ms"], "kernel_ms_per_transform": e_["kernel_ms"],
                 "traffic": (pmc or {}).get("ntt_2^20", {}).get("total_hbm_bytes_corrected"),
-                "traffic_source": "profiles/r04_pmc_traffic.json, not measured in this run",
+                "traffic_source": f"{pmc_name}, not measured in this run",
                 "note": "VALU-bound like the MSM: 10.5 M modular multiplications per 2^20 transform at ~200 G/s are 0.052 ms before any addition, carry pass "
                         "or LDS round trip; the passes issue ~4800 instructions per lane and pass (DESIGN.md section 5.5)"})(ntt.get("2^20")),
             "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items() if v[1]},
