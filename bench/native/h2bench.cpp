@@ -369,11 +369,13 @@ static void mode_msm_n(size_t n, int curve, bool timing) {
     snprintf(msg, sizeof msg, "h2_msm (host pointers) n = %zu (curve %d) == oracle best_multiexp", n, curve);
     expect(same_point(curve, got_h, want), msg);
     if (timing) {
-        for (int i = 0; i < 6; ++i) CHECK_RC(p_h2_msm_device(curve, d_s, d_b, n, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_o, nullptr));
+        hipStream_t one = nullptr;                 // H2BENCH_MSM_STREAM=1: the one-at-a-time calls on a created stream (as a caller's would be) instead of the null stream
+        if (getenv("H2BENCH_MSM_STREAM")) HIPCK(hipStreamCreateWithFlags(&one, hipStreamNonBlocking));
+        for (int i = 0; i < 6; ++i) CHECK_RC(p_h2_msm_device(curve, d_s, d_b, n, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_o, one));
         HIPCK(hipDeviceSynchronize());
         const int R = 12;
         double t0 = now_ms();
-        for (int i = 0; i < R; ++i) CHECK_RC(p_h2_msm_device(curve, d_s, d_b, n, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_o, nullptr));
+        for (int i = 0; i < R; ++i) CHECK_RC(p_h2_msm_device(curve, d_s, d_b, n, H2_FORM_MONTGOMERY, H2_OUT_JACOBIAN, d_o, one));
         const double enq_ms = (now_ms() - t0) / R;
         HIPCK(hipDeviceSynchronize());
         const double dev_ms = (now_ms() - t0) / R;
@@ -452,7 +454,7 @@ static void mode_msm_n(size_t n, int curve, bool timing) {
     (void)hipFree(d_o);
 }
 
-static void mode_msm(unsigned log_n, int curve) { mode_msm_n((size_t)1 << log_n, curve, true); }
+static void mode_msm(unsigned log_n, int curve) { mode_msm_n(((size_t)1 << log_n) + (getenv("H2BENCH_MSM_PLUS1") ? 1 : 0), curve, true); }
 
 // ---- host-pointer seam --------------------------------------------------------------------------------------------------------
 static void mode_host(unsigned log_n) {
@@ -605,6 +607,14 @@ int main(int argc, char **argv) {
     if (!load_library(argv[0])) return 2;
     if (p_h2_device_count() <= 0) { printf("no GPU: h2bench needs an MI355X\n"); return 2; }
     if (p_h2_init(0) != H2_OK) { printf("h2_init: %s\n", p_h2_last_error()); return 2; }
+    if (const char *e = getenv("H2BENCH_EXTRA_STREAMS")) {      // a process with many streams open (as a prover has): HIP multiplexes them onto few hardware queues
+        for (int i = 0; i < atoi(e); ++i) {
+            hipStream_t s;
+            void *d = nullptr;
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess && hipMalloc(&d, 256) == hipSuccess) (void)hipMemsetAsync(d, 0, 256, s);
+        }
+        (void)hipDeviceSynchronize();
+    }
     const std::string mode = argc > 1 ? argv[1] : "commit";
     auto arg = [&](int i, long dflt) { return argc > i ? atol(argv[i]) : dflt; };
     if (mode == "commit") mode_commit((unsigned)arg(2, 20), parse_list(argc > 3 ? argv[3] : "20"), (int)arg(4, 5), parse_list(argc > 5 ? argv[5] : "3"), (int)arg(6, H2_PALLAS), (int)arg(7, 1));

@@ -105,7 +105,8 @@ int msm_generic_grouped(MsmContext &cx, const MsmArgs &a, const MsmShape &sh, si
     static const int skip = [] { const char *e = ab_env("H2_GG_SKIP"); return e ? atoi(e) : 0; }();       // TIMING ONLY, WRONG RESULTS: drop side-stream fold stages (1 finish, 2 heavy, 4 rowcol, 8 planes, 16 chain)
     static const bool big_all = [] { const char *e = ab_env("H2_GG_BIG"); return !(e && atoi(e) == 0); }();
     static const int form_env = [] { const char *e = ab_env("H2_GG_FORM"); return e ? atoi(e) : 0; }();        // 1: latency form always, 2: throughput form always (A/B)
-    const bool throughput = form_env == 2 || (form_env != 1 && msm_other_generic_in_flight(&cx));
+    // (from 2^22 points on the whole sort in front of a single group costs more than the grouping loses: 837 against 900 M scalar-mults/s on three streams)
+    const bool throughput = form_env == 2 || (form_env != 1 && scalars_n < ((size_t)1 << 22) && msm_other_generic_in_flight(&cx));
     // ---- the groups, upper slices first.  Nine slices: 4 + 3 + 2 -- the first group's sort is all that stands in front of the first
     // addition, the last group's fold all that stands behind the last.  (H2_GENERIC_GROUPS="a,b,c": laboratory build only.)
     int sizes[MsmContext::kMaxGroups] = {0, 0, 0, 0}, G = 0;
@@ -126,10 +127,11 @@ int msm_generic_grouped(MsmContext &cx, const MsmArgs &a, const MsmShape &sh, si
             for (int v : env_sizes) sizes[G++] = v;
         } else {
             if (throughput) {
-                // independent calls on other streams are in flight: their sorts and folds hide beside this call's accumulate anyway, and every
-                // accumulate launch that starts beside them runs ragged -- one group (two from 2^21 points, where the whole sort in front costs more)
-                if (scalars_n < ((size_t)1 << 21) || W < 4) { sizes[0] = (int)W; G = 1; }
-                else { sizes[1] = (int)W * 4 / 9; sizes[0] = (int)W - sizes[1]; G = 2; }
+                // independent calls on other streams are in flight: their sorts and folds hide beside this call's accumulate anyway, every accumulate
+                // launch that starts beside them runs ragged, and side streams of several calls would share hardware queues: ONE group, everything on
+                // the caller's stream (2^20: 1.16-1.22 ms per call on three streams against 1.26-1.46 for any grouping; 2^22: 862 M/s)
+                sizes[0] = (int)W;
+                G = 1;
             } else {
                 // a call alone: 5 + 2 + 2 of nine slices -- the first group's sort is all that stands in front of the first addition, the last
                 // (smallest) group's fold all that stands behind the last
@@ -205,16 +207,28 @@ int msm_generic_grouped(MsmContext &cx, const MsmArgs &a, const MsmShape &sh, si
         H2_HIP(hipFuncSetAttribute((const void *)msm_combine<FB>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         cx.attr_grouped_set = true;
     }
-    for (int i = 0; i <= G; ++i)
-        if (!cx.gstream[i]) H2_HIP(hipStreamCreateWithFlags(&cx.gstream[i], hipStreamNonBlocking));
-    for (int i = 0; i < 2 + 3 * G; ++i)
+    // Hardware queues.  HIP multiplexes streams onto a handful of hardware queues (four per priority level), and every packet of a queue waits
+    // for the one before it: a side stream that happens to share the CALLER's queue runs its kernels behind the accumulate they were meant to run
+    // beside (measured inside bench.py, a dozen streams open: the second group's fold landed on the caller's queue, 1.85 ms per call against 1.55
+    // from the native driver with the same library).  High-priority streams have queues of their own but cost every other stream of the process
+    // (independent calls 1.19 -> 1.32 ms with one such stream merely open: profiles/r06_generic_grouped.txt).  So the latency form runs on THREE
+    // streams of its own, created back to back (the runtime hands a new stream the least-used queue: three in a row get different ones): one
+    // carries the accumulates and what is serial with them, two side streams the rest (the conversion, the later groups' sorts and the even groups'
+    // folds and chain links on one, the odd groups' on the other: a group's fold must not queue behind the previous group's chain link); the caller's stream waits for `ms` at the end and does
+    // nothing in between, so it does not matter whose queue it shares.  The throughput form (one group) has nothing beside its accumulate and
+    // stays on the caller's stream.
+    if (G > 1 && !cx.gstream[0])
+        for (int i = 0; i < 3; ++i) H2_HIP(hipStreamCreateWithFlags(&cx.gstream[i], hipStreamNonBlocking));
+    hipStream_t const caller = st;
+    if (G > 1) st = cx.gstream[1];
+    for (int i = 0; i < 4 + 3 * G; ++i)
         if (!cx.gev[i]) H2_HIP(hipEventCreateWithFlags(&cx.gev[i], hipEventDisableTiming));
     hipStream_t sort_s = cx.gstream[0];
     hipEvent_t ev_fork = cx.gev[0], ev_conv = cx.gev[1];
     auto ev_sorted = [&](int g) { return cx.gev[2 + 3 * g]; };
     auto ev_acc = [&](int g) { return cx.gev[3 + 3 * g]; };
     auto ev_chain = [&](int g) { return cx.gev[4 + 3 * g]; };
-    auto fold_s = [&](int g) { return g == G - 1 ? st : cx.gstream[1 + g]; };       // the last group folds on the caller's stream
+    auto fold_s = [&](int g) { return g == G - 1 ? st : cx.gstream[(g & 1) ? 2 : 0]; };          // the last group folds behind its accumulate
 
     ColIn ci;
     ColOut co;
@@ -230,6 +244,10 @@ int msm_generic_grouped(MsmContext &cx, const MsmArgs &a, const MsmShape &sh, si
     u32 *lines9 = cx.partial.as<u32>(), *planes9 = lines9 + 36 * (size_t)W * (wideS + wideNR), *ssums = cx.ssums.as<u32>();
     const u32 *pts = cx.bases9.as<u32>();
 
+    if (st != caller) {               // everything below waits for what the caller's stream holds now
+        H2_HIP(hipEventRecord(cx.gev[2 + 3 * G], caller));
+        H2_HIP(hipStreamWaitEvent(st, cx.gev[2 + 3 * G], 0));
+    }
     // ---- the bases' conversion (it reads nothing the sorts write) beside the recode and the first sort
     H2_HIP(hipEventRecord(ev_fork, st));
     H2_HIP(hipStreamWaitEvent(fold_s(0), ev_fork, 0));
@@ -325,6 +343,11 @@ int msm_generic_grouped(MsmContext &cx, const MsmArgs &a, const MsmShape &sh, si
     hipLaunchKernelGGL((msm_combine<FB>), dim3(1), dim3(64), 0, st, (const u32 *)(ssums + 32 * (size_t)grp[G - 1].w0), (int)grp[G - 1].ns, (int)c, (u32 *)a.d_out, a.out_kind,
                        mont ? 1 : 0, 0, G > 1 ? (const u32 *)(ssums + 32 * (size_t)(W + G - 2)) : (const u32 *)nullptr, 1);
     H2_HIP(hipGetLastError());
+    if (st != caller) {               // ... and the caller's stream for the result
+        H2_HIP(hipEventRecord(cx.gev[3 + 3 * G], st));
+        H2_HIP(hipStreamWaitEvent(caller, cx.gev[3 + 3 * G], 0));
+        st = caller;
+    }
     if (!cx.gdone) H2_HIP(hipEventCreateWithFlags(&cx.gdone, hipEventDisableTiming));
     H2_HIP(hipEventRecord(cx.gdone, st));
     cx.gpending = true;

@@ -274,11 +274,13 @@ struct MsmContext {
         gdone = nullptr;
     }
     bool attr_set = false, attr2_set = false, attr_bins_set = false, attr_grouped_set = false;
-    // the grouped form of a large generic multiexp (msm_generic.hip): gstream[0] sorts the groups after the first, gstream[1 + g] folds
-    // group g and carries its link of the Horner chain; gev: fork, conversion done, then per group sorted / accumulated / chained
+    // the grouped form of a large generic multiexp (msm_generic.hip), latency form: gstream[1] carries the call's accumulates (and whatever is
+    // serial with them), gstream[0] and [2] everything that runs beside them (the bases' conversion, the later groups' sorts, the groups' folds and
+    // links of the Horner chain) -- three streams created back to back, so that they sit on different hardware queues whatever queue the CALLER's stream shares
+    // with whom; gev: fork, conversion done, per group sorted / accumulated / chained, then begin / end (the caller's stream only waits on those)
     static constexpr int kMaxGroups = 4;
     hipStream_t gstream[1 + kMaxGroups] = {};
-    hipEvent_t gev[2 + 3 * kMaxGroups] = {};
+    hipEvent_t gev[4 + 3 * kMaxGroups] = {};
     // recorded behind every grouped multiexp of this context; other contexts ask it whether a generic multiexp is in flight on ANOTHER stream
     // (msm_other_generic_in_flight): independent calls side by side take the throughput form, a lone call the latency form
     hipEvent_t gdone = nullptr;
