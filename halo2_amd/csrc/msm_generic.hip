@@ -100,7 +100,7 @@ int msm_generic_grouped(MsmContext &cx, const MsmArgs &a, const MsmShape &sh, si
     const u32 m = (u32)scalars_n, cols = 2 * m, W = (u32)sh.W, NB = sh.NB, c = (u32)sh.c;
     int rc;
     static const bool fold_late = [] { const char *e = ab_env("H2_GG_FOLD_LATE"); return e && atoi(e) == 1; }();       // experiments (laboratory build)
-    static const bool lowprio = [] { const char *e = ab_env("H2_GG_LOWPRIO"); return e && atoi(e) == 1; }();
+    static const int lowprio = [] { const char *e = ab_env("H2_GG_LOWPRIO"); return e ? atoi(e) : 0; }();       // mask: 1 finish, 2 heavy, 4 rowcol, 8 planes (upper groups)
     static const int acc_block = [] { const char *e = ab_env("H2_GG_ACC_BLOCK"); return e && atoi(e) == 256 ? 256 : 512; }();       // 256: A/B
     static const int skip = [] { const char *e = ab_env("H2_GG_SKIP"); return e ? atoi(e) : 0; }();       // TIMING ONLY, WRONG RESULTS: drop side-stream fold stages (1 finish, 2 heavy, 4 rowcol, 8 planes, 16 chain)
     static const bool big_all = [] { const char *e = ab_env("H2_GG_BIG"); return !(e && atoi(e) == 0); }();
@@ -288,15 +288,19 @@ int msm_generic_grouped(MsmContext &cx, const MsmArgs &a, const MsmShape &sh, si
         const u32 *starts = cx.starts.as<u32>() + q.starts_off;
         u32 *gbuckets = buckets_all + 36 * q.bucket_off, *heavy = cx.heavy.as<u32>() + (size_t)g * (kMaxHeavy + 2);
         u32 *hscr = cx.hscratch.as<u32>() + (size_t)g * kMaxHeavy * kHeavyBlocks * 36;
-        ColStride cs = cs0;
-        cs.lowprio = (lowprio && g < G - 1) ? 1u : 0u;
-        const int sk = g < G - 1 ? skip : 0;
-        if (!(sk & 1)) hipLaunchKernelGGL((fold9_finish<FB>), dim3((q.tb + 255) / 256), dim3(256), 0, s_, (const u32 *)heads_of[g], starts, gbuckets, heavy, q.tb, q.T, lane_div, cs);
-        if (!(sk & 2)) hipLaunchKernelGGL((fold9_finish_heavy<FB>), dim3(kHeavyBlocks, kHeavyRows), dim3(256), 0, s_, (const u32 *)heads_of[g], starts, hscr, (const u32 *)heavy, q.tb, q.T, lane_div, cs);
-        if (!(sk & 2)) hipLaunchKernelGGL((fold9_finish_heavy2<FB>), dim3(kHeavyRows), dim3(64), 0, s_, (const u32 *)hscr, gbuckets, (const u32 *)heavy, cs);
-        if (!(sk & 4)) hipLaunchKernelGGL((fold9_rowcol<FB>), dim3(wideS + wideNR - 1, q.ns), dim3(256), 0, s_, (const u32 *)gbuckets, lines9 + 36 * (size_t)q.w0 * (wideS + wideNR), wideS, wideNR, cs);
+        const int sk = g < G - 1 ? skip : 0, lp = g < G - 1 ? lowprio : 0;
+        ColStride cs = cs0, csf = cs0, csh = cs0, csr = cs0, csp = cs0;
+        csf.lowprio = (lp & 1) ? 1u : 0u;
+        csh.lowprio = (lp & 2) ? 1u : 0u;
+        csr.lowprio = (lp & 4) ? 1u : 0u;
+        csp.lowprio = (lp & 8) ? 1u : 0u;
+        (void)cs;
+        if (!(sk & 1)) hipLaunchKernelGGL((fold9_finish<FB>), dim3((q.tb + 255) / 256), dim3(256), 0, s_, (const u32 *)heads_of[g], starts, gbuckets, heavy, q.tb, q.T, lane_div, csf);
+        if (!(sk & 2)) hipLaunchKernelGGL((fold9_finish_heavy<FB>), dim3(kHeavyBlocks, kHeavyRows), dim3(256), 0, s_, (const u32 *)heads_of[g], starts, hscr, (const u32 *)heavy, q.tb, q.T, lane_div, csh);
+        if (!(sk & 2)) hipLaunchKernelGGL((fold9_finish_heavy2<FB>), dim3(kHeavyRows), dim3(64), 0, s_, (const u32 *)hscr, gbuckets, (const u32 *)heavy, csh);
+        if (!(sk & 4)) hipLaunchKernelGGL((fold9_rowcol<FB>), dim3(wideS + wideNR - 1, q.ns), dim3(256), 0, s_, (const u32 *)gbuckets, lines9 + 36 * (size_t)q.w0 * (wideS + wideNR), wideS, wideNR, csr);
         if (!(sk & 8)) hipLaunchKernelGGL((fold9_planes<FB>), dim3(c - 1, q.ns), dim3(256), 0, s_, (const u32 *)(lines9 + 36 * (size_t)q.w0 * (wideS + wideNR)), planes9 + 36 * (size_t)q.w0 * 32,
-                           cx.fold_ctr.as<u32>() + q.w0, wideS, wideNR, cb, ssums + 32 * (size_t)q.w0, kOutSliceSum, mont, co, cs);
+                           cx.fold_ctr.as<u32>() + q.w0, wideS, wideNR, cb, ssums + 32 * (size_t)q.w0, kOutSliceSum, mont, co, csp);
     };
 
     // ---- sorts: the first group on the caller's stream, the others on the side stream behind it (they share hist / tagged / plan)
