@@ -72,7 +72,7 @@ def main():
            "calibration": calibration,
            "units": __doc__.split("Counter values")[1].strip().replace("\n", " "),
            "kernels": kernels}
-    acc = pick("h2::msm_accumulate<0, false, true>")
+    acc = pick("h2::msm_accumulate<0, false, true, 256>")
     if acc:
         k = max(acc, key=lambda k_: acc[k_]["FETCH_SIZE_KiB_max"])
         out["msm_accumulate_2^20"] = {

@@ -23,8 +23,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # (source file, demangled-name substring, what it is)
 KERNELS = [
-    ("msm_accumulate.hip", "msm_accumulate<0, false, true>", "registered-table accumulate, Pallas (the roofline kernel)"),
-    ("msm_accumulate.hip", "msm_accumulate<1, false, true>", "the same, Vesta"),
+    ("msm_accumulate.hip", "msm_accumulate<0, false, true, 256>", "registered-table accumulate, Pallas (the roofline kernel)"),
+    ("msm_accumulate.hip", "msm_accumulate<1, false, true, 256>", "the same, Vesta"),
     ("msm_sort.hip", "msm_s1_count<1, false>", "bucket sort pass 1: count (Pallas scalars = Fq)"),
     ("msm_sort.hip", "msm_s1_scatter<1, false>", "bucket sort pass 1: scatter"),
     ("msm_sort.hip", "msm_s2_bins", "bucket sort pass 2 (a workgroup per bin)"),

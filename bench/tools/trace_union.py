@@ -12,7 +12,7 @@ import sys
 
 def main():
     path = sys.argv[1]
-    prefix = sys.argv[2] if len(sys.argv) > 2 else "void h2::msm_accumulate<0, false, true>"
+    prefix = sys.argv[2] if len(sys.argv) > 2 else "void h2::msm_accumulate<0, false, true, 256>"
     min_us = float(sys.argv[3]) if len(sys.argv) > 3 else 600.0          # the dense 2^20 launches (skewed / small legs are shorter)
     iv = []
     for r in csv.DictReader(open(path)):
