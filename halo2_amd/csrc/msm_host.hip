@@ -103,8 +103,34 @@ static int msm_host_chunked(MsmContext &cx, int curve, const uint64_t *scalars, 
     std::lock_guard<std::mutex> lk(hp.mu);
     int rc = hp.ensure(Q);
     if (rc != H2_OK) return rc;
-    auto range = [&](unsigned q, size_t &lo, size_t &hi) { lo = n * q / Q; hi = n * (q + 1) / Q; };
-    const int c = choose_c((n + Q - 1) / Q, false);            // ONE window width for every range: their slice sums add up
+    // Range boundaries.  Equal ranges by default; H2_MSM_HOST_SPLIT="a,b,c" (laboratory build; Q percentages) makes them uneven -- a smaller LAST
+    // range shortens what stands behind the last byte (its accumulate), as long as the ranges before it keep pace with their copies.
+    static const std::vector<int> split_env = [] {
+        std::vector<int> v;
+        if (const char *e = ab_env("H2_MSM_HOST_SPLIT"))
+            for (const char *q = e; *q;) {
+                v.push_back(atoi(q));
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+        return v;
+    }();
+    size_t bnd[17];
+    {
+        int tot = 0;
+        for (int v : split_env) tot += v;
+        const bool uneven = split_env.size() == Q && tot == 100 && *std::min_element(split_env.begin(), split_env.end()) >= 1;
+        size_t acc_pct = 0;
+        bnd[0] = 0;
+        for (unsigned q = 0; q < Q; ++q) {
+            if (uneven) { acc_pct += (size_t)split_env[q]; bnd[q + 1] = q + 1 == Q ? n : (n * acc_pct / 100) & ~(size_t)63; }
+            else bnd[q + 1] = n * (q + 1) / Q;
+        }
+    }
+    auto range = [&](unsigned q, size_t &lo, size_t &hi) { lo = bnd[q]; hi = bnd[q + 1]; };
+    size_t widest = 0;
+    for (unsigned q = 0; q < Q; ++q) widest = std::max(widest, bnd[q + 1] - bnd[q]);
+    const int c = choose_c(widest, false);                     // ONE window width for every range: their slice sums add up
     auto args_of = [&](unsigned q, int phase) {
         size_t lo, hi;
         range(q, lo, hi);
