@@ -9,18 +9,24 @@
 // fold and the end of the chain -- serial.  Here:
 //
 //   * the split happens ONCE (msm_glv_digits): one row of 16-bit digit codes per window slice;
-//   * the window slices are cut into GROUPS, upper slices first (nine slices: 4 + 3 + 2).  Each group has its own two-pass sort (pass 1
+//   * the window slices are cut into GROUPS, upper slices first (a lone call: 5 + 2 + 2 of nine).  Each group has its own two-pass sort (pass 1
 //     reads the group's digit rows, 2 bytes per entry; pass 2 a workgroup per bin in LDS at every size), its own sorted list and
 //     boundary array, its own accumulate launch, its own fold;
-//   * only the FIRST group's sort stands in front of the first addition: the others are sorted on a side stream while the group before
-//     them is being accumulated (the sort kernels are light now: 24 registers, no field arithmetic), and every group but the last is
-//     folded beside the next group's accumulate;
-//   * the Horner chain is cut at the group boundaries: group g's link A_g = R_g + D_(g-1), D_g = 2^(c ns_(g+1)) A_g runs on that
-//     group's fold stream, so behind the last addition stand only the last (smallest) group's fold, its c (ns - 1) doublings and one
-//     addition.
+//   * only the FIRST group's sort stands in front of the first addition: the others are sorted beside the first accumulate (the sort
+//     kernels are light now: 8-24 registers, no field arithmetic), and every group but the last is folded beside the next group's accumulate;
+//   * the Horner chain is cut at the group boundaries: group g's link A_g = R_g + D_(g-1), D_g = 2^(c ns_(g+1)) A_g runs behind that
+//     group's fold, so behind the last addition stand only the last (smallest) group's fold, its c (ns - 1) doublings and one addition;
+//   * TWO FORMS.  Latency form (a lone call): three groups on three streams of the library's own, created back to back -- accumulates on one,
+//     everything beside them on the other two -- because HIP multiplexes streams onto four hardware queues and a side stream sharing the
+//     CALLER's queue would run behind the accumulate it was meant to run beside; the caller's stream only waits for the result.  8 CUs are left
+//     without an accumulate workgroup and the chain links are fenced onto them by LDS requests (a chain link is one wave holding a SIMD).
+//     Throughput form (another stream's generic multiexp is in flight, below 2^22 points): ONE group, everything on the caller's stream.
+//
+// Measured against round 5's form on one box (profiles/r06_generic_grouped.txt): 2^20 one call 1.50-1.58 against 1.55-1.62 ms, three streams
+// 1.16-1.20 against 1.33-1.43; 2^21 2.59-2.62 against 2.84-2.87; 2^22 4.98-5.13 against 5.68-5.74 ms.  DESIGN.md section 4.4 has the reasons.
 //
 // Results are the same group element as every other form (the order of additions inside a bucket is free: SURVEY.md appendix A.1);
-// parity against the C oracle: tests/test_gpu_parity.py, build/h2bench msm / parity.
+// parity against the C oracle: tests/test_gpu_generic_grouped.py, tests/test_gpu_parity.py, build/h2bench msm / parity.
 #include "msm_internal.cuh"
 
 namespace h2 {
