@@ -26,7 +26,7 @@
 // 1.16-1.20 against 1.33-1.43; 2^21 2.59-2.62 against 2.84-2.87; 2^22 4.98-5.13 against 5.68-5.74 ms.  DESIGN.md section 4.4 has the reasons.
 //
 // Results are the same group element as every other form (the order of additions inside a bucket is free: SURVEY.md appendix A.1);
-// parity against the C oracle: tests/test_gpu_generic_grouped.py, tests/test_gpu_parity.py, build/h2bench msm / parity.
+// parity (bit-exact canonical affine coordinates against the C restatement of the reference): tests/test_gpu_generic_grouped.py, tests/test_gpu_parity.py, build/h2bench msm / parity.
 #include "msm_internal.cuh"
 
 namespace h2 {
