@@ -175,7 +175,7 @@ int msm_generic_grouped(MsmContext &cx, const MsmArgs &a, const MsmShape &sh, si
     static const int spare_env = [] { const char *e = ab_env("H2_GG_SPARE"); return e ? atoi(e) : -1; }();
     static const int lds_env = [] { const char *e = ab_env("H2_GG_LDS"); return e ? atoi(e) : -1; }();
     const bool lds_fence = lds_env >= 0 ? lds_env == 1 : (!throughput && G > 1);
-    const u32 spare = spare_env >= 0 ? (u32)spare_env : (lds_fence ? 8u : 0u);
+    const u32 spare = spare_env >= 0 ? (u32)spare_env : (lds_fence ? std::max(1u, lanes / 512u / 32u) : 0u);      // one CU in 32: 8 of an MI355X's 256 (one per XCD)
     const u32 usable = std::max(512u, (u32)(lanes * fraction) / 512u * 512u - 512u * std::min(spare, 64u));
     size_t head_slots = 0, hist_words = 0, tagged_words = 0, plan_words = 0;
     for (int g = 0; g < G; ++g) {
