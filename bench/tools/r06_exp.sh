@@ -1,14 +1,7 @@
+# the last experiment script of round 6 as it was run (see bench/tools/README.md): a by-kernel trace of the shipped generic multiexp at 2^20 and 2^22
 R=$GRAFT_REPO_ROOT
-cd $R
-export H2BENCH_LIB=$R/build/ab/libhalo2_mi355x_ab.so
-run() { echo "== $*"; env "$@" timeout 100 build/h2bench msm ${L:-20} 0 | grep "generic best\|FAIL" | grep -v "^ok" | sed 's/.*device-resident/   /'; }
-run A=1
-run H2_MSM_HOST_SPLIT=40,38,22
-run H2_MSM_HOST_SPLIT=42,38,20
-run H2_MSM_HOST_SPLIT=45,40,15
-run H2_MSM_HOST_SPLIT=38,36,26
-run H2_MSM_HOST_SPLIT=30,30,40
-run H2_MSM_HOST_CHUNKS=4 H2_MSM_HOST_SPLIT=32,30,24,14
-run H2_MSM_HOST_CHUNKS=4 H2_MSM_HOST_SPLIT=35,30,23,12
-run H2_MSM_HOST_CHUNKS=2 H2_MSM_HOST_SPLIT=65,35
-run A=1
+export H2BENCH_MSM_DEVICE_ONLY=1
+cd /tmp; export TMPDIR=/tmp
+for L in 20 22; do
+rocprofv3 --kernel-trace -d $R/gpurun_out/r06_call_$L -o t -- $R/build/h2bench msm $L > $R/gpurun_out/r06_call_$L.log 2>&1; grep "generic best\|independent" $R/gpurun_out/r06_call_$L.log
+done
