@@ -374,9 +374,9 @@ def main():
         d_bases = torch.from_numpy(bases_full.view(np.int64)).to(dev)
         d_sc = torch.from_numpy(sc_full.view(np.int64)).to(dev)
         d_gen = torch.zeros(12, dtype=torch.int64, device=dev)
-        reps_g = 12
-        for rep_ in range(reps_g + 2):
-            if rep_ == 2:
+        reps_g, warm_g = 24, 4                # (round 6: 24 timed calls after 4 -- the first calls behind a synchronisation still see the clock ramp)
+        for rep_ in range(reps_g + warm_g):
+            if rep_ == warm_g:
                 torch.cuda.synchronize()
                 t6 = time.perf_counter()
             check(lib.h2_msm_device(curve, d_sc.data_ptr(), d_bases.data_ptr(), n + 1, h.FORM_MONTGOMERY, 0, d_gen.data_ptr(), sps[0]),
